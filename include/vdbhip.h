@@ -1,0 +1,147 @@
+/*
+ * vdbhip.h -- C ABI of the MI355X-native distance / top-k engine (libvdbhip.so).
+ *
+ * This is the drop-in boundary for the one hot path of lab-1806-vec-db:
+ * src/distance, src/vec_set, src/index_algorithm::{flat,hnsw,pq}.  The reference has no
+ * FFI on this path (everything is generic Rust, monomorphised); the narrowest seam is
+ * `DynamicIndex` (src/database/dynamic_index.rs:11-94) which forwards to the index traits
+ * (src/index_algorithm/mod.rs:35-154).  Every entry point below names the reference
+ * interface it replaces.  A Rust `extern "C"` block binds this 1:1.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; `usize` is uint64_t; DistanceAlgorithm is an int with
+ *    the reference's bincode variant order (distance/mod.rs:17-28): 0 = L2Sqr, 1 = Cosine.
+ *  - every function returns 0 on success, non-zero on failure; the message is available
+ *    through vdb_last_error() (thread-local).  Nothing aborts the process.
+ *  - read-side calls (knn*, row, len...) are re-entrant on one handle, like `&self` methods
+ *    under the reference's RwLock read guard (database/mod.rs:248-256); write-side calls
+ *    (add, swap_remove, *_build, *_attach, *_clear) need external exclusion, like `&mut self`.
+ *  - results for query q are written at out_idx[q*k .. q*k+out_count[q]) ascending by
+ *    (distance, index) -- the order of `Vec<CandidatePair>` (candidate_pair.rs:36-41);
+ *    out_count[q] = min(k, len) for Flat (flat_index.rs:163).
+ *  - `*_device` variants take device pointers valid on the index's GPU and a hipStream_t
+ *    (passed as void*); they are asynchronous unless noted.
+ *  - there is NO CPU fallback: without a usable GPU every compute entry point fails.
+ */
+#ifndef VDBHIP_H
+#define VDBHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VDB_L2SQR 0
+#define VDB_COSINE 1
+
+#define VDB_OK 0
+#define VDB_ERR_INVALID 1   /* bad argument (reference: bail!/assert!, e.g. database/mod.rs:427-429) */
+#define VDB_ERR_HIP 2       /* HIP runtime error */
+#define VDB_ERR_STATE 3     /* e.g. knn_pq without a PQ table */
+#define VDB_ERR_NOGPU 4     /* no usable gfx950 device */
+
+typedef struct vdb_index vdb_index;
+
+/* thread-local message of the last failing call on this thread */
+const char *vdb_last_error(void);
+int vdb_version(void);
+int vdb_device_count(int *out);
+
+/* ---- VecSet<f32> + DynamicIndex::new ---------------------------------------------------
+ * DynamicIndex::new(dim, dist) (dynamic_index.rs:17-19) -> an empty Flat index whose VecSet
+ * (vec_set.rs:15-20) lives row-major in HBM on `device_id`. */
+int vdb_index_create(int device_id, uint64_t dim, int dist, vdb_index **out);
+int vdb_index_destroy(vdb_index *idx);
+/* IndexIter::len / dim (index_algorithm/mod.rs:35-52), DynamicIndex::dist (:37-42) */
+int vdb_index_len(const vdb_index *idx, uint64_t *out);
+int vdb_index_dim(const vdb_index *idx, uint64_t *out);
+int vdb_index_dist(const vdb_index *idx, int *out);
+/* Index<usize> (vec_set.rs:22-30): copy row i to out[dim] */
+int vdb_index_row(const vdb_index *idx, uint64_t i, float *out);
+/* DynamicIndex::add / batch_add for Flat = VecSet::push (dynamic_index.rs:44-58, vec_set.rs:113-118);
+ * for an index that currently has an HNSW graph = HNSWIndex::add (hnsw_index.rs:538-572) with
+ * levels drawn from the index's own RNG stream.  rows is n x dim row-major; *first_id = id of rows[0]. */
+int vdb_index_add(vdb_index *idx, const float *rows, uint64_t n, uint64_t *first_id);
+/* same, rows already resident in HBM (no host copy is kept until one is needed) */
+int vdb_index_add_device(vdb_index *idx, const void *d_rows, uint64_t n, uint64_t *first_id);
+/* VecSet::swap_remove (vec_set.rs:131-137); Flat only (metadata_vec_table.rs:163-187) */
+int vdb_index_swap_remove(vdb_index *idx, uint64_t i);
+/* row sharding: ids reported by knn* are local_row + offset */
+int vdb_index_set_id_offset(vdb_index *idx, uint64_t offset);
+/* calc_dist (pyo3/mod.rs:43-48): one distance, evaluated on the GPU in reference order */
+int vdb_calc_dist(int device_id, const float *a, const float *b, uint64_t n, int dist, float *out);
+
+/* ---- FlatIndex::knn (flat_index.rs:48-57), batched over nq queries -------------------- */
+int vdb_flat_knn(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, uint64_t k,
+                 uint64_t *out_idx, float *out_dist, uint64_t *out_count);
+/* device-resident queries and outputs (out_idx u64[nq*k], out_dist f32[nq*k], out_count u64[nq]);
+ * synchronises `stream` once at the end (certification read-back). */
+int vdb_flat_knn_device(vdb_index *idx, const void *d_queries, uint64_t nq, uint64_t dim, uint64_t k,
+                        void *d_out_idx, void *d_out_dist, void *d_out_count, void *stream);
+/* tuning / test hooks for the Flat path:
+ *   mode 0 = auto (MFMA shortlist + exact re-rank + certification, exact scan for small inputs),
+ *   mode 1 = exact scan only (strict-order f32 fold for every row),
+ *   mode 2 = MFMA path forced (still certified, still falls back per query). */
+int vdb_flat_set_mode(vdb_index *idx, int mode);
+/* number of queries whose MFMA shortlist failed certification and were redone by the exact scan */
+int vdb_flat_fallback_count(const vdb_index *idx, uint64_t *out);
+
+/* ---- PQTable (distance/pq_table.rs) ----------------------------------------------------
+ * centroids: group g, centroid c at k_c*gstart[g] + c*len(g) (pq_groups, pq_table.rs:38-53),
+ * k_c = 1<<n_bits, total k_c*dim floats.  codes: n x ceil(m*n_bits/8), 4-bit low nibble = even
+ * group (pq_table.rs:66-91); NULL -> encoded on the GPU (pq_encode + find_nearest_base). */
+int vdb_pq_attach(vdb_index *idx, uint64_t n_bits, uint64_t m, const float *centroids, const uint8_t *codes);
+/* PQTable::from_vec_set (pq_table.rs:141-191): sample train_n rows (0 = all), per-group k-means
+ * (k_means.rs:61-162) on the host, encode on the GPU.  RNG = splitmix64(seed). */
+int vdb_pq_build(vdb_index *idx, uint64_t n_bits, uint64_t m, uint64_t train_n, uint64_t max_iter, float tol,
+                 uint64_t seed);
+int vdb_pq_clear(vdb_index *idx);                 /* MetadataVecTable::clear_pq_table :154-156 */
+int vdb_pq_has(const vdb_index *idx, int *out);
+int vdb_pq_info(const vdb_index *idx, uint64_t *n_bits, uint64_t *m, uint64_t *enc_dim);
+int vdb_pq_export(const vdb_index *idx, float *centroids, uint8_t *codes);
+/* FlatIndex::knn_pq (flat_index.rs:84-104) */
+int vdb_flat_knn_pq(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef,
+                    uint64_t *out_idx, float *out_dist, uint64_t *out_count);
+
+/* ---- HNSWIndex (index_algorithm/hnsw_index.rs) -----------------------------------------
+ * Graph layout (fields :98-141): level0 = n x max_m0 u32 (max_m0 = 2*min(M,10000)), len0[n];
+ * vec_level[n]; upper = CSR over nodes, node v level L>=1 at ((sum_{u<v} vec_level[u]) + L-1)*m,
+ * upper_len likewise. */
+int vdb_hnsw_build(vdb_index *idx, uint64_t M, uint64_t ef_construction, uint64_t seed, uint64_t batch,
+                   int nthreads);                  /* build_on_vec_set :595-611 (host builder) */
+int vdb_hnsw_attach(vdb_index *idx, uint64_t M, uint64_t ef_construction, const uint32_t *level0,
+                    const uint64_t *len0, const uint64_t *vec_level, const uint32_t *upper,
+                    const uint64_t *upper_len, int has_enter, uint64_t enter_point, uint64_t enter_level);
+int vdb_hnsw_clear(vdb_index *idx);               /* MetadataVecTable::clear_hnsw_index :100-106 */
+int vdb_hnsw_has(const vdb_index *idx, int *out);
+int vdb_hnsw_info(const vdb_index *idx, uint64_t *m, uint64_t *max_m0, uint64_t *upper_total, int *has_enter,
+                  uint64_t *enter_point, uint64_t *enter_level, uint64_t *default_ef);
+int vdb_hnsw_export(const vdb_index *idx, uint32_t *level0, uint64_t *len0, uint64_t *vec_level, uint32_t *upper,
+                    uint64_t *upper_len);
+/* HNSWIndex::knn_with_ef (:619-634); ef = 0 -> default_ef (knn, :614-618) */
+int vdb_hnsw_knn(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef,
+                 uint64_t *out_idx, float *out_dist, uint64_t *out_count);
+/* HNSWIndex::knn_pq (:672-697) */
+int vdb_hnsw_knn_pq(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef,
+                    uint64_t *out_idx, float *out_dist, uint64_t *out_count);
+/* per-call work counters of the last vdb_hnsw_knn on this index (SURVEY 8d bytes/query) */
+int vdb_hnsw_last_stats(const vdb_index *idx, uint64_t *n_dist, uint64_t *n_expanded);
+
+/* ---- shard merge ------------------------------------------------------------
+ * Merge S per-shard result lists (each [nq][k], ascending, counts[s][q] valid entries, global ids)
+ * into the global top-k by (distance, index).  Host utility used after the RCCL all-gather. */
+int vdb_merge_topk(const float *dists, const uint64_t *ids, const uint64_t *counts, uint64_t n_shards,
+                   uint64_t nq, uint64_t k, uint64_t *out_idx, float *out_dist, uint64_t *out_count);
+
+/* ---- measurement hooks -------------------------------------------------------------------
+ * When enabled, the dominant kernels are bracketed by HIP events on their own stream and the
+ * elapsed time is accumulated per kernel name ("flat_mfma", "flat_exact", "pq_adc", "hnsw"). */
+int vdb_prof_enable(vdb_index *idx, int on);
+int vdb_prof_reset(vdb_index *idx);
+int vdb_prof_get(vdb_index *idx, const char *kernel, double *total_ms, uint64_t *launches, double *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VDBHIP_H */

@@ -1,0 +1,96 @@
+"""ctypes binding of libvdbhip.so (C ABI: include/vdbhip.h).
+
+The product path has no CPU fallback: if the HIP library is missing this module raises on import
+of the symbol table, and every compute call fails when no gfx950 device is usable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvdbhip.so")
+
+L2SQR, COSINE = 0, 1
+
+f32p = C.POINTER(C.c_float)
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
+intp = C.POINTER(C.c_int)
+f64p = C.POINTER(C.c_double)
+vp = C.c_void_p
+u64 = C.c_uint64
+
+# name -> argtypes; every function returns int status (except the two noted below)
+SIGNATURES = {
+    "vdb_device_count": [intp],
+    "vdb_index_create": [C.c_int, u64, C.c_int, C.POINTER(vp)],
+    "vdb_index_destroy": [vp],
+    "vdb_index_len": [vp, u64p],
+    "vdb_index_dim": [vp, u64p],
+    "vdb_index_dist": [vp, intp],
+    "vdb_index_row": [vp, u64, f32p],
+    "vdb_index_add": [vp, f32p, u64, u64p],
+    "vdb_index_add_device": [vp, vp, u64, u64p],
+    "vdb_index_swap_remove": [vp, u64],
+    "vdb_index_set_id_offset": [vp, u64],
+    "vdb_calc_dist": [C.c_int, f32p, f32p, u64, C.c_int, f32p],
+    "vdb_flat_knn": [vp, f32p, u64, u64, u64, u64p, f32p, u64p],
+    "vdb_flat_knn_device": [vp, vp, u64, u64, u64, vp, vp, vp, vp],
+    "vdb_flat_set_mode": [vp, C.c_int],
+    "vdb_flat_fallback_count": [vp, u64p],
+    "vdb_pq_attach": [vp, u64, u64, f32p, u8p],
+    "vdb_pq_build": [vp, u64, u64, u64, u64, C.c_float, u64],
+    "vdb_pq_clear": [vp],
+    "vdb_pq_has": [vp, intp],
+    "vdb_pq_info": [vp, u64p, u64p, u64p],
+    "vdb_pq_export": [vp, f32p, u8p],
+    "vdb_flat_knn_pq": [vp, f32p, u64, u64, u64, u64, u64p, f32p, u64p],
+    "vdb_hnsw_build": [vp, u64, u64, u64, u64, C.c_int],
+    "vdb_hnsw_attach": [vp, u64, u64, u32p, u64p, u64p, u32p, u64p, C.c_int, u64, u64],
+    "vdb_hnsw_clear": [vp],
+    "vdb_hnsw_has": [vp, intp],
+    "vdb_hnsw_info": [vp, u64p, u64p, u64p, intp, u64p, u64p, u64p],
+    "vdb_hnsw_export": [vp, u32p, u64p, u64p, u32p, u64p],
+    "vdb_hnsw_knn": [vp, f32p, u64, u64, u64, u64, u64p, f32p, u64p],
+    "vdb_hnsw_knn_pq": [vp, f32p, u64, u64, u64, u64, u64p, f32p, u64p],
+    "vdb_hnsw_last_stats": [vp, u64p, u64p],
+    "vdb_merge_topk": [f32p, u64p, u64p, u64, u64, u64, u64p, f32p, u64p],
+    "vdb_prof_enable": [vp, C.c_int],
+    "vdb_prof_reset": [vp],
+    "vdb_prof_get": [vp, C.c_char_p, f64p, u64p, f64p],
+}
+
+_lib = None
+
+
+class VdbError(RuntimeError):
+    """Recoverable failure reported by libvdbhip (the reference raises PyRuntimeError, pyo3/mod.rs:65,85)."""
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C lab_1806_vec_db_amd/csrc).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.vdb_last_error.restype = C.c_char_p
+    lib.vdb_last_error.argtypes = []
+    lib.vdb_version.restype = C.c_int
+    lib.vdb_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+def check(status: int):
+    if status != 0:
+        msg = load().vdb_last_error().decode("utf-8", "replace")
+        raise VdbError(f"libvdbhip error {status}: {msg}")

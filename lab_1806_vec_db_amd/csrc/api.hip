@@ -1,0 +1,472 @@
+// api.hip -- extern "C" boundary of libvdbhip.so (declarations + reference citations: include/vdbhip.h).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "../../include/vdbhip.h"
+#include "index.hpp"
+#include "pq_hnsw.hpp"
+
+using namespace vdb;
+
+static thread_local std::string g_last_error;
+
+struct vdb_index {
+    Index ix;
+    vdb_index(int dev, uint64_t dim, int dist) : ix(dev, dim, dist) {}
+};
+
+#define VDB_API_BEGIN try {
+#define VDB_API_END                                   \
+    return VDB_OK;                                    \
+    }                                                 \
+    catch (const vdb::Error &e) {                     \
+        g_last_error = e.what();                      \
+        return e.code;                                \
+    }                                                 \
+    catch (const std::exception &e) {                 \
+        g_last_error = e.what();                      \
+        return VDB_ERR_INVALID;                       \
+    }                                                 \
+    catch (...) {                                     \
+        g_last_error = "unknown error";               \
+        return VDB_ERR_INVALID;                       \
+    }
+
+static void require_gpu() {
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt <= 0)
+        throw Error(VDB_ERR_NOGPU, std::string("no usable HIP device (libvdbhip has no CPU fallback): ") +
+                                       hipGetErrorString(e));
+}
+
+extern "C" {
+
+const char *vdb_last_error(void) { return g_last_error.c_str(); }
+int vdb_version(void) { return 100; }
+
+int vdb_device_count(int *out) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(out, "null out");
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    *out = (e == hipSuccess) ? cnt : 0;
+    VDB_API_END
+}
+
+int vdb_index_create(int device_id, uint64_t dim, int dist, vdb_index **out) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(out, "null out");
+    VDB_REQUIRE(dim > 0 && dim < (1u << 24), "dim must be in 1..2^24");
+    VDB_REQUIRE(dist == VDB_L2SQR || dist == VDB_COSINE, "dist must be 0 (L2Sqr) or 1 (Cosine)");
+    require_gpu();
+    *out = new vdb_index(device_id, dim, dist);
+    VDB_API_END
+}
+int vdb_index_destroy(vdb_index *idx) {
+    VDB_API_BEGIN
+    if (idx) {
+        idx->ix.use_device();
+        delete idx;
+    }
+    VDB_API_END
+}
+int vdb_index_len(const vdb_index *idx, uint64_t *out) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx && out, "null argument");
+    *out = idx->ix.n;
+    VDB_API_END
+}
+int vdb_index_dim(const vdb_index *idx, uint64_t *out) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx && out, "null argument");
+    *out = idx->ix.dim;
+    VDB_API_END
+}
+int vdb_index_dist(const vdb_index *idx, int *out) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx && out, "null argument");
+    *out = idx->ix.dist;
+    VDB_API_END
+}
+int vdb_index_row(const vdb_index *idx, uint64_t i, float *out) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx && out, "null argument");
+    const Index &ix = idx->ix;
+    VDB_REQUIRE(i < ix.n, "row index out of bounds");
+    ix.use_device();
+    VDB_HIP(hipMemcpy(out, ix.d_rows.as<float>() + i * ix.dim, ix.dim * sizeof(float), hipMemcpyDeviceToHost));
+    VDB_API_END
+}
+
+static void add_common(Index &ix, const float *rows, uint64_t n, uint64_t *first_id, bool on_device) {
+    VDB_REQUIRE(rows || n == 0, "null rows");
+    if (first_id) *first_id = ix.n;
+    if (ix.hnsw.present) {
+        // DynamicIndex::add on the HNSW arm (dynamic_index.rs:47-52): HNSWIndex::add per row
+        std::vector<float> tmp;
+        const float *h = rows;
+        if (on_device) {
+            tmp.resize(n * ix.dim);
+            ix.use_device();
+            VDB_HIP(hipMemcpy(tmp.data(), rows, n * ix.dim * sizeof(float), hipMemcpyDeviceToHost));
+            h = tmp.data();
+        }
+        hnsw_insert_rows(ix, h, n);
+        return;
+    }
+    ix.add_rows(rows, n, on_device);
+}
+int vdb_index_add(vdb_index *idx, const float *rows, uint64_t n, uint64_t *first_id) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    add_common(idx->ix, rows, n, first_id, false);
+    VDB_API_END
+}
+int vdb_index_add_device(vdb_index *idx, const void *d_rows, uint64_t n, uint64_t *first_id) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    add_common(idx->ix, static_cast<const float *>(d_rows), n, first_id, true);
+    VDB_API_END
+}
+int vdb_index_swap_remove(vdb_index *idx, uint64_t i) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    VDB_REQUIRE(!idx->ix.hnsw.present, "swap_remove needs a Flat index (clear the HNSW graph first)");
+    VDB_REQUIRE(!idx->ix.pq.present, "swap_remove invalidates the PQ table: clear it first");
+    idx->ix.swap_remove(i);
+    VDB_API_END
+}
+int vdb_index_set_id_offset(vdb_index *idx, uint64_t offset) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    idx->ix.id_offset = offset;
+    VDB_API_END
+}
+
+int vdb_calc_dist(int device_id, const float *a, const float *b, uint64_t n, int dist, float *out) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(a && b && out, "null argument");
+    VDB_REQUIRE(n > 0 && n < (1u << 24), "bad length");
+    VDB_REQUIRE(dist == VDB_L2SQR || dist == VDB_COSINE, "dist must be 0 or 1");
+    require_gpu();
+    VDB_HIP(hipSetDevice(device_id));
+    DevBuf buf;
+    buf.reserve((2 * n + 4) * sizeof(float));
+    float *d = buf.as<float>();
+    VDB_HIP(hipMemcpy(d, a, n * sizeof(float), hipMemcpyHostToDevice));       // "row"
+    VDB_HIP(hipMemcpy(d + n, b, n * sizeof(float), hipMemcpyHostToDevice));   // "query"
+    float *sq = d + 2 * n;  // [0]=|a|^2 [1]=|b|^2 [2]=out
+    launch_row_sqnorm(d, 1, (uint32_t)n, sq, nullptr);
+    launch_row_sqnorm(d + n, 1, (uint32_t)n, sq + 1, nullptr);
+    launch_scan_exact(d, 1, (uint32_t)n, d + n, 1, dist == VDB_L2SQR ? MET_L2_DIRECT : MET_COSINE, sq, sq + 1, sq + 2,
+                      4, false, nullptr);
+    VDB_HIP(hipMemcpy(out, sq + 2, sizeof(float), hipMemcpyDeviceToHost));
+    VDB_API_END
+}
+
+// ---- Flat ----------------------------------------------------------------------------------------
+static void check_query_args(const Index &ix, const void *queries, uint64_t nq, uint64_t dim, const void *out_idx,
+                             const void *out_dist) {
+    VDB_REQUIRE(dim == ix.dim, "query dimension mismatch: index dim " + std::to_string(ix.dim) + ", got " +
+                                   std::to_string(dim));
+    VDB_REQUIRE(nq == 0 || (queries && out_idx && out_dist), "null argument");
+}
+
+typedef void (*dev_search_fn)(Index &, Workspace &, const float *, uint64_t, uint64_t, uint64_t, uint64_t *, float *,
+                              uint64_t *);
+
+// host-pointer front end shared by all searches: stage queries, run, copy results back
+static void host_search(Index &ix, const float *queries, uint64_t nq, uint64_t k, uint64_t ef, uint64_t *out_idx,
+                        float *out_dist, uint64_t *out_count, dev_search_fn fn) {
+    if (nq == 0) return;
+    ix.use_device();
+    WsLease ws(ix);
+    hipStream_t s = ws->stream;
+    constexpr uint64_t CHUNK = 16384;
+    for (uint64_t q0 = 0; q0 < nq; q0 += CHUNK) {
+        uint64_t nb = std::min<uint64_t>(CHUNK, nq - q0);
+        uint64_t kk = std::max<uint64_t>(k, 1);
+        ws->q.reserve(nb * ix.dim * sizeof(float));
+        ws->out_idx.reserve(nb * kk * sizeof(uint64_t));
+        ws->out_dist.reserve(nb * kk * sizeof(float));
+        ws->out_cnt.reserve(nb * sizeof(uint64_t));
+        VDB_HIP(hipMemcpyAsync(ws->q.p, queries + q0 * ix.dim, nb * ix.dim * sizeof(float), hipMemcpyHostToDevice, s));
+        fn(ix, *ws, ws->q.as<float>(), nb, k, ef, ws->out_idx.as<uint64_t>(), ws->out_dist.as<float>(),
+           ws->out_cnt.as<uint64_t>());
+        if (k) {
+            VDB_HIP(hipMemcpyAsync(out_idx + q0 * k, ws->out_idx.p, nb * k * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+            VDB_HIP(hipMemcpyAsync(out_dist + q0 * k, ws->out_dist.p, nb * k * sizeof(float), hipMemcpyDeviceToHost, s));
+        }
+        std::vector<uint64_t> cnt(nb);
+        VDB_HIP(hipMemcpyAsync(cnt.data(), ws->out_cnt.p, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        VDB_HIP(hipStreamSynchronize(s));
+        ix.prof_collect(*ws);
+        if (out_count) std::memcpy(out_count + q0, cnt.data(), nb * sizeof(uint64_t));
+    }
+}
+
+static void flat_dev(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t, uint64_t *d_idx,
+                     float *d_dist, uint64_t *d_cnt) {
+    ix.flat_knn_device(ws, d_q, nq, k, d_idx, d_dist, d_cnt);
+}
+
+int vdb_flat_knn(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t *out_idx,
+                 float *out_dist, uint64_t *out_count) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    check_query_args(idx->ix, queries, nq, dim, out_idx, out_dist);
+    host_search(idx->ix, queries, nq, k, 0, out_idx, out_dist, out_count, flat_dev);
+    VDB_API_END
+}
+
+int vdb_flat_knn_device(vdb_index *idx, const void *d_queries, uint64_t nq, uint64_t dim, uint64_t k,
+                        void *d_out_idx, void *d_out_dist, void *d_out_count, void *stream) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    Index &ix = idx->ix;
+    check_query_args(ix, d_queries, nq, dim, d_out_idx, d_out_dist);
+    VDB_REQUIRE(nq == 0 || d_out_count, "null out_count");
+    VDB_REQUIRE(nq <= 32768, "at most 32768 queries per device call");
+    if (nq == 0) return VDB_OK;
+    ix.use_device();
+    WsLease ws(ix);
+    // order after whatever produced the queries on the caller's stream
+    VDB_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    ix.flat_knn_device(*ws, static_cast<const float *>(d_queries), nq, k, static_cast<uint64_t *>(d_out_idx),
+                       static_cast<float *>(d_out_dist), static_cast<uint64_t *>(d_out_count));
+    VDB_HIP(hipStreamSynchronize(ws->stream));
+    ix.prof_collect(*ws);
+    VDB_API_END
+}
+
+int vdb_flat_set_mode(vdb_index *idx, int mode) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    VDB_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0, 1 or 2");
+    idx->ix.flat_mode = mode;
+    VDB_API_END
+}
+int vdb_flat_fallback_count(const vdb_index *idx, uint64_t *out) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx && out, "null argument");
+    *out = idx->ix.fallback_count.load();
+    VDB_API_END
+}
+
+// ---- PQ -------------------------------------------------------------------------------------------
+int vdb_pq_attach(vdb_index *idx, uint64_t n_bits, uint64_t m, const float *centroids, const uint8_t *codes) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx && centroids, "null argument");
+    pq_attach(idx->ix, n_bits, m, centroids, codes);
+    VDB_API_END
+}
+int vdb_pq_build(vdb_index *idx, uint64_t n_bits, uint64_t m, uint64_t train_n, uint64_t max_iter, float tol,
+                 uint64_t seed) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    pq_build(idx->ix, n_bits, m, train_n, max_iter, tol, seed);
+    VDB_API_END
+}
+int vdb_pq_clear(vdb_index *idx) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    pq_clear(idx->ix);
+    VDB_API_END
+}
+int vdb_pq_has(const vdb_index *idx, int *out) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx && out, "null argument");
+    *out = idx->ix.pq.present ? 1 : 0;
+    VDB_API_END
+}
+int vdb_pq_info(const vdb_index *idx, uint64_t *n_bits, uint64_t *m, uint64_t *enc_dim) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    VDB_REQUIRE(idx->ix.pq.present, "no PQ table");
+    if (n_bits) *n_bits = idx->ix.pq.n_bits;
+    if (m) *m = idx->ix.pq.m;
+    if (enc_dim) *enc_dim = idx->ix.pq.enc_dim;
+    VDB_API_END
+}
+int vdb_pq_export(const vdb_index *idx, float *centroids, uint8_t *codes) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    const Index &ix = idx->ix;
+    VDB_REQUIRE(ix.pq.present, "no PQ table");
+    if (centroids) std::memcpy(centroids, ix.pq.h_centroids.data(), ix.pq.h_centroids.size() * sizeof(float));
+    if (codes && ix.n) {
+        ix.use_device();
+        VDB_HIP(hipMemcpy(codes, ix.pq.d_codes.p, ix.n * ix.pq.enc_dim, hipMemcpyDeviceToHost));
+    }
+    VDB_API_END
+}
+
+static void flat_pq_dev(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef,
+                        uint64_t *d_idx, float *d_dist, uint64_t *d_cnt) {
+    flat_knn_pq_device(ix, ws, d_q, nq, k, ef, d_idx, d_dist, d_cnt);
+}
+int vdb_flat_knn_pq(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef,
+                    uint64_t *out_idx, float *out_dist, uint64_t *out_count) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    check_query_args(idx->ix, queries, nq, dim, out_idx, out_dist);
+    VDB_REQUIRE(idx->ix.pq.present, "knn_pq needs a PQ table (vdb_pq_build / vdb_pq_attach)");
+    host_search(idx->ix, queries, nq, k, ef, out_idx, out_dist, out_count, flat_pq_dev);
+    VDB_API_END
+}
+
+// ---- HNSW -----------------------------------------------------------------------------------------
+int vdb_hnsw_build(vdb_index *idx, uint64_t M, uint64_t ef_construction, uint64_t seed, uint64_t batch,
+                   int nthreads) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    hnsw_build(idx->ix, M, ef_construction, seed, batch, nthreads);
+    VDB_API_END
+}
+int vdb_hnsw_attach(vdb_index *idx, uint64_t M, uint64_t ef_construction, const uint32_t *level0,
+                    const uint64_t *len0, const uint64_t *vec_level, const uint32_t *upper,
+                    const uint64_t *upper_len, int has_enter, uint64_t enter_point, uint64_t enter_level) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    hnsw_attach(idx->ix, M, ef_construction, level0, len0, vec_level, upper, upper_len, has_enter, enter_point,
+                enter_level);
+    VDB_API_END
+}
+int vdb_hnsw_clear(vdb_index *idx) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    hnsw_clear(idx->ix);
+    VDB_API_END
+}
+int vdb_hnsw_has(const vdb_index *idx, int *out) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx && out, "null argument");
+    *out = idx->ix.hnsw.present ? 1 : 0;
+    VDB_API_END
+}
+int vdb_hnsw_info(const vdb_index *idx, uint64_t *m, uint64_t *max_m0, uint64_t *upper_total, int *has_enter,
+                  uint64_t *enter_point, uint64_t *enter_level, uint64_t *default_ef) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    const HNSWState &h = idx->ix.hnsw;
+    VDB_REQUIRE(h.present, "no HNSW graph");
+    if (m) *m = h.m;
+    if (max_m0) *max_m0 = h.max_m0;
+    if (upper_total) *upper_total = h.upper_len.size();
+    if (has_enter) *has_enter = h.has_enter ? 1 : 0;
+    if (enter_point) *enter_point = h.enter_point;
+    if (enter_level) *enter_level = h.enter_level;
+    if (default_ef) *default_ef = h.default_ef;
+    VDB_API_END
+}
+int vdb_hnsw_export(const vdb_index *idx, uint32_t *level0, uint64_t *len0, uint64_t *vec_level, uint32_t *upper,
+                    uint64_t *upper_len) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    const HNSWState &h = idx->ix.hnsw;
+    VDB_REQUIRE(h.present, "no HNSW graph");
+    if (level0) std::memcpy(level0, h.level0.data(), h.level0.size() * sizeof(uint32_t));
+    if (len0) std::memcpy(len0, h.len0.data(), h.len0.size() * sizeof(uint64_t));
+    if (vec_level) std::memcpy(vec_level, h.vec_level.data(), h.vec_level.size() * sizeof(uint64_t));
+    if (upper) std::memcpy(upper, h.upper.data(), h.upper.size() * sizeof(uint32_t));
+    if (upper_len) std::memcpy(upper_len, h.upper_len.data(), h.upper_len.size() * sizeof(uint64_t));
+    VDB_API_END
+}
+
+static void hnsw_dev(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef,
+                     uint64_t *d_idx, float *d_dist, uint64_t *d_cnt) {
+    hnsw_knn_device(ix, ws, d_q, nq, k, ef, false, d_idx, d_dist, d_cnt);
+}
+static void hnsw_pq_dev(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef,
+                        uint64_t *d_idx, float *d_dist, uint64_t *d_cnt) {
+    hnsw_knn_device(ix, ws, d_q, nq, k, ef, true, d_idx, d_dist, d_cnt);
+}
+int vdb_hnsw_knn(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef,
+                 uint64_t *out_idx, float *out_dist, uint64_t *out_count) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    check_query_args(idx->ix, queries, nq, dim, out_idx, out_dist);
+    VDB_REQUIRE(idx->ix.hnsw.present, "knn_with_ef needs an HNSW graph (vdb_hnsw_build / vdb_hnsw_attach)");
+    if (ef == 0) ef = idx->ix.hnsw.default_ef;
+    host_search(idx->ix, queries, nq, k, ef, out_idx, out_dist, out_count, hnsw_dev);
+    VDB_API_END
+}
+int vdb_hnsw_knn_pq(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef,
+                    uint64_t *out_idx, float *out_dist, uint64_t *out_count) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    check_query_args(idx->ix, queries, nq, dim, out_idx, out_dist);
+    VDB_REQUIRE(idx->ix.hnsw.present, "knn_pq needs an HNSW graph");
+    VDB_REQUIRE(idx->ix.pq.present, "knn_pq needs a PQ table");
+    host_search(idx->ix, queries, nq, k, ef, out_idx, out_dist, out_count, hnsw_pq_dev);
+    VDB_API_END
+}
+int vdb_hnsw_last_stats(const vdb_index *idx, uint64_t *n_dist, uint64_t *n_expanded) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    if (n_dist) *n_dist = idx->ix.hnsw.last_n_dist.load();
+    if (n_expanded) *n_expanded = idx->ix.hnsw.last_n_expanded.load();
+    VDB_API_END
+}
+
+// ---- shard merge ------------------------------------------------------------------------------------
+int vdb_merge_topk(const float *dists, const uint64_t *ids, const uint64_t *counts, uint64_t n_shards, uint64_t nq,
+                   uint64_t k, uint64_t *out_idx, float *out_dist, uint64_t *out_count) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(dists && ids && counts && out_idx && out_dist, "null argument");
+    struct P {
+        uint32_t o;
+        uint64_t i;
+    };
+    std::vector<P> all;
+    for (uint64_t q = 0; q < nq; q++) {
+        all.clear();
+        for (uint64_t s = 0; s < n_shards; s++) {
+            uint64_t c = std::min<uint64_t>(counts[s * nq + q], k);
+            for (uint64_t j = 0; j < c; j++)
+                all.push_back({f32_orderable(dists[(s * nq + q) * k + j]), ids[(s * nq + q) * k + j]});
+        }
+        std::sort(all.begin(), all.end(), [](const P &a, const P &b) { return a.o != b.o ? a.o < b.o : a.i < b.i; });
+        uint64_t c = std::min<uint64_t>(all.size(), k);
+        for (uint64_t j = 0; j < c; j++) {
+            out_idx[q * k + j] = all[j].i;
+            out_dist[q * k + j] = f32_from_orderable(all[j].o);
+        }
+        for (uint64_t j = c; j < k; j++) {
+            out_idx[q * k + j] = 0;
+            out_dist[q * k + j] = 0.0f;
+        }
+        if (out_count) out_count[q] = c;
+    }
+    VDB_API_END
+}
+
+// ---- measurement hooks --------------------------------------------------------------------------------
+int vdb_prof_enable(vdb_index *idx, int on) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    idx->ix.prof_on = on != 0;
+    VDB_API_END
+}
+int vdb_prof_reset(vdb_index *idx) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    std::lock_guard<std::mutex> g(idx->ix.prof_mu);
+    idx->ix.prof.clear();
+    VDB_API_END
+}
+int vdb_prof_get(vdb_index *idx, const char *kernel, double *total_ms, uint64_t *launches, double *bytes) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx && kernel, "null argument");
+    std::lock_guard<std::mutex> g(idx->ix.prof_mu);
+    auto it = idx->ix.prof.find(kernel);
+    ProfEntry e = it == idx->ix.prof.end() ? ProfEntry{} : it->second;
+    if (total_ms) *total_ms = e.ms;
+    if (launches) *launches = e.launches;
+    if (bytes) *bytes = e.bytes;
+    VDB_API_END
+}
+
+}  // extern "C"

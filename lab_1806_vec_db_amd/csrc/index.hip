@@ -1,0 +1,233 @@
+// index.hip -- Index object: HBM-resident VecSet + the Flat search pipeline.
+#include "index.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace vdb {
+
+Index::Index(int dev, uint64_t d, int ds) : device(dev), dim(d), dist(ds) {
+    use_device();
+    hipDeviceProp_t prop;
+    VDB_HIP(hipGetDeviceProperties(&prop, dev));
+    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    std::string arch = prop.gcnArchName;
+    if (arch.rfind("gfx950", 0) != 0)
+        throw Error(4, "libvdbhip is built for gfx950 (MI355X) only; device reports " + arch);
+}
+
+std::unique_ptr<Workspace> Index::acquire_ws() {
+    use_device();
+    {
+        std::lock_guard<std::mutex> g(ws_mu);
+        if (!ws_free.empty()) {
+            auto ws = std::move(ws_free.back());
+            ws_free.pop_back();
+            return ws;
+        }
+    }
+    return std::make_unique<Workspace>();
+}
+void Index::release_ws(std::unique_ptr<Workspace> ws) {
+    if (!ws) return;
+    std::lock_guard<std::mutex> g(ws_mu);
+    ws_free.push_back(std::move(ws));
+}
+
+const float *Index::host_rows() const {
+    std::lock_guard<std::mutex> g(host_mu);
+    if (!host_valid) {
+        use_device();
+        h_rows.resize(size_t(n) * dim);
+        if (n) VDB_HIP(hipMemcpy(h_rows.data(), d_rows.p, size_t(n) * dim * sizeof(float), hipMemcpyDeviceToHost));
+        host_valid = true;
+    }
+    return h_rows.data();
+}
+
+// VecSet::push (vec_set.rs:113-118) for `count` rows + dist_cache (hnsw_index.rs:251-254)
+void Index::add_rows(const float *rows, uint64_t count, bool on_device) {
+    if (count == 0) return;
+    use_device();
+    VDB_REQUIRE(n + count < (1ull << 32), "a shard holds at most 2^32-1 rows (ids are u32 on the device)");
+    WsLease ws(*this);
+    hipStream_t s = ws->stream;
+    size_t row_bytes = size_t(dim) * sizeof(float);
+    d_rows.grow((n + count) * row_bytes, n * row_bytes, s);
+    d_sq.grow((n + count) * sizeof(float), n * sizeof(float), s);
+    float *dst = d_rows.as<float>() + n * dim;
+    VDB_HIP(hipMemcpyAsync(dst, rows, count * row_bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    launch_row_sqnorm(dst, count, (uint32_t)dim, d_sq.as<float>() + n, s);
+    std::vector<float> sq(count);
+    VDB_HIP(hipMemcpyAsync(sq.data(), d_sq.as<float>() + n, count * sizeof(float), hipMemcpyDeviceToHost, s));
+    VDB_HIP(hipStreamSynchronize(s));
+    for (float v : sq)
+        if (v > xsq_max && std::isfinite(v)) xsq_max = v;
+    {
+        std::lock_guard<std::mutex> g(host_mu);
+        if (on_device) {
+            host_valid = false;
+        } else if (host_valid) {
+            h_rows.insert(h_rows.end(), rows, rows + count * dim);
+        }
+    }
+    n += count;
+}
+
+// VecSet::swap_remove (vec_set.rs:131-137)
+void Index::swap_remove(uint64_t i) {
+    VDB_REQUIRE(i < n, "swap_remove: index out of bounds");
+    use_device();
+    WsLease ws(*this);
+    hipStream_t s = ws->stream;
+    uint64_t last = n - 1;
+    if (i < last) {
+        VDB_HIP(hipMemcpyAsync(d_rows.as<float>() + i * dim, d_rows.as<float>() + last * dim, dim * sizeof(float),
+                               hipMemcpyDeviceToDevice, s));
+        VDB_HIP(hipMemcpyAsync(d_sq.as<float>() + i, d_sq.as<float>() + last, sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    VDB_HIP(hipStreamSynchronize(s));
+    {
+        std::lock_guard<std::mutex> g(host_mu);
+        if (host_valid) {
+            if (i < last) std::memcpy(h_rows.data() + i * dim, h_rows.data() + last * dim, dim * sizeof(float));
+            h_rows.resize(last * dim);
+        }
+    }
+    n = last;
+    // xsq_max stays an upper bound (certification only needs a bound)
+}
+
+// ---- timing hooks ------------------------------------------------------------------------------
+void Index::prof_begin(Workspace &ws, const char *name, double bytes) {
+    if (!prof_on) return;
+    if (ws.ev_used == ws.ev_pool.size()) {
+        hipEvent_t a, b;
+        VDB_HIP(hipEventCreate(&a));
+        VDB_HIP(hipEventCreate(&b));
+        ws.ev_pool.emplace_back(a, b);
+    }
+    ws.pending.push_back({name, ws.ev_used, bytes});
+    VDB_HIP(hipEventRecord(ws.ev_pool[ws.ev_used].first, ws.stream));
+}
+void Index::prof_end(Workspace &ws) {
+    if (!prof_on) return;
+    VDB_HIP(hipEventRecord(ws.ev_pool[ws.ev_used].second, ws.stream));
+    ws.ev_used++;
+}
+void Index::prof_collect(Workspace &ws) {
+    if (ws.pending.empty()) return;
+    std::lock_guard<std::mutex> g(prof_mu);
+    for (auto &p : ws.pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ws.ev_pool[p.ev].first, ws.ev_pool[p.ev].second) == hipSuccess) {
+            auto &e = prof[p.name];
+            e.ms += ms;
+            e.launches += 1;
+            e.bytes += p.bytes;
+        }
+    }
+    ws.pending.clear();
+    ws.ev_used = 0;
+}
+
+// ---- Flat: exact scan path -----------------------------------------------------------------------
+// FlatIndex::knn (flat_index.rs:48-57) for nq queries: strict-order distances for every row, then the
+// k smallest pairs by (distance, index).
+void Index::flat_exact_device(Workspace &ws, const float *d_q, const float *d_qsq, uint64_t nq, uint32_t ksel,
+                              uint64_t k, uint64_t *d_idx, float *d_dist, uint64_t *d_cnt) {
+    hipStream_t s = ws.stream;
+    const int metric = dist == 0 ? MET_L2_DIRECT : MET_COSINE;
+    const uint64_t ld = (n + 63) & ~63ull;
+    const uint32_t nl = topk_num_lists(n);
+    const uint32_t cap = topk_capacity(ksel);
+    constexpr uint32_t BQ = 8;
+    ws.dense.reserve(size_t(BQ) * ld * sizeof(float));
+    ws.lists.reserve(size_t(BQ) * nl * cap * sizeof(uint64_t));
+    ws.keys_c.reserve(size_t(BQ) * cap * sizeof(uint64_t));
+    const bool use_lds = n >= 4096;
+    for (uint64_t q0 = 0; q0 < nq; q0 += BQ) {
+        uint32_t nb = (uint32_t)std::min<uint64_t>(BQ, nq - q0);
+        prof_begin(ws, "flat_exact", double(n) * dim * sizeof(float));
+        launch_scan_exact(d_rows.as<float>(), n, (uint32_t)dim, d_q + q0 * dim, nb, metric, d_sq.as<float>(),
+                          d_qsq ? d_qsq + q0 : nullptr, ws.dense.as<float>(), ld, use_lds, s);
+        prof_end(ws);
+        launch_topk_dense(ws.dense.as<float>(), ld, n, nb, ksel, ws.lists.as<uint64_t>(), s);
+        launch_topk_merge(ws.lists.as<uint64_t>(), nl, cap, nb, ksel, ws.keys_c.as<uint64_t>(), s);
+        launch_finalize(ws.keys_c.as<uint64_t>(), cap, nb, ksel, (uint32_t)k, id_offset, d_idx + q0 * k, d_dist + q0 * k,
+                        d_cnt + q0, s);
+    }
+}
+
+// ---- Flat: full pipeline ---------------------------------------------------------------------------
+void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t *d_idx,
+                            float *d_dist, uint64_t *d_cnt) {
+    hipStream_t s = ws.stream;
+    if (nq == 0) return;
+    if (k == 0 || n == 0) {  // ResultSet::new(0) rejects everything; empty VecSet -> empty result
+        VDB_HIP(hipMemsetAsync(d_cnt, 0, nq * sizeof(uint64_t), s));
+        return;
+    }
+    const uint64_t ksel64 = std::min<uint64_t>(k, n);
+    VDB_REQUIRE(ksel64 <= 1024, "flat knn: min(k, len) must be <= 1024 in this build");
+    const uint32_t ksel = (uint32_t)ksel64;
+    if (k > ksel) {  // slots beyond min(k, len) are defined (zero) but not counted
+        VDB_HIP(hipMemsetAsync(d_idx, 0, nq * k * sizeof(uint64_t), s));
+        VDB_HIP(hipMemsetAsync(d_dist, 0, nq * k * sizeof(float), s));
+    }
+    ws.qsq.reserve(nq * sizeof(float));
+    launch_row_sqnorm(d_q, nq, (uint32_t)dim, ws.qsq.as<float>(), s);
+
+    const uint32_t kprime = std::max<uint32_t>(32, 2 * ksel);
+    bool mfma = dist == 0 && mfma_supported((uint32_t)dim) && kprime <= 1024 && n > kprime &&
+                (flat_mode == 2 || (flat_mode == 0 && n >= 16384));
+    if (flat_mode == 1) mfma = false;
+    if (!mfma) {
+        flat_exact_device(ws, d_q, ws.qsq.as<float>(), nq, ksel, k, d_idx, d_dist, d_cnt);
+        return;
+    }
+
+    // --- MFMA shortlist -> exact re-rank -> certification --------------------------------------
+    const uint64_t ld = (n + 63) & ~63ull;
+    const uint32_t nl = topk_num_lists(n);
+    const uint32_t capp = topk_capacity(kprime);
+    const uint32_t capk = topk_capacity(ksel);
+    ws.qfrag.reserve(mfma_qfrag_floats((uint32_t)dim) * sizeof(float));
+    ws.dense.reserve(size_t(MFMA_B) * ld * sizeof(float));
+    ws.lists.reserve(size_t(MFMA_B) * nl * capp * sizeof(uint64_t));
+    ws.keys_a.reserve(nq * capp * sizeof(uint64_t));  // approximate shortlist, sorted
+    ws.keys_b.reserve(nq * capp * sizeof(uint64_t));  // exact keys of the shortlist, unsorted
+    ws.keys_c.reserve(nq * capk * sizeof(uint64_t));  // exact top-k, sorted
+    ws.flags.reserve(nq);
+    for (uint64_t q0 = 0; q0 < nq; q0 += MFMA_B) {
+        uint32_t nb = (uint32_t)std::min<uint64_t>(MFMA_B, nq - q0);
+        launch_mfma_pack_queries(d_q + q0 * dim, nb, (uint32_t)dim, ws.qfrag.as<float>(), s);
+        prof_begin(ws, "flat_mfma", double(n) * dim * sizeof(float));
+        launch_flat_mfma(d_rows.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>(), d_sq.as<float>(),
+                         ws.dense.as<float>(), ld, num_cu, s);
+        prof_end(ws);
+        launch_topk_dense(ws.dense.as<float>(), ld, n, nb, kprime, ws.lists.as<uint64_t>(), s);
+        launch_topk_merge(ws.lists.as<uint64_t>(), nl, capp, nb, kprime, ws.keys_a.as<uint64_t>() + q0 * capp, s);
+    }
+    VDB_HIP(hipMemsetAsync(ws.keys_b.p, 0xff, nq * capp * sizeof(uint64_t), s));
+    launch_rerank(d_rows.as<float>(), (uint32_t)dim, d_q, (uint32_t)nq, MET_L2_DIRECT, d_sq.as<float>(),
+                  ws.qsq.as<float>(), ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), kprime, capp, s);
+    launch_topk_merge(ws.keys_b.as<uint64_t>(), 1, capp, (uint32_t)nq, ksel, ws.keys_c.as<uint64_t>(), s);
+    launch_certify(ws.keys_c.as<uint64_t>(), capk, ws.keys_a.as<uint64_t>(), capp, (uint32_t)nq, ksel, kprime, n,
+                   ws.qsq.as<float>(), xsq_max, (uint32_t)dim, ws.flags.as<uint8_t>(), s);
+    launch_finalize(ws.keys_c.as<uint64_t>(), capk, (uint32_t)nq, ksel, (uint32_t)k, id_offset, d_idx, d_dist, d_cnt, s);
+    std::vector<uint8_t> flags(nq);
+    VDB_HIP(hipMemcpyAsync(flags.data(), ws.flags.p, nq, hipMemcpyDeviceToHost, s));
+    VDB_HIP(hipStreamSynchronize(s));
+    uint64_t redo = 0;
+    for (uint64_t q = 0; q < nq; q++) {
+        if (!flags[q]) continue;
+        redo++;
+        flat_exact_device(ws, d_q + q * dim, ws.qsq.as<float>() + q, 1, ksel, k, d_idx + q * k, d_dist + q * k,
+                          d_cnt + q);
+    }
+    if (redo) fallback_count += redo;
+}
+
+}  // namespace vdb

@@ -1,0 +1,162 @@
+// index.hpp -- the HBM-resident index object behind the C ABI (include/vdbhip.h).
+#pragma once
+#include <atomic>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace vdb {
+
+// growable device buffer (amortised doubling, like Vec<T>: vec_set.rs:113-118)
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    // contents are NOT preserved
+    void reserve(size_t bytes) {
+        if (bytes <= cap) return;
+        release();
+        size_t want = bytes < 256 ? 256 : bytes;
+        VDB_HIP(hipMalloc(&p, want));
+        cap = want;
+    }
+    // contents preserved up to `keep` bytes
+    void grow(size_t bytes, size_t keep, hipStream_t s) {
+        if (bytes <= cap) return;
+        size_t want = cap ? cap : 256;
+        while (want < bytes) want *= 2;
+        void *np = nullptr;
+        VDB_HIP(hipMalloc(&np, want));
+        if (keep) {
+            VDB_HIP(hipMemcpyAsync(np, p, keep, hipMemcpyDeviceToDevice, s));
+            VDB_HIP(hipStreamSynchronize(s));
+        }
+        if (p) (void)hipFree(p);
+        p = np;
+        cap = want;
+    }
+    template <class T>
+    T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct ProfEntry {
+    double ms = 0;
+    uint64_t launches = 0;
+    double bytes = 0;
+};
+
+// per-call scratch: one per concurrent reader (read-side calls are re-entrant, see vdbhip.h)
+struct Workspace {
+    hipStream_t stream = nullptr;
+    DevBuf q, qsq, qfrag, dense, lists, keys_a, keys_b, keys_c, flags, out_idx, out_dist, out_cnt, lut, misc;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    struct Pending {
+        std::string name;
+        size_t ev;
+        double bytes;
+    };
+    std::vector<Pending> pending;
+    size_t ev_used = 0;
+    Workspace() { VDB_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); }
+    ~Workspace() {
+        for (auto &e : ev_pool) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+struct PQState {
+    bool present = false;
+    uint64_t n_bits = 0, m = 0, kc = 0, enc_dim = 0;
+    std::vector<uint64_t> gstart;    // m+1
+    std::vector<float> h_centroids;  // kc*dim
+    std::vector<float> h_cent_cache; // m*kc
+    DevBuf d_centroids, d_cent_cache, d_codes, d_gstart;
+};
+
+struct HNSWState {
+    bool present = false;
+    uint64_t m = 0, max_m0 = 0, ef_construction = 0, default_ef = 0;
+    float inv_log_m = 0;
+    std::vector<uint32_t> level0;
+    std::vector<uint64_t> len0, vec_level, upper_off, upper_len;
+    std::vector<uint32_t> upper;
+    bool has_enter = false;
+    uint64_t enter_point = 0, enter_level = 0;
+    uint64_t rng_state = 0;
+    // device mirror (uploaded lazily when dirty)
+    bool dev_dirty = true;
+    DevBuf d_level0, d_len0, d_upper, d_upper_len, d_upper_off;
+    std::atomic<uint64_t> last_n_dist{0}, last_n_expanded{0};
+};
+
+struct Index {
+    int device = 0;
+    int num_cu = 256;
+    uint64_t dim = 0;
+    int dist = 0;
+    uint64_t n = 0;
+    uint64_t id_offset = 0;
+    DevBuf d_rows, d_sq;
+    float xsq_max = 0.0f;
+    // lazily materialised host mirror of the rows (needed by the host-side builders and vdb_index_row)
+    mutable std::vector<float> h_rows;
+    mutable bool host_valid = true;
+    mutable std::mutex host_mu;
+    int flat_mode = 0;
+    std::atomic<uint64_t> fallback_count{0};
+    PQState pq;
+    HNSWState hnsw;
+
+    std::mutex ws_mu;
+    std::vector<std::unique_ptr<Workspace>> ws_free;
+    bool prof_on = false;
+    std::mutex prof_mu;
+    std::map<std::string, ProfEntry> prof;
+
+    Index(int dev, uint64_t d, int ds);
+    void use_device() const { VDB_HIP(hipSetDevice(device)); }
+    std::unique_ptr<Workspace> acquire_ws();
+    void release_ws(std::unique_ptr<Workspace> ws);
+    const float *host_rows() const;  // materialise the host mirror if needed
+
+    void add_rows(const float *rows, uint64_t count, bool on_device);
+    void swap_remove(uint64_t i);
+
+    // timing hooks
+    void prof_begin(Workspace &ws, const char *name, double bytes);
+    void prof_end(Workspace &ws);
+    void prof_collect(Workspace &ws);  // after a stream sync
+
+    // search entry points; d_* are device pointers, results [nq][k]
+    void flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t *d_idx, float *d_dist,
+                         uint64_t *d_cnt);
+    void flat_exact_device(Workspace &ws, const float *d_q, const float *d_qsq, uint64_t nq, uint32_t ksel,
+                           uint64_t k, uint64_t *d_idx, float *d_dist, uint64_t *d_cnt);
+};
+
+struct WsLease {
+    Index &ix;
+    std::unique_ptr<Workspace> ws;
+    explicit WsLease(Index &i) : ix(i), ws(i.acquire_ws()) {}
+    ~WsLease() { ix.release_ws(std::move(ws)); }
+    Workspace &operator*() { return *ws; }
+    Workspace *operator->() { return ws.get(); }
+};
+
+}  // namespace vdb

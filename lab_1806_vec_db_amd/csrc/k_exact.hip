@@ -1,0 +1,361 @@
+// k_exact.hip -- reference-order (strict left fold, no FMA) f32 distance kernels for gfx950.
+//
+// Everything in this file must reproduce the arithmetic of /root/reference/src/distance/mod.rs
+// bit for bit: products and sums are separately rounded (mod.rs:72-77), accumulation is strictly
+// ascending in the dimension.  The file is compiled with -ffp-contract=off and the pragma below
+// repeats that, so no v_fma is formed from a*b+c.
+#include "common.hpp"
+#include "kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace vdb {
+
+enum Fold : int { FOLD_L2 = 0, FOLD_DOT = 1 };
+
+template <int FOLD>
+__device__ __forceinline__ float fold1(float acc, float x, float q) {
+    if (FOLD == FOLD_L2) {
+        float df = x - q;  // (x-q)^2 == (q-x)^2 exactly, so the argument order of flat_index.rs:52 is immaterial
+        float sq = df * df;
+        return acc + sq;
+    } else {
+        float p = x * q;
+        return acc + p;
+    }
+}
+
+// epilogue shared by scan / rerank
+__device__ __forceinline__ float epilogue(int metric, float acc, float xsq, float qsq) {
+    if (metric == MET_L2_DIRECT) return acc;
+    if (metric == MET_COSINE) {
+        // distance/mod.rs:60-69: 1 - dot / max(|a|*|b|, 1e-10)
+        float den = fmaxf(sqrtf(qsq) * sqrtf(xsq), 1e-10f);
+        float r = acc / den;
+        return 1.0f - r;
+    }
+    // distance/mod.rs:54-57 with a = stored row, b = query (hnsw_index.rs:351-355)
+    float s = xsq + qsq;
+    float t = 2.0f * acc;
+    return s - t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// row squared norms (dist_cache, distance/mod.rs:31-36): one thread per row, sequential fold
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_row_sqnorm(const float *__restrict__ X, uint64_t n, uint32_t dim,
+                                                    float *__restrict__ sq) {
+    uint64_t r = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (r >= n) return;
+    const float *x = X + r * dim;
+    float acc = 0.0f;
+    if ((dim & 3) == 0) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+#pragma unroll 4
+        for (uint32_t j = 0; j < dim / 4; j++) {
+            float4 v = x4[j];
+            acc = fold1<FOLD_DOT>(acc, v.x, v.x);
+            acc = fold1<FOLD_DOT>(acc, v.y, v.y);
+            acc = fold1<FOLD_DOT>(acc, v.z, v.z);
+            acc = fold1<FOLD_DOT>(acc, v.w, v.w);
+        }
+    } else {
+        for (uint32_t j = 0; j < dim; j++) acc = fold1<FOLD_DOT>(acc, x[j], x[j]);
+    }
+    sq[r] = acc;
+}
+
+void launch_row_sqnorm(const float *X, uint64_t n, uint32_t dim, float *sq, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_row_sqnorm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, X, n, dim, sq);
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact scan, generic variant: one thread per row reading its row straight from global memory.
+// Correct for every dim; used for dim % 4 != 0 and as the small-input path.
+// ---------------------------------------------------------------------------------------------
+template <int BQ, int FOLD>
+__global__ __launch_bounds__(256) void k_scan_exact_simple(const float *__restrict__ X, uint64_t n, uint32_t dim,
+                                                           const float *__restrict__ Q, int metric,
+                                                           const float *__restrict__ xsq,
+                                                           const float *__restrict__ qsq, float *__restrict__ out,
+                                                           uint64_t ld) {
+    uint64_t r = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (r >= n) return;
+    const float *x = X + r * dim;
+    float acc[BQ];
+#pragma unroll
+    for (int b = 0; b < BQ; b++) acc[b] = 0.0f;
+    if ((dim & 3) == 0) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        for (uint32_t j = 0; j < dim / 4; j++) {
+            float4 v = x4[j];
+#pragma unroll
+            for (int b = 0; b < BQ; b++) {
+                const float *q = Q + size_t(b) * dim + 4 * j;  // wave-uniform -> scalar loads
+                acc[b] = fold1<FOLD>(acc[b], v.x, q[0]);
+                acc[b] = fold1<FOLD>(acc[b], v.y, q[1]);
+                acc[b] = fold1<FOLD>(acc[b], v.z, q[2]);
+                acc[b] = fold1<FOLD>(acc[b], v.w, q[3]);
+            }
+        }
+    } else {
+        for (uint32_t j = 0; j < dim; j++) {
+            float v = x[j];
+#pragma unroll
+            for (int b = 0; b < BQ; b++) acc[b] = fold1<FOLD>(acc[b], v, Q[size_t(b) * dim + j]);
+        }
+    }
+    float xs = (metric == MET_L2_DIRECT) ? 0.0f : xsq[r];
+#pragma unroll
+    for (int b = 0; b < BQ; b++) {
+        float qs = (metric == MET_L2_DIRECT) ? 0.0f : qsq[b];
+        out[uint64_t(b) * ld + r] = epilogue(metric, acc[b], xs, qs);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact scan, LDS-staged variant (dim % 4 == 0): a 256-row tile is streamed in 32-column chunks
+// with fully used 128-B lines (8 lanes x 16 B per row segment), transposed through LDS so that
+// thread t folds row t in order.  Row stride 36 floats: for ds_read_b128 the 16 lanes of a
+// group hit banks 36*t mod 64 = distinct multiples of 4 -> conflict-free.
+// ---------------------------------------------------------------------------------------------
+constexpr int TR = 256;
+constexpr int CW = 32;
+constexpr int LDT = CW + 4;
+
+template <int BQ, int FOLD>
+__global__ __launch_bounds__(256) void k_scan_exact_lds(const float *__restrict__ X, uint64_t n, uint32_t dim,
+                                                        const float *__restrict__ Q, int metric,
+                                                        const float *__restrict__ xsq,
+                                                        const float *__restrict__ qsq, float *__restrict__ out,
+                                                        uint64_t ld) {
+    __shared__ __attribute__((aligned(16))) float tile[2][TR * LDT];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t row0 = uint64_t(blockIdx.x) * TR;
+    const uint32_t nchunk = (dim + CW - 1) / CW;
+
+    float4 stage[8];
+    auto load_chunk = [&](uint32_t c) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint32_t f = i * 256 + tid;
+            uint32_t r = f >> 3, c4 = f & 7;
+            uint64_t row = row0 + r;
+            if (row >= n) row = n - 1;
+            uint32_t col = c * CW + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col < dim) v = *reinterpret_cast<const float4 *>(X + row * dim + col);
+            stage[i] = v;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint32_t f = i * 256 + tid;
+            uint32_t r = f >> 3, c4 = f & 7;
+            *reinterpret_cast<float4 *>(&tile[buf][r * LDT + c4 * 4]) = stage[i];
+        }
+    };
+
+    float acc[BQ];
+#pragma unroll
+    for (int b = 0; b < BQ; b++) acc[b] = 0.0f;
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (uint32_t c = 0; c < nchunk; c++) {
+        int buf = c & 1;
+        if (c + 1 < nchunk) load_chunk(c + 1);
+        uint32_t cols = dim - c * CW;
+        if (cols > CW) cols = CW;
+        const float *trow = &tile[buf][tid * LDT];
+        for (uint32_t j = 0; j < cols; j += 4) {
+            float4 v = *reinterpret_cast<const float4 *>(trow + j);
+#pragma unroll
+            for (int b = 0; b < BQ; b++) {
+                const float *q = Q + size_t(b) * dim + c * CW + j;  // wave-uniform
+                acc[b] = fold1<FOLD>(acc[b], v.x, q[0]);
+                acc[b] = fold1<FOLD>(acc[b], v.y, q[1]);
+                acc[b] = fold1<FOLD>(acc[b], v.z, q[2]);
+                acc[b] = fold1<FOLD>(acc[b], v.w, q[3]);
+            }
+        }
+        if (c + 1 < nchunk) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    uint64_t r = row0 + tid;
+    if (r < n) {
+        float xs = (metric == MET_L2_DIRECT) ? 0.0f : xsq[r];
+#pragma unroll
+        for (int b = 0; b < BQ; b++) {
+            float qs = (metric == MET_L2_DIRECT) ? 0.0f : qsq[b];
+            out[uint64_t(b) * ld + r] = epilogue(metric, acc[b], xs, qs);
+        }
+    }
+}
+
+template <int BQ>
+static void scan_exact_bq(const float *X, uint64_t n, uint32_t dim, const float *Q, int metric, const float *xsq,
+                          const float *qsq, float *out, uint64_t ld, bool use_lds, hipStream_t s) {
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    bool lds = use_lds && (dim & 3) == 0;
+    if (metric == MET_L2_DIRECT) {
+        if (lds)
+            hipLaunchKernelGGL((k_scan_exact_lds<BQ, FOLD_L2>), grid, block, 0, s, X, n, dim, Q, metric, xsq, qsq, out, ld);
+        else
+            hipLaunchKernelGGL((k_scan_exact_simple<BQ, FOLD_L2>), grid, block, 0, s, X, n, dim, Q, metric, xsq, qsq, out, ld);
+    } else {
+        if (lds)
+            hipLaunchKernelGGL((k_scan_exact_lds<BQ, FOLD_DOT>), grid, block, 0, s, X, n, dim, Q, metric, xsq, qsq, out, ld);
+        else
+            hipLaunchKernelGGL((k_scan_exact_simple<BQ, FOLD_DOT>), grid, block, 0, s, X, n, dim, Q, metric, xsq, qsq, out, ld);
+    }
+}
+
+void launch_scan_exact(const float *X, uint64_t n, uint32_t dim, const float *Q, uint32_t nq, int metric,
+                       const float *xsq, const float *qsq, float *out, uint64_t ld, bool use_lds, hipStream_t s) {
+    if (n == 0 || nq == 0) return;
+    switch (nq) {
+        case 1: scan_exact_bq<1>(X, n, dim, Q, metric, xsq, qsq, out, ld, use_lds, s); break;
+        case 2: scan_exact_bq<2>(X, n, dim, Q, metric, xsq, qsq, out, ld, use_lds, s); break;
+        case 3: scan_exact_bq<3>(X, n, dim, Q, metric, xsq, qsq, out, ld, use_lds, s); break;
+        case 4: scan_exact_bq<4>(X, n, dim, Q, metric, xsq, qsq, out, ld, use_lds, s); break;
+        case 5: scan_exact_bq<5>(X, n, dim, Q, metric, xsq, qsq, out, ld, use_lds, s); break;
+        case 6: scan_exact_bq<6>(X, n, dim, Q, metric, xsq, qsq, out, ld, use_lds, s); break;
+        case 7: scan_exact_bq<7>(X, n, dim, Q, metric, xsq, qsq, out, ld, use_lds, s); break;
+        case 8: scan_exact_bq<8>(X, n, dim, Q, metric, xsq, qsq, out, ld, use_lds, s); break;
+        default: throw Error(1, "launch_scan_exact: nq must be 1..8");
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// re-rank (ResultSet::pq_resort's dist_fn, candidate_pair.rs:102-108; also the exact stage after
+// the MFMA shortlist): one thread per (query, candidate) folds its row in reference order.
+// ---------------------------------------------------------------------------------------------
+template <int FOLD>
+__global__ __launch_bounds__(64) void k_rerank(const float *__restrict__ X, uint32_t dim,
+                                               const float *__restrict__ Q, int metric,
+                                               const float *__restrict__ xsq, const float *__restrict__ qsq,
+                                               const uint64_t *__restrict__ cand, uint64_t *__restrict__ out,
+                                               uint32_t ncand, uint32_t ldc) {
+    uint32_t q = blockIdx.y;
+    uint32_t j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= ncand) return;
+    uint64_t c = cand[uint64_t(q) * ldc + j];
+    if (c == PAIR_NONE) {
+        out[uint64_t(q) * ldc + j] = PAIR_NONE;
+        return;
+    }
+    uint32_t idx = uint32_t(c);
+    const float *x = X + uint64_t(idx) * dim;
+    const float *qv = Q + uint64_t(q) * dim;  // block-uniform
+    float acc = 0.0f;
+    if ((dim & 3) == 0) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+#pragma unroll 8
+        for (uint32_t t = 0; t < dim / 4; t++) {
+            float4 v = x4[t];
+            acc = fold1<FOLD>(acc, v.x, qv[4 * t + 0]);
+            acc = fold1<FOLD>(acc, v.y, qv[4 * t + 1]);
+            acc = fold1<FOLD>(acc, v.z, qv[4 * t + 2]);
+            acc = fold1<FOLD>(acc, v.w, qv[4 * t + 3]);
+        }
+    } else {
+        for (uint32_t t = 0; t < dim; t++) acc = fold1<FOLD>(acc, x[t], qv[t]);
+    }
+    float xs = (metric == MET_L2_DIRECT) ? 0.0f : xsq[idx];
+    float qs = (metric == MET_L2_DIRECT) ? 0.0f : qsq[q];
+    out[uint64_t(q) * ldc + j] = pair_key(epilogue(metric, acc, xs, qs), idx);
+}
+
+void launch_rerank(const float *X, uint32_t dim, const float *Q, uint32_t nq, int metric, const float *xsq,
+                   const float *qsq, const uint64_t *cand, uint64_t *out, uint32_t ncand, uint32_t ldc,
+                   hipStream_t s) {
+    if (nq == 0 || ncand == 0) return;
+    dim3 grid((ncand + 63) / 64, nq), block(64);
+    if (metric == MET_L2_DIRECT)
+        hipLaunchKernelGGL((k_rerank<FOLD_L2>), grid, block, 0, s, X, dim, Q, metric, xsq, qsq, cand, out, ncand, ldc);
+    else
+        hipLaunchKernelGGL((k_rerank<FOLD_DOT>), grid, block, 0, s, X, dim, Q, metric, xsq, qsq, cand, out, ncand, ldc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// pair keys -> reference-shaped outputs
+// ---------------------------------------------------------------------------------------------
+__global__ void k_finalize(const uint64_t *__restrict__ keys, uint32_t ldk, uint32_t nq, uint32_t ksel,
+                           uint32_t kstride, uint64_t id_offset, uint64_t *__restrict__ out_idx,
+                           float *__restrict__ out_dist, uint64_t *__restrict__ out_count) {
+    uint32_t q = blockIdx.x;
+    uint32_t cnt = 0;
+    for (uint32_t j = threadIdx.x; j < ksel; j += blockDim.x) {
+        uint64_t c = keys[uint64_t(q) * ldk + j];
+        bool ok = c != PAIR_NONE;
+        out_idx[uint64_t(q) * kstride + j] = ok ? uint64_t(uint32_t(c)) + id_offset : 0;
+        out_dist[uint64_t(q) * kstride + j] = ok ? f32_from_orderable(uint32_t(c >> 32)) : 0.0f;
+        cnt += ok;
+    }
+    // keys are sorted with PAIR_NONE last, so the count is the number of valid entries
+    __shared__ uint32_t total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    atomicAdd(&total, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0 && out_count) out_count[q] = total;
+}
+
+void launch_finalize(const uint64_t *keys, uint32_t ldk, uint32_t nq, uint32_t ksel, uint32_t kstride,
+                     uint64_t id_offset, uint64_t *out_idx, float *out_dist, uint64_t *out_count, hipStream_t s) {
+    if (nq == 0) return;
+    hipLaunchKernelGGL(k_finalize, dim3(nq), dim3(64), 0, s, keys, ldk, nq, ksel, kstride, id_offset, out_idx,
+                       out_dist, out_count);
+}
+
+// ---------------------------------------------------------------------------------------------
+// certification of an MFMA shortlist.
+//   approx key(r)  = xsq[r] - 2*S(r,q) (S = MFMA fma chain), approx distance a(r) = key(r) + qsq[q]
+//   exact distance e(r) = strict-order f32 fold (the reference's value)
+// Both differ from the real-number distance by at most
+//   E = 2.5 * (dim+8) * 2^-24 * (sqrt(xsq_max) + sqrt(qsq))^2
+// (standard gamma_n bounds on an n-term f32 sum of products, doubled for the two computations).
+// Every row outside the shortlist has key >= kappa (the largest shortlisted key), hence
+// e(r) >= kappa + qsq - E.  If the k-th smallest exact distance D_k among the shortlisted rows
+// satisfies D_k < kappa + qsq - E, no outside row can enter the exact top-k: certified.
+// When the shortlist holds every row (n <= k') it is trivially certified.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_certify(const uint64_t *__restrict__ exact_sorted, uint32_t lde,
+                          const uint64_t *__restrict__ approx_sorted, uint32_t lda, uint32_t nq, uint32_t k,
+                          uint32_t kprime, uint64_t n_rows, const float *__restrict__ qsq, float xsq_max,
+                          uint32_t dim, uint8_t *__restrict__ flags) {
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    if (n_rows <= kprime) {
+        flags[q] = 0;
+        return;
+    }
+    uint32_t kk = k < kprime ? k : kprime;
+    uint64_t ek = exact_sorted[uint64_t(q) * lde + (kk - 1)];
+    uint64_t ak = approx_sorted[uint64_t(q) * lda + (kprime - 1)];
+    if (ek == PAIR_NONE || ak == PAIR_NONE) {  // cannot happen for n_rows > kprime; be safe
+        flags[q] = 1;
+        return;
+    }
+    float dk = f32_from_orderable(uint32_t(ek >> 32));
+    float kappa = f32_from_orderable(uint32_t(ak >> 32));
+    float qs = qsq[q];
+    float nrm = sqrtf(xsq_max) + sqrtf(qs);
+    float E = 2.5f * float(dim + 8) * 5.9604645e-8f * nrm * nrm;
+    bool ok = dk < (kappa + qs) - E;  // NaN anywhere -> not ok
+    flags[q] = ok ? 0 : 1;
+}
+
+void launch_certify(const uint64_t *exact_sorted, uint32_t lde, const uint64_t *approx_sorted, uint32_t lda,
+                    uint32_t nq, uint32_t k, uint32_t kprime, uint64_t n_rows, const float *qsq, float xsq_max,
+                    uint32_t dim, uint8_t *flags, hipStream_t s) {
+    if (nq == 0) return;
+    hipLaunchKernelGGL(k_certify, dim3((nq + 63) / 64), dim3(64), 0, s, exact_sorted, lde, approx_sorted, lda, nq, k,
+                       kprime, n_rows, qsq, xsq_max, dim, flags);
+}
+
+}  // namespace vdb

@@ -1,0 +1,173 @@
+// k_topk.hip -- wavefront-level top-k select under the CandidatePair total order.
+//
+// ResultSet (candidate_pair.rs:43-82) keeps the k smallest pairs by (distance, index).  For an
+// ascending-index scan (FlatIndex::knn, flat_index.rs:48-57; the ADC scan of knn_pq :98-101) the
+// BTreeSet's strict-`<` replacement rule (candidate_pair.rs:66-71) yields exactly the k smallest
+// under the lexicographic order, so selection here is order-free: each pair becomes one u64
+// (common.hpp pair_key) and unsigned comparison is the reference's Ord.
+//
+// One 64-lane wave owns a sorted list of 64*R keys spread over R registers per lane
+// (position p lives in register p/64, lane p%64).  A candidate is admitted only when it is
+// smaller than the current k-th element (tau), found with a ballot; insertion is a lane shift
+// (DPP/ds_bpermute via __shfl_up) per register.  With k << chunk the admit rate is
+// ~k*ln(chunk/k)/chunk, so the stream side (one float4 per lane per step) dominates.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace vdb {
+
+uint32_t topk_num_lists(uint64_t n) { return n == 0 ? 1u : (uint32_t)((n + TOPK_CHUNK - 1) / TOPK_CHUNK); }
+uint32_t topk_capacity(uint32_t k) {
+    uint32_t r = 1;
+    while (64u * r < k) r *= 2;
+    return 64u * r;
+}
+
+template <int R>
+struct WaveList {
+    uint64_t v[R];
+    uint64_t tau;  // element at position k-1 (wave-uniform)
+    uint32_t k;
+
+    __device__ void init(uint32_t kk) {
+#pragma unroll
+        for (int r = 0; r < R; r++) v[r] = PAIR_NONE;
+        tau = PAIR_NONE;
+        k = kk;
+    }
+    // insert a wave-uniform key e (e < tau guaranteed by the caller)
+    __device__ void insert(uint64_t e) {
+        const uint32_t lane = threadIdx.x & 63;
+        bool placed = false;  // once placed, e is the carry pushed out of the previous register
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            uint64_t cur = v[r];
+            uint64_t mask = placed ? ~0ull : __ballot(cur > e);
+            if (mask != 0) {
+                uint32_t pos = placed ? 0u : (uint32_t)__builtin_ctzll(mask);
+                uint64_t carry = __shfl(cur, 63);
+                uint64_t up = __shfl_up(cur, 1);
+                v[r] = lane < pos ? cur : (lane == pos ? e : up);
+                e = carry;
+                placed = true;
+            }
+        }
+        uint32_t p = k - 1;
+        uint64_t t = PAIR_NONE;
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if ((p >> 6) == (uint32_t)r) t = __shfl(v[r], p & 63);
+        tau = t;
+    }
+    // offer one key per lane (PAIR_NONE = nothing)
+    __device__ void offer(uint64_t c) {
+        uint64_t m = __ballot(c < tau);
+        while (m) {
+            uint32_t src = (uint32_t)__builtin_ctzll(m);
+            uint64_t e = __shfl(c, src);
+            if (e < tau) insert(e);  // tau may have tightened since the ballot
+            m &= m - 1;
+        }
+    }
+    __device__ void store(uint64_t *dst) const {  // dst: 64*R entries
+        const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+        for (int r = 0; r < R; r++) dst[r * 64 + lane] = v[r];
+    }
+};
+
+// level 1: grid = (ceil(nlists/4), nq), block = 256 (4 waves, one list each)
+template <int R>
+__global__ __launch_bounds__(256) void k_topk_dense(const float *__restrict__ keys, uint64_t ld, uint64_t n,
+                                                    uint32_t k, uint32_t nlists, uint64_t *__restrict__ lists) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t list = blockIdx.x * 4 + wave;
+    const uint32_t q = blockIdx.y;
+    if (list >= nlists) return;
+    WaveList<R> wl;
+    wl.init(k);
+    const float *kq = keys + uint64_t(q) * ld;
+    uint64_t begin = uint64_t(list) * TOPK_CHUNK;
+    uint64_t end = begin + TOPK_CHUNK < n ? begin + TOPK_CHUNK : n;
+    const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(keys) & 15) == 0);
+    for (uint64_t base = begin; base < end; base += 256) {
+        uint64_t i0 = base + uint64_t(lane) * 4;
+        float f[4];
+        if (vec_ok && i0 + 3 < end) {
+            float4 t = *reinterpret_cast<const float4 *>(kq + i0);
+            f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) f[e] = (i0 + e < end) ? kq[i0 + e] : 0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            uint64_t c = (i0 + e < end) ? pair_key(f[e], uint32_t(i0 + e)) : PAIR_NONE;
+            wl.offer(c);
+        }
+    }
+    wl.store(lists + (uint64_t(q) * nlists + list) * (64 * R));
+}
+
+// level 2: one wave per query merges nlists*cap_in keys
+template <int R>
+__global__ __launch_bounds__(64) void k_topk_merge(const uint64_t *__restrict__ lists, uint32_t nlists,
+                                                   uint32_t cap_in, uint32_t k, uint64_t *__restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t q = blockIdx.x;
+    WaveList<R> wl;
+    wl.init(k);
+    const uint64_t *src = lists + uint64_t(q) * nlists * cap_in;
+    uint64_t total = uint64_t(nlists) * cap_in;
+    uint64_t rounds = (total + 63) / 64;  // same trip count in every lane: all take part in the ballots
+    for (uint64_t it = 0; it < rounds; it++) {
+        uint64_t i = it * 64 + lane;
+        uint64_t c = i < total ? src[i] : PAIR_NONE;
+        wl.offer(c);
+    }
+    wl.store(out + uint64_t(q) * (64 * R));
+}
+
+template <int R>
+static void topk_dense_r(const float *keys, uint64_t ld, uint64_t n, uint32_t nq, uint32_t k, uint64_t *lists,
+                         hipStream_t s) {
+    uint32_t nl = topk_num_lists(n);
+    hipLaunchKernelGGL((k_topk_dense<R>), dim3((nl + 3) / 4, nq), dim3(256), 0, s, keys, ld, n, k, nl, lists);
+}
+template <int R>
+static void topk_merge_r(const uint64_t *lists, uint32_t nlists, uint32_t cap_in, uint32_t nq, uint32_t k,
+                         uint64_t *out, hipStream_t s) {
+    hipLaunchKernelGGL((k_topk_merge<R>), dim3(nq), dim3(64), 0, s, lists, nlists, cap_in, k, out);
+}
+
+#define VDB_DISPATCH_R(cap, CALL)                                   \
+    switch ((cap) / 64) {                                           \
+        case 1: CALL(1); break;                                     \
+        case 2: CALL(2); break;                                     \
+        case 4: CALL(4); break;                                     \
+        case 8: CALL(8); break;                                     \
+        case 16: CALL(16); break;                                   \
+        default: throw Error(1, "top-k: k must be <= 1024");        \
+    }
+
+void launch_topk_dense(const float *keys, uint64_t ld, uint64_t n, uint32_t nq, uint32_t k, uint64_t *lists,
+                       hipStream_t s) {
+    if (nq == 0) return;
+    VDB_REQUIRE(k >= 1, "top-k: k must be >= 1");
+    uint32_t cap = topk_capacity(k);
+#define CALL(R) topk_dense_r<R>(keys, ld, n, nq, k, lists, s)
+    VDB_DISPATCH_R(cap, CALL)
+#undef CALL
+}
+
+void launch_topk_merge(const uint64_t *lists, uint32_t nlists, uint32_t cap_in, uint32_t nq, uint32_t k,
+                       uint64_t *out, hipStream_t s) {
+    if (nq == 0) return;
+    VDB_REQUIRE(k >= 1, "top-k: k must be >= 1");
+    uint32_t cap = topk_capacity(k);
+#define CALL(R) topk_merge_r<R>(lists, nlists, cap_in, nq, k, out, s)
+    VDB_DISPATCH_R(cap, CALL)
+#undef CALL
+}
+
+}  // namespace vdb

@@ -1,0 +1,58 @@
+// kernels.hpp -- launch wrappers of the gfx950 kernels (definitions in k_*.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace vdb {
+
+// how a (row, query) pair turns into a distance; all folds are strict left-to-right f32
+enum Metric : int {
+    MET_L2_DIRECT = 0,  // sum (x-q)^2                     distance/mod.rs:75-77   (Flat, re-sorts)
+    MET_COSINE = 1,     // 1 - dot/max(|x||q|,1e-10)       distance/mod.rs:60-69
+    MET_L2_CACHED = 2,  // (xx + qq) - 2*dot(x,q)          distance/mod.rs:54-57   (HNSW)
+};
+
+// ---- k_exact.hip ---------------------------------------------------------------------------
+// sq[i] = dot(x_i, x_i) in reference order (DistanceAlgorithm::dist_cache, distance/mod.rs:31-36)
+void launch_row_sqnorm(const float *X, uint64_t n, uint32_t dim, float *sq, hipStream_t s);
+// dense exact distances out[b*ld + i] for nq (<= 8) queries against rows [0,n)
+void launch_scan_exact(const float *X, uint64_t n, uint32_t dim, const float *Q, uint32_t nq, int metric,
+                       const float *xsq, const float *qsq, float *out, uint64_t ld, bool use_lds, hipStream_t s);
+// exact distance of every candidate: in/out are pair keys [nq][ldc]; PAIR_NONE entries pass through
+void launch_rerank(const float *X, uint32_t dim, const float *Q, uint32_t nq, int metric, const float *xsq,
+                   const float *qsq, const uint64_t *cand, uint64_t *out, uint32_t ncand, uint32_t ldc,
+                   hipStream_t s);
+// first `ksel` pair keys of each query -> (u64 id + id_offset, f32 distance) at out[q*kstride + j],
+// out_count[q] = number of valid pairs
+void launch_finalize(const uint64_t *keys, uint32_t ldk, uint32_t nq, uint32_t ksel, uint32_t kstride,
+                     uint64_t id_offset, uint64_t *out_idx, float *out_dist, uint64_t *out_count, hipStream_t s);
+// certification of an MFMA shortlist (see k_exact.hip): flags[q] = 1 when the exact top-k might
+// not be contained in the shortlist
+void launch_certify(const uint64_t *exact_sorted, uint32_t lde, const uint64_t *approx_sorted, uint32_t lda,
+                    uint32_t nq, uint32_t k, uint32_t kprime, uint64_t n_rows, const float *qsq, float xsq_max,
+                    uint32_t dim, uint8_t *flags, hipStream_t s);
+
+// ---- k_topk.hip ----------------------------------------------------------------------------
+// rows per level-1 list
+constexpr uint32_t TOPK_CHUNK = 8192;
+uint32_t topk_num_lists(uint64_t n);
+uint32_t topk_capacity(uint32_t k);  // entries per list (multiple of 64, >= k)
+// level 1: dense f32 keys[q*ld + i], i in [0,n) -> lists[q][list][cap] sorted ascending pair keys
+void launch_topk_dense(const float *keys, uint64_t ld, uint64_t n, uint32_t nq, uint32_t k, uint64_t *lists,
+                       hipStream_t s);
+// level 2: merge `nlists` lists of `cap_in` pair keys per query -> out[q][cap] sorted ascending
+void launch_topk_merge(const uint64_t *lists, uint32_t nlists, uint32_t cap_in, uint32_t nq, uint32_t k,
+                       uint64_t *out, hipStream_t s);
+
+// ---- k_mfma.hip ----------------------------------------------------------------------------
+constexpr uint32_t MFMA_B = 32;  // queries per corpus pass
+// Q [nq<=32][dim] -> fragment-ordered image (dim/16 steps x 2 halves x 64 lanes x float4); dim % 16 == 0
+void launch_mfma_pack_queries(const float *Q, uint32_t nq, uint32_t dim, float *qfrag, hipStream_t s);
+// approximate keys out[b*ld + i] = xsq[i] - 2*dot(x_i, q_b) for b < 32 (rows >= n untouched)
+void launch_flat_mfma(const float *X, uint64_t n, uint32_t dim, const float *qfrag, const float *xsq, float *out,
+                      uint64_t ld, int num_cu, hipStream_t s);
+size_t mfma_qfrag_floats(uint32_t dim);
+bool mfma_supported(uint32_t dim);
+
+}  // namespace vdb

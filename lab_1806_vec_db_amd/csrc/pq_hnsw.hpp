@@ -1,0 +1,24 @@
+// pq_hnsw.hpp -- PQ (pq.hip) and HNSW (hnsw.hip, hnsw_build.cpp) entry points used by api.hip.
+#pragma once
+#include "index.hpp"
+
+namespace vdb {
+
+// ---- PQ (distance/pq_table.rs) ----
+void pq_attach(Index &ix, uint64_t n_bits, uint64_t m, const float *centroids, const uint8_t *codes);
+void pq_build(Index &ix, uint64_t n_bits, uint64_t m, uint64_t train_n, uint64_t max_iter, float tol, uint64_t seed);
+void pq_clear(Index &ix);
+void flat_knn_pq_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef,
+                        uint64_t *d_idx, float *d_dist, uint64_t *d_cnt);
+
+// ---- HNSW (index_algorithm/hnsw_index.rs) ----
+void hnsw_build(Index &ix, uint64_t M, uint64_t ef_construction, uint64_t seed, uint64_t batch, int nthreads);
+void hnsw_attach(Index &ix, uint64_t M, uint64_t ef_construction, const uint32_t *level0, const uint64_t *len0,
+                 const uint64_t *vec_level, const uint32_t *upper, const uint64_t *upper_len, int has_enter,
+                 uint64_t enter_point, uint64_t enter_level);
+void hnsw_clear(Index &ix);
+void hnsw_insert_rows(Index &ix, const float *rows, uint64_t n);
+void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef, bool use_pq,
+                     uint64_t *d_idx, float *d_dist, uint64_t *d_cnt);
+
+}  // namespace vdb

@@ -1,0 +1,267 @@
+"""GpuIndex -- host-side mirror of the reference's index traits over the C ABI.
+
+Method names and argument meaning follow src/index_algorithm/mod.rs (IndexIter, IndexKNN, IndexKNNWithEf,
+IndexPQ, IndexBuilder) and src/database/dynamic_index.rs:11-94 (DynamicIndex).  All arithmetic runs in
+libvdbhip.so on the GPU; this file only marshals numpy arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+DIST_NAMES = {"l2sqr": L.L2SQR, "cosine": L.COSINE}  # pyo3/mod.rs:15-22
+
+
+def parse_dist(dist) -> int:
+    if isinstance(dist, str):
+        try:
+            return DIST_NAMES[dist.lower()]
+        except KeyError:
+            raise ValueError(f"Invalid distance function: {dist}") from None  # PyValueError, pyo3/mod.rs:20
+    if dist in (0, 1):
+        return int(dist)
+    raise ValueError(f"Invalid distance function: {dist}")
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+def calc_dist(a, b, dist="cosine", device: int = 0) -> float:
+    """calc_dist (pyo3/mod.rs:43-48), evaluated on the GPU in reference order."""
+    kind = parse_dist(dist)
+    a, b = _f32(a).ravel(), _f32(b).ravel()
+    n = min(a.size, b.size)  # zip truncates (distance/mod.rs:73)
+    out = C.c_float(0)
+    L.check(L.load().vdb_calc_dist(device, _ptr(a, L.f32p), _ptr(b, L.f32p), n, kind, C.byref(out)))
+    return float(out.value)
+
+
+class GpuIndex:
+    """One HBM-resident VecSet<f32> with optional PQ table and HNSW graph (DynamicIndex + PQTable)."""
+
+    def __init__(self, dim: int, dist="cosine", device: int = 0):
+        self._lib = L.load()
+        self._h = L.vp()
+        self.device = device
+        L.check(self._lib.vdb_index_create(device, int(dim), parse_dist(dist), C.byref(self._h)))
+
+    # -- lifetime ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.vdb_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- IndexIter ----------------------------------------------------------------------------------
+    def __len__(self) -> int:
+        v = C.c_uint64()
+        L.check(self._lib.vdb_index_len(self._h, C.byref(v)))
+        return int(v.value)
+
+    @property
+    def dim(self) -> int:
+        v = C.c_uint64()
+        L.check(self._lib.vdb_index_dim(self._h, C.byref(v)))
+        return int(v.value)
+
+    @property
+    def dist(self) -> int:
+        v = C.c_int()
+        L.check(self._lib.vdb_index_dist(self._h, C.byref(v)))
+        return int(v.value)
+
+    def __getitem__(self, i: int) -> np.ndarray:
+        out = np.empty(self.dim, dtype=np.float32)
+        L.check(self._lib.vdb_index_row(self._h, int(i), _ptr(out, L.f32p)))
+        return out
+
+    # -- IndexBuilder ----------------------------------------------------------------------------------
+    def add(self, vec) -> int:
+        return self.batch_add(_f32(vec).reshape(1, -1))[0]
+
+    def batch_add(self, rows) -> list[int]:
+        rows = _f32(rows)
+        if rows.ndim != 2 or rows.shape[1] != self.dim:
+            raise L.VdbError(f"dimension mismatch: index dim {self.dim}, got shape {rows.shape}")
+        first = C.c_uint64()
+        L.check(self._lib.vdb_index_add(self._h, _ptr(rows, L.f32p), rows.shape[0], C.byref(first)))
+        return list(range(int(first.value), int(first.value) + rows.shape[0]))
+
+    def add_device(self, data_ptr: int, n: int) -> int:
+        """Append n rows already resident on this GPU (e.g. torch tensor .data_ptr())."""
+        first = C.c_uint64()
+        L.check(self._lib.vdb_index_add_device(self._h, L.vp(data_ptr), int(n), C.byref(first)))
+        return int(first.value)
+
+    def swap_remove(self, i: int):
+        L.check(self._lib.vdb_index_swap_remove(self._h, int(i)))
+
+    def set_id_offset(self, off: int):
+        L.check(self._lib.vdb_index_set_id_offset(self._h, int(off)))
+
+    # -- searches ------------------------------------------------------------------------------------------
+    def _search(self, fn, queries, k, ef=None):
+        q = _f32(queries)
+        single = q.ndim == 1
+        q = q.reshape(1, -1) if single else q
+        nq, dim = q.shape
+        kk = max(int(k), 1)
+        idx = np.zeros((nq, kk), dtype=np.uint64)
+        dist = np.zeros((nq, kk), dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.uint64)
+        args = [self._h, _ptr(q, L.f32p), nq, dim, int(k)]
+        if ef is not None:
+            args.append(int(ef))
+        args += [_ptr(idx, L.u64p), _ptr(dist, L.f32p), _ptr(cnt, L.u64p)]
+        L.check(fn(*args))
+        if single:
+            c = int(cnt[0])
+            return idx[0, :c].copy(), dist[0, :c].copy()
+        return idx[:, :int(k)], dist[:, :int(k)], cnt
+
+    def knn(self, queries, k: int):
+        """IndexKNN::knn: Flat -> FlatIndex::knn; with an HNSW graph -> HNSWIndex::knn (default ef)
+        (dynamic_index.rs:68-73)."""
+        if self.has_hnsw():
+            return self._search(self._lib.vdb_hnsw_knn, queries, k, 0)
+        return self._search(self._lib.vdb_flat_knn, queries, k)
+
+    def flat_knn(self, queries, k: int):
+        return self._search(self._lib.vdb_flat_knn, queries, k)
+
+    def knn_with_ef(self, queries, k: int, ef: int):
+        """IndexKNNWithEf::knn_with_ef; Flat ignores ef (dynamic_index.rs:75-80)."""
+        if self.has_hnsw():
+            return self._search(self._lib.vdb_hnsw_knn, queries, k, ef)
+        return self._search(self._lib.vdb_flat_knn, queries, k)
+
+    def knn_pq(self, queries, k: int, ef: int):
+        """IndexPQ::knn_pq (dynamic_index.rs:82-93)."""
+        if self.has_hnsw():
+            return self._search(self._lib.vdb_hnsw_knn_pq, queries, k, ef)
+        return self._search(self._lib.vdb_flat_knn_pq, queries, k, ef)
+
+    def flat_knn_device(self, q_ptr: int, nq: int, k: int, out_idx_ptr: int, out_dist_ptr: int, out_cnt_ptr: int,
+                        stream: int = 0):
+        L.check(self._lib.vdb_flat_knn_device(self._h, L.vp(q_ptr), int(nq), self.dim, int(k), L.vp(out_idx_ptr),
+                                              L.vp(out_dist_ptr), L.vp(out_cnt_ptr), L.vp(stream)))
+
+    def set_flat_mode(self, mode: int):
+        L.check(self._lib.vdb_flat_set_mode(self._h, int(mode)))
+
+    def flat_fallback_count(self) -> int:
+        v = C.c_uint64()
+        L.check(self._lib.vdb_flat_fallback_count(self._h, C.byref(v)))
+        return int(v.value)
+
+    # -- PQ ------------------------------------------------------------------------------------------------
+    def pq_attach(self, n_bits: int, m: int, centroids, codes=None):
+        c = _f32(centroids).ravel()
+        cd = None if codes is None else np.ascontiguousarray(codes, dtype=np.uint8)
+        L.check(self._lib.vdb_pq_attach(self._h, n_bits, m, _ptr(c, L.f32p), _ptr(cd, L.u8p)))
+
+    def pq_build(self, n_bits: int = 4, m: int | None = None, train_n: int = 0, max_iter: int = 20,
+                 tol: float = 1e-6, seed: int = 42):
+        m = -(-self.dim // 3) if m is None else m
+        L.check(self._lib.vdb_pq_build(self._h, n_bits, m, train_n, max_iter, tol, seed))
+
+    def pq_clear(self):
+        L.check(self._lib.vdb_pq_clear(self._h))
+
+    def has_pq(self) -> bool:
+        v = C.c_int()
+        L.check(self._lib.vdb_pq_has(self._h, C.byref(v)))
+        return bool(v.value)
+
+    def pq_export(self):
+        nb, m, ed = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        L.check(self._lib.vdb_pq_info(self._h, C.byref(nb), C.byref(m), C.byref(ed)))
+        cent = np.zeros((1 << nb.value) * self.dim, dtype=np.float32)
+        codes = np.zeros((len(self), ed.value), dtype=np.uint8)
+        L.check(self._lib.vdb_pq_export(self._h, _ptr(cent, L.f32p), _ptr(codes, L.u8p)))
+        return {"n_bits": int(nb.value), "m": int(m.value), "centroids": cent, "codes": codes}
+
+    # -- HNSW ------------------------------------------------------------------------------------------------
+    def hnsw_build(self, M: int = 16, ef_construction: int = 200, seed: int = 42, batch: int = 1,
+                   nthreads: int = 1):
+        L.check(self._lib.vdb_hnsw_build(self._h, M, ef_construction, seed, batch, nthreads))
+
+    def hnsw_attach(self, M: int, ef_construction: int, g: dict):
+        l0 = np.ascontiguousarray(g["level0"], dtype=np.uint32)
+        len0 = np.ascontiguousarray(g["len0"], dtype=np.uint64)
+        vl = np.ascontiguousarray(g["vec_level"], dtype=np.uint64)
+        up = np.ascontiguousarray(g["upper"], dtype=np.uint32)
+        ul = np.ascontiguousarray(g["upper_len"], dtype=np.uint64)
+        L.check(self._lib.vdb_hnsw_attach(self._h, M, ef_construction, _ptr(l0, L.u32p), _ptr(len0, L.u64p),
+                                          _ptr(vl, L.u64p), _ptr(up, L.u32p), _ptr(ul, L.u64p),
+                                          int(g["has_enter"]), int(g["enter_point"]), int(g["enter_level"])))
+
+    def hnsw_clear(self):
+        L.check(self._lib.vdb_hnsw_clear(self._h))
+
+    def has_hnsw(self) -> bool:
+        v = C.c_int()
+        L.check(self._lib.vdb_hnsw_has(self._h, C.byref(v)))
+        return bool(v.value)
+
+    def hnsw_export(self) -> dict:
+        m, mm0, tot, ep, el, de = (C.c_uint64() for _ in range(6))
+        he = C.c_int()
+        L.check(self._lib.vdb_hnsw_info(self._h, C.byref(m), C.byref(mm0), C.byref(tot), C.byref(he), C.byref(ep),
+                                        C.byref(el), C.byref(de)))
+        n = len(self)
+        g = {
+            "n": n, "m": int(m.value), "max_m0": int(mm0.value),
+            "level0": np.zeros(n * mm0.value, dtype=np.uint32), "len0": np.zeros(n, dtype=np.uint64),
+            "vec_level": np.zeros(n, dtype=np.uint64), "upper": np.zeros(tot.value * m.value, dtype=np.uint32),
+            "upper_len": np.zeros(tot.value, dtype=np.uint64), "has_enter": int(he.value),
+            "enter_point": int(ep.value), "enter_level": int(el.value), "default_ef": int(de.value),
+        }
+        L.check(self._lib.vdb_hnsw_export(self._h, _ptr(g["level0"], L.u32p), _ptr(g["len0"], L.u64p),
+                                          _ptr(g["vec_level"], L.u64p), _ptr(g["upper"], L.u32p),
+                                          _ptr(g["upper_len"], L.u64p)))
+        return g
+
+    def hnsw_last_stats(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        L.check(self._lib.vdb_hnsw_last_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    # -- measurement ---------------------------------------------------------------------------------------------
+    def prof_enable(self, on: bool = True):
+        L.check(self._lib.vdb_prof_enable(self._h, 1 if on else 0))
+
+    def prof_reset(self):
+        L.check(self._lib.vdb_prof_reset(self._h))
+
+    def prof_get(self, kernel: str):
+        ms, n, by = C.c_double(), C.c_uint64(), C.c_double()
+        L.check(self._lib.vdb_prof_get(self._h, kernel.encode(), C.byref(ms), C.byref(n), C.byref(by)))
+        return {"ms": float(ms.value), "launches": int(n.value), "bytes": float(by.value)}
+
+
+def merge_topk(dists: np.ndarray, ids: np.ndarray, counts: np.ndarray, k: int):
+    """Merge per-shard sorted lists [S][nq][k] into the global top-k by (distance, index)."""
+    d = _f32(dists)
+    i = np.ascontiguousarray(ids, dtype=np.uint64)
+    c = np.ascontiguousarray(counts, dtype=np.uint64)
+    S, nq = d.shape[0], d.shape[1]
+    oi = np.zeros((nq, k), dtype=np.uint64)
+    od = np.zeros((nq, k), dtype=np.float32)
+    oc = np.zeros(nq, dtype=np.uint64)
+    L.check(L.load().vdb_merge_topk(_ptr(d, L.f32p), _ptr(i, L.u64p), _ptr(c, L.u64p), S, nq, k, _ptr(oi, L.u64p),
+                                    _ptr(od, L.f32p), _ptr(oc, L.u64p)))
+    return oi, od, oc

@@ -1,0 +1,193 @@
+"""GPU parity: Flat brute force through the C ABI vs the CPU oracle.
+
+Bar (north_star): neighbour indices identical, f32 distances within 1e-5 relative.  The HIP path is
+stricter than that by construction: the distances that leave the library are recomputed in the
+reference's summation order, so the tests assert bit-exact equality and only fall back to the
+tolerance if that ever fails (the assert message says which).
+"""
+import numpy as np
+import pytest
+
+from conftest import gist_like
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5  # north_star tolerance for f32 distances
+
+
+def _check(idx_g, dist_g, idx_o, dist_o):
+    assert idx_g.tolist() == idx_o.tolist(), f"neighbour indices differ: {idx_g} vs {idx_o}"
+    if not np.array_equal(dist_g, dist_o):
+        np.testing.assert_allclose(dist_g, dist_o, rtol=REL_TOL, atol=0)
+        pytest.fail("distances within 1e-5 but not bit-exact")
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import lab_1806_vec_db_amd as vdb
+    from oracle import oracle as O
+    return vdb, O
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("dist", ["l2sqr", "cosine"])
+def test_gist1000_flat_parity(mods, gist_base, gist_test, mode, dist):
+    """BASELINE config 1: Flat on gist_1000 x gist_test, k=10 (ground-truth protocol of gen_gnd.rs:54-72)."""
+    vdb, O = mods
+    ix = vdb.GpuIndex(960, dist)
+    ix.batch_add(gist_base)
+    ix.set_flat_mode(mode)
+    nq = 100
+    idx, d, cnt = ix.flat_knn(gist_test[:nq], 10)
+    kind = 0 if dist == "l2sqr" else 1
+    oi, od, oc = O.flat_knn_batch(gist_base, gist_test[:nq], 10, kind, nthreads=8)
+    assert cnt.tolist() == oc.tolist()
+    for q in range(nq):
+        _check(idx[q], d[q], oi[q], od[q])
+
+
+def test_survey_golden_vectors(mods, gist_base, gist_test):
+    """SURVEY 8c golden candidates (numpy emulation of the strict f32 fold)."""
+    vdb, _ = mods
+    ix = vdb.GpuIndex(960, "l2sqr")
+    ix.batch_add(gist_base)
+    i0, d0 = ix.flat_knn(gist_test[0], 10)
+    assert i0.tolist() == [918, 467, 725, 988, 207, 56, 18, 348, 27, 632]
+    assert float(d0[0]).hex() == "0x1.00b9120000000p+0"
+    i999, d999 = ix.flat_knn(gist_test[999], 10)
+    assert i999.tolist() == [313, 167, 127, 168, 198, 165, 68, 269, 82, 43]
+    assert float(d999[0]).hex() == "0x1.f5bc520000000p-3"
+
+
+def test_flat_index_test_restated(mods, gist_base):
+    """flat_index.rs:117-170: 12-dim clip, L2Sqr, query = row 200, k = 4."""
+    vdb, O = mods
+    b12 = np.ascontiguousarray(gist_base[:, :12])
+    ix = vdb.GpuIndex(12, "l2sqr")
+    ix.batch_add(b12)
+    idx, d = ix.flat_knn(b12[200], 4)
+    assert len(idx) == 4 and idx[0] == 200 and abs(d[0]) < 1e-6
+    assert all(d[i] <= d[i + 1] for i in range(3))
+    assert idx.tolist() == [200, 750, 471, 793]
+    oi, od = O.flat_knn(b12, b12[200], 4)
+    _check(idx, d, oi, od)
+
+
+@pytest.mark.parametrize("dim", [4, 13, 32, 64, 96, 100, 960])
+@pytest.mark.parametrize("dist", ["l2sqr", "cosine"])
+def test_dims_and_edges(mods, dim, dist):
+    vdb, O = mods
+    rng = np.random.default_rng(dim)
+    base = rng.standard_normal((777, dim)).astype(np.float32)
+    qs = rng.standard_normal((9, dim)).astype(np.float32)
+    kind = 0 if dist == "l2sqr" else 1
+    ix = vdb.GpuIndex(dim, dist)
+    # empty index -> empty result (flat_index.rs:163)
+    i, d = ix.flat_knn(qs[0], 5)
+    assert len(i) == 0
+    ix.batch_add(base[:300])
+    ix.batch_add(base[300:])  # growth path
+    assert len(ix) == 777
+    np.testing.assert_array_equal(ix[776], base[776])
+    for mode in (1, 2):
+        ix.set_flat_mode(mode)
+        for k in (1, 10, 65, 777, 1000):
+            idx, dd, cnt = ix.flat_knn(qs, k)
+            assert (cnt == min(k, 777)).all()
+            for q in range(qs.shape[0]):
+                oi, od = O.flat_knn(base, qs[q], k, kind)
+                c = int(cnt[q])
+                _check(idx[q, :c], dd[q, :c], oi, od)
+    i, d = ix.flat_knn(qs[0], 0)
+    assert len(i) == 0
+    # dimension mismatch is an error, not a silent truncation
+    with pytest.raises(vdb.VdbError):
+        ix.flat_knn(np.zeros(dim + 1, np.float32), 3)
+
+
+def test_ties_and_duplicates(mods):
+    """Duplicated rows: equal distances must come back in ascending index order (candidate_pair.rs:36-41)."""
+    vdb, O = mods
+    rng = np.random.default_rng(7)
+    dim = 64
+    uniq = rng.standard_normal((50, dim)).astype(np.float32)
+    base = np.concatenate([uniq] * 400)  # 20000 rows, every row present 400 times
+    q = uniq[3] + 0.01
+    for mode in (1, 2):
+        ix = vdb.GpuIndex(dim, "l2sqr")
+        ix.batch_add(base)
+        ix.set_flat_mode(mode)
+        idx, d = ix.flat_knn(q, 25)
+        oi, od = O.flat_knn(base, q, 25)
+        _check(idx, d, oi, od)
+    assert ix.flat_fallback_count() >= 1  # the MFMA shortlist cannot certify 400-way ties
+
+
+def test_nan_and_inf_rows(mods):
+    vdb, O = mods
+    rng = np.random.default_rng(11)
+    base = rng.standard_normal((500, 32)).astype(np.float32)
+    base[17, 3] = np.nan
+    base[40, 0] = np.inf
+    q = rng.standard_normal(32).astype(np.float32)
+    ix = vdb.GpuIndex(32, "l2sqr")
+    ix.batch_add(base)
+    idx, d = ix.flat_knn(q, 500)
+    oi, od = O.flat_knn(base, q, 500)
+    assert idx.tolist() == oi.tolist()
+    np.testing.assert_array_equal(np.isnan(d), np.isnan(od))
+    m = ~np.isnan(od)
+    np.testing.assert_array_equal(d[m], od[m])
+
+
+@pytest.mark.parametrize("n", [20000, 70001])
+def test_gistlike_mfma_parity(mods, n):
+    """Gist1M-shaped synthetic rows at a size the oracle finishes in seconds; MFMA path forced."""
+    vdb, O = mods
+    base = gist_like(n, seed=1806)
+    qs = gist_like(40, seed=1807)
+    ix = vdb.GpuIndex(960, "l2sqr")
+    ix.batch_add(base)
+    ix.set_flat_mode(2)
+    idx, d, cnt = ix.flat_knn(qs, 10)
+    oi, od, oc = O.flat_knn_batch(base, qs, 10, 0, nthreads=8)
+    for q in range(qs.shape[0]):
+        _check(idx[q], d[q], oi[q], od[q])
+    # auto mode must agree too
+    ix.set_flat_mode(0)
+    idx2, d2, _ = ix.flat_knn(qs, 10)
+    np.testing.assert_array_equal(idx, idx2)
+    np.testing.assert_array_equal(d, d2)
+    print("fallbacks:", ix.flat_fallback_count())
+
+
+def test_swap_remove_and_offset(mods):
+    vdb, O = mods
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal((100, 16)).astype(np.float32)
+    ix = vdb.GpuIndex(16, "l2sqr")
+    ix.batch_add(base)
+    ix.swap_remove(10)  # vec_set.rs:131-137
+    ref = base.copy()
+    ref[10] = ref[99]
+    ref = ref[:99]
+    assert len(ix) == 99
+    np.testing.assert_array_equal(ix[10], base[99])
+    idx, d = ix.flat_knn(base[5], 7)
+    oi, od = O.flat_knn(ref, base[5], 7)
+    _check(idx, d, oi, od)
+    ix.set_id_offset(1000)
+    idx2, _ = ix.flat_knn(base[5], 7)
+    assert (idx2 == idx + 1000).all()
+
+
+def test_calc_dist(mods):
+    vdb, O = mods
+    assert abs(vdb.calc_dist([1, 2, 3], [4, 5, 6], "l2sqr") - 27.0) < 1e-6  # distance/mod.rs:138-143
+    assert abs(vdb.calc_dist([1, 2, 3], [2, 4, 6], "cosine")) < 1e-6       # distance/mod.rs:145-150 (f32 here)
+    with pytest.raises(ValueError):
+        vdb.calc_dist([1.0], [1.0], "manhattan")
+    rng = np.random.default_rng(5)
+    a, b = rng.standard_normal(960).astype(np.float32), rng.standard_normal(960).astype(np.float32)
+    for name, kind in (("l2sqr", 0), ("cosine", 1)):
+        assert vdb.calc_dist(a, b, name) == O.dist(kind, a, b)
