@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Flat brute-force k-NN, Gist1M-shaped corpus, queries/s at recall@10.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
+torch.distributed.run, one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1] / configs[4]): corpus N=1,000,000 x 960 f32, L2Sqr, k=10, one step = one
+batch of nq=1000 queries (the size of data/gist_test.bin) through FlatIndex::knn semantics.  Gist1M is not
+available offline, so rows are synthetic gist-shaped (per-dimension mean/std of data/gist_1000.bin,
+|N(mu,sigma)| clipped to [0,0.8], 4 decimals), generated on the GPU from a fixed seed; queries likewise.
+With N ranks the SAME 1M corpus is row-sharded (strong scaling): per-shard local top-k, one RCCL
+all-gather of [nq,k], exact merge by (distance, index) on every rank.
+
+Timed region: queries and corpus already resident in HBM; K steps between barrier+synchronize pairs; the
+maximum over ranks is reported.  `roofline` is computed from HIP-event timings of the dominant kernel
+(flat_mfma) taken inside the library on its own stream during the timed steps.  `cpu_baseline` is the CPU
+oracle (a C restatement of the reference's Rust path, kind "port") timed on rank 0 at N=1 on a bounded
+query sample of the same corpus, and doubles as a parity check of the GPU results.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def gist_like_gpu(torch, n, dim, seed, device, chunk=131072):
+    stats = np.load(os.path.join(ROOT, "tests", "golden", "gist_dim_stats.npy"))
+    mu = torch.from_numpy(np.resize(stats[0], dim).astype(np.float32)).to(device)
+    sd = torch.from_numpy(np.resize(stats[1], dim).astype(np.float32)).to(device)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = torch.empty((n, dim), dtype=torch.float32, device=device)
+    for r0 in range(0, n, chunk):
+        r1 = min(n, r0 + chunk)
+        x = torch.randn((r1 - r0, dim), generator=g, device=device, dtype=torch.float32)
+        x.mul_(sd).add_(mu).abs_().clamp_(0.0, 0.8)
+        x.mul_(10000.0).round_().div_(10000.0)
+        out[r0:r1] = x
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=1_000_000)
+    ap.add_argument("--dim", type=int, default=960)
+    ap.add_argument("--nq", type=int, default=1000)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--cpu-queries", type=int, default=64, help="queries timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--mode", type=int, default=0, help="flat mode: 0 auto, 1 exact scan, 2 MFMA forced")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import lab_1806_vec_db_amd as vdb
+    from lab_1806_vec_db_amd.shard import allgather_merge, shard_bounds
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    n, dim, nq, k = args.rows, args.dim, args.nq, args.k
+    # identical corpus on every rank (same seed), each keeps its row block
+    base = gist_like_gpu(torch, n, dim, 1806, device)
+    queries = gist_like_gpu(torch, nq, dim, 1807, device)
+    r0, r1 = shard_bounds(n, world, rank)
+    shard = base[r0:r1].contiguous()
+    torch.cuda.synchronize()
+
+    ix = vdb.GpuIndex(dim, "l2sqr", device=local_rank)
+    ix.add_device(shard.data_ptr(), r1 - r0)
+    ix.set_id_offset(r0)
+    ix.set_flat_mode(args.mode)
+    host_base = None
+    if rank == 0 and world == 1 and args.cpu_queries > 0:
+        host_base = base.cpu().numpy()
+    del base, shard
+    torch.cuda.empty_cache()
+
+    o_idx = torch.zeros((nq, k), dtype=torch.int64, device=device)
+    o_dist = torch.zeros((nq, k), dtype=torch.float32, device=device)
+    o_cnt = torch.zeros((nq,), dtype=torch.int64, device=device)
+
+    def step():
+        ix.flat_knn_device(queries.data_ptr(), nq, k, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr())
+        return allgather_merge(o_idx, o_dist, o_cnt, k, gpu_index=ix)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    ix.prof_enable(True)
+    ix.prof_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ix.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel = "flat_mfma" if ix.prof_get("flat_mfma")["launches"] else "flat_exact"
+    p = ix.prof_get(kernel)
+    roofline = None
+    if p["launches"]:
+        avg_ms = p["ms"] / p["launches"]
+        bytes_per_launch = p["bytes"] / p["launches"]  # shard_rows * dim * 4
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
+                    "avg_launch_ms": round(avg_ms, 4), "launches": p["launches"],
+                    "bytes_per_launch": bytes_per_launch}
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    qps = nq * args.steps / elapsed
+    out = {
+        "metric": "queries/sec at recall@10, Gist1M d=960 (Flat brute force, L2Sqr, k=10)",
+        "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "flat_knn_gist1m", "rows": n, "dim": dim, "queries_per_step": nq, "k": k,
+                   "dist": "L2Sqr", "queries_per_corpus_pass": 32,
+                   "parallelism": f"row-shard x{world}" if world > 1 else "single GPU"},
+        "roofline": roofline, "recall_at_10": None, "fallback_queries": ix.flat_fallback_count(),
+    }
+
+    # ---- CPU baseline + parity (rank 0, N=1 only) ------------------------------------------------------
+    if host_base is not None:
+        from oracle import oracle as O
+
+        O.build()
+        ncpu = min(args.cpu_queries, nq)
+        threads = min(len(os.sched_getaffinity(0)), 16)  # the GPU box's CPU share for one GPU
+        hq = queries[:ncpu].cpu().numpy()
+        t0 = time.perf_counter()
+        ci, cd, cc = O.flat_knn_batch(host_base, hq, k, O.L2SQR, nthreads=threads)
+        cpu_s = time.perf_counter() - t0
+        gi = res[0][:ncpu].cpu().numpy().astype(np.uint64)
+        gd = res[1][:ncpu].cpu().numpy()
+        idx_equal = bool(np.array_equal(gi, ci))
+        dist_equal = bool(np.array_equal(gd, cd))
+        rec = float(np.mean([O.recall(ci[q], gi[q]) for q in range(ncpu)]))
+        out["recall_at_10"] = rec
+        out["parity"] = {"queries_checked": ncpu, "indices_identical": idx_equal, "distances_bit_exact": dist_equal}
+        out["cpu_baseline"] = {"value": round(ncpu / cpu_s, 2), "unit": "queries/s", "cores": threads,
+                               "kind": "port",
+                               "sample": f"{ncpu} of the {nq} queries against the full {n}x{dim} corpus, "
+                                         f"one query per thread (mirrors rayon par_iter, examples/bench.rs:414-416)"}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -134,6 +134,11 @@ int vdb_hnsw_last_stats(const vdb_index *idx, uint64_t *n_dist, uint64_t *n_expa
 int vdb_merge_topk(const float *dists, const uint64_t *ids, const uint64_t *counts, uint64_t n_shards,
                    uint64_t nq, uint64_t k, uint64_t *out_idx, float *out_dist, uint64_t *out_count);
 
+/* same merge on the index's GPU (inputs = the all-gathered tensors, ids < 2^32); returns synchronised */
+int vdb_merge_topk_device(vdb_index *idx, const void *d_dists, const void *d_ids, const void *d_counts,
+                          uint64_t n_shards, uint64_t nq, uint64_t k, void *d_out_idx, void *d_out_dist,
+                          void *d_out_count, void *stream);
+
 /* ---- measurement hooks -------------------------------------------------------------------
  * When enabled, the dominant kernels are bracketed by HIP events on their own stream and the
  * elapsed time is accumulated per kernel name ("flat_mfma", "flat_exact", "pq_adc", "hnsw"). */

@@ -443,6 +443,33 @@ int vdb_merge_topk(const float *dists, const uint64_t *ids, const uint64_t *coun
     VDB_API_END
 }
 
+// device-resident variant: inputs/outputs on the index's GPU, ids < 2^32; synchronous on return
+int vdb_merge_topk_device(vdb_index *idx, const void *d_dists, const void *d_ids, const void *d_counts,
+                          uint64_t n_shards, uint64_t nq, uint64_t k, void *d_out_idx, void *d_out_dist,
+                          void *d_out_count, void *stream) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx && d_dists && d_ids && d_counts && d_out_idx && d_out_dist && d_out_count, "null argument");
+    VDB_REQUIRE(k >= 1 && k <= 1024, "k must be in 1..1024");
+    VDB_REQUIRE(nq <= 65535 && n_shards <= 65535, "too many queries or shards for one call");
+    Index &ix = idx->ix;
+    ix.use_device();
+    WsLease ws(ix);
+    VDB_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    uint32_t cap = topk_capacity((uint32_t)k);
+    ws->lists.reserve(nq * n_shards * cap * sizeof(uint64_t));
+    ws->keys_c.reserve(nq * cap * sizeof(uint64_t));
+    launch_pack_pairs(static_cast<const float *>(d_dists), static_cast<const uint64_t *>(d_ids),
+                      static_cast<const uint64_t *>(d_counts), (uint32_t)n_shards, (uint32_t)nq, (uint32_t)k, cap,
+                      ws->lists.as<uint64_t>(), ws->stream);
+    launch_topk_merge(ws->lists.as<uint64_t>(), (uint32_t)n_shards, cap, (uint32_t)nq, (uint32_t)k,
+                      ws->keys_c.as<uint64_t>(), ws->stream);
+    launch_finalize(ws->keys_c.as<uint64_t>(), cap, (uint32_t)nq, (uint32_t)k, (uint32_t)k, 0,
+                    static_cast<uint64_t *>(d_out_idx), static_cast<float *>(d_out_dist),
+                    static_cast<uint64_t *>(d_out_count), ws->stream);
+    VDB_HIP(hipStreamSynchronize(ws->stream));
+    VDB_API_END
+}
+
 // ---- measurement hooks --------------------------------------------------------------------------------
 int vdb_prof_enable(vdb_index *idx, int on) {
     VDB_API_BEGIN

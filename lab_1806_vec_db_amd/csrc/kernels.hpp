@@ -45,6 +45,9 @@ void launch_topk_dense(const float *keys, uint64_t ld, uint64_t n, uint32_t nq, 
 void launch_topk_merge(const uint64_t *lists, uint32_t nlists, uint32_t cap_in, uint32_t nq, uint32_t k,
                        uint64_t *out, hipStream_t s);
 
+void launch_pack_pairs(const float *dists, const uint64_t *ids, const uint64_t *counts, uint32_t S, uint32_t nq,
+                       uint32_t k, uint32_t cap_in, uint64_t *lists, hipStream_t s);
+
 // ---- k_mfma.hip ----------------------------------------------------------------------------
 constexpr uint32_t MFMA_B = 32;  // queries per corpus pass
 // Q [nq<=32][dim] -> fragment-ordered image (dim/16 steps x 2 halves x 64 lanes x float4); dim % 16 == 0

@@ -1,0 +1,595 @@
+// pq.hip -- product quantisation on gfx950: lookup-table build, asymmetric-distance (ADC) scan with the
+// per-query table pinned in LDS, reference-order re-sort, GPU encoder; plus the host-side PQ table
+// management (attach / build / clear).  Reference: src/distance/pq_table.rs, src/distance/k_means.rs,
+// FlatIndex::knn_pq (src/index_algorithm/flat_index.rs:84-104), ResultSet::pq_resort
+// (src/index_algorithm/candidate_pair.rs:102-108).
+//
+// Bit-exactness: an ADC distance is sum_{i<m} lut[i*k + code_i] accumulated from 0.0 in ascending
+// group order (pq_table.rs:254-292).  One thread owns one code row and adds in that order, so the sums
+// equal the reference's bit for bit; the LUT entries themselves are strict-order folds.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+#include "pq_hnsw.hpp"
+
+#pragma clang fp contract(off)
+
+namespace vdb {
+
+// ---------------------------------------------------------------------------------------------------
+// create_lookup (pq_table.rs:195-224): lut[q][g*kc + c] = l2(qslice, cent) | dot(qslice, cent)
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_pq_lut(const float *__restrict__ Q, uint32_t dim, const float *__restrict__ cent,
+                         const uint64_t *__restrict__ gstart, uint32_t m, uint32_t kc, int cosine,
+                         float *__restrict__ lut) {
+    uint32_t q = blockIdx.y;
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m * kc) return;
+    uint32_t g = e / kc, c = e % kc;
+    uint32_t s = (uint32_t)gstart[g], gd = (uint32_t)gstart[g + 1] - s;
+    const float *v = Q + uint64_t(q) * dim + s;
+    const float *cc = cent + uint64_t(kc) * s + uint64_t(c) * gd;
+    float acc = 0.0f;
+    if (cosine) {
+        for (uint32_t j = 0; j < gd; j++) {
+            float p = v[j] * cc[j];
+            acc = acc + p;
+        }
+    } else {
+        for (uint32_t j = 0; j < gd; j++) {
+            float df = v[j] - cc[j];
+            float sq = df * df;
+            acc = acc + sq;
+        }
+    }
+    lut[uint64_t(q) * m * kc + e] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ADC scan (pq_table.rs:239-301 applied to every code row, flat_index.rs:98-101).
+// BQ queries per pass share each code byte; their lookup tables sit in LDS (m*kc floats each;
+// 20 KB for m=320, 4 bit).  16 consecutive floats of one group span 16 distinct banks, so a
+// ds_read_b32 gather by code value is conflict-free whatever the codes are.
+// LUT_IN_LDS = false: tables too large for LDS (8-bit codes with large m) are read through L1/L2.
+// ---------------------------------------------------------------------------------------------------
+template <int BQ, int NBITS, bool LUT_IN_LDS>
+__global__ __launch_bounds__(256) void k_pq_adc(const uint8_t *__restrict__ codes, uint64_t n, uint32_t enc_dim,
+                                                uint32_t m, const float *__restrict__ lut_g,
+                                                const float *__restrict__ cent_cache_g, int cosine,
+                                                const float *__restrict__ qsq, uint32_t nq,
+                                                float *__restrict__ out, uint64_t ld) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr uint32_t KC = 1u << NBITS;
+    const uint32_t lsz = m * KC;
+    const float *lut[BQ];
+    const float *ccache = cent_cache_g;
+    if (LUT_IN_LDS) {
+        for (uint32_t i = threadIdx.x; i < lsz * BQ; i += 256) {
+            uint32_t b = i / lsz;
+            smem[i] = b < nq ? lut_g[i] : 0.0f;
+        }
+        if (cosine)
+            for (uint32_t i = threadIdx.x; i < lsz; i += 256) smem[lsz * BQ + i] = cent_cache_g[i];
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < BQ; b++) lut[b] = smem + b * lsz;
+        ccache = smem + lsz * BQ;
+    } else {
+#pragma unroll
+        for (int b = 0; b < BQ; b++) lut[b] = lut_g + (b < (int)nq ? b : 0) * uint64_t(lsz);
+    }
+    for (uint64_t row = uint64_t(blockIdx.x) * 256 + threadIdx.x; row < n; row += uint64_t(gridDim.x) * 256) {
+        const uint8_t *cr = codes + row * enc_dim;
+        float sum[BQ];
+#pragma unroll
+        for (int b = 0; b < BQ; b++) sum[b] = 0.0f;
+        float cdp = 0.0f;
+        auto push = [&](uint32_t i, uint32_t code) {
+            if (i >= m) return;  // pq_table.rs:258-260
+            uint32_t at = i * KC + code;
+#pragma unroll
+            for (int b = 0; b < BQ; b++) sum[b] = sum[b] + lut[b][at];
+            if (cosine) cdp = cdp + ccache[at];
+        };
+        if ((enc_dim & 3) == 0) {
+            const uint32_t *cw = reinterpret_cast<const uint32_t *>(cr);
+            for (uint32_t w = 0; w < enc_dim / 4; w++) {
+                uint32_t word = cw[w];
+#pragma unroll
+                for (int byte = 0; byte < 4; byte++) {
+                    uint32_t u = (word >> (8 * byte)) & 0xff;
+                    uint32_t bi = w * 4 + byte;
+                    if (NBITS == 4) {
+                        push(2 * bi, u & 0xf);  // low nibble = even group (pq_table.rs:274-280)
+                        push(2 * bi + 1, u >> 4);
+                    } else {
+                        push(bi, u);
+                    }
+                }
+            }
+        } else {
+            for (uint32_t bi = 0; bi < enc_dim; bi++) {
+                uint32_t u = cr[bi];
+                if (NBITS == 4) {
+                    push(2 * bi, u & 0xf);
+                    push(2 * bi + 1, u >> 4);
+                } else {
+                    push(bi, u);
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < BQ; b++) {
+            if (b >= (int)nq) break;
+            float d = sum[b];
+            if (cosine) {  // pq_table.rs:294-299
+                float norm0 = sqrtf(cdp);
+                float norm1 = sqrtf(qsq[b]);
+                float den = fmaxf(norm0 * norm1, 1e-10f);
+                float r = sum[b] / den;
+                d = 1.0f - r;
+            }
+            out[uint64_t(b) * ld + row] = d;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ResultSet::pq_resort (candidate_pair.rs:102-108): replay `add` over the candidates in ADC order.
+// `add` admits a pair when the set is not full, or when its DISTANCE is strictly smaller than the worst
+// distance (candidate_pair.rs:61-74) -- not the lexicographic test -- so ties at the cut keep the
+// earlier-in-ADC-order pair.  One wave per query keeps the set as a sorted register list.
+// ---------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(64) void k_pq_resort(const uint64_t *__restrict__ exact_keys, uint32_t ncand,
+                                                  uint32_t ldc, uint32_t k, uint64_t *__restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t q = blockIdx.x;
+    uint64_t v[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) v[r] = PAIR_NONE;
+    uint64_t tau = PAIR_NONE;
+    for (uint32_t j = 0; j < ncand; j++) {
+        uint64_t e = exact_keys[uint64_t(q) * ldc + j];  // wave-uniform
+        if (e == PAIR_NONE) continue;
+        if (uint32_t(e >> 32) >= uint32_t(tau >> 32)) continue;  // full and not strictly closer
+        bool placed = false;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            uint64_t cur = v[r];
+            uint64_t mask = placed ? ~0ull : __ballot(cur > e);
+            if (mask != 0) {
+                uint32_t pos = placed ? 0u : (uint32_t)__builtin_ctzll(mask);
+                uint64_t carry = __shfl(cur, 63);
+                uint64_t up = __shfl_up(cur, 1);
+                v[r] = lane < pos ? cur : (lane == pos ? e : up);
+                e = carry;
+                placed = true;
+            }
+        }
+        uint32_t p = k - 1;
+        uint64_t t = PAIR_NONE;
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if ((p >> 6) == (uint32_t)r) t = __shfl(v[r], p & 63);
+        tau = t;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) out[uint64_t(q) * (64 * R) + r * 64 + lane] = v[r];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pq_encode (pq_table.rs:66-91) + find_nearest_base (k_means.rs:40-57): per group the centroid with the
+// smallest (distance, index) under the CandidatePair order; one thread per row.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool pair_less(float da, uint32_t ia, float db, uint32_t ib) {
+    uint32_t oa = f32_orderable(da), ob = f32_orderable(db);
+    return oa != ob ? oa < ob : ia < ib;
+}
+
+__global__ __launch_bounds__(256) void k_pq_encode(const float *__restrict__ X, uint64_t n, uint32_t dim,
+                                                   const float *__restrict__ cent,
+                                                   const float *__restrict__ cent_sq,
+                                                   const uint64_t *__restrict__ gstart, uint32_t m, uint32_t kc,
+                                                   uint32_t n_bits, int cosine, uint32_t enc_dim,
+                                                   uint8_t *__restrict__ codes) {
+    uint64_t row = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (row >= n) return;
+    const float *x = X + row * dim;
+    uint8_t *dst = codes + row * enc_dim;
+    uint32_t pending = 0;
+    for (uint32_t g = 0; g < m; g++) {
+        uint32_t s = (uint32_t)gstart[g], gd = (uint32_t)gstart[g + 1] - s;
+        const float *v = x + s;
+        const float *cg = cent + uint64_t(kc) * s;
+        float vnorm = 0.0f;
+        if (cosine) {  // cosine_distance recomputes vec_norm(a) per pair (distance/mod.rs:60-64); same value every time
+            float a = 0.0f;
+            for (uint32_t j = 0; j < gd; j++) {
+                float p = v[j] * v[j];
+                a = a + p;
+            }
+            vnorm = sqrtf(a);
+        }
+        uint32_t best = 0;
+        float bd = 0.0f;
+        for (uint32_t c = 0; c < kc; c++) {
+            const float *cc = cg + uint64_t(c) * gd;
+            float acc = 0.0f;
+            float d;
+            if (cosine) {
+                for (uint32_t j = 0; j < gd; j++) {
+                    float p = v[j] * cc[j];
+                    acc = acc + p;
+                }
+                float den = fmaxf(vnorm * sqrtf(cent_sq[g * kc + c]), 1e-10f);
+                float r = acc / den;
+                d = 1.0f - r;
+            } else {
+                for (uint32_t j = 0; j < gd; j++) {
+                    float df = v[j] - cc[j];
+                    float sq = df * df;
+                    acc = acc + sq;
+                }
+                d = acc;
+            }
+            if (c == 0 || pair_less(d, c, bd, best)) {
+                bd = d;
+                best = c;
+            }
+        }
+        if (n_bits == 4) {
+            if ((g & 1) == 0) {
+                pending = best;
+                if (g == m - 1) dst[g / 2] = (uint8_t)pending;  // odd m: last byte holds one code
+            } else {
+                dst[g / 2] = (uint8_t)(pending | (best << 4));
+            }
+        } else {
+            dst[g] = (uint8_t)best;
+        }
+    }
+}
+
+// ===================================================================================================
+// host side
+// ===================================================================================================
+
+// pq_groups (pq_table.rs:38-53)
+static std::vector<uint64_t> pq_groups(uint64_t dim, uint64_t m) {
+    std::vector<uint64_t> g{0};
+    uint64_t cur = 0;
+    while (cur < dim) {
+        uint64_t rem = m - (g.size() - 1);
+        uint64_t gs = (dim - cur + rem - 1) / rem;
+        cur += gs;
+        g.push_back(cur);
+    }
+    return g;
+}
+
+static float host_dot(const float *a, const float *b, size_t n) {
+    float acc = 0.0f;
+    for (size_t i = 0; i < n; i++) {
+        float p = a[i] * b[i];
+        acc = acc + p;
+    }
+    return acc;
+}
+static float host_l2(const float *a, const float *b, size_t n) {
+    float acc = 0.0f;
+    for (size_t i = 0; i < n; i++) {
+        float df = a[i] - b[i];
+        float sq = df * df;
+        acc = acc + sq;
+    }
+    return acc;
+}
+static float host_dist(int dist, const float *a, const float *b, size_t n) {
+    if (dist == 0) return host_l2(a, b, n);
+    float na = std::sqrt(host_dot(a, a, n)), nb = std::sqrt(host_dot(b, b, n));
+    float den = std::fmax(na * nb, 1e-10f);
+    return 1.0f - host_dot(a, b, n) / den;
+}
+
+void pq_clear(Index &ix) {
+    ix.pq.present = false;
+    ix.pq.d_codes.release();
+}
+
+static void pq_install(Index &ix, uint64_t n_bits, uint64_t m, const float *centroids) {
+    VDB_REQUIRE(n_bits == 4 || n_bits == 8, "n_bits must be 4 or 8 in PQTable.");  // pq_table.rs:142-145
+    VDB_REQUIRE(m > 0 && m <= ix.dim, "m must be in 1..=dim");
+    PQState &pq = ix.pq;
+    pq.present = false;
+    pq.n_bits = n_bits;
+    pq.m = m;
+    pq.kc = 1ull << n_bits;
+    pq.enc_dim = n_bits == 4 ? (m + 1) / 2 : m;
+    pq.gstart = pq_groups(ix.dim, m);
+    VDB_REQUIRE(pq.gstart.size() == m + 1, "pq_groups produced fewer groups than m");
+    pq.h_centroids.assign(centroids, centroids + pq.kc * ix.dim);
+    pq.h_cent_cache.assign(m * pq.kc, 0.0f);
+    // dot(c,c) is needed by the cosine ADC (pq_table.rs:160-165) and by the cosine encoder
+    for (uint64_t g = 0; g < m; g++) {
+        uint64_t s = pq.gstart[g], gd = pq.gstart[g + 1] - s;
+        for (uint64_t c = 0; c < pq.kc; c++) {
+            const float *cc = pq.h_centroids.data() + pq.kc * s + c * gd;
+            pq.h_cent_cache[g * pq.kc + c] = host_dot(cc, cc, gd);
+        }
+    }
+    ix.use_device();
+    pq.d_centroids.reserve(pq.h_centroids.size() * sizeof(float));
+    pq.d_cent_cache.reserve(pq.h_cent_cache.size() * sizeof(float));
+    pq.d_gstart.reserve(pq.gstart.size() * sizeof(uint64_t));
+    VDB_HIP(hipMemcpy(pq.d_centroids.p, pq.h_centroids.data(), pq.h_centroids.size() * sizeof(float), hipMemcpyHostToDevice));
+    VDB_HIP(hipMemcpy(pq.d_cent_cache.p, pq.h_cent_cache.data(), pq.h_cent_cache.size() * sizeof(float), hipMemcpyHostToDevice));
+    VDB_HIP(hipMemcpy(pq.d_gstart.p, pq.gstart.data(), pq.gstart.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    pq.d_codes.reserve(std::max<uint64_t>(ix.n, 1) * pq.enc_dim);
+}
+
+static void pq_encode_all(Index &ix) {
+    PQState &pq = ix.pq;
+    if (ix.n == 0) return;
+    WsLease ws(ix);
+    hipLaunchKernelGGL(k_pq_encode, dim3((unsigned)((ix.n + 255) / 256)), dim3(256), 0, ws->stream,
+                       ix.d_rows.as<float>(), ix.n, (uint32_t)ix.dim, pq.d_centroids.as<float>(),
+                       pq.d_cent_cache.as<float>(), pq.d_gstart.as<uint64_t>(), (uint32_t)pq.m, (uint32_t)pq.kc,
+                       (uint32_t)pq.n_bits, ix.dist == 1 ? 1 : 0, (uint32_t)pq.enc_dim, pq.d_codes.as<uint8_t>());
+    VDB_HIP(hipStreamSynchronize(ws->stream));
+}
+
+void pq_attach(Index &ix, uint64_t n_bits, uint64_t m, const float *centroids, const uint8_t *codes) {
+    pq_install(ix, n_bits, m, centroids);
+    if (codes) {
+        if (ix.n) VDB_HIP(hipMemcpy(ix.pq.d_codes.p, codes, ix.n * ix.pq.enc_dim, hipMemcpyHostToDevice));
+    } else {
+        pq_encode_all(ix);
+    }
+    ix.pq.present = true;
+}
+
+// ---- k-means (k_means.rs:61-162), host side, one RNG stream per group so groups can run in parallel ----
+static uint64_t splitmix64(uint64_t &s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static float uniform01(uint64_t &s) { return (float(uint32_t(splitmix64(s) >> 40)) + 0.5f) * (1.0f / 16777216.0f); }
+
+static size_t nearest_centroid(const float *v, const float *cents, size_t k, size_t gd, int dist) {
+    size_t best = 0;
+    float bd = 0;
+    for (size_t c = 0; c < k; c++) {
+        float d = host_dist(dist, v, cents + c * gd, gd);
+        uint32_t od = f32_orderable(d), ob = f32_orderable(bd);
+        if (c == 0 || od < ob) {  // equal distance keeps the smaller index
+            bd = d;
+            best = c;
+        }
+    }
+    return best;
+}
+
+static void kmeans_group(const float *train, size_t nt, size_t dim, size_t c0, size_t c1, size_t k, size_t max_iter,
+                         float tol, int dist, uint64_t seed, float *cent) {
+    size_t gd = c1 - c0;
+    std::vector<float> sel(nt * gd);
+    for (size_t i = 0; i < nt; i++) std::memcpy(&sel[i * gd], train + i * dim + c0, gd * sizeof(float));
+    uint64_t rng = seed;
+    // k-means++ seeding (k_means.rs:61-87): weights are running-min distances
+    size_t first = splitmix64(rng) % nt;
+    std::memcpy(cent, &sel[first * gd], gd * sizeof(float));
+    std::vector<float> w(nt, INFINITY);
+    for (size_t idx = 1; idx < k; idx++) {
+        const float *prev = cent + (idx - 1) * gd;
+        bool bad = false;
+        float total = 0;
+        for (size_t i = 0; i < nt; i++) {
+            float d = host_dist(dist, prev, &sel[i * gd], gd);
+            if (std::isnan(w[i]))
+                w[i] = d;
+            else if (!std::isnan(d) && d < w[i])
+                w[i] = d;
+            if (!(w[i] >= 0.0f) || std::isinf(w[i])) bad = true;
+            total += w[i];
+        }
+        size_t c;
+        if (bad || !(total > 0.0f) || std::isinf(total)) {
+            c = splitmix64(rng) % nt;  // WeightedIndex error -> uniform (k_means.rs:80-82)
+        } else {
+            float u = uniform01(rng) * total, cum = 0;
+            c = nt - 1;
+            for (size_t i = 0; i < nt; i++) {
+                cum += w[i];
+                if (cum > u) {
+                    c = i;
+                    break;
+                }
+            }
+        }
+        std::memcpy(cent + idx * gd, &sel[c * gd], gd * sizeof(float));
+    }
+    // Lloyd (k_means.rs:95-162)
+    std::vector<float> sums(k * gd);
+    std::vector<size_t> cnt(k);
+    for (size_t it = 0; it < max_iter; it++) {
+        std::fill(sums.begin(), sums.end(), 0.0f);
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (size_t i = 0; i < nt; i++) {
+            size_t c = nearest_centroid(&sel[i * gd], cent, k, gd, dist);
+            cnt[c]++;
+            for (size_t j = 0; j < gd; j++) sums[c * gd + j] += sel[i * gd + j];
+        }
+        float max_diff = -INFINITY;
+        for (size_t c = 0; c < k; c++) {
+            if (cnt[c] == 0)
+                std::memcpy(&sums[c * gd], cent + c * gd, gd * sizeof(float));
+            else
+                for (size_t j = 0; j < gd; j++) sums[c * gd + j] /= float(cnt[c]);
+            float d = host_l2(cent + c * gd, &sums[c * gd], gd);
+            if (!std::isnan(d) && d > max_diff) max_diff = d;
+        }
+        std::memcpy(cent, sums.data(), k * gd * sizeof(float));
+        if (max_diff < tol) break;
+    }
+}
+
+// PQTable::from_vec_set (pq_table.rs:141-191): sample, per-group k-means on the host, encode on the GPU
+void pq_build(Index &ix, uint64_t n_bits, uint64_t m, uint64_t train_n, uint64_t max_iter, float tol,
+              uint64_t seed) {
+    VDB_REQUIRE(n_bits == 4 || n_bits == 8, "n_bits must be 4 or 8 in PQTable.");
+    VDB_REQUIRE(m > 0 && m <= ix.dim, "m must be in 1..=dim");
+    VDB_REQUIRE(ix.n > 0, "Cannot build PQ table for an empty table");  // metadata_vec_table.rs:120-122
+    const float *rows = ix.host_rows();
+    size_t n = ix.n, dim = ix.dim, kc = 1ull << n_bits;
+    std::vector<float> sample;
+    const float *train = rows;
+    size_t nt = n;
+    uint64_t rng = seed;
+    if (train_n && train_n < n) {  // VecSet::random_sample (vec_set.rs:154-163)
+        std::vector<size_t> perm(n);
+        for (size_t i = 0; i < n; i++) perm[i] = i;
+        sample.resize(train_n * dim);
+        for (size_t i = 0; i < train_n; i++) {
+            size_t j = i + splitmix64(rng) % (n - i);
+            std::swap(perm[i], perm[j]);
+            std::memcpy(&sample[i * dim], rows + perm[i] * dim, dim * sizeof(float));
+        }
+        train = sample.data();
+        nt = train_n;
+    }
+    auto gs = pq_groups(dim, m);
+    std::vector<float> cent(kc * dim);
+    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    unsigned nth = (unsigned)std::min<uint64_t>(hw, m);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nth; t++)
+        th.emplace_back([&, t]() {
+            for (uint64_t g = t; g < m; g += nth) {
+                uint64_t gseed = seed ^ (0xD1B54A32D192ED03ull * (g + 1));
+                kmeans_group(train, nt, dim, gs[g], gs[g + 1], kc, max_iter, tol, ix.dist, gseed,
+                             cent.data() + kc * gs[g]);
+            }
+        });
+    for (auto &t : th) t.join();
+    pq_install(ix, n_bits, m, cent.data());
+    pq_encode_all(ix);
+    ix.pq.present = true;
+}
+
+// ---- FlatIndex::knn_pq (flat_index.rs:84-104) --------------------------------------------------------
+template <int BQ, int NBITS>
+static void adc_launch(Index &ix, Workspace &ws, const float *lut, const float *qsq, uint32_t nb, float *out,
+                       uint64_t ld) {
+    PQState &pq = ix.pq;
+    size_t lsz = pq.m * pq.kc * sizeof(float);
+    size_t need = lsz * BQ + (ix.dist == 1 ? lsz : 0);
+    bool in_lds = need <= 150 * 1024;
+    uint32_t grid = (uint32_t)std::min<uint64_t>((ix.n + 255) / 256, uint64_t(ix.num_cu) * 8);
+    int cosine = ix.dist == 1 ? 1 : 0;
+    if (in_lds) {
+        static bool attr = false;
+        if (!attr) {
+            VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pq_adc<BQ, NBITS, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr = true;
+        }
+        hipLaunchKernelGGL((k_pq_adc<BQ, NBITS, true>), dim3(grid), dim3(256), need, ws.stream,
+                           pq.d_codes.as<uint8_t>(), ix.n, (uint32_t)pq.enc_dim, (uint32_t)pq.m, lut,
+                           pq.d_cent_cache.as<float>(), cosine, qsq, nb, out, ld);
+    } else {
+        hipLaunchKernelGGL((k_pq_adc<BQ, NBITS, false>), dim3(grid), dim3(256), 0, ws.stream,
+                           pq.d_codes.as<uint8_t>(), ix.n, (uint32_t)pq.enc_dim, (uint32_t)pq.m, lut,
+                           pq.d_cent_cache.as<float>(), cosine, qsq, nb, out, ld);
+    }
+}
+
+void pq_make_luts(Index &ix, Workspace &ws, const float *d_q, uint64_t nq) {
+    PQState &pq = ix.pq;
+    uint32_t lsz = (uint32_t)(pq.m * pq.kc);
+    ws.lut.reserve(nq * lsz * sizeof(float));
+    hipLaunchKernelGGL(k_pq_lut, dim3((lsz + 255) / 256, (unsigned)nq), dim3(256), 0, ws.stream, d_q,
+                       (uint32_t)ix.dim, pq.d_centroids.as<float>(), pq.d_gstart.as<uint64_t>(), (uint32_t)pq.m,
+                       (uint32_t)pq.kc, ix.dist == 1 ? 1 : 0, ws.lut.as<float>());
+}
+
+void pq_resort_launch(const uint64_t *exact_keys, uint32_t ncand, uint32_t ldc, uint32_t nq, uint32_t k,
+                      uint64_t *out, hipStream_t s) {
+    uint32_t cap = topk_capacity(k);
+    switch (cap / 64) {
+        case 1: hipLaunchKernelGGL((k_pq_resort<1>), dim3(nq), dim3(64), 0, s, exact_keys, ncand, ldc, k, out); break;
+        case 2: hipLaunchKernelGGL((k_pq_resort<2>), dim3(nq), dim3(64), 0, s, exact_keys, ncand, ldc, k, out); break;
+        case 4: hipLaunchKernelGGL((k_pq_resort<4>), dim3(nq), dim3(64), 0, s, exact_keys, ncand, ldc, k, out); break;
+        case 8: hipLaunchKernelGGL((k_pq_resort<8>), dim3(nq), dim3(64), 0, s, exact_keys, ncand, ldc, k, out); break;
+        case 16: hipLaunchKernelGGL((k_pq_resort<16>), dim3(nq), dim3(64), 0, s, exact_keys, ncand, ldc, k, out); break;
+        default: throw Error(1, "pq_resort: k must be <= 1024");
+    }
+}
+
+void flat_knn_pq_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef,
+                        uint64_t *d_idx, float *d_dist, uint64_t *d_cnt) {
+    hipStream_t s = ws.stream;
+    PQState &pq = ix.pq;
+    if (nq == 0) return;
+    if (k == 0 || ix.n == 0) {
+        VDB_HIP(hipMemsetAsync(d_cnt, 0, nq * sizeof(uint64_t), s));
+        return;
+    }
+    const uint64_t n = ix.n;
+    const uint64_t efk64 = std::min<uint64_t>(std::max(ef, k), n);  // ResultSet::new(ef.max(k)) flat_index.rs:96
+    const uint64_t ksel64 = std::min<uint64_t>(k, n);
+    VDB_REQUIRE(efk64 <= 1024, "knn_pq: min(max(ef, k), len) must be <= 1024 in this build");
+    const uint32_t efk = (uint32_t)efk64, ksel = (uint32_t)ksel64;
+    if (k > ksel) {
+        VDB_HIP(hipMemsetAsync(d_idx, 0, nq * k * sizeof(uint64_t), s));
+        VDB_HIP(hipMemsetAsync(d_dist, 0, nq * k * sizeof(float), s));
+    }
+    ws.qsq.reserve(nq * sizeof(float));
+    launch_row_sqnorm(d_q, nq, (uint32_t)ix.dim, ws.qsq.as<float>(), s);
+    pq_make_luts(ix, ws, d_q, nq);
+
+    const uint64_t ld = (n + 63) & ~63ull;
+    const uint32_t nl = topk_num_lists(n);
+    const uint32_t cape = topk_capacity(efk), capk = topk_capacity(ksel);
+    const uint32_t lsz = (uint32_t)(pq.m * pq.kc);
+    // queries per pass: as many lookup tables as fit beside each other in LDS (<= 4)
+    size_t lbytes = size_t(lsz) * sizeof(float);
+    uint32_t BQ = lbytes * 4 + (ix.dist == 1 ? lbytes : 0) <= 150 * 1024 ? 4 : (lbytes * 2 + (ix.dist == 1 ? lbytes : 0) <= 150 * 1024 ? 2 : 1);
+    ws.dense.reserve(size_t(4) * ld * sizeof(float));
+    ws.lists.reserve(size_t(4) * nl * cape * sizeof(uint64_t));
+    ws.keys_a.reserve(nq * cape * sizeof(uint64_t));
+    ws.keys_b.reserve(nq * cape * sizeof(uint64_t));
+    ws.keys_c.reserve(nq * capk * sizeof(uint64_t));
+    for (uint64_t q0 = 0; q0 < nq; q0 += BQ) {
+        uint32_t nb = (uint32_t)std::min<uint64_t>(BQ, nq - q0);
+        const float *lut = ws.lut.as<float>() + q0 * lsz;
+        const float *qs = ws.qsq.as<float>() + q0;
+        ix.prof_begin(ws, "pq_adc", double(n) * pq.enc_dim);
+        if (pq.n_bits == 4) {
+            if (BQ == 4) adc_launch<4, 4>(ix, ws, lut, qs, nb, ws.dense.as<float>(), ld);
+            else if (BQ == 2) adc_launch<2, 4>(ix, ws, lut, qs, nb, ws.dense.as<float>(), ld);
+            else adc_launch<1, 4>(ix, ws, lut, qs, nb, ws.dense.as<float>(), ld);
+        } else {
+            if (BQ == 4) adc_launch<4, 8>(ix, ws, lut, qs, nb, ws.dense.as<float>(), ld);
+            else if (BQ == 2) adc_launch<2, 8>(ix, ws, lut, qs, nb, ws.dense.as<float>(), ld);
+            else adc_launch<1, 8>(ix, ws, lut, qs, nb, ws.dense.as<float>(), ld);
+        }
+        ix.prof_end(ws);
+        launch_topk_dense(ws.dense.as<float>(), ld, n, nb, efk, ws.lists.as<uint64_t>(), s);
+        launch_topk_merge(ws.lists.as<uint64_t>(), nl, cape, nb, efk, ws.keys_a.as<uint64_t>() + q0 * cape, s);
+    }
+    // exact distances of the ADC shortlist in ADC order, then the reference's re-sort
+    VDB_HIP(hipMemsetAsync(ws.keys_b.p, 0xff, nq * cape * sizeof(uint64_t), s));
+    launch_rerank(ix.d_rows.as<float>(), (uint32_t)ix.dim, d_q, (uint32_t)nq, ix.dist == 0 ? MET_L2_DIRECT : MET_COSINE,
+                  ix.d_sq.as<float>(), ws.qsq.as<float>(), ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), efk,
+                  cape, s);
+    pq_resort_launch(ws.keys_b.as<uint64_t>(), efk, cape, (uint32_t)nq, ksel, ws.keys_c.as<uint64_t>(), s);
+    launch_finalize(ws.keys_c.as<uint64_t>(), capk, (uint32_t)nq, ksel, (uint32_t)k, ix.id_offset, d_idx, d_dist,
+                    d_cnt, s);
+}
+
+}  // namespace vdb

@@ -2,10 +2,6 @@
 #include "pq_hnsw.hpp"
 namespace vdb {
 #define NI throw Error(3, "not implemented yet")
-void pq_attach(Index &, uint64_t, uint64_t, const float *, const uint8_t *) { NI; }
-void pq_build(Index &, uint64_t, uint64_t, uint64_t, uint64_t, float, uint64_t) { NI; }
-void pq_clear(Index &ix) { ix.pq.present = false; }
-void flat_knn_pq_device(Index &, Workspace &, const float *, uint64_t, uint64_t, uint64_t, uint64_t *, float *, uint64_t *) { NI; }
 void hnsw_build(Index &, uint64_t, uint64_t, uint64_t, uint64_t, int) { NI; }
 void hnsw_attach(Index &, uint64_t, uint64_t, const uint32_t *, const uint64_t *, const uint64_t *, const uint32_t *, const uint64_t *, int, uint64_t, uint64_t) { NI; }
 void hnsw_clear(Index &ix) { ix.hnsw.present = false; }

@@ -1,0 +1,115 @@
+"""GPU parity: PQ encode, ADC scan and FlatIndex::knn_pq through the C ABI vs the CPU oracle.
+
+Integer work (codes, neighbour indices) must be bit-exact; the returned distances are the exact
+re-sorted ones (flat_index.rs:102) and are asserted bit-exact as well.  Centroids are RNG-dependent in
+the reference (parity unpinned), so they are an INPUT: trained once by the library and handed to the oracle.
+"""
+import numpy as np
+import pytest
+
+from conftest import gist_like
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import lab_1806_vec_db_amd as vdb
+    from oracle import oracle as O
+    return vdb, O
+
+
+def _oracle_pq(O, ix, base, kind):
+    pq = ix.pq_export()
+    opq = O.PQ.from_centroids(ix.dim, pq["m"], pq["n_bits"], kind, pq["centroids"])
+    opq.encode_all(base)
+    return pq, opq
+
+
+@pytest.mark.parametrize("dist,kind", [("l2sqr", 0), ("cosine", 1)])
+@pytest.mark.parametrize("n_bits,m", [(4, 320), (4, 240), (8, 96), (8, 320)])
+def test_gist1000_knn_pq(mods, gist_base, gist_test, dist, kind, n_bits, m):
+    vdb, O = mods
+    ix = vdb.GpuIndex(960, dist)
+    ix.batch_add(gist_base)
+    ix.pq_build(n_bits=n_bits, m=m, train_n=300, max_iter=5, seed=3)
+    assert ix.has_pq()
+    pq, opq = _oracle_pq(O, ix, gist_base, kind)
+    assert np.array_equal(pq["codes"], opq.codes), "GPU pq_encode differs from the oracle"
+    for ef in (10, 100, 200):
+        idx, d, cnt = ix.knn_pq(gist_test[:24], 10, ef)
+        for q in range(24):
+            oi, od = O.flat_knn_pq(gist_base, opq, gist_test[q], 10, ef, kind)
+            assert idx[q].tolist() == oi.tolist(), (ef, q)
+            assert np.array_equal(d[q], od), (ef, q)
+    ix.pq_clear()
+    assert not ix.has_pq()
+    with pytest.raises(vdb.VdbError):
+        ix.knn_pq(gist_test[0], 10, 100)
+
+
+@pytest.mark.parametrize("dist,kind", [("l2sqr", 0), ("cosine", 1)])
+def test_small_odd_m_and_n_lt_k(mods, dist, kind):
+    """pq_table.rs:324-372 setting (5 vectors, dim 8, m 2, 16 centroids > 5 points) and an odd m."""
+    vdb, O = mods
+    rng = np.random.default_rng(42)
+    for dim, m, n in ((8, 2, 5), (13, 7, 64), (13, 5, 64)):
+        base = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+        ix = vdb.GpuIndex(dim, dist)
+        ix.batch_add(base)
+        ix.pq_build(n_bits=4, m=m, train_n=0, seed=42)
+        pq, opq = _oracle_pq(O, ix, base, kind)
+        assert np.array_equal(pq["codes"], opq.codes)
+        for q in range(n if n < 8 else 8):
+            for k, ef in ((3, 3), (n, n), (2, 50)):
+                gi, gd = ix.knn_pq(base[q], k, ef)
+                oi, od = O.flat_knn_pq(base, opq, base[q], k, ef, kind)
+                assert gi.tolist() == oi.tolist(), (dim, m, q, k, ef)
+                assert np.array_equal(gd, od)
+
+
+def test_attach_external_codes(mods, gist_base, gist_test):
+    """vdb_pq_attach with centroids AND codes supplied (reference-built tables)."""
+    vdb, O = mods
+    opq = O.PQ.train(gist_base, 320, 4, 0, k_means_size=200, max_iter=3, seed=9)
+    ix = vdb.GpuIndex(960, "l2sqr")
+    ix.batch_add(gist_base)
+    ix.pq_attach(4, 320, opq.centroids, opq.codes)
+    idx, d, cnt = ix.knn_pq(gist_test[:16], 10, 128)
+    for q in range(16):
+        oi, od = O.flat_knn_pq(gist_base, opq, gist_test[q], 10, 128)
+        assert idx[q].tolist() == oi.tolist() and np.array_equal(d[q], od)
+
+
+def test_pq_resort_ties(mods):
+    """Duplicated rows give exact-distance ties at the cut; pq_resort keeps the earlier-in-ADC-order pair
+    (candidate_pair.rs:61-74,102-108), which is NOT the lexicographic rule."""
+    vdb, O = mods
+    rng = np.random.default_rng(5)
+    uniq = rng.standard_normal((40, 24)).astype(np.float32)
+    base = np.concatenate([uniq, uniq, uniq])[rng.permutation(120)]
+    ix = vdb.GpuIndex(24, "l2sqr")
+    ix.batch_add(base)
+    ix.pq_build(n_bits=4, m=8, train_n=0, max_iter=4, seed=1)
+    pq, opq = _oracle_pq(O, ix, base, 0)
+    for q in range(10):
+        for k, ef in ((4, 30), (5, 7), (7, 120)):
+            gi, gd = ix.knn_pq(uniq[q] + 0.05, k, ef)
+            oi, od = O.flat_knn_pq(base, opq, uniq[q] + 0.05, k, ef)
+            assert gi.tolist() == oi.tolist(), (q, k, ef)
+            assert np.array_equal(gd, od)
+
+
+def test_gistlike_knn_pq_large(mods):
+    vdb, O = mods
+    base = gist_like(30000, seed=1806)
+    qs = gist_like(12, seed=1807)
+    ix = vdb.GpuIndex(960, "l2sqr")
+    ix.batch_add(base)
+    ix.pq_build(n_bits=4, m=320, train_n=1000, max_iter=5, seed=42)
+    pq, opq = _oracle_pq(O, ix, base, 0)
+    assert np.array_equal(pq["codes"], opq.codes)
+    idx, d, cnt = ix.knn_pq(qs, 10, 128)
+    for q in range(qs.shape[0]):
+        oi, od = O.flat_knn_pq(base, opq, qs[q], 10, 128)
+        assert idx[q].tolist() == oi.tolist() and np.array_equal(d[q], od)
