@@ -1,0 +1,890 @@
+// hnsw.hip -- HNSW on gfx950: host-side graph builder (the reference builds on the CPU too) and the
+// GPU search kernel.  Reference: src/index_algorithm/hnsw_index.rs.
+//
+// Search (knn_with_ef :619-634, knn_pq :672-697) must replay the reference's data-dependent walk
+// exactly, because the visit order decides which nodes are ever scored:
+//   * distances are the reference's values bit for bit: cached form (cache[idx] + qcache) - 2*dot(row, q)
+//     with dot a strict left fold (distance/mod.rs:54-57, hnsw_index.rs:351-355), or the ADC sum;
+//   * greedy descent (:306-330): one sweep scores every link of the current node in stored order and
+//     moves to each strictly closer one in turn;
+//   * level 0 (:258-291): pop the smallest unexpanded pair; stop when it is not `< worst` under the full
+//     (distance, index) order (check_candidate, candidate_pair.rs:55-57); score unvisited links in stored
+//     order; ResultSet::add admits on strictly smaller DISTANCE (candidate_pair.rs:61-74).
+// One 64-lane wave owns one query: the result set is a sorted register list (as in k_topk.hip), the
+// candidate queue is an unsorted LDS pool with a wave-parallel min scan (only pairs that pass
+// check_candidate when they are found are kept: a pair that fails it then can never pass it later, because
+// the worst result only improves, so the walk is unchanged), the visited set is a per-query bitmap in HBM
+// updated with atomicOr, and one lane scores one neighbour.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+#include "pq_hnsw.hpp"
+
+#pragma clang fp contract(off)
+
+namespace vdb {
+
+// ===================================================================================================
+// device side
+// ===================================================================================================
+
+struct HnswDev {
+    const float *rows;
+    const float *xsq;  // dot(x,x) per row
+    const uint32_t *level0;
+    const uint32_t *len0;
+    const uint32_t *upper;
+    const uint32_t *upper_len;
+    const uint64_t *upper_off;
+    uint64_t n;
+    uint32_t dim, m, max_m0;
+    uint32_t enter_point, enter_level;
+    int cosine;
+    // PQ (ADC walk)
+    const uint8_t *codes;
+    const float *cent_cache;
+    uint32_t enc_dim, pq_m, pq_kc, n_bits;
+};
+
+constexpr uint32_t HNSW_POOL = 2048;  // candidate pool entries per query (LDS)
+
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint64_t o = __shfl_xor(v, off);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// exact cached-form distance of row idx to the query held in LDS (strict left fold over the dimension)
+__device__ __forceinline__ float hnsw_exact_dist(const HnswDev &g, const float *qlds, float qsq, uint32_t idx) {
+    const float *x = g.rows + uint64_t(idx) * g.dim;
+    float acc = 0.0f;
+    if ((g.dim & 3) == 0) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        const float4 *q4 = reinterpret_cast<const float4 *>(qlds);
+#pragma unroll 8
+        for (uint32_t t = 0; t < g.dim / 4; t++) {
+            float4 v = x4[t];
+            float4 q = q4[t];
+            float p;
+            p = v.x * q.x; acc = acc + p;
+            p = v.y * q.y; acc = acc + p;
+            p = v.z * q.z; acc = acc + p;
+            p = v.w * q.w; acc = acc + p;
+        }
+    } else {
+        for (uint32_t t = 0; t < g.dim; t++) {
+            float p = x[t] * qlds[t];
+            acc = acc + p;
+        }
+    }
+    float xs = g.xsq[idx];
+    if (g.cosine) {  // cosine_distance_cached with norms sqrt(dot) (distance/mod.rs:66-69, :31-36)
+        float den = fmaxf(sqrtf(xs) * sqrtf(qsq), 1e-10f);
+        float r = acc / den;
+        return 1.0f - r;
+    }
+    float s = xs + qsq;
+    float t2 = 2.0f * acc;
+    return s - t2;
+}
+
+// ADC distance of code row idx (pq_table.rs:239-301); lut in LDS or global
+__device__ __forceinline__ float hnsw_adc_dist(const HnswDev &g, const float *lut, float qsq, uint32_t idx) {
+    const uint8_t *cr = g.codes + uint64_t(idx) * g.enc_dim;
+    float sum = 0.0f, cdp = 0.0f;
+    const uint32_t kc = g.pq_kc, m = g.pq_m;
+    for (uint32_t b = 0; b < g.enc_dim; b++) {
+        uint32_t u = cr[b];
+        if (g.n_bits == 4) {
+            uint32_t i = 2 * b;
+            if (i < m) {
+                sum = sum + lut[i * kc + (u & 0xf)];
+                if (g.cosine) cdp = cdp + g.cent_cache[i * kc + (u & 0xf)];
+            }
+            i++;
+            if (i < m) {
+                sum = sum + lut[i * kc + (u >> 4)];
+                if (g.cosine) cdp = cdp + g.cent_cache[i * kc + (u >> 4)];
+            }
+        } else {
+            sum = sum + lut[b * kc + u];
+            if (g.cosine) cdp = cdp + g.cent_cache[b * kc + u];
+        }
+    }
+    if (!g.cosine) return sum;
+    float den = fmaxf(sqrtf(cdp) * sqrtf(qsq), 1e-10f);
+    float r = sum / den;
+    return 1.0f - r;
+}
+
+template <int R, bool ADC>
+__global__ __launch_bounds__(64) void k_hnsw_search(HnswDev g, const float *__restrict__ Q,
+                                                    const float *__restrict__ qsq_all,
+                                                    const float *__restrict__ lut_all, uint32_t lut_in_lds,
+                                                    uint32_t ef, uint32_t *__restrict__ visited,
+                                                    uint64_t visited_words, uint64_t *__restrict__ out /*[nq][64R]*/,
+                                                    unsigned long long *__restrict__ stats /*[2]*/,
+                                                    uint32_t *__restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint64_t *pool = reinterpret_cast<uint64_t *>(smem_raw);
+    float *fl = reinterpret_cast<float *>(smem_raw + HNSW_POOL * sizeof(uint64_t));
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t q = blockIdx.x;
+    const float qsq = qsq_all[q];
+    uint32_t *vis = visited + uint64_t(q) * visited_words;
+
+    const float *lut = nullptr;
+    if (ADC) {
+        const float *lg = lut_all + uint64_t(q) * g.pq_m * g.pq_kc;
+        if (lut_in_lds) {
+            for (uint32_t i = lane; i < g.pq_m * g.pq_kc; i += 64) fl[i] = lg[i];
+            lut = fl;
+        } else {
+            lut = lg;
+        }
+    } else {
+        for (uint32_t i = lane; i < g.dim; i += 64) fl[i] = Q[uint64_t(q) * g.dim + i];
+    }
+    __syncthreads();
+
+    auto dist_of = [&](uint32_t idx) -> float {
+        return ADC ? hnsw_adc_dist(g, lut, qsq, idx) : hnsw_exact_dist(g, fl, qsq, idx);
+    };
+
+    unsigned long long n_dist = 0, n_exp = 0;
+
+    // ---- greedy descent, levels enter_level .. 1 (hnsw_index.rs:306-350) ---------------------------
+    uint32_t cur = g.enter_point;
+    float cur_d = 0.0f;
+    {
+        float d = 0.0f;
+        if (lane == 0) d = dist_of(cur);
+        cur_d = __shfl(d, 0);
+        n_dist++;
+    }
+    for (uint32_t level = g.enter_level; level >= 1; level--) {
+        n_dist++;  // the reference re-scores the current node at the start of every level (:313)
+        for (;;) {
+            uint64_t slot = g.upper_off[cur] + level - 1;
+            uint32_t len = g.upper_len[slot];
+            const uint32_t *lk = g.upper + slot * g.m;
+            bool moved = false;
+            for (uint32_t base = 0; base < len; base += 64) {  // m <= 64 in practice; loop keeps it general
+                uint32_t j = base + lane;
+                uint32_t nb = j < len ? lk[j] : 0;
+                float d = 0.0f;
+                if (j < len) d = dist_of(nb);
+                uint32_t cnt = len - base < 64 ? len - base : 64;
+                n_dist += cnt;
+                for (uint32_t t = 0; t < cnt; t++) {  // stored order, strict improvement
+                    float dt = __shfl(d, t);
+                    uint32_t nt = __shfl(nb, t);
+                    if (dt < cur_d) {
+                        cur_d = dt;
+                        cur = nt;
+                        moved = true;
+                    }
+                }
+            }
+            if (!moved) break;
+        }
+    }
+
+    // ---- level 0 best-first search (hnsw_index.rs:258-291) -----------------------------------------
+    uint64_t rv[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) rv[r] = PAIR_NONE;
+    uint64_t tau = PAIR_NONE;  // pair at position ef-1 (NONE until the set is full)
+    auto rs_insert = [&](uint64_t e) {
+        bool placed = false;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            uint64_t c = rv[r];
+            uint64_t mask = placed ? ~0ull : __ballot(c > e);
+            if (mask != 0) {
+                uint32_t pos = placed ? 0u : (uint32_t)__builtin_ctzll(mask);
+                uint64_t carry = __shfl(c, 63);
+                uint64_t up = __shfl_up(c, 1);
+                rv[r] = lane < pos ? c : (lane == pos ? e : up);
+                e = carry;
+                placed = true;
+            }
+        }
+        uint32_t p = ef - 1;
+        uint64_t t = PAIR_NONE;
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if ((p >> 6) == (uint32_t)r) t = __shfl(rv[r], p & 63);
+        tau = t;
+    };
+    uint32_t pool_n = 0;
+    bool overflow = false;
+    auto pool_push = [&](uint64_t e) {
+        if (pool_n == HNSW_POOL) {
+            // drop pairs that can no longer be expanded (>= worst); they would only ever end the walk
+            uint32_t kept = 0;
+            for (uint32_t base = 0; base < pool_n; base += 64) {
+                uint32_t i = base + lane;
+                uint64_t v = i < pool_n ? pool[i] : PAIR_NONE;
+                bool live = v < tau;
+                uint64_t mask = __ballot(live);
+                uint32_t before = __builtin_popcountll(mask & ((1ull << lane) - 1));
+                __builtin_amdgcn_wave_barrier();
+                if (live) pool[kept + before] = v;  // kept + before <= i: never overwrites unread entries
+                __builtin_amdgcn_wave_barrier();
+                kept += __builtin_popcountll(mask);
+            }
+            pool_n = kept;
+            if (pool_n == HNSW_POOL) {
+                overflow = true;
+                return;
+            }
+        }
+        if (lane == 0) pool[pool_n] = e;
+        pool_n++;
+    };
+
+    {
+        if (lane == 0) atomicOr(&vis[cur >> 5], 1u << (cur & 31));
+        uint64_t e = pair_key(cur_d, cur);
+        rs_insert(e);
+        pool_push(e);
+    }
+    while (pool_n > 0 && !overflow) {
+        __builtin_amdgcn_wave_barrier();
+        // pop_first: smallest pair in the pool
+        uint64_t best = PAIR_NONE;
+        for (uint32_t i = lane; i < pool_n; i += 64) {
+            uint64_t v = pool[i];
+            best = v < best ? v : best;
+        }
+        best = wave_min_u64(best);
+        if (!(best < tau)) break;  // check_candidate: size < ef (tau == NONE) or pair < worst
+        // remove it (pairs are unique)
+        for (uint32_t base = 0; base < pool_n; base += 64) {
+            uint32_t i = base + lane;
+            bool hit = i < pool_n && pool[i] == best;
+            uint64_t mask = __ballot(hit);
+            if (mask) {
+                uint64_t lastv = pool[pool_n - 1];
+                __builtin_amdgcn_wave_barrier();
+                if (hit) pool[i] = lastv;
+                break;
+            }
+        }
+        pool_n--;
+        n_exp++;
+        const uint32_t p = uint32_t(best);
+        const uint32_t len = g.len0[p];
+        const uint32_t *lk = g.level0 + uint64_t(p) * g.max_m0;
+        for (uint32_t base = 0; base < len && !overflow; base += 64) {
+            uint32_t j = base + lane;
+            uint32_t nb = 0;
+            bool fresh = false;
+            if (j < len) {
+                nb = lk[j];
+                uint32_t bit = 1u << (nb & 31);
+                uint32_t old = atomicOr(&vis[nb >> 5], bit);
+                fresh = (old & bit) == 0;
+            }
+            float d = 0.0f;
+            if (fresh) d = dist_of(nb);
+            uint64_t fm = __ballot(fresh);
+            n_dist += __builtin_popcountll(fm);
+            while (fm) {  // stored order
+                uint32_t t = (uint32_t)__builtin_ctzll(fm);
+                fm &= fm - 1;
+                uint64_t e = pair_key(__shfl(d, t), __shfl(nb, t));
+                bool cand = e < tau;                                  // check_candidate before the add
+                bool admit = uint32_t(e >> 32) < uint32_t(tau >> 32);  // ResultSet::add: strictly closer or not full
+                if (admit) rs_insert(e);
+                if (cand) pool_push(e);
+            }
+        }
+    }
+    if (overflow && lane == 0) atomicOr(err, 1u);
+#pragma unroll
+    for (int r = 0; r < R; r++) out[uint64_t(q) * (64 * R) + r * 64 + lane] = rv[r];
+    if (lane == 0) {
+        atomicAdd(&stats[0], n_dist);
+        atomicAdd(&stats[1], n_exp);
+    }
+}
+
+// ===================================================================================================
+// host side: graph builder (hnsw_index.rs:143-256, :391-475, :538-611)
+// ===================================================================================================
+
+namespace {
+
+struct Pair {
+    float d;
+    uint64_t i;
+};
+inline int f32_total_cmp(float a, float b) {
+    bool an = std::isnan(a), bn = std::isnan(b);
+    if (an || bn) return int(an) - int(bn);
+    return a < b ? -1 : (a > b ? 1 : 0);
+}
+inline int pair_cmp(const Pair &a, const Pair &b) {
+    int c = f32_total_cmp(a.d, b.d);
+    if (c) return c;
+    return a.i < b.i ? -1 : (a.i > b.i ? 1 : 0);
+}
+// ResultSet (candidate_pair.rs:43-82) as an ascending vector
+struct RSet {
+    size_t k;
+    std::vector<Pair> v;
+    explicit RSet(size_t kk) : k(kk) {}
+    void insert_sorted(const Pair &p) {
+        auto it = std::lower_bound(v.begin(), v.end(), p, [](const Pair &a, const Pair &b) { return pair_cmp(a, b) < 0; });
+        if (it != v.end() && pair_cmp(*it, p) == 0) return;
+        v.insert(it, p);
+    }
+    bool add(const Pair &p) {
+        if (v.size() < k) {
+            insert_sorted(p);
+            return true;
+        }
+        if (!v.empty() && f32_total_cmp(p.d, v.back().d) < 0) {
+            v.pop_back();
+            insert_sorted(p);
+            return true;
+        }
+        return false;
+    }
+    bool check_candidate(const Pair &p) const { return v.size() < k || pair_cmp(p, v.back()) < 0; }
+};
+
+struct Scratch {
+    std::vector<uint32_t> stamp;
+    uint32_t epoch = 0;
+    std::vector<Pair> heap;
+    void prepare(size_t n) {
+        if (stamp.size() < n) {
+            stamp.assign(n, 0);
+            epoch = 0;
+        }
+        if (++epoch == 0) {
+            std::fill(stamp.begin(), stamp.end(), 0);
+            epoch = 1;
+        }
+        heap.clear();
+    }
+};
+
+struct Builder {
+    HNSWState &h;
+    const float *rows;
+    const float *cache;  // dist_cache per row (dot for L2, norm for Cosine)
+    uint64_t dim;
+    int dist;
+
+    float dot(const float *a, const float *b) const {
+        float acc = 0.0f;
+        for (uint64_t i = 0; i < dim; i++) {
+            float p = a[i] * b[i];
+            acc = acc + p;
+        }
+        return acc;
+    }
+    // DistanceAdapter<(&[T],f32),(&[T],f32)> (distance/mod.rs:120-129)
+    float dist_cached(const float *a, const float *b, float ca, float cb) const {
+        if (dist == 0) {
+            float s = ca + cb;
+            float t = 2.0f * dot(a, b);
+            return s - t;
+        }
+        float den = std::fmax(ca * cb, 1e-10f);
+        return 1.0f - dot(a, b) / den;
+    }
+    float to_query(uint64_t idx, const float *q, float qc) const { return dist_cached(rows + idx * dim, q, cache[idx], qc); }
+    float inner(uint64_t a, uint64_t b) const { return dist_cached(rows + a * dim, rows + b * dim, cache[a], cache[b]); }
+
+    const uint32_t *links(uint64_t v, uint64_t level, size_t &len) const {
+        if (level == 0) {
+            len = h.len0[v];
+            return h.level0.data() + v * h.max_m0;
+        }
+        uint64_t slot = h.upper_off[v] + level - 1;
+        len = h.upper_len[slot];
+        return h.upper.data() + slot * h.m;
+    }
+    void put_links(uint64_t v, uint64_t level, const std::vector<uint32_t> &l) {
+        if (level == 0) {
+            h.len0[v] = l.size();
+            std::copy(l.begin(), l.end(), h.level0.begin() + v * h.max_m0);
+        } else {
+            uint64_t slot = h.upper_off[v] + level - 1;
+            h.upper_len[slot] = l.size();
+            std::copy(l.begin(), l.end(), h.upper.begin() + slot * h.m);
+        }
+    }
+    // search_on_level (hnsw_index.rs:258-304)
+    RSet search_on_level(uint64_t ep, uint64_t level, size_t ef, const float *q, float qc, Scratch &s) const {
+        s.prepare(h.len0.size());
+        RSet res(ef);
+        auto cmp = [](const Pair &a, const Pair &b) { return pair_cmp(a, b) > 0; };  // min-heap
+        s.stamp[ep] = s.epoch;
+        Pair e{to_query(ep, q, qc), ep};
+        res.add(e);
+        s.heap.push_back(e);
+        while (!s.heap.empty()) {
+            std::pop_heap(s.heap.begin(), s.heap.end(), cmp);
+            Pair p = s.heap.back();
+            s.heap.pop_back();
+            if (!res.check_candidate(p)) break;
+            size_t len;
+            const uint32_t *lk = links(p.i, level, len);
+            for (size_t j = 0; j < len; j++) {
+                uint64_t nb = lk[j];
+                if (s.stamp[nb] == s.epoch) continue;
+                s.stamp[nb] = s.epoch;
+                Pair np{to_query(nb, q, qc), nb};
+                res.add(np);
+                s.heap.push_back(np);
+                std::push_heap(s.heap.begin(), s.heap.end(), cmp);
+            }
+        }
+        return res;
+    }
+    // greedy_search_until_level (hnsw_index.rs:306-350)
+    uint64_t greedy_until(uint64_t target, const float *q, float qc) const {
+        uint64_t level = h.enter_level, cur = h.enter_point;
+        while (level > target) {
+            float cur_d = to_query(cur, q, qc);
+            for (;;) {
+                bool flag = false;
+                size_t len;
+                const uint32_t *lk = links(cur, level, len);
+                for (size_t j = 0; j < len; j++) {
+                    float nd = to_query(lk[j], q, qc);
+                    if (nd < cur_d) {
+                        cur_d = nd;
+                        cur = lk[j];
+                        flag = true;
+                    }
+                }
+                if (!flag) break;
+            }
+            level--;
+        }
+        return cur;
+    }
+    // ResultSet::heuristic (candidate_pair.rs:85-99)
+    std::vector<uint32_t> heuristic(const RSet &set, size_t m) const {
+        std::vector<uint32_t> out;
+        for (const Pair &p : set.v) {
+            if (out.size() >= m) break;
+            bool ok = true;
+            for (uint32_t t : out)
+                if (!(inner(p.i, t) >= p.d)) {
+                    ok = false;
+                    break;
+                }
+            if (ok) out.push_back((uint32_t)p.i);
+        }
+        return out;
+    }
+    // arrange_links (hnsw_index.rs:204-224)
+    void arrange_links(uint64_t v, uint64_t level, uint64_t newv) {
+        size_t limit = level == 0 ? h.max_m0 : h.m;
+        size_t len;
+        const uint32_t *lk = links(v, level, len);
+        std::vector<uint32_t> l(lk, lk + len);
+        l.push_back((uint32_t)newv);
+        if (l.size() <= limit) {
+            put_links(v, level, l);
+            return;
+        }
+        RSet set(limit + 1);
+        for (uint32_t t : l) set.add(Pair{inner(v, t), t});
+        put_links(v, level, heuristic(set, limit));
+    }
+    // connect_new_links (hnsw_index.rs:226-239)
+    void connect_new_links(uint64_t v, uint64_t level, const RSet &cand) {
+        auto nb = heuristic(cand, h.m);  // M, not max_m0, even on level 0
+        put_links(v, level, nb);
+        for (uint32_t t : nb) arrange_links(t, level, v);
+    }
+    // push_init (hnsw_index.rs:244-256) for a row that is already in the VecSet
+    void push_init(uint64_t idx, uint64_t level) {
+        h.level0.resize((idx + 1) * h.max_m0, 0);
+        h.len0.resize(idx + 1, 0);
+        h.vec_level.resize(idx + 1, level);
+        h.vec_level[idx] = level;
+        h.upper_off.resize(idx + 2);
+        uint64_t tot = h.upper_off[idx];
+        h.upper.resize((tot + level) * h.m, 0);
+        h.upper_len.resize(tot + level, 0);
+        h.upper_off[idx + 1] = tot + level;
+    }
+    // HNSWIndex::add (hnsw_index.rs:538-572), row idx already pushed
+    void add(uint64_t idx, uint64_t level, Scratch &s) {
+        push_init(idx, level);
+        if (!h.has_enter) {
+            h.has_enter = true;
+            h.enter_level = level;
+            h.enter_point = idx;
+            return;
+        }
+        const float *q = rows + idx * dim;
+        float qc = cache[idx];
+        uint64_t enter_level = h.enter_level;
+        uint64_t cur = level < enter_level ? greedy_until(level, q, qc) : h.enter_point;
+        uint64_t top = std::min(level, enter_level);
+        for (uint64_t l = top + 1; l-- > 0;) {
+            RSet cand = search_on_level(cur, l, h.ef_construction, q, qc, s);
+            cur = cand.v.front().i;
+            connect_new_links(idx, l, cand);
+        }
+        if (level > enter_level) {
+            h.enter_level = level;
+            h.enter_point = idx;
+        }
+    }
+    // add_parallel (hnsw_index.rs:399-457): candidates against the pre-batch graph in parallel
+    void add_batch(uint64_t first, uint64_t nb, const uint64_t *levels, int nthreads, Scratch &s0) {
+        if (first < 1000 /* start_batch_since :506 */ || nb == 1) {
+            for (uint64_t i = 0; i < nb; i++) add(first + i, levels[i], s0);
+            return;
+        }
+        for (uint64_t i = 0; i < nb; i++) push_init(first + i, levels[i]);
+        const uint64_t enter_point = h.enter_point, enter_level = h.enter_level;
+        std::vector<std::vector<RSet>> cands(nb);
+        auto work = [&](uint64_t i, Scratch &s) {
+            uint64_t idx = first + i, level = h.vec_level[idx];
+            const float *q = rows + idx * dim;
+            float qc = cache[idx];
+            uint64_t cur = level < enter_level ? greedy_until(level, q, qc) : enter_point;
+            uint64_t top = std::min(level, enter_level);
+            for (uint64_t l = top + 1; l-- > 0;) {
+                RSet c = search_on_level(cur, l, h.ef_construction, q, qc, s);
+                cur = c.v.front().i;
+                for (uint64_t r = 0; r < i; r++)  // rhs_idx < idx && vec_level[rhs] >= level (:431-437)
+                    if (h.vec_level[first + r] >= l) c.add(Pair{inner(idx, first + r), first + r});
+                cands[i].push_back(std::move(c));
+            }
+        };
+        int nt = std::max(1, std::min<int>(nthreads, (int)nb));
+        if (nt == 1) {
+            for (uint64_t i = 0; i < nb; i++) work(i, s0);
+        } else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; t++)
+                th.emplace_back([&, t]() {
+                    Scratch s;
+                    for (uint64_t i = t; i < nb; i += nt) work(i, s);
+                });
+            for (auto &x : th) x.join();
+        }
+        for (uint64_t i = 0; i < nb; i++) {
+            uint64_t idx = first + i, level = h.vec_level[idx];
+            uint64_t top = std::min(level, enter_level);
+            size_t slot = 0;
+            for (uint64_t l = top + 1; l-- > 0;) connect_new_links(idx, l, cands[i][slot++]);
+        }
+        for (uint64_t i = 0; i < nb; i++) {
+            uint64_t idx = first + i;
+            if (h.vec_level[idx] > h.enter_level) {
+                h.enter_level = h.vec_level[idx];
+                h.enter_point = idx;
+            }
+        }
+    }
+};
+
+uint64_t splitmix64(uint64_t &s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// rand_level (hnsw_index.rs:144-147) with u in (0,1) from the index's own stream
+uint64_t rand_level(uint64_t &state, float inv_log_m) {
+    float u = (float(uint32_t(splitmix64(state) >> 40)) + 0.5f) * (1.0f / 16777216.0f);
+    return (uint64_t)std::floor(-std::log(u) * inv_log_m);
+}
+
+void hnsw_config(HNSWState &h, uint64_t M, uint64_t efc) {  // IndexBuilder::new (hnsw_index.rs:493-506)
+    h.m = std::min<uint64_t>(M, 10000);
+    h.max_m0 = h.m * 2;
+    h.ef_construction = std::max(efc, h.max_m0);
+    h.default_ef = h.ef_construction / 2;
+    h.inv_log_m = 1.0f / std::log((float)h.m);
+}
+
+std::vector<float> host_cache(Index &ix) {
+    std::vector<float> c(ix.n);
+    ix.use_device();
+    if (ix.n) VDB_HIP(hipMemcpy(c.data(), ix.d_sq.p, ix.n * sizeof(float), hipMemcpyDeviceToHost));
+    if (ix.dist == 1)
+        for (auto &v : c) v = std::sqrt(v);  // Cosine caches vec_norm (distance/mod.rs:31-36)
+    return c;
+}
+
+void reset_graph(HNSWState &h) {
+    h.level0.clear();
+    h.len0.clear();
+    h.vec_level.clear();
+    h.upper.clear();
+    h.upper_len.clear();
+    h.upper_off.assign(1, 0);
+    h.has_enter = false;
+    h.enter_point = h.enter_level = 0;
+    h.dev_dirty = true;
+}
+
+}  // namespace
+
+void hnsw_clear(Index &ix) {
+    ix.hnsw.present = false;
+    reset_graph(ix.hnsw);
+    ix.hnsw.d_level0.release();
+    ix.hnsw.d_upper.release();
+}
+
+void hnsw_build(Index &ix, uint64_t M, uint64_t ef_construction, uint64_t seed, uint64_t batch, int nthreads) {
+    VDB_REQUIRE(M >= 2, "M must be >= 2");
+    HNSWState &h = ix.hnsw;
+    h.present = false;
+    reset_graph(h);
+    hnsw_config(h, M, ef_construction);
+    h.rng_state = seed;
+    const float *rows = ix.host_rows();
+    std::vector<float> cache = host_cache(ix);
+    Builder b{h, rows, cache.data(), ix.dim, ix.dist};
+    uint64_t n = ix.n;
+    std::vector<uint64_t> levels(n);
+    for (uint64_t i = 0; i < n; i++) levels[i] = rand_level(h.rng_state, h.inv_log_m);
+    Scratch s;
+    uint64_t cur = 0;
+    while (cur < n) {
+        uint64_t bs = 1;
+        if (cur >= 1000) {  // next_batch_size (:391-397) with rayon's 4*threads replaced by `batch`
+            bs = std::min<uint64_t>(std::max<uint64_t>(batch, 1), cur / h.m);
+            if (bs < 1) bs = 1;
+        }
+        uint64_t next = std::min(n, cur + bs);
+        b.add_batch(cur, next - cur, levels.data() + cur, nthreads, s);
+        cur = next;
+    }
+    h.present = true;
+    h.dev_dirty = true;
+}
+
+void hnsw_attach(Index &ix, uint64_t M, uint64_t ef_construction, const uint32_t *level0, const uint64_t *len0,
+                 const uint64_t *vec_level, const uint32_t *upper, const uint64_t *upper_len, int has_enter,
+                 uint64_t enter_point, uint64_t enter_level) {
+    VDB_REQUIRE(M >= 2, "M must be >= 2");
+    HNSWState &h = ix.hnsw;
+    h.present = false;
+    reset_graph(h);
+    hnsw_config(h, M, ef_construction);
+    uint64_t n = ix.n;
+    VDB_REQUIRE(n == 0 || (level0 && len0 && vec_level), "null graph arrays");
+    h.level0.assign(level0, level0 + n * h.max_m0);
+    h.len0.assign(len0, len0 + n);
+    h.vec_level.assign(vec_level, vec_level + n);
+    h.upper_off.assign(n + 1, 0);
+    for (uint64_t i = 0; i < n; i++) h.upper_off[i + 1] = h.upper_off[i] + vec_level[i];
+    uint64_t tot = h.upper_off[n];
+    VDB_REQUIRE(tot == 0 || (upper && upper_len), "null upper-level arrays");
+    h.upper.assign(upper, upper + tot * h.m);
+    h.upper_len.assign(upper_len, upper_len + tot);
+    // validate: every link must be a valid node, every length within its limit (get_links_len_checked :160-169)
+    for (uint64_t v = 0; v < n; v++) {
+        VDB_REQUIRE(h.len0[v] <= h.max_m0, "links_len exceeds limit");
+        for (uint64_t j = 0; j < h.len0[v]; j++) VDB_REQUIRE(h.level0[v * h.max_m0 + j] < n, "link out of range");
+    }
+    for (uint64_t sidx = 0; sidx < tot; sidx++) {
+        VDB_REQUIRE(h.upper_len[sidx] <= h.m, "links_len exceeds limit");
+        for (uint64_t j = 0; j < h.upper_len[sidx]; j++) VDB_REQUIRE(h.upper[sidx * h.m + j] < n, "link out of range");
+    }
+    h.has_enter = has_enter != 0;
+    VDB_REQUIRE(!h.has_enter || enter_point < n, "enter point out of range");
+    VDB_REQUIRE(!h.has_enter || enter_level <= h.vec_level[enter_point], "enter level above the node's level");
+    h.enter_point = enter_point;
+    h.enter_level = enter_level;
+    h.present = true;
+    h.dev_dirty = true;
+}
+
+// DynamicIndex::add on the HNSW arm (dynamic_index.rs:47-52)
+void hnsw_insert_rows(Index &ix, const float *rows, uint64_t count) {
+    HNSWState &h = ix.hnsw;
+    Scratch s;
+    for (uint64_t i = 0; i < count; i++) {
+        ix.add_rows(rows + i * ix.dim, 1, false);
+        const float *hr = ix.host_rows();
+        std::vector<float> cache = host_cache(ix);
+        Builder b{h, hr, cache.data(), ix.dim, ix.dist};
+        b.add(ix.n - 1, rand_level(h.rng_state, h.inv_log_m), s);
+    }
+    h.dev_dirty = true;
+}
+
+static void hnsw_upload(Index &ix) {
+    HNSWState &h = ix.hnsw;
+    if (!h.dev_dirty) return;
+    ix.use_device();
+    uint64_t n = ix.n;
+    std::vector<uint32_t> len0(n), ulen(h.upper_len.size());
+    for (uint64_t i = 0; i < n; i++) len0[i] = (uint32_t)h.len0[i];
+    for (size_t i = 0; i < ulen.size(); i++) ulen[i] = (uint32_t)h.upper_len[i];
+    h.d_level0.reserve(std::max<size_t>(h.level0.size(), 1) * 4);
+    h.d_len0.reserve(std::max<size_t>(n, 1) * 4);
+    h.d_upper.reserve(std::max<size_t>(h.upper.size(), 1) * 4);
+    h.d_upper_len.reserve(std::max<size_t>(ulen.size(), 1) * 4);
+    h.d_upper_off.reserve((n + 1) * 8);
+    if (n) {
+        VDB_HIP(hipMemcpy(h.d_level0.p, h.level0.data(), h.level0.size() * 4, hipMemcpyHostToDevice));
+        VDB_HIP(hipMemcpy(h.d_len0.p, len0.data(), n * 4, hipMemcpyHostToDevice));
+    }
+    if (!h.upper.empty()) VDB_HIP(hipMemcpy(h.d_upper.p, h.upper.data(), h.upper.size() * 4, hipMemcpyHostToDevice));
+    if (!ulen.empty()) VDB_HIP(hipMemcpy(h.d_upper_len.p, ulen.data(), ulen.size() * 4, hipMemcpyHostToDevice));
+    VDB_HIP(hipMemcpy(h.d_upper_off.p, h.upper_off.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+    h.dev_dirty = false;
+}
+
+// defined in pq.hip
+void pq_make_luts(Index &ix, Workspace &ws, const float *d_q, uint64_t nq);
+void pq_resort_launch(const uint64_t *exact_keys, uint32_t ncand, uint32_t ldc, uint32_t nq, uint32_t k,
+                      uint64_t *out, hipStream_t s);
+
+template <int R, bool ADC>
+static void hnsw_launch(const HnswDev &g, const float *d_q, const float *qsq, const float *lut, uint32_t lut_in_lds,
+                        uint32_t ef, uint32_t *vis, uint64_t vwords, uint64_t *out, unsigned long long *stats,
+                        uint32_t *err, uint32_t nq, size_t lds, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hnsw_search<R, ADC>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_hnsw_search<R, ADC>), dim3(nq), dim3(64), lds, s, g, d_q, qsq, lut, lut_in_lds, ef, vis,
+                       vwords, out, stats, err);
+}
+
+void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef, bool use_pq,
+                     uint64_t *d_idx, float *d_dist, uint64_t *d_cnt) {
+    hipStream_t s = ws.stream;
+    HNSWState &h = ix.hnsw;
+    if (nq == 0) return;
+    if (k == 0 || ix.n == 0 || !h.has_enter) {  // knn_with_ef on an empty index returns nothing (:625-627)
+        VDB_HIP(hipMemsetAsync(d_cnt, 0, nq * sizeof(uint64_t), s));
+        return;
+    }
+    VDB_REQUIRE(h.len0.size() == ix.n, "HNSW graph does not cover every row (rebuild or re-attach it)");
+    hnsw_upload(ix);
+    const uint64_t n = ix.n;
+    const uint64_t efk64 = std::max(ef, k);  // ef.max(k) :628
+    VDB_REQUIRE(efk64 <= 1024, "hnsw knn: max(ef, k) must be <= 1024 in this build");
+    const uint32_t efk = (uint32_t)efk64;
+    const uint32_t cape = topk_capacity(efk);
+    const uint32_t ksel = (uint32_t)std::min<uint64_t>(k, efk);
+    const uint32_t capk = topk_capacity(ksel);
+    VDB_HIP(hipMemsetAsync(d_idx, 0, nq * k * sizeof(uint64_t), s));
+    VDB_HIP(hipMemsetAsync(d_dist, 0, nq * k * sizeof(float), s));
+
+    ws.qsq.reserve(nq * sizeof(float));
+    launch_row_sqnorm(d_q, nq, (uint32_t)ix.dim, ws.qsq.as<float>(), s);
+    PQState &pq = ix.pq;
+    uint32_t lut_in_lds = 0;
+    size_t lds = HNSW_POOL * sizeof(uint64_t);
+    if (use_pq) {
+        pq_make_luts(ix, ws, d_q, nq);
+        size_t lb = pq.m * pq.kc * sizeof(float);
+        if (lb <= 32 * 1024) {
+            lut_in_lds = 1;
+            lds += lb;
+        }
+    } else {
+        lds += ix.dim * sizeof(float);
+    }
+    HnswDev g{};
+    g.rows = ix.d_rows.as<float>();
+    g.xsq = ix.d_sq.as<float>();
+    g.level0 = h.d_level0.as<uint32_t>();
+    g.len0 = h.d_len0.as<uint32_t>();
+    g.upper = h.d_upper.as<uint32_t>();
+    g.upper_len = h.d_upper_len.as<uint32_t>();
+    g.upper_off = h.d_upper_off.as<uint64_t>();
+    g.n = n;
+    g.dim = (uint32_t)ix.dim;
+    g.m = (uint32_t)h.m;
+    g.max_m0 = (uint32_t)h.max_m0;
+    g.enter_point = (uint32_t)h.enter_point;
+    g.enter_level = (uint32_t)h.enter_level;
+    g.cosine = ix.dist == 1 ? 1 : 0;
+    if (use_pq) {
+        g.codes = pq.d_codes.as<uint8_t>();
+        g.cent_cache = pq.d_cent_cache.as<float>();
+        g.enc_dim = (uint32_t)pq.enc_dim;
+        g.pq_m = (uint32_t)pq.m;
+        g.pq_kc = (uint32_t)pq.kc;
+        g.n_bits = (uint32_t)pq.n_bits;
+    }
+    const uint64_t vwords = (n + 31) / 32;
+    constexpr uint64_t QB = 1024;  // queries per launch (bounds the visited bitmaps: QB * n/8 bytes)
+    ws.misc.reserve(QB * vwords * sizeof(uint32_t) + 64);
+    ws.keys_a.reserve(nq * cape * sizeof(uint64_t));
+    ws.keys_b.reserve(nq * cape * sizeof(uint64_t));
+    ws.keys_c.reserve(nq * capk * sizeof(uint64_t));
+    ws.flags.reserve(64);
+    VDB_HIP(hipMemsetAsync(ws.flags.p, 0, 64, s));
+    unsigned long long *stats = reinterpret_cast<unsigned long long *>(ws.flags.as<uint8_t>() + 16);
+    uint32_t *err = reinterpret_cast<uint32_t *>(ws.flags.p);
+    for (uint64_t q0 = 0; q0 < nq; q0 += QB) {
+        uint32_t nb = (uint32_t)std::min<uint64_t>(QB, nq - q0);
+        VDB_HIP(hipMemsetAsync(ws.misc.p, 0, uint64_t(nb) * vwords * sizeof(uint32_t), s));
+        const float *lut = use_pq ? ws.lut.as<float>() + q0 * pq.m * pq.kc : nullptr;
+        uint64_t *outk = ws.keys_a.as<uint64_t>() + q0 * cape;
+        ix.prof_begin(ws, "hnsw", 0.0);
+#define HL(R)                                                                                                          \
+    if (use_pq)                                                                                                        \
+        hnsw_launch<R, true>(g, d_q + q0 * ix.dim, ws.qsq.as<float>() + q0, lut, lut_in_lds, efk, ws.misc.as<uint32_t>(), \
+                             vwords, outk, stats, err, nb, lds, s);                                                    \
+    else                                                                                                               \
+        hnsw_launch<R, false>(g, d_q + q0 * ix.dim, ws.qsq.as<float>() + q0, lut, lut_in_lds, efk, ws.misc.as<uint32_t>(), \
+                              vwords, outk, stats, err, nb, lds, s);
+        switch (cape / 64) {
+            case 1: HL(1); break;
+            case 2: HL(2); break;
+            case 4: HL(4); break;
+            case 8: HL(8); break;
+            case 16: HL(16); break;
+            default: throw Error(1, "hnsw knn: ef too large");
+        }
+#undef HL
+        ix.prof_end(ws);
+    }
+    if (use_pq) {
+        // pq_resort with the cached-form distance (hnsw_index.rs:693-695)
+        VDB_HIP(hipMemsetAsync(ws.keys_b.p, 0xff, nq * cape * sizeof(uint64_t), s));
+        launch_rerank(ix.d_rows.as<float>(), (uint32_t)ix.dim, d_q, (uint32_t)nq, ix.dist == 0 ? MET_L2_CACHED : MET_COSINE,
+                      ix.d_sq.as<float>(), ws.qsq.as<float>(), ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), efk, cape, s);
+        pq_resort_launch(ws.keys_b.as<uint64_t>(), efk, cape, (uint32_t)nq, ksel, ws.keys_c.as<uint64_t>(), s);
+        launch_finalize(ws.keys_c.as<uint64_t>(), capk, (uint32_t)nq, ksel, (uint32_t)k, ix.id_offset, d_idx, d_dist, d_cnt, s);
+    } else {
+        // into_sorted_vec_limit(k) (:632)
+        launch_finalize(ws.keys_a.as<uint64_t>(), cape, (uint32_t)nq, ksel, (uint32_t)k, ix.id_offset, d_idx, d_dist, d_cnt, s);
+    }
+    unsigned char hostbuf[64];
+    VDB_HIP(hipMemcpyAsync(hostbuf, ws.flags.p, 64, hipMemcpyDeviceToHost, s));
+    VDB_HIP(hipStreamSynchronize(s));
+    uint32_t e;
+    std::memcpy(&e, hostbuf, 4);
+    unsigned long long st[2];
+    std::memcpy(st, hostbuf + 16, 16);
+    h.last_n_dist = st[0];
+    h.last_n_expanded = st[1];
+    VDB_REQUIRE(e == 0, "hnsw search: candidate pool overflow (more than 2048 live candidates; degenerate duplicates)");
+}
+
+}  // namespace vdb
