@@ -32,12 +32,14 @@ def allgather_merge(local_idx, local_dist, local_cnt, k: int, group=None, gpu_in
     if world == 1:
         return local_idx, local_dist, local_cnt
     nq = local_idx.shape[0]
-    g_idx = torch.empty((world, nq, k), dtype=local_idx.dtype, device=local_idx.device)
-    g_dist = torch.empty((world, nq, k), dtype=local_dist.dtype, device=local_dist.device)
-    g_cnt = torch.empty((world, nq), dtype=local_cnt.dtype, device=local_cnt.device)
+    # all_gather_into_tensor concatenates along dim 0: [world*nq, k] viewed as [world, nq, k]
+    g_idx = torch.empty((world * nq, k), dtype=local_idx.dtype, device=local_idx.device)
+    g_dist = torch.empty((world * nq, k), dtype=local_dist.dtype, device=local_dist.device)
+    g_cnt = torch.empty((world * nq,), dtype=local_cnt.dtype, device=local_cnt.device)
     dist.all_gather_into_tensor(g_idx, local_idx.contiguous(), group=group)
     dist.all_gather_into_tensor(g_dist, local_dist.contiguous(), group=group)
     dist.all_gather_into_tensor(g_cnt, local_cnt.contiguous(), group=group)
+    g_idx, g_dist, g_cnt = g_idx.view(world, nq, k), g_dist.view(world, nq, k), g_cnt.view(world, nq)
     if local_idx.is_cuda:
         if gpu_index is None:
             raise ValueError("allgather_merge on CUDA tensors needs the rank's GpuIndex")

@@ -1,0 +1,79 @@
+"""CPU rehearsal of the multi-GPU path with the gloo backend, world_size 2 and 3.
+
+Each rank holds a contiguous row shard, produces its local top-k with GLOBAL ids (here by the CPU oracle,
+standing in for the per-GPU kernels), then runs the product's all-gather + exact merge
+(lab_1806_vec_db_amd.shard.allgather_merge).  The merged result must equal the unsharded result exactly.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, dim, nq, k, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lab_1806_vec_db_amd.shard import allgather_merge, shard_bounds
+        from oracle import oracle as O
+
+        rng = np.random.default_rng(123)
+        base = rng.standard_normal((n, dim)).astype(np.float32)
+        base[n // 2] = base[3]  # a duplicate row across shards -> exact distance tie across ranks
+        qs = rng.standard_normal((nq, dim)).astype(np.float32)
+        r0, r1 = shard_bounds(n, world, rank)
+        li = np.zeros((nq, k), dtype=np.int64)
+        ld = np.zeros((nq, k), dtype=np.float32)
+        lc = np.zeros(nq, dtype=np.int64)
+        for q in range(nq):
+            i, d = O.flat_knn(base[r0:r1], qs[q], k) if r1 > r0 else (np.zeros(0, np.uint64), np.zeros(0, np.float32))
+            c = len(i)
+            li[q, :c] = i.astype(np.int64) + r0  # vdb_index_set_id_offset
+            ld[q, :c] = d
+            lc[q] = c
+        mi, md, mc = allgather_merge(torch.from_numpy(li), torch.from_numpy(ld), torch.from_numpy(lc), k)
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), idx=mi.numpy(), dist=md.numpy(), cnt=mc.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 501), (3, 100), (2, 7)])
+def test_row_shard_allgather_merge_equals_unsharded(tmp_path, world, n):
+    from oracle import oracle as O
+
+    dim, nq, k = 24, 6, 10
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n, dim, nq, k, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(123)
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    base[n // 2] = base[3]
+    qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    outs = [np.load(os.path.join(tmp_path, f"r{r}.npz")) for r in range(world)]
+    for q in range(nq):
+        oi, od = O.flat_knn(base, qs[q], k)
+        for o in outs:  # every rank holds the full merged answer
+            c = int(o["cnt"][q])
+            assert c == len(oi)
+            assert o["idx"][q, :c].tolist() == oi.tolist()
+            assert np.array_equal(o["dist"][q, :c], od)
+
+
+def test_shard_bounds():
+    from lab_1806_vec_db_amd.shard import shard_bounds
+
+    assert [shard_bounds(10, 3, r) for r in range(3)] == [(0, 4), (4, 8), (8, 10)]
+    assert [shard_bounds(2, 4, r) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    assert shard_bounds(1_000_000, 8, 7) == (875000, 1000000)
