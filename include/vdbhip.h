@@ -84,6 +84,8 @@ int vdb_flat_knn_device(vdb_index *idx, const void *d_queries, uint64_t nq, uint
  *   mode 1 = exact scan only (strict-order f32 fold for every row),
  *   mode 2 = MFMA path forced (still certified, still falls back per query). */
 int vdb_flat_set_mode(vdb_index *idx, int mode);
+/* developer tuning knobs (kernel variants); results never depend on them */
+int vdb_set_param(vdb_index *idx, const char *name, int64_t value);
 /* number of queries whose MFMA shortlist failed certification and were redone by the exact scan */
 int vdb_flat_fallback_count(const vdb_index *idx, uint64_t *out);
 

@@ -248,6 +248,16 @@ int vdb_flat_set_mode(vdb_index *idx, int mode) {
     idx->ix.flat_mode = mode;
     VDB_API_END
 }
+int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx && name, "null argument");
+    std::string n(name);
+    if (n == "mfma_variant")
+        mfma_set_variant((int)value);
+    else
+        throw Error(VDB_ERR_INVALID, "unknown parameter " + n);
+    VDB_API_END
+}
 int vdb_flat_fallback_count(const vdb_index *idx, uint64_t *out) {
     VDB_API_BEGIN
     VDB_REQUIRE(idx && out, "null argument");

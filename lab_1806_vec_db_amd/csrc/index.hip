@@ -55,10 +55,18 @@ void Index::add_rows(const float *rows, uint64_t count, bool on_device) {
     hipStream_t s = ws->stream;
     size_t row_bytes = size_t(dim) * sizeof(float);
     d_rows.grow((n + count) * row_bytes, n * row_bytes, s);
-    d_sq.grow((n + count) * sizeof(float), n * sizeof(float), s);
+    d_sq.grow((n + count + 128) * sizeof(float), n * sizeof(float), s);  // +128: kernels may read a few entries past n
     float *dst = d_rows.as<float>() + n * dim;
     VDB_HIP(hipMemcpyAsync(dst, rows, count * row_bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     launch_row_sqnorm(dst, count, (uint32_t)dim, d_sq.as<float>() + n, s);
+    if (mfma_supported((uint32_t)dim)) {
+        // refresh the fragment-ordered mirror for every 16-row tile that received rows
+        uint64_t tiles_new = ((n + count + 15) / 16 + 3) & ~3ull;  // rounded up so a 64-row item never leaves the buffer
+        uint64_t tiles_old = n / 16;                                // the partially filled tile is rewritten
+        uint64_t tile_bytes = 16 * row_bytes;
+        d_tiled.grow(tiles_new * tile_bytes, tiles_old * tile_bytes, s);
+        launch_tile_rows(d_rows.as<float>(), n + count, (uint32_t)dim, tiles_old, tiles_new, d_tiled.as<float>(), s);
+    }
     std::vector<float> sq(count);
     VDB_HIP(hipMemcpyAsync(sq.data(), d_sq.as<float>() + n, count * sizeof(float), hipMemcpyDeviceToHost, s));
     VDB_HIP(hipStreamSynchronize(s));
@@ -86,6 +94,10 @@ void Index::swap_remove(uint64_t i) {
         VDB_HIP(hipMemcpyAsync(d_rows.as<float>() + i * dim, d_rows.as<float>() + last * dim, dim * sizeof(float),
                                hipMemcpyDeviceToDevice, s));
         VDB_HIP(hipMemcpyAsync(d_sq.as<float>() + i, d_sq.as<float>() + last, sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    if (mfma_supported((uint32_t)dim)) {  // rewrite the tiles of the moved row and of the removed last row
+        launch_tile_rows(d_rows.as<float>(), last, (uint32_t)dim, i / 16, i / 16 + 1, d_tiled.as<float>(), s);
+        launch_tile_rows(d_rows.as<float>(), last, (uint32_t)dim, last / 16, last / 16 + 1, d_tiled.as<float>(), s);
     }
     VDB_HIP(hipStreamSynchronize(s));
     {
@@ -189,33 +201,56 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     }
 
     // --- MFMA shortlist -> exact re-rank -> certification --------------------------------------
-    const uint64_t ld = (n + 63) & ~63ull;
-    const uint32_t nl = topk_num_lists(n);
+    // phase 1: keys of a strided row sample for every query -> tau[q] = k'-th smallest sampled key, an
+    //          upper bound of the k'-th smallest key over all rows (the sample is a subset of the rows)
+    // phase 2: one corpus pass per 32 queries that appends only the keys <= tau[q] (expected ~k'*step hits)
+    // phase 3: shortlist = k' smallest appended pairs per query
     const uint32_t capp = topk_capacity(kprime);
     const uint32_t capk = topk_capacity(ksel);
-    ws.qfrag.reserve(mfma_qfrag_floats((uint32_t)dim) * sizeof(float));
-    ws.dense.reserve(size_t(MFMA_B) * ld * sizeof(float));
-    ws.lists.reserve(size_t(MFMA_B) * nl * capp * sizeof(uint64_t));
-    ws.keys_a.reserve(nq * capp * sizeof(uint64_t));  // approximate shortlist, sorted
-    ws.keys_b.reserve(nq * capp * sizeof(uint64_t));  // exact keys of the shortlist, unsorted
-    ws.keys_c.reserve(nq * capk * sizeof(uint64_t));  // exact top-k, sorted
-    ws.flags.reserve(nq);
-    for (uint64_t q0 = 0; q0 < nq; q0 += MFMA_B) {
-        uint32_t nb = (uint32_t)std::min<uint64_t>(MFMA_B, nq - q0);
-        launch_mfma_pack_queries(d_q + q0 * dim, nb, (uint32_t)dim, ws.qfrag.as<float>(), s);
-        prof_begin(ws, "flat_mfma", double(n) * dim * sizeof(float));
-        launch_flat_mfma(d_rows.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>(), d_sq.as<float>(),
-                         ws.dense.as<float>(), ld, num_cu, s);
-        prof_end(ws);
-        launch_topk_dense(ws.dense.as<float>(), ld, n, nb, kprime, ws.lists.as<uint64_t>(), s);
-        launch_topk_merge(ws.lists.as<uint64_t>(), nl, capp, nb, kprime, ws.keys_a.as<uint64_t>() + q0 * capp, s);
+    const uint64_t nbatch = (nq + MFMA_B - 1) / MFMA_B;
+    const uint64_t nq_pad = nbatch * MFMA_B;
+    const uint64_t n_s = mfma_sample_rows(n);
+    const uint64_t ld_s = (n_s + 63) & ~63ull;
+    const uint32_t nl_s = topk_num_lists(n_s);
+    constexpr uint32_t CAND_CAP = 8192;
+    const size_t qf = mfma_qfrag_floats((uint32_t)dim);
+    ws.qfrag.reserve(nbatch * qf * sizeof(float));
+    ws.dense.reserve(nq_pad * ld_s * sizeof(float));
+    ws.lists.reserve(std::max<size_t>(nq_pad * nl_s * capp, nq_pad * size_t(CAND_CAP)) * sizeof(uint64_t));
+    ws.keys_a.reserve(nq_pad * capp * sizeof(uint64_t));  // approximate shortlist, sorted
+    ws.keys_b.reserve(nq_pad * capp * sizeof(uint64_t));  // exact keys of the shortlist, unsorted
+    ws.keys_c.reserve(nq_pad * capk * sizeof(uint64_t));  // exact top-k, sorted
+    ws.misc.reserve(nq_pad * (sizeof(float) + sizeof(uint32_t)));  // tau | hit counters
+    ws.flags.reserve(nq_pad);
+    float *d_tau = ws.misc.as<float>();
+    uint32_t *d_hits = reinterpret_cast<uint32_t *>(d_tau + nq_pad);
+    for (uint64_t b = 0; b < nbatch; b++) {
+        uint32_t nb = (uint32_t)std::min<uint64_t>(MFMA_B, nq - b * MFMA_B);
+        launch_mfma_pack_queries(d_q + b * MFMA_B * dim, nb, (uint32_t)dim, ws.qfrag.as<float>() + b * qf, s);
+        launch_flat_mfma_sample(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>() + b * qf, d_sq.as<float>(),
+                                ws.dense.as<float>() + b * MFMA_B * ld_s, ld_s, num_cu, s);
     }
+    launch_topk_dense(ws.dense.as<float>(), ld_s, n_s, (uint32_t)nq_pad, kprime, ws.lists.as<uint64_t>(), s);
+    launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, capp, (uint32_t)nq_pad, kprime, ws.keys_a.as<uint64_t>(), s);
+    launch_extract_tau(ws.keys_a.as<uint64_t>(), capp, (uint32_t)nq_pad, kprime, d_tau, s);
+    uint64_t *d_cand = ws.lists.as<uint64_t>();  // the sample lists are dead now
+    VDB_HIP(hipMemsetAsync(d_cand, 0xff, nq_pad * size_t(CAND_CAP) * sizeof(uint64_t), s));
+    VDB_HIP(hipMemsetAsync(d_hits, 0, nq_pad * sizeof(uint32_t), s));
+    for (uint64_t b = 0; b < nbatch; b++) {
+        prof_begin(ws, "flat_mfma", double(n) * dim * sizeof(float));
+        launch_flat_mfma_filter(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>() + b * qf, d_sq.as<float>(),
+                                d_tau + b * MFMA_B, d_cand + b * MFMA_B * size_t(CAND_CAP), d_hits + b * MFMA_B, CAND_CAP,
+                                num_cu, s);
+        prof_end(ws);
+    }
+    launch_topk_merge(d_cand, 1, CAND_CAP, (uint32_t)nq, kprime, ws.keys_a.as<uint64_t>(), s);
     VDB_HIP(hipMemsetAsync(ws.keys_b.p, 0xff, nq * capp * sizeof(uint64_t), s));
     launch_rerank(d_rows.as<float>(), (uint32_t)dim, d_q, (uint32_t)nq, MET_L2_DIRECT, d_sq.as<float>(),
                   ws.qsq.as<float>(), ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), kprime, capp, s);
     launch_topk_merge(ws.keys_b.as<uint64_t>(), 1, capp, (uint32_t)nq, ksel, ws.keys_c.as<uint64_t>(), s);
     launch_certify(ws.keys_c.as<uint64_t>(), capk, ws.keys_a.as<uint64_t>(), capp, (uint32_t)nq, ksel, kprime, n,
                    ws.qsq.as<float>(), xsq_max, (uint32_t)dim, ws.flags.as<uint8_t>(), s);
+    launch_flag_overflow(d_hits, CAND_CAP, (uint32_t)nq, ws.flags.as<uint8_t>(), s);
     launch_finalize(ws.keys_c.as<uint64_t>(), capk, (uint32_t)nq, ksel, (uint32_t)k, id_offset, d_idx, d_dist, d_cnt, s);
     std::vector<uint8_t> flags(nq);
     VDB_HIP(hipMemcpyAsync(flags.data(), ws.flags.p, nq, hipMemcpyDeviceToHost, s));

@@ -113,6 +113,7 @@ struct Index {
     uint64_t n = 0;
     uint64_t id_offset = 0;
     DevBuf d_rows, d_sq;
+    DevBuf d_tiled;  // MFMA-fragment-ordered mirror of d_rows (k_mfma.hip), only when mfma_supported(dim)
     float xsq_max = 0.0f;
     // lazily materialised host mirror of the rows (needed by the host-side builders and vdb_index_row)
     mutable std::vector<float> h_rows;

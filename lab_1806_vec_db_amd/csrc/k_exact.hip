@@ -317,8 +317,11 @@ void launch_finalize(const uint64_t *keys, uint32_t ldk, uint32_t nq, uint32_t k
 //   approx key(r)  = xsq[r] - 2*S(r,q) (S = MFMA fma chain), approx distance a(r) = key(r) + qsq[q]
 //   exact distance e(r) = strict-order f32 fold (the reference's value)
 // Both differ from the real-number distance by at most
-//   E = 2.5 * (dim+8) * 2^-24 * (sqrt(xsq_max) + sqrt(qsq))^2
-// (standard gamma_n bounds on an n-term f32 sum of products, doubled for the two computations).
+//   E = 2.5 * (dim+8) * 2^-24 * (sqrt(xsq_max) + sqrt(qsq))^2  +  5e-5 * sqrt(xsq_max * qsq)
+// first term: standard gamma_n bounds on an n-term f32 sum of products, doubled for the two computations;
+// second term: the split-bf16 contraction of k_flat_mfma -- each product x_j*q_j is off by at most
+// 3*2^-17 |x_j q_j| (hi/lo representation of both factors + the dropped lo*lo term), the key carries
+// -2*S, and sum |x_j q_j| <= |x||q|: 2 * 3 * 2^-17 = 4.6e-5, rounded up.
 // Every row outside the shortlist has key >= kappa (the largest shortlisted key), hence
 // e(r) >= kappa + qsq - E.  If the k-th smallest exact distance D_k among the shortlisted rows
 // satisfies D_k < kappa + qsq - E, no outside row can enter the exact top-k: certified.
@@ -345,9 +348,33 @@ __global__ void k_certify(const uint64_t *__restrict__ exact_sorted, uint32_t ld
     float kappa = f32_from_orderable(uint32_t(ak >> 32));
     float qs = qsq[q];
     float nrm = sqrtf(xsq_max) + sqrtf(qs);
-    float E = 2.5f * float(dim + 8) * 5.9604645e-8f * nrm * nrm;
+    float E = 2.5f * float(dim + 8) * 5.9604645e-8f * nrm * nrm + 5e-5f * sqrtf(xsq_max) * sqrtf(qs);
     bool ok = dk < (kappa + qs) - E;  // NaN anywhere -> not ok
     flags[q] = ok ? 0 : 1;
+}
+
+// tau[q] = key of the kprime-th smallest sampled pair (+inf when the sample holds fewer)
+__global__ void k_extract_tau(const uint64_t *__restrict__ sorted, uint32_t ld, uint32_t nq, uint32_t kprime,
+                              float *__restrict__ tau) {
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    uint64_t e = sorted[uint64_t(q) * ld + (kprime - 1)];
+    tau[q] = e == PAIR_NONE ? INFINITY : f32_from_orderable(uint32_t(e >> 32));
+}
+void launch_extract_tau(const uint64_t *sorted, uint32_t ld, uint32_t nq, uint32_t kprime, float *tau, hipStream_t s) {
+    if (nq == 0) return;
+    hipLaunchKernelGGL(k_extract_tau, dim3((nq + 63) / 64), dim3(64), 0, s, sorted, ld, nq, kprime, tau);
+}
+
+// flags[q] |= 1 when the filter pass dropped candidates of query q (more hits than slots)
+__global__ void k_flag_overflow(const uint32_t *__restrict__ cnt, uint32_t cap, uint32_t nq, uint8_t *__restrict__ flags) {
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    if (cnt[q] > cap) flags[q] = 1;
+}
+void launch_flag_overflow(const uint32_t *cnt, uint32_t cap, uint32_t nq, uint8_t *flags, hipStream_t s) {
+    if (nq == 0) return;
+    hipLaunchKernelGGL(k_flag_overflow, dim3((nq + 63) / 64), dim3(64), 0, s, cnt, cap, nq, flags);
 }
 
 void launch_certify(const uint64_t *exact_sorted, uint32_t lde, const uint64_t *approx_sorted, uint32_t lda,

@@ -1,99 +1,215 @@
 // k_mfma.hip -- batched Flat brute force on the gfx950 matrix cores.
 //
 // FlatIndex::knn (flat_index.rs:48-57) is called once per query in the reference.  Batched over
-// B = 32 queries the distance computation is a dense contraction S = X * Q^T, streamed once over
-// the corpus per 32 queries: 3.84 GB of HBM reads per pass for Gist1M instead of 32 x 3.84 GB.
-// This kernel produces APPROXIMATE ranking keys  key(r,b) = |x_r|^2 - 2 * S(r,b)  (the expanded
-// form of distance/mod.rs:54-57 without the per-query constant); the keys only build a shortlist.
-// The exact, reference-order distances of the shortlist are recomputed by k_rerank (k_exact.hip)
-// and the shortlist is certified (k_certify); the results that leave the library are bit-identical
-// to the reference's strict f32 fold.
+// B = 32 queries the distance stage is a dense contraction S = X * Q^T, streamed once over the corpus
+// per 32 queries: 3.84 GB of HBM reads per pass for Gist1M instead of 32 x 3.84 GB.
+// This kernel produces APPROXIMATE ranking keys  key(r,b) = |x_r|^2 - 2 * S(r,b)  (the expanded form of
+// distance/mod.rs:54-57 without the per-query constant); the keys only build a shortlist.  The exact,
+// reference-order distances of the shortlist are recomputed by k_rerank (k_exact.hip) and the shortlist
+// is certified (k_certify) with an error bound that covers this kernel's arithmetic; what leaves the
+// library is bit-identical to the reference's strict f32 fold.
 //
-// Mapping (v_mfma_f32_16x16x4_f32, exact f32 fma chain, 32 cycles per instruction per SIMD):
-//   A[i][k] : lane l supplies X[row0 + (l&15)][c],  k-slot = l>>4
-//   B[k][j] : lane l supplies Q[qbase + (l&15)][c], same k-slot
-//   D[i][j] : lane l holds rows 4*(l>>4)+{0..3}, query (l&15)
-// A lane loads one float4 = columns 16*s + 4*(l>>4) + {0..3} of its row per step s and spends its
-// four elements on four MFMAs, so the four lanes of a row read 64 contiguous bytes per step and a
-// 128-B line is consumed in two steps.  The k order inside the contraction is permuted relative to
-// memory order; A and B use the same permutation, and the sum is an approximation anyway.
+// Arithmetic: split-bf16.  Every f32 value v is stored as hi = bf16(v), lo = bf16(v - hi)
+// (|v - hi - lo| <= 2^-17 |v|) and x*q is taken as xh*qh + xh*ql + xl*qh on
+// v_mfma_f32_16x16x32_bf16 with f32 accumulation: three bf16 MFMAs at 16x the f32 MFMA rate, i.e. 3/16
+// of the matrix-pipe time (and energy) of the exact-f32 MFMA form.  Measured on MI355X the f32-MFMA
+// variant of this kernel sat at 4.5-4.9 TB/s with the matrix pipe ~50 % busy, while a pure read of the
+// same stream reaches 6.25 TB/s; the bf16x3 form leaves the kernel bound by HBM alone.  The dropped
+// term xl*ql and the representation error are <= 3*2^-17 |x_j q_j| per product -- accounted for in E
+// (k_certify), far below the gaps between neighbours that matter for a shortlist.
 //
-// Q (32 x dim f32 = 120 KB for dim 960) lives in LDS as a fragment-ordered image so that every
-// B fragment is one lane-linear, conflict-free ds_read_b128.  X never touches LDS: it is read once,
-// by exactly one wave, straight into VGPRs with a PD-step deep register ring (GEMV regime).
+// Layout: the VecSet has a fragment-ordered mirror in HBM (same bytes as the rows, 4 B per element):
+//   XT[tile of 16 rows][k-block of 32 columns][hi|lo][lane 0..63] -> 16 B = 8 bf16 = columns
+//   32*kb + 8*(lane>>4) + 0..7 of row 16*tile + (lane&15)
+// which is exactly the A operand of v_mfma_f32_16x16x32_bf16 (lane l: A[row l&15][k = 8*(l>>4)+j]).  One
+// wave load is one contiguous 1 KB; a wave's 32-row item is one contiguous 120 KB stream.  (Loading the
+// fragments straight from row-major rows makes the address unit issue 64 separate 16-B accesses per wave
+// load -- measured TA ~90 % busy -- because quad-adjacent lanes sit in different rows.)
+// Q lives in LDS as the matching B-operand image [kb][query half][hi|lo][lane] (120 KB for d = 960):
+// every B fragment is one lane-linear, conflict-free ds_read_b128.  X never touches LDS: it is read
+// once, by exactly one wave, straight into VGPRs through a register ring (GEMV regime).
 #include "common.hpp"
 #include "kernels.hpp"
 
 namespace vdb {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 size_t mfma_qfrag_floats(uint32_t dim) { return size_t(dim) * MFMA_B; }
-bool mfma_supported(uint32_t dim) { return dim >= 32 && (dim % 32) == 0 && size_t(dim) * MFMA_B * 4 <= 150 * 1024; }
+bool mfma_supported(uint32_t dim) { return dim >= 64 && (dim % 64) == 0 && size_t(dim) * MFMA_B * 4 <= 128 * 1024; }
+constexpr int MFMA_RT = 2;              // 16-row tiles per wave item
+constexpr uint32_t MFMA_WGBUF = 1536;   // per-workgroup LDS hit buffer entries (MODE_FILTER), ~6x the expected load
+uint64_t mfma_row_pad() { return 64; }  // rows of padding the kernel may touch past n (xsq reads)
+static int g_mfma_variant = 0;
+void mfma_set_variant(int v) { g_mfma_variant = v; }
 
-__global__ void k_mfma_pack_queries(const float *__restrict__ Q, uint32_t nq, uint32_t dim,
-                                    float4 *__restrict__ qfrag) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t S = dim / 16;
-    if (i >= S * 128) return;
-    uint32_t l = i & 63, h = (i >> 6) & 1, s = i >> 7;
+// hi/lo split of 8 consecutive f32 -> two packed bf16x8 (v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN)
+__device__ __forceinline__ void split8(const float4 &a, const float4 &b, uint4 &hi, uint4 &lo) {
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned short h[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        __bf16 hb = (__bf16)v[i];
+        float hf = (float)hb;
+        __bf16 lb = (__bf16)(v[i] - hf);
+        h[i] = __builtin_bit_cast(unsigned short, hb);
+        l[i] = __builtin_bit_cast(unsigned short, lb);
+    }
+    hi = make_uint4(h[0] | (uint32_t(h[1]) << 16), h[2] | (uint32_t(h[3]) << 16), h[4] | (uint32_t(h[5]) << 16),
+                    h[6] | (uint32_t(h[7]) << 16));
+    lo = make_uint4(l[0] | (uint32_t(l[1]) << 16), l[2] | (uint32_t(l[3]) << 16), l[4] | (uint32_t(l[5]) << 16),
+                    l[6] | (uint32_t(l[7]) << 16));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// rows [16*tile0, 16*tile1) of the row-major VecSet -> fragment-ordered split-bf16 mirror (rows >= n: zero)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tile_rows(const float *__restrict__ X, uint64_t n, uint32_t dim,
+                                                   uint64_t tile0, uint64_t tile1, uint4 *__restrict__ T) {
+    const uint32_t KB = dim / 32;
+    uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;  // (tile, kb, lane)
+    uint64_t total = (tile1 - tile0) * KB * 64;
+    if (i >= total) return;
+    uint32_t l = uint32_t(i & 63);
+    uint64_t tk = i >> 6;
+    uint32_t kb = uint32_t(tk % KB);
+    uint64_t tile = tile0 + tk / KB;
+    uint64_t row = tile * 16 + (l & 15);
+    uint32_t col = kb * 32 + 8 * (l >> 4);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (row < n) {
+        a = *reinterpret_cast<const float4 *>(X + row * dim + col);
+        b = *reinterpret_cast<const float4 *>(X + row * dim + col + 4);
+    }
+    uint4 hi, lo;
+    split8(a, b, hi, lo);
+    T[((tile * KB + kb) * 2 + 0) * 64 + l] = hi;
+    T[((tile * KB + kb) * 2 + 1) * 64 + l] = lo;
+}
+
+void launch_tile_rows(const float *X, uint64_t n, uint32_t dim, uint64_t tile0, uint64_t tile1, float *T,
+                      hipStream_t s) {
+    if (tile1 <= tile0) return;
+    uint64_t total = (tile1 - tile0) * (dim / 32) * 64;
+    hipLaunchKernelGGL(k_tile_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, X, n, dim, tile0, tile1,
+                       reinterpret_cast<uint4 *>(T));
+}
+
+// Q [nq<=32][dim] -> B-operand image [kb][half][hi|lo][lane] (queries >= nq: zero)
+__global__ void k_mfma_pack_queries(const float *__restrict__ Q, uint32_t nq, uint32_t dim, uint4 *__restrict__ qfrag) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // (kb, half, lane)
+    uint32_t KB = dim / 32;
+    if (i >= KB * 128) return;
+    uint32_t l = i & 63, h = (i >> 6) & 1, kb = i >> 7;
     uint32_t q = h * 16 + (l & 15);
-    uint32_t c = s * 16 + 4 * (l >> 4);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q < nq) v = *reinterpret_cast<const float4 *>(Q + size_t(q) * dim + c);
-    qfrag[i] = v;
+    uint32_t c = kb * 32 + 8 * (l >> 4);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (q < nq) {
+        a = *reinterpret_cast<const float4 *>(Q + size_t(q) * dim + c);
+        b = *reinterpret_cast<const float4 *>(Q + size_t(q) * dim + c + 4);
+    }
+    uint4 hi, lo;
+    split8(a, b, hi, lo);
+    qfrag[((kb * 2 + h) * 2 + 0) * 64 + l] = hi;
+    qfrag[((kb * 2 + h) * 2 + 1) * 64 + l] = lo;
 }
 
 void launch_mfma_pack_queries(const float *Q, uint32_t nq, uint32_t dim, float *qfrag, hipStream_t s) {
-    uint32_t total = (dim / 16) * 128;
+    uint32_t total = (dim / 32) * 128;
     hipLaunchKernelGGL(k_mfma_pack_queries, dim3((total + 255) / 256), dim3(256), 0, s, Q, nq, dim,
-                       reinterpret_cast<float4 *>(qfrag));
+                       reinterpret_cast<uint4 *>(qfrag));
 }
 
-template <int RT, int PD, int NT>
-__global__ __launch_bounds__(NT, 1) void k_flat_mfma(const float *__restrict__ X, uint64_t n, uint32_t dim,
-                                                     const float4 *__restrict__ qfrag,
-                                                     const float *__restrict__ xsq, float *__restrict__ out,
-                                                     uint64_t ld, uint32_t n_items) {
-    extern __shared__ __attribute__((aligned(16))) float4 qs[];  // [S][2][64]
-    const uint32_t S = dim / 16;
-    for (uint32_t i = threadIdx.x; i < S * 128; i += NT) qs[i] = qfrag[i];
-    __syncthreads();
+// ---------------------------------------------------------------------------------------------------
+// RT row tiles of 16 rows per wave item, ring of R = PD+1 k-blocks, NT threads per (persistent) workgroup
+// ---------------------------------------------------------------------------------------------------
+// MODE_SAMPLE: visit every `item_step`-th item and write its keys densely (out[b*ld + j*16*RT + row_in_item],
+//              +inf for rows >= n): a strided sample whose k'-th smallest key per query is an upper bound tau
+//              of the k'-th smallest key over all rows.
+// MODE_FILTER: visit every item and append pair_key(key,row) of the keys <= tau[b] to cand[b][..] (atomic
+//              slot counter per query); nothing else is written.  Writing all B x N keys instead costs 18 % of
+//              the kernel (measured: 0.768 ms vs 0.629 ms per pass) although it is 3 % of the bytes, because
+//              the stores are 64-B pieces scattered over 32 rows of the key matrix.
+enum { MODE_SAMPLE = 0, MODE_FILTER = 1 };
 
+struct MfmaArgs {
+    const uint4 *XT;
+    const uint4 *qfrag;
+    const float *xsq;
+    uint64_t n;
+    uint32_t dim, n_items, item_step;
+    // MODE_SAMPLE
+    float *out;
+    uint64_t ld;
+    // MODE_FILTER
+    const float *tau;   // [32]
+    uint64_t *cand;     // [32][cap]
+    uint32_t *cnt;      // [32]
+    uint32_t cap;
+    uint32_t debug;
+};
+
+template <int RT, int PD, int NT, int MODE>
+__global__ __launch_bounds__(NT, 1) void k_flat_mfma(MfmaArgs a) {
+    const uint4 *__restrict__ XT = a.XT;
+    const uint4 *__restrict__ qfrag = a.qfrag;
+    const float *__restrict__ xsq = a.xsq;
+    const uint64_t n = a.n;
+    const uint32_t dim = a.dim;
+    const uint32_t n_visit = (a.n_items + a.item_step - 1) / a.item_step;  // items this launch visits
+    extern __shared__ __attribute__((aligned(16))) uint4 qs[];  // [KB][2 halves][hi|lo][64], then the hit buffers
+    const uint32_t KB = dim / 32;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr uint32_t NW = NT / 64;
+    // per-workgroup hit buffer (MODE_FILTER): pairs that pass the threshold are parked in LDS and handed to the
+    // global per-query candidate lists once, when the workgroup has finished streaming.  Alternatives
+    // measured on MI355X: a global slot atomic per hit inside the item loop forces s_waitcnt vmcnt(0) (drains
+    // the prefetch ring: 0.667 ms/pass instead of 0.636); per-wave buffers flushed at the end serialise ~2000
+    // atomics per query counter in the kernel's tail (0.667 ms); flushing per 8 hits is worse (0.712 ms).
+    // Here each workgroup reserves its range with ONE atomic per query (256 per counter per pass).
+    uint64_t *hit_key = reinterpret_cast<uint64_t *>(qs + KB * 256);
+    uint32_t *hit_q = reinterpret_cast<uint32_t *>(hit_key + MFMA_WGBUF);
+    uint32_t *hit_n = hit_q + MFMA_WGBUF;  // [0] entries, [1..32] per-query counts, [33..64] per-query bases
+    if (MODE == MODE_FILTER && threadIdx.x < 80) hit_n[threadIdx.x] = 0;
+    for (uint32_t i = threadIdx.x; i < KB * 256; i += NT) qs[i] = qfrag[i];
+    __syncthreads();
+
     const uint32_t r = lane & 15, g = lane >> 4;
     const uint32_t stride = gridDim.x * NW;
     const uint32_t first = blockIdx.x * NW + wave;
-    if (first >= n_items) return;
+    float tau[2] = {0.f, 0.f};
+    if (MODE == MODE_FILTER) {
+        tau[0] = a.tau[r];
+        tau[1] = a.tau[16 + r];
+        if (a.debug & 1) tau[0] = tau[1] = -INFINITY;  // timing experiment: no hits
+    }
 
-    // The X stream is one continuous sequence of (item, step) pairs per wave; a cursor runs PD steps
-    // ahead of the MFMAs and never stops at an item boundary, so every load is unconditional (the
-    // compiler can then count vmcnt instead of draining it) and HBM latency is covered across items.
-    // Past the wave's last item the cursor re-reads that item (L2 hits, results unused).
-    uint32_t c_item = first, c_s = 0;
-    const float4 *cp[RT];
-    auto set_ptrs = [&](uint32_t item) {
-        if (item >= n_items) item = n_items - 1;
-#pragma unroll
-        for (int t = 0; t < RT; t++) {
-            uint64_t row = uint64_t(item) * (16 * RT) + t * 16 + r;
-            if (row >= n) row = n - 1;  // tail: read a valid row, the result is never stored
-            cp[t] = reinterpret_cast<const float4 *>(X + row * dim) + g;
-        }
+    // The X stream is one continuous sequence of (item, k-block) pairs per wave; a cursor runs PD k-blocks
+    // ahead of the MFMAs and never stops at an item boundary, so every load is unconditional (the compiler
+    // counts vmcnt instead of draining it) and HBM latency is covered across items.  Past the wave's last
+    // item the cursor re-reads that item (L2 hits, results unused).
+    uint32_t c_item = first, c_kb = 0;
+    const uint4 *cp;  // this lane's 16 B of (item, tile 0, kb 0, hi); tile t is KB*128 uint4 further
+    auto set_ptrs = [&](uint32_t v) {  // v = ordinal among the visited items
+        if (v >= n_visit) v = n_visit - 1;
+        cp = XT + uint64_t(v) * a.item_step * RT * KB * 128 + lane;
     };
     set_ptrs(c_item);
-    // Register ring of R = PD+1 slots: step i consumes slot i%R while the load for step i+PD lands in
-    // slot (i-1)%R, the slot whose MFMAs were issued one step earlier.  With the loop unrolled by R
+    // Register ring of R = PD+1 slots: k-block i is consumed from slot i%R while the loads for k-block
+    // i+PD land in slot (i-1)%R, whose MFMAs were issued one step earlier.  With the loop unrolled by R
     // every slot keeps its registers across the back edge (no rotation copies, no vmcnt(0) drain).
     constexpr int R = PD + 1;
-    float4 ring[R][RT];
-    auto fetch = [&](float4(&dst)[RT]) {
+    uint4 ring[R][RT][2];
+    auto fetch = [&](uint4(&dst)[RT][2]) {
 #pragma unroll
-        for (int t = 0; t < RT; t++) dst[t] = cp[t][c_s * 4];
-        c_s++;
-        if (c_s == S) {
-            c_s = 0;
+        for (int t = 0; t < RT; t++) {
+            dst[t][0] = cp[((uint64_t(t) * KB + c_kb) * 2 + 0) * 64];
+            dst[t][1] = cp[((uint64_t(t) * KB + c_kb) * 2 + 1) * 64];
+        }
+        c_kb++;
+        if (c_kb == KB) {
+            c_kb = 0;
             c_item += stride;
             set_ptrs(c_item);
         }
@@ -101,110 +217,204 @@ __global__ __launch_bounds__(NT, 1) void k_flat_mfma(const float *__restrict__ X
 #pragma unroll
     for (int p = 0; p < PD; p++) fetch(ring[p]);
 
-    float4 bfr[2][2];  // B fragments, double-buffered one step ahead (R is even: parity is static)
-    bfr[0][0] = qs[lane];
-    bfr[0][1] = qs[64 + lane];
-    for (uint32_t item = first; item < n_items; item += stride) {
-        const uint64_t row0 = uint64_t(item) * (16 * RT);
+    auto flush_hits = [&]() {  // whole workgroup, after every wave has left its item loop
+        __syncthreads();
+        uint32_t total = hit_n[0];
+        if (total > MFMA_WGBUF) total = MFMA_WGBUF;
+        uint32_t rank[(MFMA_WGBUF + NT - 1) / NT];
+#pragma unroll
+        for (uint32_t j = 0; j < (MFMA_WGBUF + NT - 1) / NT; j++) {
+            uint32_t i = j * NT + threadIdx.x;
+            rank[j] = i < total ? atomicAdd(&hit_n[1 + hit_q[i]], 1u) : 0u;  // rank inside (workgroup, query)
+        }
+        __syncthreads();
+        if (threadIdx.x < 32 && hit_n[1 + threadIdx.x] > 0)
+            hit_n[33 + threadIdx.x] = atomicAdd(&a.cnt[threadIdx.x], hit_n[1 + threadIdx.x]);  // reserve a range
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < (MFMA_WGBUF + NT - 1) / NT; j++) {
+            uint32_t i = j * NT + threadIdx.x;
+            if (i < total) {
+                uint32_t q = hit_q[i];
+                uint32_t slot = hit_n[33 + q] + rank[j];
+                if (slot < a.cap) a.cand[uint64_t(q) * a.cap + slot] = hit_key[i];
+            }
+        }
+    };
+    for (uint32_t item = first; item < n_visit; item += stride) {
+        const uint64_t row0 = uint64_t(item) * a.item_step * (16 * RT);
+        // |x|^2 of the item's 16*RT rows through SCALAR loads (the address is wave-uniform): SMEM is tracked
+        // by lgkmcnt, so reading it in the epilogue does not drain the vector-memory prefetch ring.  (As
+        // vector loads the compiler sinks them next to their use and emits s_waitcnt vmcnt(1) there: one full
+        // HBM round trip of the ring per item, ~6 % of the kernel.)
+        // (constant address space + uniform address => s_load_dword*, not global_load)
+        typedef const __attribute__((address_space(4))) float *cfloat_p;
+        cfloat_p xs_item = (cfloat_p)(xsq + uint64_t(__builtin_amdgcn_readfirstlane(item)) * a.item_step * (16 * RT));
         f32x4 acc[RT][2];
 #pragma unroll
         for (int t = 0; t < RT; t++) {
             acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
             acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        for (uint32_t s0 = 0; s0 < S; s0 += R) {
+        for (uint32_t k0 = 0; k0 < KB; k0 += R) {
 #pragma unroll
             for (int p = 0; p < R; p++) {
                 fetch(ring[(p + R - 1) % R]);
-                const uint32_t sn = (s0 + p + 1 == S) ? 0 : s0 + p + 1;
-                bfr[(p + 1) & 1][0] = qs[(sn * 2 + 0) * 64 + lane];
-                bfr[(p + 1) & 1][1] = qs[(sn * 2 + 1) * 64 + lane];
-                const float4 b0 = bfr[p & 1][0], b1 = bfr[p & 1][1];
+                const uint32_t kb = k0 + p;
+                bf16x8 qh[2], ql[2];
 #pragma unroll
-                for (int t = 0; t < RT; t++) {
-                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[p][t].x, b0.x, acc[t][0], 0, 0, 0);
-                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[p][t].x, b1.x, acc[t][1], 0, 0, 0);
+                for (int h = 0; h < 2; h++) {
+                    qh[h] = __builtin_bit_cast(bf16x8, qs[((kb * 2 + h) * 2 + 0) * 64 + lane]);
+                    ql[h] = __builtin_bit_cast(bf16x8, qs[((kb * 2 + h) * 2 + 1) * 64 + lane]);
                 }
 #pragma unroll
                 for (int t = 0; t < RT; t++) {
-                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[p][t].y, b0.y, acc[t][0], 0, 0, 0);
-                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[p][t].y, b1.y, acc[t][1], 0, 0, 0);
-                }
+                    const bf16x8 xh = __builtin_bit_cast(bf16x8, ring[p][t][0]);
+                    const bf16x8 xl = __builtin_bit_cast(bf16x8, ring[p][t][1]);
 #pragma unroll
-                for (int t = 0; t < RT; t++) {
-                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[p][t].z, b0.z, acc[t][0], 0, 0, 0);
-                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[p][t].z, b1.z, acc[t][1], 0, 0, 0);
-                }
-#pragma unroll
-                for (int t = 0; t < RT; t++) {
-                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[p][t].w, b0.w, acc[t][0], 0, 0, 0);
-                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[p][t].w, b1.w, acc[t][1], 0, 0, 0);
+                    for (int h = 0; h < 2; h++) {
+                        acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, qh[h], acc[t][h], 0, 0, 0);
+                        acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, ql[h], acc[t][h], 0, 0, 0);
+                        acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, qh[h], acc[t][h], 0, 0, 0);
+                    }
                 }
             }
         }
         // epilogue: lane holds rows rb..rb+3 of each row tile for queries r and 16+r
+        float xsv[16 * RT];  // all norms of the item first (wide s_load), then per-lane selects on values
+#pragma unroll
+        for (int i = 0; i < 16 * RT; i++) xsv[i] = xs_item[i];
 #pragma unroll
         for (int t = 0; t < RT; t++) {
             const uint64_t rb = row0 + t * 16 + 4 * g;
-            if (rb + 3 < n) {
-                const float4 xs = *reinterpret_cast<const float4 *>(xsq + rb);
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    float4 key;
-                    key.x = xs.x - 2.0f * acc[t][h][0];
-                    key.y = xs.y - 2.0f * acc[t][h][1];
-                    key.z = xs.z - 2.0f * acc[t][h][2];
-                    key.w = xs.w - 2.0f * acc[t][h][3];
-                    *reinterpret_cast<float4 *>(out + uint64_t(h * 16 + r) * ld + rb) = key;
-                }
-            } else {
+            for (int h = 0; h < 2; h++) {
+                float key[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    if (rb + e < n) {
-                        float xs = xsq[rb + e];
-                        out[uint64_t(r) * ld + rb + e] = xs - 2.0f * acc[t][0][e];
-                        out[uint64_t(16 + r) * ld + rb + e] = xs - 2.0f * acc[t][1][e];
+                    const float x0 = xsv[t * 16 + 0 + e], x1 = xsv[t * 16 + 4 + e];
+                    const float x2 = xsv[t * 16 + 8 + e], x3 = xsv[t * 16 + 12 + e];
+                    const float xv = g == 0 ? x0 : (g == 1 ? x1 : (g == 2 ? x2 : x3));
+                    key[e] = xv - 2.0f * acc[t][h][e];
+                }
+                if (MODE == MODE_SAMPLE) {
+                    float4 kv;
+                    kv.x = rb + 0 < n ? key[0] : INFINITY;
+                    kv.y = rb + 1 < n ? key[1] : INFINITY;
+                    kv.z = rb + 2 < n ? key[2] : INFINITY;
+                    kv.w = rb + 3 < n ? key[3] : INFINITY;
+                    const uint64_t col = uint64_t(item) * (16 * RT) + t * 16 + 4 * g;  // dense position in the sample
+                    *reinterpret_cast<float4 *>(a.out + uint64_t(h * 16 + r) * a.ld + col) = kv;
+                } else {
+                    const uint32_t q = h * 16 + r;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (key[e] <= tau[h] && rb + e < n) {  // rare: ~k' * item_step hits per query in total
+                            uint32_t pos = atomicAdd(hit_n, 1u);  // LDS atomic: waits on lgkmcnt only
+                            if (pos < MFMA_WGBUF) {
+                                hit_key[pos] = pair_key(key[e], uint32_t(rb + e));
+                                hit_q[pos] = q;
+                            } else {
+                                atomicAdd(&a.cnt[q], a.cap + 1);  // buffer full: mark the query as overflowed (-> exact fallback)
+                            }
+                        }
                     }
                 }
             }
         }
     }
+    if (MODE == MODE_FILTER) flush_hits();
 }
 
-template <int RT, int PD, int NT>
-static void flat_mfma_launch(const float *X, uint64_t n, uint32_t dim, const float *qfrag, const float *xsq,
-                             float *out, uint64_t ld, int num_cu, hipStream_t s) {
-    size_t lds = size_t(dim) * MFMA_B * sizeof(float);
+template <int RT, int PD, int NT, int MODE>
+static void flat_mfma_launch(const MfmaArgs &a, int num_cu, hipStream_t s) {
+    constexpr uint32_t NWL = NT / 64;
+    size_t lds = size_t(a.dim) * MFMA_B * sizeof(float) + size_t(MFMA_WGBUF) * 12 + 80 * 4 + 16;
     static bool attr_done = false;
     if (!attr_done) {
-        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_mfma<RT, PD, NT>),
+        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_mfma<RT, PD, NT, MODE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     constexpr uint32_t NW = NT / 64;
-    uint64_t items = (n + 16 * RT - 1) / (16 * RT);
-    VDB_REQUIRE(items < (1ull << 31), "flat_mfma: too many rows for one shard");
+    uint32_t n_visit = (a.n_items + a.item_step - 1) / a.item_step;
     uint32_t grid = (uint32_t)num_cu;
-    uint64_t need = (items + NW - 1) / NW;
-    if (need < grid) grid = (uint32_t)need;
+    uint32_t need = (n_visit + NW - 1) / NW;
+    if (need < grid) grid = need;
     if (grid == 0) return;
-    hipLaunchKernelGGL((k_flat_mfma<RT, PD, NT>), dim3(grid), dim3(NT), lds, s, X, n, dim,
-                       reinterpret_cast<const float4 *>(qfrag), xsq, out, ld, (uint32_t)items);
+    hipLaunchKernelGGL((k_flat_mfma<RT, PD, NT, MODE>), dim3(grid), dim3(NT), lds, s, a);
 }
 
-void launch_flat_mfma(const float *X, uint64_t n, uint32_t dim, const float *qfrag, const float *xsq, float *out,
-                      uint64_t ld, int num_cu, hipStream_t s) {
-    VDB_REQUIRE(mfma_supported(dim), "flat_mfma: dim must be a multiple of 32 with 32*dim*4 <= 150 KiB");
-    VDB_REQUIRE((ld & 3) == 0, "flat_mfma: ld must be a multiple of 4");
+template <int MODE>
+static void flat_mfma_dispatch(const MfmaArgs &a, int num_cu, hipStream_t s) {
+    uint32_t KB = a.dim / 32;  // the ring size R = PD+1 must divide KB
+    if (KB % 6 == 0) {
+        if (g_mfma_variant == 1)
+            flat_mfma_launch<MFMA_RT, 5, 256, MODE>(a, num_cu, s);
+        else if (g_mfma_variant == 2)
+            flat_mfma_launch<MFMA_RT, 2, 512, MODE>(a, num_cu, s);
+        else if (g_mfma_variant == 3)
+            flat_mfma_launch<MFMA_RT, 2, 256, MODE>(a, num_cu, s);
+        else
+            flat_mfma_launch<MFMA_RT, 5, 512, MODE>(a, num_cu, s);
+    } else if (KB % 4 == 0) {
+        flat_mfma_launch<MFMA_RT, 3, 512, MODE>(a, num_cu, s);
+    } else {
+        flat_mfma_launch<MFMA_RT, 1, 512, MODE>(a, num_cu, s);
+    }
+}
+
+uint32_t mfma_num_items(uint64_t n) { return (uint32_t)((n + 16 * MFMA_RT - 1) / (16 * MFMA_RT)); }
+// every `step`-th item is sampled; at least 256 items (8192 rows) when the corpus has that many
+uint32_t mfma_sample_step(uint64_t n) {
+    uint32_t items = mfma_num_items(n);
+    uint32_t step = items / 256;
+    return step < 1 ? 1 : (step > 64 ? 64 : step);
+}
+uint64_t mfma_sample_rows(uint64_t n) {
+    uint32_t items = mfma_num_items(n), step = mfma_sample_step(n);
+    return uint64_t((items + step - 1) / step) * 16 * MFMA_RT;
+}
+
+void launch_flat_mfma_sample(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, const float *xsq,
+                             float *out, uint64_t ld, int num_cu, hipStream_t s) {
+    VDB_REQUIRE(mfma_supported(dim), "flat_mfma: dim must be a multiple of 64 with 32*dim*4 <= 128 KiB");
+    VDB_REQUIRE((ld & 3) == 0 && ld >= mfma_sample_rows(n), "flat_mfma: ld must cover the sample");
+    VDB_REQUIRE(n < (1ull << 32), "flat_mfma: too many rows for one shard");
     if (n == 0) return;
-    uint32_t S = dim / 16;
-    // ring size R = PD+1 must be even and divide S = dim/16
-    if (S % 6 == 0)
-        flat_mfma_launch<2, 5, 512>(X, n, dim, qfrag, xsq, out, ld, num_cu, s);
-    else if (S % 4 == 0)
-        flat_mfma_launch<2, 3, 512>(X, n, dim, qfrag, xsq, out, ld, num_cu, s);
-    else
-        flat_mfma_launch<2, 1, 512>(X, n, dim, qfrag, xsq, out, ld, num_cu, s);
+    MfmaArgs a{};
+    a.XT = reinterpret_cast<const uint4 *>(XT);
+    a.qfrag = reinterpret_cast<const uint4 *>(qfrag);
+    a.xsq = xsq;
+    a.n = n;
+    a.dim = dim;
+    a.n_items = mfma_num_items(n);
+    a.item_step = mfma_sample_step(n);
+    a.out = out;
+    a.ld = ld;
+    flat_mfma_dispatch<MODE_SAMPLE>(a, num_cu, s);
+}
+
+void launch_flat_mfma_filter(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, const float *xsq,
+                             const float *tau, uint64_t *cand, uint32_t *cnt, uint32_t cap, int num_cu,
+                             hipStream_t s) {
+    VDB_REQUIRE(mfma_supported(dim), "flat_mfma: dim must be a multiple of 64 with 32*dim*4 <= 128 KiB");
+    VDB_REQUIRE(n < (1ull << 32), "flat_mfma: too many rows for one shard");
+    if (n == 0) return;
+    MfmaArgs a{};
+    a.XT = reinterpret_cast<const uint4 *>(XT);
+    a.qfrag = reinterpret_cast<const uint4 *>(qfrag);
+    a.xsq = xsq;
+    a.n = n;
+    a.dim = dim;
+    a.n_items = mfma_num_items(n);
+    a.item_step = 1;
+    a.tau = tau;
+    a.cand = cand;
+    a.cnt = cnt;
+    a.cap = cap;
+    a.debug = g_mfma_variant >= 16 ? (g_mfma_variant >> 4) : 0;
+    flat_mfma_dispatch<MODE_FILTER>(a, num_cu, s);
 }
 
 }  // namespace vdb

@@ -33,6 +33,9 @@ void launch_certify(const uint64_t *exact_sorted, uint32_t lde, const uint64_t *
                     uint32_t nq, uint32_t k, uint32_t kprime, uint64_t n_rows, const float *qsq, float xsq_max,
                     uint32_t dim, uint8_t *flags, hipStream_t s);
 
+void launch_extract_tau(const uint64_t *sorted, uint32_t ld, uint32_t nq, uint32_t kprime, float *tau, hipStream_t s);
+void launch_flag_overflow(const uint32_t *cnt, uint32_t cap, uint32_t nq, uint8_t *flags, hipStream_t s);
+
 // ---- k_topk.hip ----------------------------------------------------------------------------
 // rows per level-1 list
 constexpr uint32_t TOPK_CHUNK = 8192;
@@ -52,10 +55,22 @@ void launch_pack_pairs(const float *dists, const uint64_t *ids, const uint64_t *
 constexpr uint32_t MFMA_B = 32;  // queries per corpus pass
 // Q [nq<=32][dim] -> fragment-ordered image (dim/16 steps x 2 halves x 64 lanes x float4); dim % 16 == 0
 void launch_mfma_pack_queries(const float *Q, uint32_t nq, uint32_t dim, float *qfrag, hipStream_t s);
-// approximate keys out[b*ld + i] = xsq[i] - 2*dot(x_i, q_b) for b < 32 (rows >= n untouched)
-void launch_flat_mfma(const float *X, uint64_t n, uint32_t dim, const float *qfrag, const float *xsq, float *out,
-                      uint64_t ld, int num_cu, hipStream_t s);
+// fragment-ordered mirror of rows: tiles [tile0, tile1) of 16 rows each; T holds ceil(n/16) tiles rounded up to 4
+void launch_tile_rows(const float *X, uint64_t n, uint32_t dim, uint64_t tile0, uint64_t tile1, float *T,
+                      hipStream_t s);
+// approximate keys key(i,b) = xsq[i] - 2*dot(x_i, q_b) for b < 32; XT = fragment-ordered mirror.
+// sample: keys of a strided sample of rows, dense: out[b*ld + j], j < mfma_sample_rows(n) (+inf past n)
+void launch_flat_mfma_sample(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, const float *xsq,
+                             float *out, uint64_t ld, int num_cu, hipStream_t s);
+// filter: pair keys of all rows with key <= tau[b] appended to cand[b][0..cap) (cnt[b] counts every hit)
+void launch_flat_mfma_filter(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, const float *xsq,
+                             const float *tau, uint64_t *cand, uint32_t *cnt, uint32_t cap, int num_cu,
+                             hipStream_t s);
+uint64_t mfma_sample_rows(uint64_t n);
+uint32_t mfma_sample_step(uint64_t n);
 size_t mfma_qfrag_floats(uint32_t dim);
+void mfma_set_variant(int v);  // tuning hook (0 = default)
+uint64_t mfma_row_pad();
 bool mfma_supported(uint32_t dim);
 
 }  // namespace vdb

@@ -167,6 +167,9 @@ class GpuIndex:
     def set_flat_mode(self, mode: int):
         L.check(self._lib.vdb_flat_set_mode(self._h, int(mode)))
 
+    def set_param(self, name: str, value: int):
+        L.check(self._lib.vdb_set_param(self._h, name.encode(), int(value)))
+
     def flat_fallback_count(self) -> int:
         v = C.c_uint64()
         L.check(self._lib.vdb_flat_fallback_count(self._h, C.byref(v)))
