@@ -134,8 +134,15 @@ def main():
         avg_ms = p["ms"] / p["launches"]
         bytes_per_launch = p["bytes"] / p["launches"]  # shard_rows * dim * 4
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch from the committed PMC passes (same kernel, same shard size only)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_flat_mfma.json")))
+            if kernel == "flat_mfma" and abs(pmc["algorithmic_bytes_per_launch"] - bytes_per_launch) < 1:
+                traffic = pmc["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel,
                     "avg_launch_ms": round(avg_ms, 4), "launches": p["launches"],
                     "bytes_per_launch": bytes_per_launch}
 
