@@ -224,25 +224,19 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     ws.flags.reserve(nq_pad);
     float *d_tau = ws.misc.as<float>();
     uint32_t *d_hits = reinterpret_cast<uint32_t *>(d_tau + nq_pad);
-    for (uint64_t b = 0; b < nbatch; b++) {
-        uint32_t nb = (uint32_t)std::min<uint64_t>(MFMA_B, nq - b * MFMA_B);
-        launch_mfma_pack_queries(d_q + b * MFMA_B * dim, nb, (uint32_t)dim, ws.qfrag.as<float>() + b * qf, s);
-        launch_flat_mfma_sample(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>() + b * qf, d_sq.as<float>(),
-                                ws.dense.as<float>() + b * MFMA_B * ld_s, ld_s, num_cu, s);
-    }
+    launch_mfma_pack_queries(d_q, (uint32_t)nq, (uint32_t)dim, ws.qfrag.as<float>(), s);
+    launch_flat_mfma_sample(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>(), (uint32_t)nbatch, d_sq.as<float>(),
+                            ws.dense.as<float>(), ld_s, num_cu, s);
     launch_topk_dense(ws.dense.as<float>(), ld_s, n_s, (uint32_t)nq_pad, kprime, ws.lists.as<uint64_t>(), s);
     launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, capp, (uint32_t)nq_pad, kprime, ws.keys_a.as<uint64_t>(), s);
     launch_extract_tau(ws.keys_a.as<uint64_t>(), capp, (uint32_t)nq_pad, kprime, d_tau, s);
     uint64_t *d_cand = ws.lists.as<uint64_t>();  // the sample lists are dead now
     VDB_HIP(hipMemsetAsync(d_cand, 0xff, nq_pad * size_t(CAND_CAP) * sizeof(uint64_t), s));
     VDB_HIP(hipMemsetAsync(d_hits, 0, nq_pad * sizeof(uint32_t), s));
-    for (uint64_t b = 0; b < nbatch; b++) {
-        prof_begin(ws, "flat_mfma", double(n) * dim * sizeof(float));
-        launch_flat_mfma_filter(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>() + b * qf, d_sq.as<float>(),
-                                d_tau + b * MFMA_B, d_cand + b * MFMA_B * size_t(CAND_CAP), d_hits + b * MFMA_B, CAND_CAP,
-                                num_cu, s);
-        prof_end(ws);
-    }
+    prof_begin(ws, "flat_mfma", double(nbatch) * double(n) * dim * sizeof(float));
+    launch_flat_mfma_filter(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>(), (uint32_t)nbatch, d_sq.as<float>(),
+                            d_tau, d_cand, d_hits, CAND_CAP, num_cu, s);
+    prof_end(ws);
     launch_topk_merge(d_cand, 1, CAND_CAP, (uint32_t)nq, kprime, ws.keys_a.as<uint64_t>(), s);
     VDB_HIP(hipMemsetAsync(ws.keys_b.p, 0xff, nq * capp * sizeof(uint64_t), s));
     launch_rerank(d_rows.as<float>(), (uint32_t)dim, d_q, (uint32_t)nq, MET_L2_DIRECT, d_sq.as<float>(),

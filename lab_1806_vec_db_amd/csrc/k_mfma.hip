@@ -96,13 +96,14 @@ void launch_tile_rows(const float *X, uint64_t n, uint32_t dim, uint64_t tile0, 
                        reinterpret_cast<uint4 *>(T));
 }
 
-// Q [nq<=32][dim] -> B-operand image [kb][half][hi|lo][lane] (queries >= nq: zero)
+// Q [nq][dim] -> per batch of 32 queries a B-operand image [kb][half][hi|lo][lane] (queries >= nq: zero)
 __global__ void k_mfma_pack_queries(const float *__restrict__ Q, uint32_t nq, uint32_t dim, uint4 *__restrict__ qfrag) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // (kb, half, lane)
     uint32_t KB = dim / 32;
     if (i >= KB * 128) return;
+    qfrag += uint64_t(blockIdx.y) * KB * 256;
     uint32_t l = i & 63, h = (i >> 6) & 1, kb = i >> 7;
-    uint32_t q = h * 16 + (l & 15);
+    uint32_t q = blockIdx.y * MFMA_B + h * 16 + (l & 15);
     uint32_t c = kb * 32 + 8 * (l >> 4);
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     if (q < nq) {
@@ -117,251 +118,275 @@ __global__ void k_mfma_pack_queries(const float *__restrict__ Q, uint32_t nq, ui
 
 void launch_mfma_pack_queries(const float *Q, uint32_t nq, uint32_t dim, float *qfrag, hipStream_t s) {
     uint32_t total = (dim / 32) * 128;
-    hipLaunchKernelGGL(k_mfma_pack_queries, dim3((total + 255) / 256), dim3(256), 0, s, Q, nq, dim,
+    uint32_t nbatch = (nq + MFMA_B - 1) / MFMA_B;
+    if (nbatch == 0) return;
+    hipLaunchKernelGGL(k_mfma_pack_queries, dim3((total + 255) / 256, nbatch), dim3(256), 0, s, Q, nq, dim,
                        reinterpret_cast<uint4 *>(qfrag));
 }
 
 // ---------------------------------------------------------------------------------------------------
-// RT row tiles of 16 rows per wave item, ring of R = PD+1 k-blocks, NT threads per (persistent) workgroup
+// 2 row tiles of 16 rows per wave item, ring of R = PD+1 k-blocks, 512 threads per (persistent) workgroup
 // ---------------------------------------------------------------------------------------------------
-// MODE_SAMPLE: visit every `item_step`-th item and write its keys densely (out[b*ld + j*16*RT + row_in_item],
+// MODE_SAMPLE: visit every `item_step`-th item and write its keys densely (out[q*ld + j*32 + row_in_item],
 //              +inf for rows >= n): a strided sample whose k'-th smallest key per query is an upper bound tau
-//              of the k'-th smallest key over all rows.
-// MODE_FILTER: visit every item and append pair_key(key,row) of the keys <= tau[b] to cand[b][..] (atomic
-//              slot counter per query); nothing else is written.  Writing all B x N keys instead costs 18 % of
-//              the kernel (measured: 0.768 ms vs 0.629 ms per pass) although it is 3 % of the bytes, because
-//              the stores are 64-B pieces scattered over 32 rows of the key matrix.
+//              of the k'-th smallest key over all rows.  blockIdx.y = query batch.
+// MODE_FILTER: for every query batch in turn, visit every item and collect pair_key(key,row) of the keys
+//              <= tau[q]; nothing else is written.  (Writing all B x N keys instead costs 18 % of the kernel
+//              -- measured 0.768 ms vs 0.629 ms per pass -- although it is 3 % of the bytes, because the stores
+//              are 64-B pieces scattered over 32 rows of the key matrix.)  ONE launch walks all batches: a
+//              workgroup that has finished batch b starts batch b+1 at once (no grid-wide ramp-down / ramp-up
+//              per 32 queries), and the next batch's Q image is prefetched into registers while the
+//              workgroup's other waves finish, so the LDS refill is a register->LDS copy.
 enum { MODE_SAMPLE = 0, MODE_FILTER = 1 };
 
 struct MfmaArgs {
     const uint4 *XT;
-    const uint4 *qfrag;
+    const uint4 *qfrag;  // [nbatch][KB*256]
     const float *xsq;
     uint64_t n;
-    uint32_t dim, n_items, item_step;
+    uint32_t dim, n_items, item_step, nbatch;
     // MODE_SAMPLE
-    float *out;
+    float *out;          // [nbatch*32][ld]
     uint64_t ld;
     // MODE_FILTER
-    const float *tau;   // [32]
-    uint64_t *cand;     // [32][cap]
-    uint32_t *cnt;      // [32]
+    const float *tau;    // [nbatch*32]
+    uint64_t *cand;      // [nbatch*32][cap]
+    uint32_t *cnt;       // [nbatch*32]
     uint32_t cap;
     uint32_t debug;
 };
 
-template <int RT, int PD, int NT, int MODE>
-__global__ __launch_bounds__(NT, 1) void k_flat_mfma(MfmaArgs a) {
+template <int PD, int MODE>
+__global__ __launch_bounds__(512, 1) void k_flat_mfma(MfmaArgs a) {
+    constexpr int NT = 512, RT = MFMA_RT;
+    constexpr uint32_t NW = NT / 64;
     const uint4 *__restrict__ XT = a.XT;
-    const uint4 *__restrict__ qfrag = a.qfrag;
     const float *__restrict__ xsq = a.xsq;
     const uint64_t n = a.n;
     const uint32_t dim = a.dim;
-    const uint32_t n_visit = (a.n_items + a.item_step - 1) / a.item_step;  // items this launch visits
-    extern __shared__ __attribute__((aligned(16))) uint4 qs[];  // [KB][2 halves][hi|lo][64], then the hit buffers
+    const uint32_t n_visit = (a.n_items + a.item_step - 1) / a.item_step;  // items one pass visits
+    extern __shared__ __attribute__((aligned(16))) uint4 qs[];  // [KB][2 halves][hi|lo][64], then the hit buffer
     const uint32_t KB = dim / 32;
+    const uint32_t qn = KB * 256;  // uint4 in one Q image
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr uint32_t NW = NT / 64;
     // per-workgroup hit buffer (MODE_FILTER): pairs that pass the threshold are parked in LDS and handed to the
-    // global per-query candidate lists once, when the workgroup has finished streaming.  Alternatives
-    // measured on MI355X: a global slot atomic per hit inside the item loop forces s_waitcnt vmcnt(0) (drains
-    // the prefetch ring: 0.667 ms/pass instead of 0.636); per-wave buffers flushed at the end serialise ~2000
+    // global per-query candidate lists once per batch, when the workgroup has finished streaming.  Measured
+    // alternatives: a global slot atomic per hit inside the item loop forces s_waitcnt vmcnt(0) (drains the
+    // prefetch ring: 0.667 ms/pass instead of 0.636); per-wave buffers flushed at the end serialise ~2000
     // atomics per query counter in the kernel's tail (0.667 ms); flushing per 8 hits is worse (0.712 ms).
     // Here each workgroup reserves its range with ONE atomic per query (256 per counter per pass).
-    uint64_t *hit_key = reinterpret_cast<uint64_t *>(qs + KB * 256);
+    uint64_t *hit_key = reinterpret_cast<uint64_t *>(qs + qn);
     uint32_t *hit_q = reinterpret_cast<uint32_t *>(hit_key + MFMA_WGBUF);
     uint32_t *hit_n = hit_q + MFMA_WGBUF;  // [0] entries, [1..32] per-query counts, [33..64] per-query bases
-    if (MODE == MODE_FILTER && threadIdx.x < 80) hit_n[threadIdx.x] = 0;
-    for (uint32_t i = threadIdx.x; i < KB * 256; i += NT) qs[i] = qfrag[i];
-    __syncthreads();
 
     const uint32_t r = lane & 15, g = lane >> 4;
     const uint32_t stride = gridDim.x * NW;
     const uint32_t first = blockIdx.x * NW + wave;
-    float tau[2] = {0.f, 0.f};
-    if (MODE == MODE_FILTER) {
-        tau[0] = a.tau[r];
-        tau[1] = a.tau[16 + r];
-        if (a.debug & 1) tau[0] = tau[1] = -INFINITY;  // timing experiment: no hits
-    }
+    const uint32_t b_begin = MODE == MODE_SAMPLE ? blockIdx.y : 0;
+    const uint32_t b_end = MODE == MODE_SAMPLE ? blockIdx.y + 1 : a.nbatch;
 
-    // The X stream is one continuous sequence of (item, k-block) pairs per wave; a cursor runs PD k-blocks
-    // ahead of the MFMAs and never stops at an item boundary, so every load is unconditional (the compiler
-    // counts vmcnt instead of draining it) and HBM latency is covered across items.  Past the wave's last
-    // item the cursor re-reads that item (L2 hits, results unused).
-    uint32_t c_item = first, c_kb = 0;
-    const uint4 *cp;  // this lane's 16 B of (item, tile 0, kb 0, hi); tile t is KB*128 uint4 further
-    auto set_ptrs = [&](uint32_t v) {  // v = ordinal among the visited items
-        if (v >= n_visit) v = n_visit - 1;
-        cp = XT + uint64_t(v) * a.item_step * RT * KB * 128 + lane;
+    // Q image staging through registers (<= 128 KB / 512 threads = 16 uint4 per thread)
+    constexpr int QREG = 16;
+    uint4 qreg[QREG];
+    auto q_load = [&](uint32_t b) {
+        const uint4 *src = a.qfrag + uint64_t(b) * qn;
+#pragma unroll
+        for (int j = 0; j < QREG; j++) {
+            uint32_t i = j * NT + threadIdx.x;
+            qreg[j] = i < qn ? src[i] : make_uint4(0, 0, 0, 0);
+        }
     };
-    set_ptrs(c_item);
-    // Register ring of R = PD+1 slots: k-block i is consumed from slot i%R while the loads for k-block
-    // i+PD land in slot (i-1)%R, whose MFMAs were issued one step earlier.  With the loop unrolled by R
-    // every slot keeps its registers across the back edge (no rotation copies, no vmcnt(0) drain).
+    auto q_store = [&]() {
+#pragma unroll
+        for (int j = 0; j < QREG; j++) {
+            uint32_t i = j * NT + threadIdx.x;
+            if (i < qn) qs[i] = qreg[j];
+        }
+    };
+
     constexpr int R = PD + 1;
-    uint4 ring[R][RT][2];
-    auto fetch = [&](uint4(&dst)[RT][2]) {
-#pragma unroll
-        for (int t = 0; t < RT; t++) {
-            dst[t][0] = cp[((uint64_t(t) * KB + c_kb) * 2 + 0) * 64];
-            dst[t][1] = cp[((uint64_t(t) * KB + c_kb) * 2 + 1) * 64];
+    q_load(b_begin);
+    for (uint32_t b = b_begin; b < b_end; b++) {
+        q_store();
+        if (MODE == MODE_FILTER && threadIdx.x < 80) hit_n[threadIdx.x] = 0;
+        __syncthreads();
+        float tau[2] = {0.f, 0.f};
+        if (MODE == MODE_FILTER) {
+            tau[0] = a.tau[b * MFMA_B + r];
+            tau[1] = a.tau[b * MFMA_B + 16 + r];
+            if (a.debug & 1) tau[0] = tau[1] = -INFINITY;  // timing experiment: no hits
         }
-        c_kb++;
-        if (c_kb == KB) {
-            c_kb = 0;
-            c_item += stride;
-            set_ptrs(c_item);
-        }
-    };
-#pragma unroll
-    for (int p = 0; p < PD; p++) fetch(ring[p]);
 
-    auto flush_hits = [&]() {  // whole workgroup, after every wave has left its item loop
-        __syncthreads();
-        uint32_t total = hit_n[0];
-        if (total > MFMA_WGBUF) total = MFMA_WGBUF;
-        uint32_t rank[(MFMA_WGBUF + NT - 1) / NT];
+        // The X stream is one continuous sequence of (item, k-block) pairs per wave; a cursor runs PD k-blocks
+        // ahead of the MFMAs and never stops at an item boundary, so every load is unconditional (the compiler
+        // counts vmcnt instead of draining it) and HBM latency is covered across items.  Past the wave's last
+        // item the cursor re-reads that item (L2 hits, results unused).
+        uint32_t c_item = first, c_kb = 0;
+        const uint4 *cp;  // this lane's 16 B of (item, tile 0, kb 0, hi); tile t is KB*128 uint4 further
+        auto set_ptrs = [&](uint32_t v) {  // v = ordinal among the visited items
+            if (v >= n_visit) v = n_visit - 1;
+            cp = XT + uint64_t(v) * a.item_step * RT * KB * 128 + lane;
+        };
+        set_ptrs(c_item);
+        // Register ring of R = PD+1 slots: k-block i is consumed from slot i%R while the loads for k-block
+        // i+PD land in slot (i-1)%R, whose MFMAs were issued one step earlier.  With the loop unrolled by R
+        // every slot keeps its registers across the back edge (no rotation copies, no vmcnt(0) drain).
+        uint4 ring[R][RT][2];
+        auto fetch = [&](uint4(&dst)[RT][2]) {
 #pragma unroll
-        for (uint32_t j = 0; j < (MFMA_WGBUF + NT - 1) / NT; j++) {
-            uint32_t i = j * NT + threadIdx.x;
-            rank[j] = i < total ? atomicAdd(&hit_n[1 + hit_q[i]], 1u) : 0u;  // rank inside (workgroup, query)
-        }
-        __syncthreads();
-        if (threadIdx.x < 32 && hit_n[1 + threadIdx.x] > 0)
-            hit_n[33 + threadIdx.x] = atomicAdd(&a.cnt[threadIdx.x], hit_n[1 + threadIdx.x]);  // reserve a range
-        __syncthreads();
-#pragma unroll
-        for (uint32_t j = 0; j < (MFMA_WGBUF + NT - 1) / NT; j++) {
-            uint32_t i = j * NT + threadIdx.x;
-            if (i < total) {
-                uint32_t q = hit_q[i];
-                uint32_t slot = hit_n[33 + q] + rank[j];
-                if (slot < a.cap) a.cand[uint64_t(q) * a.cap + slot] = hit_key[i];
+            for (int t = 0; t < RT; t++) {
+                dst[t][0] = cp[((uint64_t(t) * KB + c_kb) * 2 + 0) * 64];
+                dst[t][1] = cp[((uint64_t(t) * KB + c_kb) * 2 + 1) * 64];
             }
-        }
-    };
-    for (uint32_t item = first; item < n_visit; item += stride) {
-        const uint64_t row0 = uint64_t(item) * a.item_step * (16 * RT);
-        // |x|^2 of the item's 16*RT rows through SCALAR loads (the address is wave-uniform): SMEM is tracked
-        // by lgkmcnt, so reading it in the epilogue does not drain the vector-memory prefetch ring.  (As
-        // vector loads the compiler sinks them next to their use and emits s_waitcnt vmcnt(1) there: one full
-        // HBM round trip of the ring per item, ~6 % of the kernel.)
-        // (constant address space + uniform address => s_load_dword*, not global_load)
-        typedef const __attribute__((address_space(4))) float *cfloat_p;
-        cfloat_p xs_item = (cfloat_p)(xsq + uint64_t(__builtin_amdgcn_readfirstlane(item)) * a.item_step * (16 * RT));
-        f32x4 acc[RT][2];
+            c_kb++;
+            if (c_kb == KB) {
+                c_kb = 0;
+                c_item += stride;
+                set_ptrs(c_item);
+            }
+        };
 #pragma unroll
-        for (int t = 0; t < RT; t++) {
-            acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        for (uint32_t k0 = 0; k0 < KB; k0 += R) {
+        for (int p = 0; p < PD; p++) fetch(ring[p]);
+
+        for (uint32_t item = first; item < n_visit; item += stride) {
+            const uint64_t row0 = uint64_t(item) * a.item_step * (16 * RT);
+            // |x|^2 of the item's 32 rows through SCALAR loads (the address is wave-uniform): SMEM is tracked by
+            // lgkmcnt, so reading it in the epilogue does not drain the vector-memory prefetch ring.  (As vector
+            // loads the compiler sinks them next to their use and emits s_waitcnt vmcnt(1) there: one full HBM
+            // round trip of the ring per item.)  constant address space + uniform address => s_load_dwordx8.
+            typedef const __attribute__((address_space(4))) float *cfloat_p;
+            cfloat_p xs_item = (cfloat_p)(xsq + uint64_t(__builtin_amdgcn_readfirstlane(item)) * a.item_step * (16 * RT));
+            f32x4 acc[RT][2];
 #pragma unroll
-            for (int p = 0; p < R; p++) {
-                fetch(ring[(p + R - 1) % R]);
-                const uint32_t kb = k0 + p;
-                bf16x8 qh[2], ql[2];
+            for (int t = 0; t < RT; t++) {
+                acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            for (uint32_t k0 = 0; k0 < KB; k0 += R) {
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    qh[h] = __builtin_bit_cast(bf16x8, qs[((kb * 2 + h) * 2 + 0) * 64 + lane]);
-                    ql[h] = __builtin_bit_cast(bf16x8, qs[((kb * 2 + h) * 2 + 1) * 64 + lane]);
-                }
-#pragma unroll
-                for (int t = 0; t < RT; t++) {
-                    const bf16x8 xh = __builtin_bit_cast(bf16x8, ring[p][t][0]);
-                    const bf16x8 xl = __builtin_bit_cast(bf16x8, ring[p][t][1]);
+                for (int p = 0; p < R; p++) {
+                    fetch(ring[(p + R - 1) % R]);
+                    const uint32_t kb = k0 + p;
+                    bf16x8 qh[2], ql[2];
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
-                        acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, qh[h], acc[t][h], 0, 0, 0);
-                        acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, ql[h], acc[t][h], 0, 0, 0);
-                        acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, qh[h], acc[t][h], 0, 0, 0);
+                        qh[h] = __builtin_bit_cast(bf16x8, qs[((kb * 2 + h) * 2 + 0) * 64 + lane]);
+                        ql[h] = __builtin_bit_cast(bf16x8, qs[((kb * 2 + h) * 2 + 1) * 64 + lane]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < RT; t++) {
+                        const bf16x8 xh = __builtin_bit_cast(bf16x8, ring[p][t][0]);
+                        const bf16x8 xl = __builtin_bit_cast(bf16x8, ring[p][t][1]);
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, qh[h], acc[t][h], 0, 0, 0);
+                            acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, ql[h], acc[t][h], 0, 0, 0);
+                            acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, qh[h], acc[t][h], 0, 0, 0);
+                        }
                     }
                 }
             }
-        }
-        // epilogue: lane holds rows rb..rb+3 of each row tile for queries r and 16+r
-        float xsv[16 * RT];  // all norms of the item first (wide s_load), then per-lane selects on values
+            // epilogue: lane holds rows rb..rb+3 of each row tile for queries r and 16+r
+            float xsv[16 * RT];  // all norms of the item first (wide s_load), then per-lane selects on values
 #pragma unroll
-        for (int i = 0; i < 16 * RT; i++) xsv[i] = xs_item[i];
+            for (int i = 0; i < 16 * RT; i++) xsv[i] = xs_item[i];
 #pragma unroll
-        for (int t = 0; t < RT; t++) {
-            const uint64_t rb = row0 + t * 16 + 4 * g;
+            for (int t = 0; t < RT; t++) {
+                const uint64_t rb = row0 + t * 16 + 4 * g;
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                float key[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float x0 = xsv[t * 16 + 0 + e], x1 = xsv[t * 16 + 4 + e];
-                    const float x2 = xsv[t * 16 + 8 + e], x3 = xsv[t * 16 + 12 + e];
-                    const float xv = g == 0 ? x0 : (g == 1 ? x1 : (g == 2 ? x2 : x3));
-                    key[e] = xv - 2.0f * acc[t][h][e];
-                }
-                if (MODE == MODE_SAMPLE) {
-                    float4 kv;
-                    kv.x = rb + 0 < n ? key[0] : INFINITY;
-                    kv.y = rb + 1 < n ? key[1] : INFINITY;
-                    kv.z = rb + 2 < n ? key[2] : INFINITY;
-                    kv.w = rb + 3 < n ? key[3] : INFINITY;
-                    const uint64_t col = uint64_t(item) * (16 * RT) + t * 16 + 4 * g;  // dense position in the sample
-                    *reinterpret_cast<float4 *>(a.out + uint64_t(h * 16 + r) * a.ld + col) = kv;
-                } else {
-                    const uint32_t q = h * 16 + r;
+                for (int h = 0; h < 2; h++) {
+                    float key[4];
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
-                        if (key[e] <= tau[h] && rb + e < n) {  // rare: ~k' * item_step hits per query in total
-                            uint32_t pos = atomicAdd(hit_n, 1u);  // LDS atomic: waits on lgkmcnt only
-                            if (pos < MFMA_WGBUF) {
-                                hit_key[pos] = pair_key(key[e], uint32_t(rb + e));
-                                hit_q[pos] = q;
-                            } else {
-                                atomicAdd(&a.cnt[q], a.cap + 1);  // buffer full: mark the query as overflowed (-> exact fallback)
+                        const float x0 = xsv[t * 16 + 0 + e], x1 = xsv[t * 16 + 4 + e];
+                        const float x2 = xsv[t * 16 + 8 + e], x3 = xsv[t * 16 + 12 + e];
+                        const float xv = g == 0 ? x0 : (g == 1 ? x1 : (g == 2 ? x2 : x3));
+                        key[e] = xv - 2.0f * acc[t][h][e];
+                    }
+                    if (MODE == MODE_SAMPLE) {
+                        float4 kv;
+                        kv.x = rb + 0 < n ? key[0] : INFINITY;
+                        kv.y = rb + 1 < n ? key[1] : INFINITY;
+                        kv.z = rb + 2 < n ? key[2] : INFINITY;
+                        kv.w = rb + 3 < n ? key[3] : INFINITY;
+                        const uint64_t col = uint64_t(item) * (16 * RT) + t * 16 + 4 * g;  // dense position in the sample
+                        *reinterpret_cast<float4 *>(a.out + (uint64_t(b) * MFMA_B + h * 16 + r) * a.ld + col) = kv;
+                    } else {
+                        const uint32_t q = h * 16 + r;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            if (key[e] <= tau[h] && rb + e < n) {  // rare: ~k' * sample step hits per query in total
+                                uint32_t pos = atomicAdd(hit_n, 1u);  // LDS atomic: waits on lgkmcnt only
+                                if (pos < MFMA_WGBUF) {
+                                    hit_key[pos] = pair_key(key[e], uint32_t(rb + e));
+                                    hit_q[pos] = q;
+                                } else {  // buffer full: mark the query as overflowed (-> exact fallback)
+                                    atomicAdd(&a.cnt[b * MFMA_B + q], a.cap + 1);
+                                }
                             }
                         }
                     }
                 }
             }
         }
+        if (b + 1 < b_end) q_load(b + 1);  // lands while the other waves finish and the hits are flushed
+        __syncthreads();                   // every wave has left the item loop: qs and the hit buffer are quiescent
+        if (MODE == MODE_FILTER) {
+            uint32_t total = hit_n[0];
+            if (total > MFMA_WGBUF) total = MFMA_WGBUF;
+            constexpr uint32_t NJ = (MFMA_WGBUF + NT - 1) / NT;
+            uint32_t rank[NJ];
+#pragma unroll
+            for (uint32_t j = 0; j < NJ; j++) {
+                uint32_t i = j * NT + threadIdx.x;
+                rank[j] = i < total ? atomicAdd(&hit_n[1 + hit_q[i]], 1u) : 0u;  // rank inside (workgroup, query)
+            }
+            __syncthreads();
+            if (threadIdx.x < 32 && hit_n[1 + threadIdx.x] > 0)  // reserve this workgroup's range: one atomic per query
+                hit_n[33 + threadIdx.x] = atomicAdd(&a.cnt[b * MFMA_B + threadIdx.x], hit_n[1 + threadIdx.x]);
+            __syncthreads();
+#pragma unroll
+            for (uint32_t j = 0; j < NJ; j++) {
+                uint32_t i = j * NT + threadIdx.x;
+                if (i < total) {
+                    uint32_t q = hit_q[i];
+                    uint32_t slot = hit_n[33 + q] + rank[j];
+                    if (slot < a.cap) a.cand[(uint64_t(b) * MFMA_B + q) * a.cap + slot] = hit_key[i];
+                }
+            }
+            __syncthreads();
+        }
     }
-    if (MODE == MODE_FILTER) flush_hits();
 }
 
-template <int RT, int PD, int NT, int MODE>
+template <int PD, int MODE>
 static void flat_mfma_launch(const MfmaArgs &a, int num_cu, hipStream_t s) {
-    constexpr uint32_t NWL = NT / 64;
     size_t lds = size_t(a.dim) * MFMA_B * sizeof(float) + size_t(MFMA_WGBUF) * 12 + 80 * 4 + 16;
     static bool attr_done = false;
     if (!attr_done) {
-        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_mfma<RT, PD, NT, MODE>),
+        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_mfma<PD, MODE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    constexpr uint32_t NW = NT / 64;
+    constexpr uint32_t NW = 8;
     uint32_t n_visit = (a.n_items + a.item_step - 1) / a.item_step;
     uint32_t grid = (uint32_t)num_cu;
     uint32_t need = (n_visit + NW - 1) / NW;
     if (need < grid) grid = need;
-    if (grid == 0) return;
-    hipLaunchKernelGGL((k_flat_mfma<RT, PD, NT, MODE>), dim3(grid), dim3(NT), lds, s, a);
+    if (grid == 0 || a.nbatch == 0) return;
+    dim3 g(grid, MODE == MODE_SAMPLE ? a.nbatch : 1);
+    hipLaunchKernelGGL((k_flat_mfma<PD, MODE>), g, dim3(512), lds, s, a);
 }
 
 template <int MODE>
 static void flat_mfma_dispatch(const MfmaArgs &a, int num_cu, hipStream_t s) {
     uint32_t KB = a.dim / 32;  // the ring size R = PD+1 must divide KB
-    if (KB % 6 == 0) {
-        if (g_mfma_variant == 1)
-            flat_mfma_launch<MFMA_RT, 5, 256, MODE>(a, num_cu, s);
-        else if (g_mfma_variant == 2)
-            flat_mfma_launch<MFMA_RT, 2, 512, MODE>(a, num_cu, s);
-        else if (g_mfma_variant == 3)
-            flat_mfma_launch<MFMA_RT, 2, 256, MODE>(a, num_cu, s);
-        else
-            flat_mfma_launch<MFMA_RT, 5, 512, MODE>(a, num_cu, s);
-    } else if (KB % 4 == 0) {
-        flat_mfma_launch<MFMA_RT, 3, 512, MODE>(a, num_cu, s);
-    } else {
-        flat_mfma_launch<MFMA_RT, 1, 512, MODE>(a, num_cu, s);
-    }
+    if (KB % 6 == 0)
+        flat_mfma_launch<5, MODE>(a, num_cu, s);
+    else if (KB % 4 == 0)
+        flat_mfma_launch<3, MODE>(a, num_cu, s);
+    else
+        flat_mfma_launch<1, MODE>(a, num_cu, s);
 }
 
 uint32_t mfma_num_items(uint64_t n) { return (uint32_t)((n + 16 * MFMA_RT - 1) / (16 * MFMA_RT)); }
@@ -376,12 +401,10 @@ uint64_t mfma_sample_rows(uint64_t n) {
     return uint64_t((items + step - 1) / step) * 16 * MFMA_RT;
 }
 
-void launch_flat_mfma_sample(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, const float *xsq,
-                             float *out, uint64_t ld, int num_cu, hipStream_t s) {
+static MfmaArgs mfma_args(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t nbatch,
+                          const float *xsq) {
     VDB_REQUIRE(mfma_supported(dim), "flat_mfma: dim must be a multiple of 64 with 32*dim*4 <= 128 KiB");
-    VDB_REQUIRE((ld & 3) == 0 && ld >= mfma_sample_rows(n), "flat_mfma: ld must cover the sample");
     VDB_REQUIRE(n < (1ull << 32), "flat_mfma: too many rows for one shard");
-    if (n == 0) return;
     MfmaArgs a{};
     a.XT = reinterpret_cast<const uint4 *>(XT);
     a.qfrag = reinterpret_cast<const uint4 *>(qfrag);
@@ -389,25 +412,27 @@ void launch_flat_mfma_sample(const float *XT, uint64_t n, uint32_t dim, const fl
     a.n = n;
     a.dim = dim;
     a.n_items = mfma_num_items(n);
+    a.nbatch = nbatch;
+    return a;
+}
+
+void launch_flat_mfma_sample(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t nbatch,
+                             const float *xsq, float *out, uint64_t ld, int num_cu, hipStream_t s) {
+    if (n == 0 || nbatch == 0) return;
+    MfmaArgs a = mfma_args(XT, n, dim, qfrag, nbatch, xsq);
+    VDB_REQUIRE((ld & 3) == 0 && ld >= mfma_sample_rows(n), "flat_mfma: ld must cover the sample");
+    VDB_REQUIRE(nbatch <= 65535, "flat_mfma: too many query batches");
     a.item_step = mfma_sample_step(n);
     a.out = out;
     a.ld = ld;
     flat_mfma_dispatch<MODE_SAMPLE>(a, num_cu, s);
 }
 
-void launch_flat_mfma_filter(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, const float *xsq,
-                             const float *tau, uint64_t *cand, uint32_t *cnt, uint32_t cap, int num_cu,
-                             hipStream_t s) {
-    VDB_REQUIRE(mfma_supported(dim), "flat_mfma: dim must be a multiple of 64 with 32*dim*4 <= 128 KiB");
-    VDB_REQUIRE(n < (1ull << 32), "flat_mfma: too many rows for one shard");
-    if (n == 0) return;
-    MfmaArgs a{};
-    a.XT = reinterpret_cast<const uint4 *>(XT);
-    a.qfrag = reinterpret_cast<const uint4 *>(qfrag);
-    a.xsq = xsq;
-    a.n = n;
-    a.dim = dim;
-    a.n_items = mfma_num_items(n);
+void launch_flat_mfma_filter(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t nbatch,
+                             const float *xsq, const float *tau, uint64_t *cand, uint32_t *cnt, uint32_t cap,
+                             int num_cu, hipStream_t s) {
+    if (n == 0 || nbatch == 0) return;
+    MfmaArgs a = mfma_args(XT, n, dim, qfrag, nbatch, xsq);
     a.item_step = 1;
     a.tau = tau;
     a.cand = cand;

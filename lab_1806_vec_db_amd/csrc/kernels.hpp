@@ -53,19 +53,20 @@ void launch_pack_pairs(const float *dists, const uint64_t *ids, const uint64_t *
 
 // ---- k_mfma.hip ----------------------------------------------------------------------------
 constexpr uint32_t MFMA_B = 32;  // queries per corpus pass
-// Q [nq<=32][dim] -> fragment-ordered image (dim/16 steps x 2 halves x 64 lanes x float4); dim % 16 == 0
+// Q [nq][dim] -> ceil(nq/32) fragment-ordered split-bf16 images of mfma_qfrag_floats(dim) floats each
 void launch_mfma_pack_queries(const float *Q, uint32_t nq, uint32_t dim, float *qfrag, hipStream_t s);
 // fragment-ordered mirror of rows: tiles [tile0, tile1) of 16 rows each; T holds ceil(n/16) tiles rounded up to 4
 void launch_tile_rows(const float *X, uint64_t n, uint32_t dim, uint64_t tile0, uint64_t tile1, float *T,
                       hipStream_t s);
-// approximate keys key(i,b) = xsq[i] - 2*dot(x_i, q_b) for b < 32; XT = fragment-ordered mirror.
-// sample: keys of a strided sample of rows, dense: out[b*ld + j], j < mfma_sample_rows(n) (+inf past n)
-void launch_flat_mfma_sample(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, const float *xsq,
-                             float *out, uint64_t ld, int num_cu, hipStream_t s);
-// filter: pair keys of all rows with key <= tau[b] appended to cand[b][0..cap) (cnt[b] counts every hit)
-void launch_flat_mfma_filter(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, const float *xsq,
-                             const float *tau, uint64_t *cand, uint32_t *cnt, uint32_t cap, int num_cu,
-                             hipStream_t s);
+// approximate keys key(i,q) = xsq[i] - 2*dot(x_i, q); XT = fragment-ordered mirror; qfrag = nbatch images.
+// sample: keys of a strided sample of rows, dense: out[q*ld + j], j < mfma_sample_rows(n) (+inf past n)
+void launch_flat_mfma_sample(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t nbatch,
+                             const float *xsq, float *out, uint64_t ld, int num_cu, hipStream_t s);
+// filter: ONE launch walks all nbatch passes; pair keys of all rows with key <= tau[q] land in cand[q][0..cap)
+// (cnt[q] counts every hit, so cnt[q] > cap means candidates were dropped)
+void launch_flat_mfma_filter(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t nbatch,
+                             const float *xsq, const float *tau, uint64_t *cand, uint32_t *cnt, uint32_t cap,
+                             int num_cu, hipStream_t s);
 uint64_t mfma_sample_rows(uint64_t n);
 uint32_t mfma_sample_step(uint64_t n);
 size_t mfma_qfrag_floats(uint32_t dim);
