@@ -137,14 +137,16 @@ def main():
         traffic = None  # HBM bytes per launch from the committed PMC passes (same kernel, same shard size only)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_flat_mfma.json")))
-            if kernel == "flat_mfma" and abs(pmc["algorithmic_bytes_per_launch"] - bytes_per_launch) < 1:
-                traffic = pmc["hbm_bytes_per_launch"]
+            passes = -(-nq // 32)  # one flat_mfma launch walks ceil(nq/32) corpus passes
+            if kernel == "flat_mfma" and abs(pmc["algorithmic_bytes_per_pass"] * passes - bytes_per_launch) < 1:
+                traffic = pmc["hbm_bytes_per_pass"] * passes
         except (OSError, KeyError, ValueError):
             pass
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel,
                     "avg_launch_ms": round(avg_ms, 4), "launches": p["launches"],
-                    "bytes_per_launch": bytes_per_launch}
+                    "bytes_per_launch": bytes_per_launch,
+                    "units_per_launch": f"{-(-nq // 32)} corpus passes x {r1 - r0} rows x {dim} x 4 B"}
 
     if rank != 0:
         if world > 1:
