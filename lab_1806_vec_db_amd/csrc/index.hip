@@ -70,8 +70,10 @@ void Index::add_rows(const float *rows, uint64_t count, bool on_device) {
     std::vector<float> sq(count);
     VDB_HIP(hipMemcpyAsync(sq.data(), d_sq.as<float>() + n, count * sizeof(float), hipMemcpyDeviceToHost, s));
     VDB_HIP(hipStreamSynchronize(s));
-    for (float v : sq)
+    for (float v : sq) {
         if (v > xsq_max && std::isfinite(v)) xsq_max = v;
+        if (v > 0.0f && v < xsq_min_pos) xsq_min_pos = v;
+    }
     {
         std::lock_guard<std::mutex> g(host_mu);
         if (on_device) {
@@ -192,7 +194,8 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     launch_row_sqnorm(d_q, nq, (uint32_t)dim, ws.qsq.as<float>(), s);
 
     const uint32_t kprime = std::max<uint32_t>(32, 2 * ksel);
-    bool mfma = dist == 0 && mfma_supported((uint32_t)dim) && kprime <= 1024 && n > kprime &&
+    const int cosine = dist == 1 ? 1 : 0;
+    bool mfma = mfma_supported((uint32_t)dim) && kprime <= 1024 && n > kprime &&
                 (flat_mode == 2 || (flat_mode == 0 && n >= 16384));
     if (flat_mode == 1) mfma = false;
     if (!mfma) {
@@ -226,7 +229,7 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     uint32_t *d_hits = reinterpret_cast<uint32_t *>(d_tau + nq_pad);
     launch_mfma_pack_queries(d_q, (uint32_t)nq, (uint32_t)dim, ws.qfrag.as<float>(), s);
     launch_flat_mfma_sample(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>(), (uint32_t)nbatch, d_sq.as<float>(),
-                            ws.dense.as<float>(), ld_s, num_cu, s);
+                            cosine, ws.dense.as<float>(), ld_s, num_cu, s);
     launch_topk_dense(ws.dense.as<float>(), ld_s, n_s, (uint32_t)nq_pad, kprime, ws.lists.as<uint64_t>(), s);
     launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, capp, (uint32_t)nq_pad, kprime, ws.keys_a.as<uint64_t>(), s);
     launch_extract_tau(ws.keys_a.as<uint64_t>(), capp, (uint32_t)nq_pad, kprime, d_tau, s);
@@ -235,15 +238,15 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     VDB_HIP(hipMemsetAsync(d_hits, 0, nq_pad * sizeof(uint32_t), s));
     prof_begin(ws, "flat_mfma", double(nbatch) * double(n) * dim * sizeof(float));
     launch_flat_mfma_filter(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>(), (uint32_t)nbatch, d_sq.as<float>(),
-                            d_tau, d_cand, d_hits, CAND_CAP, num_cu, s);
+                            cosine, d_tau, d_cand, d_hits, CAND_CAP, num_cu, s);
     prof_end(ws);
     launch_topk_merge(d_cand, 1, CAND_CAP, (uint32_t)nq, kprime, ws.keys_a.as<uint64_t>(), s);
     VDB_HIP(hipMemsetAsync(ws.keys_b.p, 0xff, nq * capp * sizeof(uint64_t), s));
-    launch_rerank(d_rows.as<float>(), (uint32_t)dim, d_q, (uint32_t)nq, MET_L2_DIRECT, d_sq.as<float>(),
+    launch_rerank(d_rows.as<float>(), (uint32_t)dim, d_q, (uint32_t)nq, cosine ? MET_COSINE : MET_L2_DIRECT, d_sq.as<float>(),
                   ws.qsq.as<float>(), ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), kprime, capp, s);
     launch_topk_merge(ws.keys_b.as<uint64_t>(), 1, capp, (uint32_t)nq, ksel, ws.keys_c.as<uint64_t>(), s);
     launch_certify(ws.keys_c.as<uint64_t>(), capk, ws.keys_a.as<uint64_t>(), capp, (uint32_t)nq, ksel, kprime, n,
-                   ws.qsq.as<float>(), xsq_max, (uint32_t)dim, ws.flags.as<uint8_t>(), s);
+                   ws.qsq.as<float>(), xsq_max, xsq_min_pos, cosine, (uint32_t)dim, ws.flags.as<uint8_t>(), s);
     launch_flag_overflow(d_hits, CAND_CAP, (uint32_t)nq, ws.flags.as<uint8_t>(), s);
     launch_finalize(ws.keys_c.as<uint64_t>(), capk, (uint32_t)nq, ksel, (uint32_t)k, id_offset, d_idx, d_dist, d_cnt, s);
     std::vector<uint8_t> flags(nq);

@@ -327,10 +327,17 @@ void launch_finalize(const uint64_t *keys, uint32_t ldk, uint32_t nq, uint32_t k
 // satisfies D_k < kappa + qsq - E, no outside row can enter the exact top-k: certified.
 // When the shortlist holds every row (n <= k') it is trivially certified.
 // ---------------------------------------------------------------------------------------------
+//
+// Cosine (keys -S/|x|, approximate distance a = 1 + key/|q|): S is off by at most
+// ((dim+8)*2^-24 + 3*2^-17) |x||q| in the MFMA form and dim*2^-24 |x||q| in the strict fold, the norms by
+// dim*2^-25 relative each, so both distances are within E_cos = 2.5*(dim+8)*2^-24 + 6e-5 of the real one
+// -- provided the reference's max(|x||q|, 1e-10) clamp (distance/mod.rs:68) is inactive for every non-zero
+// row, which is checked through the smallest positive row norm; otherwise the query is not certified.
+// ---------------------------------------------------------------------------------------------
 __global__ void k_certify(const uint64_t *__restrict__ exact_sorted, uint32_t lde,
                           const uint64_t *__restrict__ approx_sorted, uint32_t lda, uint32_t nq, uint32_t k,
                           uint32_t kprime, uint64_t n_rows, const float *__restrict__ qsq, float xsq_max,
-                          uint32_t dim, uint8_t *__restrict__ flags) {
+                          float xsq_min_pos, int cosine, uint32_t dim, uint8_t *__restrict__ flags) {
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     if (n_rows <= kprime) {
@@ -347,9 +354,17 @@ __global__ void k_certify(const uint64_t *__restrict__ exact_sorted, uint32_t ld
     float dk = f32_from_orderable(uint32_t(ek >> 32));
     float kappa = f32_from_orderable(uint32_t(ak >> 32));
     float qs = qsq[q];
-    float nrm = sqrtf(xsq_max) + sqrtf(qs);
-    float E = 2.5f * float(dim + 8) * 5.9604645e-8f * nrm * nrm + 5e-5f * sqrtf(xsq_max) * sqrtf(qs);
-    bool ok = dk < (kappa + qs) - E;  // NaN anywhere -> not ok
+    bool ok;
+    if (cosine) {
+        float qn = sqrtf(qs);
+        float E = 2.5f * float(dim + 8) * 5.9604645e-8f + 6e-5f;
+        bool clamp_free = sqrtf(xsq_min_pos) * qn > 1e-9f;  // 10x margin over the 1e-10 clamp
+        ok = clamp_free && dk < (1.0f + kappa / qn) - E;
+    } else {
+        float nrm = sqrtf(xsq_max) + sqrtf(qs);
+        float E = 2.5f * float(dim + 8) * 5.9604645e-8f * nrm * nrm + 5e-5f * sqrtf(xsq_max) * sqrtf(qs);
+        ok = dk < (kappa + qs) - E;  // NaN anywhere -> not ok
+    }
     flags[q] = ok ? 0 : 1;
 }
 
@@ -379,10 +394,10 @@ void launch_flag_overflow(const uint32_t *cnt, uint32_t cap, uint32_t nq, uint8_
 
 void launch_certify(const uint64_t *exact_sorted, uint32_t lde, const uint64_t *approx_sorted, uint32_t lda,
                     uint32_t nq, uint32_t k, uint32_t kprime, uint64_t n_rows, const float *qsq, float xsq_max,
-                    uint32_t dim, uint8_t *flags, hipStream_t s) {
+                    float xsq_min_pos, int cosine, uint32_t dim, uint8_t *flags, hipStream_t s) {
     if (nq == 0) return;
     hipLaunchKernelGGL(k_certify, dim3((nq + 63) / 64), dim3(64), 0, s, exact_sorted, lde, approx_sorted, lda, nq, k,
-                       kprime, n_rows, qsq, xsq_max, dim, flags);
+                       kprime, n_rows, qsq, xsq_max, xsq_min_pos, cosine, dim, flags);
 }
 
 }  // namespace vdb

@@ -154,6 +154,7 @@ struct MfmaArgs {
     uint32_t *cnt;       // [nbatch*32]
     uint32_t cap;
     uint32_t debug;
+    int cosine;          // keys for DistanceAlgorithm::Cosine: -S/|x| (ranks like 1 - S/(|x||q|) for a fixed query)
 };
 
 template <int PD, int MODE>
@@ -301,7 +302,10 @@ __global__ __launch_bounds__(512, 1) void k_flat_mfma(MfmaArgs a) {
                         const float x0 = xsv[t * 16 + 0 + e], x1 = xsv[t * 16 + 4 + e];
                         const float x2 = xsv[t * 16 + 8 + e], x3 = xsv[t * 16 + 12 + e];
                         const float xv = g == 0 ? x0 : (g == 1 ? x1 : (g == 2 ? x2 : x3));
-                        key[e] = xv - 2.0f * acc[t][h][e];
+                        if (a.cosine)  // zero-norm rows: S = 0 and the reference distance is exactly 1 -> key 0
+                            key[e] = -acc[t][h][e] * (xv > 0.0f ? __frsqrt_rn(xv) : 0.0f);
+                        else
+                            key[e] = xv - 2.0f * acc[t][h][e];
                     }
                     if (MODE == MODE_SAMPLE) {
                         float4 kv;
@@ -402,7 +406,7 @@ uint64_t mfma_sample_rows(uint64_t n) {
 }
 
 static MfmaArgs mfma_args(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t nbatch,
-                          const float *xsq) {
+                          const float *xsq, int cosine) {
     VDB_REQUIRE(mfma_supported(dim), "flat_mfma: dim must be a multiple of 64 with 32*dim*4 <= 128 KiB");
     VDB_REQUIRE(n < (1ull << 32), "flat_mfma: too many rows for one shard");
     MfmaArgs a{};
@@ -413,13 +417,14 @@ static MfmaArgs mfma_args(const float *XT, uint64_t n, uint32_t dim, const float
     a.dim = dim;
     a.n_items = mfma_num_items(n);
     a.nbatch = nbatch;
+    a.cosine = cosine;
     return a;
 }
 
 void launch_flat_mfma_sample(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t nbatch,
-                             const float *xsq, float *out, uint64_t ld, int num_cu, hipStream_t s) {
+                             const float *xsq, int cosine, float *out, uint64_t ld, int num_cu, hipStream_t s) {
     if (n == 0 || nbatch == 0) return;
-    MfmaArgs a = mfma_args(XT, n, dim, qfrag, nbatch, xsq);
+    MfmaArgs a = mfma_args(XT, n, dim, qfrag, nbatch, xsq, cosine);
     VDB_REQUIRE((ld & 3) == 0 && ld >= mfma_sample_rows(n), "flat_mfma: ld must cover the sample");
     VDB_REQUIRE(nbatch <= 65535, "flat_mfma: too many query batches");
     a.item_step = mfma_sample_step(n);
@@ -429,10 +434,10 @@ void launch_flat_mfma_sample(const float *XT, uint64_t n, uint32_t dim, const fl
 }
 
 void launch_flat_mfma_filter(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t nbatch,
-                             const float *xsq, const float *tau, uint64_t *cand, uint32_t *cnt, uint32_t cap,
-                             int num_cu, hipStream_t s) {
+                             const float *xsq, int cosine, const float *tau, uint64_t *cand, uint32_t *cnt,
+                             uint32_t cap, int num_cu, hipStream_t s) {
     if (n == 0 || nbatch == 0) return;
-    MfmaArgs a = mfma_args(XT, n, dim, qfrag, nbatch, xsq);
+    MfmaArgs a = mfma_args(XT, n, dim, qfrag, nbatch, xsq, cosine);
     a.item_step = 1;
     a.tau = tau;
     a.cand = cand;

@@ -31,7 +31,7 @@ void launch_finalize(const uint64_t *keys, uint32_t ldk, uint32_t nq, uint32_t k
 // not be contained in the shortlist
 void launch_certify(const uint64_t *exact_sorted, uint32_t lde, const uint64_t *approx_sorted, uint32_t lda,
                     uint32_t nq, uint32_t k, uint32_t kprime, uint64_t n_rows, const float *qsq, float xsq_max,
-                    uint32_t dim, uint8_t *flags, hipStream_t s);
+                    float xsq_min_pos, int cosine, uint32_t dim, uint8_t *flags, hipStream_t s);
 
 void launch_extract_tau(const uint64_t *sorted, uint32_t ld, uint32_t nq, uint32_t kprime, float *tau, hipStream_t s);
 void launch_flag_overflow(const uint32_t *cnt, uint32_t cap, uint32_t nq, uint8_t *flags, hipStream_t s);
@@ -60,13 +60,14 @@ void launch_tile_rows(const float *X, uint64_t n, uint32_t dim, uint64_t tile0, 
                       hipStream_t s);
 // approximate keys key(i,q) = xsq[i] - 2*dot(x_i, q); XT = fragment-ordered mirror; qfrag = nbatch images.
 // sample: keys of a strided sample of rows, dense: out[q*ld + j], j < mfma_sample_rows(n) (+inf past n)
+// cosine != 0: keys are -dot(x_i,q)/|x_i| (0 for zero rows), which rank like the cosine distance
 void launch_flat_mfma_sample(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t nbatch,
-                             const float *xsq, float *out, uint64_t ld, int num_cu, hipStream_t s);
+                             const float *xsq, int cosine, float *out, uint64_t ld, int num_cu, hipStream_t s);
 // filter: ONE launch walks all nbatch passes; pair keys of all rows with key <= tau[q] land in cand[q][0..cap)
 // (cnt[q] counts every hit, so cnt[q] > cap means candidates were dropped)
 void launch_flat_mfma_filter(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t nbatch,
-                             const float *xsq, const float *tau, uint64_t *cand, uint32_t *cnt, uint32_t cap,
-                             int num_cu, hipStream_t s);
+                             const float *xsq, int cosine, const float *tau, uint64_t *cand, uint32_t *cnt,
+                             uint32_t cap, int num_cu, hipStream_t s);
 uint64_t mfma_sample_rows(uint64_t n);
 uint32_t mfma_sample_step(uint64_t n);
 size_t mfma_qfrag_floats(uint32_t dim);

@@ -141,16 +141,17 @@ def test_nan_and_inf_rows(mods):
 
 
 @pytest.mark.parametrize("n", [20000, 70001])
-def test_gistlike_mfma_parity(mods, n):
+@pytest.mark.parametrize("dist,kind", [("l2sqr", 0), ("cosine", 1)])
+def test_gistlike_mfma_parity(mods, n, dist, kind):
     """Gist1M-shaped synthetic rows at a size the oracle finishes in seconds; MFMA path forced."""
     vdb, O = mods
     base = gist_like(n, seed=1806)
     qs = gist_like(40, seed=1807)
-    ix = vdb.GpuIndex(960, "l2sqr")
+    ix = vdb.GpuIndex(960, dist)
     ix.batch_add(base)
     ix.set_flat_mode(2)
     idx, d, cnt = ix.flat_knn(qs, 10)
-    oi, od, oc = O.flat_knn_batch(base, qs, 10, 0, nthreads=8)
+    oi, od, oc = O.flat_knn_batch(base, qs, 10, kind, nthreads=8)
     for q in range(qs.shape[0]):
         _check(idx[q], d[q], oi[q], od[q])
     # auto mode must agree too
@@ -159,6 +160,53 @@ def test_gistlike_mfma_parity(mods, n):
     np.testing.assert_array_equal(idx, idx2)
     np.testing.assert_array_equal(d, d2)
     print("fallbacks:", ix.flat_fallback_count())
+
+
+def test_cosine_degenerate_norms_mfma(mods):
+    """Cosine through the MFMA path with zero rows, rows so small that the reference's max(|a||b|, 1e-10)
+    clamp (distance/mod.rs:68) is active, a zero query and a tiny query: certification must refuse what it
+    cannot bound and the exact scan must take over."""
+    vdb, O = mods
+    rng = np.random.default_rng(21)
+    base = rng.standard_normal((3000, 64)).astype(np.float32)
+    base[5] = 0.0
+    base[77] = 0.0
+    base[100] *= 1e-9
+    base[2000] *= 1e-12
+    qs = rng.standard_normal((6, 64)).astype(np.float32)
+    qs[1] = 0.0
+    qs[2] *= 1e-8
+    qs[3] = -base[9]  # far side: distances near 2
+    ix = vdb.GpuIndex(64, "cosine")
+    ix.batch_add(base)
+    for mode in (1, 2):
+        ix.set_flat_mode(mode)
+        for k in (1, 10, 40):
+            idx, d, cnt = ix.flat_knn(qs, k)
+            for q in range(qs.shape[0]):
+                oi, od = O.flat_knn(base, qs[q], k, 1)
+                _check(idx[q], d[q], oi, od)
+    assert ix.flat_fallback_count() > 0
+
+
+def test_mfma_nan_rows_and_queries(mods):
+    vdb, O = mods
+    rng = np.random.default_rng(31)
+    base = rng.standard_normal((5000, 128)).astype(np.float32)
+    base[17, 3] = np.nan
+    base[4000, 0] = np.inf
+    qs = rng.standard_normal((4, 128)).astype(np.float32)
+    qs[2, 5] = np.nan
+    ix = vdb.GpuIndex(128, "l2sqr")
+    ix.batch_add(base)
+    ix.set_flat_mode(2)
+    idx, d, cnt = ix.flat_knn(qs, 10)
+    for q in range(4):
+        oi, od = O.flat_knn(base, qs[q], 10)
+        assert idx[q].tolist() == oi.tolist(), q
+        m = ~np.isnan(od)
+        np.testing.assert_array_equal(np.isnan(d[q]), np.isnan(od))
+        np.testing.assert_array_equal(d[q][m], od[m])
 
 
 def test_swap_remove_and_offset(mods):
