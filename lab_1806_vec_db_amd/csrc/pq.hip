@@ -55,7 +55,7 @@ __global__ void k_pq_lut(const float *__restrict__ Q, uint32_t dim, const float 
 // LUT_IN_LDS = false: tables too large for LDS (8-bit codes with large m) are read through L1/L2.
 // ---------------------------------------------------------------------------------------------------
 template <int BQ, int NBITS, bool LUT_IN_LDS>
-__global__ __launch_bounds__(256) void k_pq_adc(const uint8_t *__restrict__ codes, uint64_t n, uint32_t enc_dim,
+__global__ __launch_bounds__(1024) void k_pq_adc(const uint8_t *__restrict__ codes, uint64_t n, uint32_t enc_dim,
                                                 uint32_t m, const float *__restrict__ lut_g,
                                                 const float *__restrict__ cent_cache_g, int cosine,
                                                 const float *__restrict__ qsq, uint32_t nq,
@@ -66,12 +66,12 @@ __global__ __launch_bounds__(256) void k_pq_adc(const uint8_t *__restrict__ code
     const float *lut[BQ];
     const float *ccache = cent_cache_g;
     if (LUT_IN_LDS) {
-        for (uint32_t i = threadIdx.x; i < lsz * BQ; i += 256) {
+        for (uint32_t i = threadIdx.x; i < lsz * BQ; i += blockDim.x) {
             uint32_t b = i / lsz;
             smem[i] = b < nq ? lut_g[i] : 0.0f;
         }
         if (cosine)
-            for (uint32_t i = threadIdx.x; i < lsz; i += 256) smem[lsz * BQ + i] = cent_cache_g[i];
+            for (uint32_t i = threadIdx.x; i < lsz; i += blockDim.x) smem[lsz * BQ + i] = cent_cache_g[i];
         __syncthreads();
 #pragma unroll
         for (int b = 0; b < BQ; b++) lut[b] = smem + b * lsz;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void k_pq_adc(const uint8_t *__restrict__ code
 #pragma unroll
         for (int b = 0; b < BQ; b++) lut[b] = lut_g + (b < (int)nq ? b : 0) * uint64_t(lsz);
     }
-    for (uint64_t row = uint64_t(blockIdx.x) * 256 + threadIdx.x; row < n; row += uint64_t(gridDim.x) * 256) {
+    for (uint64_t row = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; row < n; row += uint64_t(gridDim.x) * blockDim.x) {
         const uint8_t *cr = codes + row * enc_dim;
         float sum[BQ];
 #pragma unroll
@@ -93,7 +93,27 @@ __global__ __launch_bounds__(256) void k_pq_adc(const uint8_t *__restrict__ code
             for (int b = 0; b < BQ; b++) sum[b] = sum[b] + lut[b][at];
             if (cosine) cdp = cdp + ccache[at];
         };
-        if ((enc_dim & 3) == 0) {
+        if ((enc_dim & 15) == 0) {  // 16 code bytes per load
+            const uint4 *cw = reinterpret_cast<const uint4 *>(cr);
+            for (uint32_t w = 0; w < enc_dim / 16; w++) {
+                const uint4 v = cw[w];
+                const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int wi = 0; wi < 4; wi++) {
+#pragma unroll
+                    for (int byte = 0; byte < 4; byte++) {
+                        uint32_t u = (words[wi] >> (8 * byte)) & 0xff;
+                        uint32_t bi = w * 16 + wi * 4 + byte;
+                        if (NBITS == 4) {
+                            push(2 * bi, u & 0xf);  // low nibble = even group (pq_table.rs:274-280)
+                            push(2 * bi + 1, u >> 4);
+                        } else {
+                            push(bi, u);
+                        }
+                    }
+                }
+            }
+        } else if ((enc_dim & 3) == 0) {
             const uint32_t *cw = reinterpret_cast<const uint32_t *>(cr);
             for (uint32_t w = 0; w < enc_dim / 4; w++) {
                 uint32_t word = cw[w];
@@ -102,7 +122,7 @@ __global__ __launch_bounds__(256) void k_pq_adc(const uint8_t *__restrict__ code
                     uint32_t u = (word >> (8 * byte)) & 0xff;
                     uint32_t bi = w * 4 + byte;
                     if (NBITS == 4) {
-                        push(2 * bi, u & 0xf);  // low nibble = even group (pq_table.rs:274-280)
+                        push(2 * bi, u & 0xf);
                         push(2 * bi + 1, u >> 4);
                     } else {
                         push(bi, u);
@@ -489,8 +509,10 @@ static void adc_launch(Index &ix, Workspace &ws, const float *lut, const float *
     size_t lsz = pq.m * pq.kc * sizeof(float);
     size_t need = lsz * BQ + (ix.dist == 1 ? lsz : 0);
     bool in_lds = need <= 150 * 1024;
-    uint32_t grid = (uint32_t)std::min<uint64_t>((ix.n + 255) / 256, uint64_t(ix.num_cu) * 8);
     int cosine = ix.dist == 1 ? 1 : 0;
+    // LUTs in LDS: one 1024-thread workgroup per CU (16 waves keep the LDS gather pipe busy); else 8 x 256
+    uint32_t nt = in_lds ? 1024 : 256;
+    uint32_t grid = (uint32_t)std::min<uint64_t>((ix.n + nt - 1) / nt, uint64_t(ix.num_cu) * (in_lds ? 1 : 8));
     if (in_lds) {
         static bool attr = false;
         if (!attr) {
@@ -498,11 +520,11 @@ static void adc_launch(Index &ix, Workspace &ws, const float *lut, const float *
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr = true;
         }
-        hipLaunchKernelGGL((k_pq_adc<BQ, NBITS, true>), dim3(grid), dim3(256), need, ws.stream,
+        hipLaunchKernelGGL((k_pq_adc<BQ, NBITS, true>), dim3(grid), dim3(nt), need, ws.stream,
                            pq.d_codes.as<uint8_t>(), ix.n, (uint32_t)pq.enc_dim, (uint32_t)pq.m, lut,
                            pq.d_cent_cache.as<float>(), cosine, qsq, nb, out, ld);
     } else {
-        hipLaunchKernelGGL((k_pq_adc<BQ, NBITS, false>), dim3(grid), dim3(256), 0, ws.stream,
+        hipLaunchKernelGGL((k_pq_adc<BQ, NBITS, false>), dim3(grid), dim3(nt), 0, ws.stream,
                            pq.d_codes.as<uint8_t>(), ix.n, (uint32_t)pq.enc_dim, (uint32_t)pq.m, lut,
                            pq.d_cent_cache.as<float>(), cosine, qsq, nb, out, ld);
     }
@@ -559,28 +581,36 @@ void flat_knn_pq_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq,
     // queries per pass: as many lookup tables as fit beside each other in LDS (<= 4)
     size_t lbytes = size_t(lsz) * sizeof(float);
     uint32_t BQ = lbytes * 4 + (ix.dist == 1 ? lbytes : 0) <= 150 * 1024 ? 4 : (lbytes * 2 + (ix.dist == 1 ? lbytes : 0) <= 150 * 1024 ? 2 : 1);
-    ws.dense.reserve(size_t(4) * ld * sizeof(float));
-    ws.lists.reserve(size_t(4) * nl * cape * sizeof(uint64_t));
+    // ADC distances of a group of GQ queries are kept dense so that the top-ef select and its merge run with
+    // GQ x (N/8192) waves -- a 4-query launch would leave the GPU mostly idle
+    uint64_t GQ = std::min<uint64_t>(64, (size_t(512) << 20) / (ld * sizeof(float)));
+    GQ = std::max<uint64_t>(BQ, GQ / BQ * BQ);
+    ws.dense.reserve(GQ * ld * sizeof(float));
+    ws.lists.reserve(GQ * nl * cape * sizeof(uint64_t));
     ws.keys_a.reserve(nq * cape * sizeof(uint64_t));
     ws.keys_b.reserve(nq * cape * sizeof(uint64_t));
     ws.keys_c.reserve(nq * capk * sizeof(uint64_t));
-    for (uint64_t q0 = 0; q0 < nq; q0 += BQ) {
-        uint32_t nb = (uint32_t)std::min<uint64_t>(BQ, nq - q0);
-        const float *lut = ws.lut.as<float>() + q0 * lsz;
-        const float *qs = ws.qsq.as<float>() + q0;
-        ix.prof_begin(ws, "pq_adc", double(n) * pq.enc_dim);
-        if (pq.n_bits == 4) {
-            if (BQ == 4) adc_launch<4, 4>(ix, ws, lut, qs, nb, ws.dense.as<float>(), ld);
-            else if (BQ == 2) adc_launch<2, 4>(ix, ws, lut, qs, nb, ws.dense.as<float>(), ld);
-            else adc_launch<1, 4>(ix, ws, lut, qs, nb, ws.dense.as<float>(), ld);
-        } else {
-            if (BQ == 4) adc_launch<4, 8>(ix, ws, lut, qs, nb, ws.dense.as<float>(), ld);
-            else if (BQ == 2) adc_launch<2, 8>(ix, ws, lut, qs, nb, ws.dense.as<float>(), ld);
-            else adc_launch<1, 8>(ix, ws, lut, qs, nb, ws.dense.as<float>(), ld);
+    for (uint64_t g0 = 0; g0 < nq; g0 += GQ) {
+        const uint64_t gn = std::min<uint64_t>(GQ, nq - g0);
+        for (uint64_t q0 = g0; q0 < g0 + gn; q0 += BQ) {
+            uint32_t nb = (uint32_t)std::min<uint64_t>(BQ, g0 + gn - q0);
+            const float *lut = ws.lut.as<float>() + q0 * lsz;
+            const float *qs = ws.qsq.as<float>() + q0;
+            float *dst = ws.dense.as<float>() + (q0 - g0) * ld;
+            ix.prof_begin(ws, "pq_adc", double(n) * pq.enc_dim);
+            if (pq.n_bits == 4) {
+                if (BQ == 4) adc_launch<4, 4>(ix, ws, lut, qs, nb, dst, ld);
+                else if (BQ == 2) adc_launch<2, 4>(ix, ws, lut, qs, nb, dst, ld);
+                else adc_launch<1, 4>(ix, ws, lut, qs, nb, dst, ld);
+            } else {
+                if (BQ == 4) adc_launch<4, 8>(ix, ws, lut, qs, nb, dst, ld);
+                else if (BQ == 2) adc_launch<2, 8>(ix, ws, lut, qs, nb, dst, ld);
+                else adc_launch<1, 8>(ix, ws, lut, qs, nb, dst, ld);
+            }
+            ix.prof_end(ws);
         }
-        ix.prof_end(ws);
-        launch_topk_dense(ws.dense.as<float>(), ld, n, nb, efk, ws.lists.as<uint64_t>(), s);
-        launch_topk_merge(ws.lists.as<uint64_t>(), nl, cape, nb, efk, ws.keys_a.as<uint64_t>() + q0 * cape, s);
+        launch_topk_dense(ws.dense.as<float>(), ld, n, (uint32_t)gn, efk, ws.lists.as<uint64_t>(), s);
+        launch_topk_merge(ws.lists.as<uint64_t>(), nl, cape, (uint32_t)gn, efk, ws.keys_a.as<uint64_t>() + g0 * cape, s);
     }
     // exact distances of the ADC shortlist in ADC order, then the reference's re-sort
     VDB_HIP(hipMemsetAsync(ws.keys_b.p, 0xff, nq * cape * sizeof(uint64_t), s));
