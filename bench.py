@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--cpu-queries", type=int, default=64, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--mode", type=int, default=0, help="flat mode: 0 auto, 1 exact scan, 2 MFMA forced")
+    ap.add_argument("--dump", type=str, default="", help="rank 0 saves the last step's results to this .npz (tests)")
     args = ap.parse_args()
 
     import torch
@@ -73,11 +74,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # VDB_DIST_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: ranks share the visible
+    # GPUs and the all-gather goes through host memory.  The driver's runs use the default (nccl = RCCL).
+    backend = os.environ.get("VDB_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     n, dim, nq, k = args.rows, args.dim, args.nq, args.k
     # identical corpus on every rank (same seed), each keeps its row block
@@ -103,6 +112,8 @@ def main():
 
     def step():
         ix.flat_knn_device(queries.data_ptr(), nq, k, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr())
+        if backend != "nccl" and world > 1:
+            return allgather_merge(o_idx.cpu(), o_dist.cpu(), o_cnt.cpu(), k)
         return allgather_merge(o_idx, o_dist, o_cnt, k, gpu_index=ix)
 
     def fence():
@@ -123,7 +134,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ix.prof_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -153,6 +164,8 @@ def main():
             dist.destroy_process_group()
         return
 
+    if args.dump:
+        np.savez(args.dump, idx=res[0].cpu().numpy(), dist=res[1].cpu().numpy(), cnt=res[2].cpu().numpy())
     qps = nq * args.steps / elapsed
     out = {
         "metric": "queries/sec at recall@10, Gist1M d=960 (Flat brute force, L2Sqr, k=10)",

@@ -1,0 +1,41 @@
+"""GPU: rehearsal of bench.py's N>1 path on a one-GPU box (VDB_DIST_BACKEND=gloo: ranks share the GPU, the
+all-gather goes through host memory).  The merged results of 2 and 3 row shards must equal the 1-GPU results."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(world, dump, port):
+    env = dict(os.environ, VDB_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    args = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--rows", "60000", "--nq", "96", "--cpu-queries",
+            "0", "--dump", dump]
+    if world == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_sharded_bench_equals_single(tmp_path):
+    r1 = _run(1, str(tmp_path / "w1.npz"), 29611)
+    assert r1["n_gpus"] == 1 and r1["roofline"]["frac"] > 0
+    a = np.load(tmp_path / "w1.npz")
+    for world, port in ((2, 29612), (3, 29613)):
+        r = _run(world, str(tmp_path / f"w{world}.npz"), port)
+        assert r["n_gpus"] == world and r["scaling"] == "strong"
+        b = np.load(tmp_path / f"w{world}.npz")
+        assert np.array_equal(a["idx"], b["idx"])
+        assert np.array_equal(a["dist"], b["dist"])
+        assert np.array_equal(a["cnt"], b["cnt"])
