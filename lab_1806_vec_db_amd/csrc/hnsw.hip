@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <thread>
 
 #include "pq_hnsw.hpp"
@@ -731,6 +732,8 @@ void hnsw_insert_rows(Index &ix, const float *rows, uint64_t count) {
 
 static void hnsw_upload(Index &ix) {
     HNSWState &h = ix.hnsw;
+    static std::mutex mu;  // read-side calls are re-entrant: the lazy upload must happen once
+    std::lock_guard<std::mutex> lock(mu);
     if (!h.dev_dirty) return;
     ix.use_device();
     uint64_t n = ix.n;

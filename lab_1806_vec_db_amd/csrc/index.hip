@@ -252,14 +252,32 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     std::vector<uint8_t> flags(nq);
     VDB_HIP(hipMemcpyAsync(flags.data(), ws.flags.p, nq, hipMemcpyDeviceToHost, s));
     VDB_HIP(hipStreamSynchronize(s));
-    uint64_t redo = 0;
-    for (uint64_t q = 0; q < nq; q++) {
-        if (!flags[q]) continue;
-        redo++;
-        flat_exact_device(ws, d_q + q * dim, ws.qsq.as<float>() + q, 1, ksel, k, d_idx + q * k, d_dist + q * k,
-                          d_cnt + q);
+    // uncertified queries: gather them, redo them 8 per corpus pass with the exact scan, scatter the results
+    std::vector<uint64_t> redo;
+    for (uint64_t q = 0; q < nq; q++)
+        if (flags[q]) redo.push_back(q);
+    if (redo.empty()) return;
+    fallback_count += redo.size();
+    const uint64_t nr = redo.size();
+    DevBuf rq, rqs, ri, rd, rc;  // small, rare: allocated on demand
+    rq.reserve(nr * dim * sizeof(float));
+    rqs.reserve(nr * sizeof(float));
+    ri.reserve(nr * k * sizeof(uint64_t));
+    rd.reserve(nr * k * sizeof(float));
+    rc.reserve(nr * sizeof(uint64_t));
+    for (uint64_t j = 0; j < nr; j++) {
+        VDB_HIP(hipMemcpyAsync(rq.as<float>() + j * dim, d_q + redo[j] * dim, dim * sizeof(float), hipMemcpyDeviceToDevice, s));
+        VDB_HIP(hipMemcpyAsync(rqs.as<float>() + j, ws.qsq.as<float>() + redo[j], sizeof(float), hipMemcpyDeviceToDevice, s));
     }
-    if (redo) fallback_count += redo;
+    VDB_HIP(hipMemsetAsync(ri.p, 0, nr * k * sizeof(uint64_t), s));
+    VDB_HIP(hipMemsetAsync(rd.p, 0, nr * k * sizeof(float), s));
+    flat_exact_device(ws, rq.as<float>(), rqs.as<float>(), nr, ksel, k, ri.as<uint64_t>(), rd.as<float>(), rc.as<uint64_t>());
+    for (uint64_t j = 0; j < nr; j++) {
+        VDB_HIP(hipMemcpyAsync(d_idx + redo[j] * k, ri.as<uint64_t>() + j * k, k * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+        VDB_HIP(hipMemcpyAsync(d_dist + redo[j] * k, rd.as<float>() + j * k, k * sizeof(float), hipMemcpyDeviceToDevice, s));
+        VDB_HIP(hipMemcpyAsync(d_cnt + redo[j], rc.as<uint64_t>() + j, sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+    }
+    VDB_HIP(hipStreamSynchronize(s));  // rq..rc are freed on return
 }
 
 }  // namespace vdb
