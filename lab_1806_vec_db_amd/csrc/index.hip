@@ -174,6 +174,38 @@ void Index::flat_exact_device(Workspace &ws, const float *d_q, const float *d_qs
     }
 }
 
+// ---- Flat, k > 1024: exact distances of every row, full sort of the (distance, index) pairs -------------------
+void Index::flat_sorted_device(Workspace &ws, const float *d_q, uint64_t nq, uint64_t ksel, uint64_t k, uint64_t *d_idx,
+                               float *d_dist, uint64_t *d_cnt) {
+    hipStream_t s = ws.stream;
+    VDB_REQUIRE(k < (1ull << 31), "flat knn: k too large");
+    const int metric = dist == 0 ? MET_L2_DIRECT : MET_COSINE;
+    const uint64_t ld = (n + 63) & ~63ull;
+    constexpr uint32_t BQ = 8;
+    size_t tb = sort_pairs_temp_bytes(n);
+    ws.qsq.reserve(nq * sizeof(float));
+    launch_row_sqnorm(d_q, nq, (uint32_t)dim, ws.qsq.as<float>(), s);
+    ws.dense.reserve(size_t(BQ) * ld * sizeof(float));
+    ws.keys_a.reserve(n * sizeof(uint64_t));
+    ws.keys_b.reserve(n * sizeof(uint64_t));
+    ws.lists.reserve(tb + 256);
+    if (k > ksel) {
+        VDB_HIP(hipMemsetAsync(d_idx, 0, nq * k * sizeof(uint64_t), s));
+        VDB_HIP(hipMemsetAsync(d_dist, 0, nq * k * sizeof(float), s));
+    }
+    for (uint64_t q0 = 0; q0 < nq; q0 += BQ) {
+        uint32_t nb = (uint32_t)std::min<uint64_t>(BQ, nq - q0);
+        launch_scan_exact(d_rows.as<float>(), n, (uint32_t)dim, d_q + q0 * dim, nb, metric, d_sq.as<float>(),
+                          ws.qsq.as<float>() + q0, ws.dense.as<float>(), ld, n >= 4096, s);
+        for (uint32_t b = 0; b < nb; b++) {
+            launch_sort_pairs(ws.dense.as<float>() + b * ld, n, ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(),
+                              ws.lists.p, tb, s);
+            launch_finalize(ws.keys_b.as<uint64_t>(), (uint32_t)n, 1, (uint32_t)ksel, (uint32_t)k, id_offset,
+                            d_idx + (q0 + b) * k, d_dist + (q0 + b) * k, d_cnt + q0 + b, s);
+        }
+    }
+}
+
 // ---- Flat: full pipeline ---------------------------------------------------------------------------
 void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t *d_idx,
                             float *d_dist, uint64_t *d_cnt) {
@@ -184,7 +216,10 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
         return;
     }
     const uint64_t ksel64 = std::min<uint64_t>(k, n);
-    VDB_REQUIRE(ksel64 <= 1024, "flat knn: min(k, len) must be <= 1024 in this build");
+    if (ksel64 > 1024) {  // beyond the register-resident select: exact scan + full radix sort per query
+        flat_sorted_device(ws, d_q, nq, ksel64, k, d_idx, d_dist, d_cnt);
+        return;
+    }
     const uint32_t ksel = (uint32_t)ksel64;
     if (k > ksel) {  // slots beyond min(k, len) are defined (zero) but not counted
         VDB_HIP(hipMemsetAsync(d_idx, 0, nq * k * sizeof(uint64_t), s));

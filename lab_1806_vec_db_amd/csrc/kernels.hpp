@@ -51,6 +51,11 @@ void launch_topk_merge(const uint64_t *lists, uint32_t nlists, uint32_t cap_in, 
 void launch_pack_pairs(const float *dists, const uint64_t *ids, const uint64_t *counts, uint32_t S, uint32_t nq,
                        uint32_t k, uint32_t cap_in, uint64_t *lists, hipStream_t s);
 
+// ---- k_sort.hip (k > 1024) -----------------------------------------------------------------
+size_t sort_pairs_temp_bytes(uint64_t n);
+void launch_sort_pairs(const float *dist, uint64_t n, uint64_t *tmp_keys, uint64_t *out, void *temp, size_t temp_bytes,
+                       hipStream_t s);
+
 // ---- k_mfma.hip ----------------------------------------------------------------------------
 constexpr uint32_t MFMA_B = 32;  // queries per corpus pass
 // Q [nq][dim] -> ceil(nq/32) fragment-ordered split-bf16 images of mfma_qfrag_floats(dim) floats each

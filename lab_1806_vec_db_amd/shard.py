@@ -2,8 +2,8 @@
 
 Rows are independent for Flat and PQ-Flat, so shard s holds the contiguous block
 [s*ceil(N/S), min(N, (s+1)*ceil(N/S))) and reports GLOBAL ids (vdb_index_set_id_offset).
-Every rank computes its local top-k for all queries; ONE all-gather of [nq, k] (f32 distance, i64 id,
-i64 count) per rank over RCCL/xGMI follows, then each rank merges the S sorted lists per query by the
+Every rank computes its local top-k for all queries; ONE all-gather of a single byte buffer per rank
+([nq, k] i64 ids + [nq, k] f32 distances + [nq] i64 counts = 128 KB at nq = 1000, k = 10) over RCCL/xGMI follows, then each rank merges the S sorted lists per query by the
 CandidatePair order (distance, index) -- top-k under a total order is decomposable, so the result equals
 the unsharded one exactly.  One process per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm,
 "gloo" is used for the CPU rehearsal in tests/.
@@ -32,14 +32,17 @@ def allgather_merge(local_idx, local_dist, local_cnt, k: int, group=None, gpu_in
     if world == 1:
         return local_idx, local_dist, local_cnt
     nq = local_idx.shape[0]
-    # all_gather_into_tensor concatenates along dim 0: [world*nq, k] viewed as [world, nq, k]
-    g_idx = torch.empty((world * nq, k), dtype=local_idx.dtype, device=local_idx.device)
-    g_dist = torch.empty((world * nq, k), dtype=local_dist.dtype, device=local_dist.device)
-    g_cnt = torch.empty((world * nq,), dtype=local_cnt.dtype, device=local_cnt.device)
-    dist.all_gather_into_tensor(g_idx, local_idx.contiguous(), group=group)
-    dist.all_gather_into_tensor(g_dist, local_dist.contiguous(), group=group)
-    dist.all_gather_into_tensor(g_cnt, local_cnt.contiguous(), group=group)
-    g_idx, g_dist, g_cnt = g_idx.view(world, nq, k), g_dist.view(world, nq, k), g_cnt.view(world, nq)
+    # ONE collective: ids (i64), distances (f32) and counts (i64) travel in a single byte buffer per rank
+    parts = (local_idx.contiguous().view(torch.uint8).reshape(-1), local_dist.contiguous().view(torch.uint8).reshape(-1),
+             local_cnt.contiguous().view(torch.uint8).reshape(-1))
+    sizes = [p.numel() for p in parts]
+    mine = torch.cat(parts)
+    gathered = torch.empty((world, mine.numel()), dtype=torch.uint8, device=mine.device)
+    dist.all_gather_into_tensor(gathered.view(-1), mine, group=group)
+    o0, o1 = sizes[0], sizes[0] + sizes[1]
+    g_idx = gathered[:, :o0].contiguous().view(local_idx.dtype).view(world, nq, k)
+    g_dist = gathered[:, o0:o1].contiguous().view(local_dist.dtype).view(world, nq, k)
+    g_cnt = gathered[:, o1:].contiguous().view(local_cnt.dtype).view(world, nq)
     if local_idx.is_cuda:
         if gpu_index is None:
             raise ValueError("allgather_merge on CUDA tensors needs the rank's GpuIndex")

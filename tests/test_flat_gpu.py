@@ -209,6 +209,24 @@ def test_mfma_nan_rows_and_queries(mods):
         np.testing.assert_array_equal(d[q][m], od[m])
 
 
+@pytest.mark.parametrize("dist,kind", [("l2sqr", 0), ("cosine", 1)])
+def test_large_k_sort_path(mods, dist, kind):
+    """k > 1024 (e.g. db.search(k=len)): full (distance, index) sort of the exact distances."""
+    vdb, O = mods
+    rng = np.random.default_rng(77)
+    base = rng.standard_normal((5000, 48)).astype(np.float32)
+    base[100] = base[7]  # exact tie
+    qs = rng.standard_normal((3, 48)).astype(np.float32)
+    ix = vdb.GpuIndex(48, dist)
+    ix.batch_add(base)
+    for k in (1025, 3000, 5000, 7000):
+        idx, d, cnt = ix.flat_knn(qs, k)
+        assert (cnt == min(k, 5000)).all()
+        for q in range(3):
+            oi, od = O.flat_knn(base, qs[q], k, kind)
+            _check(idx[q, :len(oi)], d[q, :len(od)], oi, od)
+
+
 def test_swap_remove_and_offset(mods):
     vdb, O = mods
     rng = np.random.default_rng(3)
