@@ -58,7 +58,8 @@ def main():
     ap.add_argument("--dim", type=int, default=960)
     ap.add_argument("--nq", type=int, default=1000)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--cpu-queries", type=int, default=64, help="queries timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-queries", type=int, default=512,
+                    help="queries timed on the CPU oracle and parity-checked (0 = skip); 512 = ~12 s on 16 cores")
     ap.add_argument("--mode", type=int, default=0, help="flat mode: 0 auto, 1 exact scan, 2 MFMA forced")
     ap.add_argument("--dump", type=str, default="", help="rank 0 saves the last step's results to this .npz (tests)")
     args = ap.parse_args()

@@ -66,15 +66,16 @@ __global__ __launch_bounds__(1024) void k_pq_adc(const uint8_t *__restrict__ cod
     const float *lut[BQ];
     const float *ccache = cent_cache_g;
     if (LUT_IN_LDS) {
+        // entry-major, query-minor: the BQ values of one (group, code) entry are adjacent, so one ds_read_b128
+        // (BQ = 4) serves all queries of the pass -- half the LDS cycles of four ds_read_b32 gathers.  Distinct
+        // codes of a group still land in distinct banks (16 entries x 16 B = all 64 banks).
         for (uint32_t i = threadIdx.x; i < lsz * BQ; i += blockDim.x) {
-            uint32_t b = i / lsz;
-            smem[i] = b < nq ? lut_g[i] : 0.0f;
+            uint32_t b = i / lsz, e = i % lsz;
+            smem[e * BQ + b] = b < nq ? lut_g[i] : 0.0f;
         }
         if (cosine)
             for (uint32_t i = threadIdx.x; i < lsz; i += blockDim.x) smem[lsz * BQ + i] = cent_cache_g[i];
         __syncthreads();
-#pragma unroll
-        for (int b = 0; b < BQ; b++) lut[b] = smem + b * lsz;
         ccache = smem + lsz * BQ;
     } else {
 #pragma unroll
@@ -89,8 +90,24 @@ __global__ __launch_bounds__(1024) void k_pq_adc(const uint8_t *__restrict__ cod
         auto push = [&](uint32_t i, uint32_t code) {
             if (i >= m) return;  // pq_table.rs:258-260
             uint32_t at = i * KC + code;
+            if (LUT_IN_LDS) {
+                if (BQ == 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(smem + at * 4);
+                    sum[0] = sum[0] + v.x;
+                    sum[1 % BQ] = sum[1 % BQ] + v.y;
+                    sum[2 % BQ] = sum[2 % BQ] + v.z;
+                    sum[3 % BQ] = sum[3 % BQ] + v.w;
+                } else if (BQ == 2) {
+                    const float2 v = *reinterpret_cast<const float2 *>(smem + at * 2);
+                    sum[0] = sum[0] + v.x;
+                    sum[1 % BQ] = sum[1 % BQ] + v.y;
+                } else {
+                    sum[0] = sum[0] + smem[at];
+                }
+            } else {
 #pragma unroll
-            for (int b = 0; b < BQ; b++) sum[b] = sum[b] + lut[b][at];
+                for (int b = 0; b < BQ; b++) sum[b] = sum[b] + lut[b][at];
+            }
             if (cosine) cdp = cdp + ccache[at];
         };
         if ((enc_dim & 15) == 0) {  // 16 code bytes per load
