@@ -254,6 +254,8 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
     std::string n(name);
     if (n == "mfma_variant")
         mfma_set_variant((int)value);
+    else if (n == "flat_share")
+        mfma_set_share((int)value);
     else
         throw Error(VDB_ERR_INVALID, "unknown parameter " + n);
     VDB_API_END

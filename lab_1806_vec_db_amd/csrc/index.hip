@@ -258,7 +258,8 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     ws.keys_a.reserve(nq_pad * capp * sizeof(uint64_t));  // approximate shortlist, sorted
     ws.keys_b.reserve(nq_pad * capp * sizeof(uint64_t));  // exact keys of the shortlist, unsorted
     ws.keys_c.reserve(nq_pad * capk * sizeof(uint64_t));  // exact top-k, sorted
-    ws.misc.reserve(nq_pad * (sizeof(float) + sizeof(uint32_t)));  // tau | hit counters
+    const size_t sync_words = mfma_sync_words((uint32_t)nbatch, num_cu);
+    ws.misc.reserve(nq_pad * (sizeof(float) + sizeof(uint32_t)) + sync_words * sizeof(uint32_t));  // tau | hit counters | rendezvous
     ws.flags.reserve(nq_pad);
     float *d_tau = ws.misc.as<float>();
     uint32_t *d_hits = reinterpret_cast<uint32_t *>(d_tau + nq_pad);
@@ -270,10 +271,13 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     launch_extract_tau(ws.keys_a.as<uint64_t>(), capp, (uint32_t)nq_pad, kprime, d_tau, s);
     uint64_t *d_cand = ws.lists.as<uint64_t>();  // the sample lists are dead now
     VDB_HIP(hipMemsetAsync(d_cand, 0xff, nq_pad * size_t(CAND_CAP) * sizeof(uint64_t), s));
-    VDB_HIP(hipMemsetAsync(d_hits, 0, nq_pad * sizeof(uint32_t), s));
-    prof_begin(ws, "flat_mfma", double(nbatch) * double(n) * dim * sizeof(float));
+    uint32_t *d_sync = d_hits + nq_pad;
+    VDB_HIP(hipMemsetAsync(d_hits, 0, (nq_pad + sync_words) * sizeof(uint32_t), s));
+    // algorithmic bytes: one corpus pass (N*d*4) serves 32*share queries (bytes/query = N*d*4 / B)
+    const uint64_t hbm_passes = (nbatch + mfma_share() - 1) / mfma_share();
+    prof_begin(ws, "flat_mfma", double(hbm_passes) * double(n) * dim * sizeof(float));
     launch_flat_mfma_filter(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>(), (uint32_t)nbatch, d_sq.as<float>(),
-                            cosine, d_tau, d_cand, d_hits, CAND_CAP, num_cu, s);
+                            cosine, d_tau, d_cand, d_hits, CAND_CAP, d_sync, num_cu, s);
     prof_end(ws);
     launch_topk_merge(d_cand, 1, CAND_CAP, (uint32_t)nq, kprime, ws.keys_a.as<uint64_t>(), s);
     VDB_HIP(hipMemsetAsync(ws.keys_b.p, 0xff, nq * capp * sizeof(uint64_t), s));

@@ -39,10 +39,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 size_t mfma_qfrag_floats(uint32_t dim) { return size_t(dim) * MFMA_B; }
 bool mfma_supported(uint32_t dim) { return dim >= 64 && (dim % 64) == 0 && size_t(dim) * MFMA_B * 4 <= 128 * 1024; }
 constexpr int MFMA_RT = 2;              // 16-row tiles per wave item
-constexpr uint32_t MFMA_WGBUF = 1536;   // per-workgroup LDS hit buffer entries (MODE_FILTER), ~6x the expected load
+constexpr uint32_t MFMA_WGBUF = 3072;   // per-workgroup LDS hit buffer entries (MODE_FILTER): 36 KB beside the 120 KB Q image
 uint64_t mfma_row_pad() { return 64; }  // rows of padding the kernel may touch past n (xsq reads)
 static int g_mfma_variant = 0;
 void mfma_set_variant(int v) { g_mfma_variant = v; }
+static uint32_t g_mfma_share = 2;  // query batches per HBM pass (XCD-shared passes, see k_flat_mfma)
+void mfma_set_share(int v) { g_mfma_share = v < 1 ? 1 : (v > 8 ? 8 : (uint32_t)v); }
+uint32_t mfma_share() { return g_mfma_share; }
+size_t mfma_sync_words(uint32_t nbatch, int num_cu) { return size_t(num_cu) * (nbatch + 1); }
 
 // hi/lo split of 8 consecutive f32 -> two packed bf16x8 (v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN)
 __device__ __forceinline__ void split8(const float4 &a, const float4 &b, uint4 &hi, uint4 &lo) {
@@ -154,6 +158,8 @@ struct MfmaArgs {
     uint32_t *cnt;       // [nbatch*32]
     uint32_t cap;
     uint32_t debug;
+    uint32_t *sync;      // MODE_FILTER, share > 1: arrival counters [groups][passes], zeroed before the launch
+    uint32_t share;      // MODE_FILTER: workgroups per XCD group that ride one HBM pass with different query batches
     int cosine;          // keys for DistanceAlgorithm::Cosine: -S/|x| (ranks like 1 - S/(|x||q|) for a fixed query)
 };
 
@@ -181,10 +187,25 @@ __global__ __launch_bounds__(512, 1) void k_flat_mfma(MfmaArgs a) {
     uint32_t *hit_n = hit_q + MFMA_WGBUF;  // [0] entries, [1..32] per-query counts, [33..64] per-query bases
 
     const uint32_t r = lane & 15, g = lane >> 4;
-    const uint32_t stride = gridDim.x * NW;
-    const uint32_t first = blockIdx.x * NW + wave;
-    const uint32_t b_begin = MODE == MODE_SAMPLE ? blockIdx.y : 0;
+    // XCD-shared passes (MODE_FILTER, share = S > 1): measured with tools/stream_probe.hip, S workgroups on the SAME
+    // XCD that read the same stream at the same time are served once from HBM and S times from that XCD's L2
+    // (S = 2: 0.643 ms for what one reader streams in 0.62 ms; on different XCDs it costs 2x).  Workgroups are
+    // dealt round-robin over the 8 XCDs (block b -> XCD b % 8; placement affects speed only, never results), so
+    // the S members of a group are the blocks with equal b % 8 and equal (b / 8) / S.  All members walk the same
+    // items; member m serves query batches m, m + S, m + 2S, ...  One HBM pass then serves 32 * S queries.
+    uint32_t S_ = 1, member = 0, group = blockIdx.x, n_groups = gridDim.x;
+    if (MODE == MODE_FILTER && a.share > 1) {
+        S_ = a.share;
+        const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        member = slot % S_;
+        group = (slot / S_) * 8 + xcd;
+        n_groups = gridDim.x / S_;
+    }
+    const uint32_t stride = n_groups * NW;
+    const uint32_t first = group * NW + wave;
+    const uint32_t b_begin = MODE == MODE_SAMPLE ? blockIdx.y : member;
     const uint32_t b_end = MODE == MODE_SAMPLE ? blockIdx.y + 1 : a.nbatch;
+    const uint32_t b_step = S_;
 
     // Q image staging through registers (<= 128 KB / 512 threads = 16 uint4 per thread)
     constexpr int QREG = 16;
@@ -206,10 +227,23 @@ __global__ __launch_bounds__(512, 1) void k_flat_mfma(MfmaArgs a) {
     };
 
     constexpr int R = PD + 1;
-    q_load(b_begin);
-    for (uint32_t b = b_begin; b < b_end; b++) {
+    if (b_begin < b_end) q_load(b_begin);
+    for (uint32_t b = b_begin; b < b_end; b += b_step) {
         q_store();
         if (MODE == MODE_FILTER && threadIdx.x < 80) hit_n[threadIdx.x] = 0;
+        if (MODE == MODE_FILTER && S_ > 1 && a.sync && threadIdx.x == 0) {
+            // rendezvous of the group's members before each shared pass: L2 sharing only works while they read
+            // the same lines within a few microseconds of each other, and without it their start times drift
+            // apart batch after batch.  Bounded spin: a member that is not resident (or already finished)
+            // only costs speed, never correctness.
+            uint32_t *ctr = a.sync + uint64_t(group) * ((a.nbatch + S_ - 1) / S_) + (b / S_);
+            uint32_t want = b + S_ <= a.nbatch || a.nbatch % S_ == 0 ? S_ : a.nbatch % S_;  // members with a batch in this pass
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int spin = 0; spin < 4000; spin++) {
+                if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
         __syncthreads();
         float tau[2] = {0.f, 0.f};
         if (MODE == MODE_FILTER) {
@@ -333,7 +367,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_mfma(MfmaArgs a) {
                 }
             }
         }
-        if (b + 1 < b_end) q_load(b + 1);  // lands while the other waves finish and the hits are flushed
+        if (b + b_step < b_end) q_load(b + b_step);  // lands while the other waves finish and the hits are flushed
         __syncthreads();                   // every wave has left the item loop: qs and the hit buffer are quiescent
         if (MODE == MODE_FILTER) {
             uint32_t total = hit_n[0];
@@ -376,16 +410,30 @@ static void flat_mfma_launch(const MfmaArgs &a, int num_cu, hipStream_t s) {
     uint32_t n_visit = (a.n_items + a.item_step - 1) / a.item_step;
     uint32_t grid = (uint32_t)num_cu;
     uint32_t need = (n_visit + NW - 1) / NW;
-    if (need < grid) grid = need;
-    if (grid == 0 || a.nbatch == 0) return;
-    dim3 g(grid, MODE == MODE_SAMPLE ? a.nbatch : 1);
-    hipLaunchKernelGGL((k_flat_mfma<PD, MODE>), g, dim3(512), lds, s, a);
+    MfmaArgs b = a;
+    if (MODE == MODE_FILTER && b.share > 1) {
+        // sharing needs whole XCD groups: grid a multiple of 8*share, every group with work, >= share batches
+        uint32_t unit = 8 * b.share;
+        grid = grid / unit * unit;
+        if (grid == 0 || need < grid / b.share || b.nbatch < b.share) {
+            b.share = 1;
+            grid = (uint32_t)num_cu;
+        }
+    }
+    if (b.share <= 1 && need < grid) grid = need;
+    if (grid == 0 || b.nbatch == 0) return;
+    dim3 g(grid, MODE == MODE_SAMPLE ? b.nbatch : 1);
+    hipLaunchKernelGGL((k_flat_mfma<PD, MODE>), g, dim3(512), lds, s, b);
 }
 
 template <int MODE>
 static void flat_mfma_dispatch(const MfmaArgs &a, int num_cu, hipStream_t s) {
     uint32_t KB = a.dim / 32;  // the ring size R = PD+1 must divide KB
-    if (KB % 6 == 0)
+    if (KB % 6 == 0 && (g_mfma_variant & 15) == 2)
+        flat_mfma_launch<2, MODE>(a, num_cu, s);
+    else if (KB % 6 == 0 && (g_mfma_variant & 15) == 1)
+        flat_mfma_launch<1, MODE>(a, num_cu, s);
+    else if (KB % 6 == 0)
         flat_mfma_launch<5, MODE>(a, num_cu, s);
     else if (KB % 4 == 0)
         flat_mfma_launch<3, MODE>(a, num_cu, s);
@@ -435,7 +483,7 @@ void launch_flat_mfma_sample(const float *XT, uint64_t n, uint32_t dim, const fl
 
 void launch_flat_mfma_filter(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t nbatch,
                              const float *xsq, int cosine, const float *tau, uint64_t *cand, uint32_t *cnt,
-                             uint32_t cap, int num_cu, hipStream_t s) {
+                             uint32_t cap, uint32_t *sync, int num_cu, hipStream_t s) {
     if (n == 0 || nbatch == 0) return;
     MfmaArgs a = mfma_args(XT, n, dim, qfrag, nbatch, xsq, cosine);
     a.item_step = 1;
@@ -444,6 +492,8 @@ void launch_flat_mfma_filter(const float *XT, uint64_t n, uint32_t dim, const fl
     a.cnt = cnt;
     a.cap = cap;
     a.debug = g_mfma_variant >= 16 ? (g_mfma_variant >> 4) : 0;
+    a.share = g_mfma_share;
+    a.sync = sync;
     flat_mfma_dispatch<MODE_FILTER>(a, num_cu, s);
 }
 

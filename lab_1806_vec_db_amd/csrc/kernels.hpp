@@ -72,11 +72,14 @@ void launch_flat_mfma_sample(const float *XT, uint64_t n, uint32_t dim, const fl
 // (cnt[q] counts every hit, so cnt[q] > cap means candidates were dropped)
 void launch_flat_mfma_filter(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t nbatch,
                              const float *xsq, int cosine, const float *tau, uint64_t *cand, uint32_t *cnt,
-                             uint32_t cap, int num_cu, hipStream_t s);
+                             uint32_t cap, uint32_t *sync /* mfma_sync_words() zeroed words */, int num_cu, hipStream_t s);
+size_t mfma_sync_words(uint32_t nbatch, int num_cu);
 uint64_t mfma_sample_rows(uint64_t n);
 uint32_t mfma_sample_step(uint64_t n);
 size_t mfma_qfrag_floats(uint32_t dim);
 void mfma_set_variant(int v);  // tuning hook (0 = default)
+void mfma_set_share(int v);    // query batches (of 32) that ride one HBM pass through XCD-local L2 sharing (1, 2, 4, 8)
+uint32_t mfma_share();
 uint64_t mfma_row_pad();
 bool mfma_supported(uint32_t dim);
 

@@ -3,6 +3,7 @@ sys.path.insert(0, '.')
 import lab_1806_vec_db_amd as vdb
 n, dim, nq, k = 1_000_000, 960, 1024, 10
 variants = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else [0]
+shares = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [2]
 g = torch.Generator(device='cuda'); g.manual_seed(1806)
 base = (torch.randn(n, dim, device='cuda', generator=g) * 0.045 + 0.07).abs_().clamp_(0, 0.8)
 qs = (torch.randn(nq, dim, device='cuda', generator=g) * 0.045 + 0.07).abs_().clamp_(0, 0.8)
@@ -14,6 +15,8 @@ ix.prof_enable(True)
 ix.set_flat_mode(2)
 ref = None
 for rnd in range(2):
+ for sh in shares:
+  ix.set_param('flat_share', sh)
   for v in variants:
     ix.set_param('mfma_variant', v)
     ix.prof_reset()
@@ -25,4 +28,4 @@ for rnd in range(2):
     ok = True
     if ref is None: ref = (oi.clone(), od.clone())
     else: ok = bool((ref[0] == oi).all() and (ref[1] == od).all())
-    print(f"variant {v} rnd {rnd}: total {dt*1e3:.2f} ms -> {nq/dt:.0f} QPS; kernel {p['ms']/p['launches']:.3f} ms, {gbs:.0f} GB/s; same={ok} fb={ix.flat_fallback_count()}")
+    print(f"share {sh} variant {v} rnd {rnd}: total {dt*1e3:.2f} ms -> {nq/dt:.0f} QPS; kernel {p['ms']/p['launches']:.3f} ms, {gbs:.0f} GB/s; same={ok} fb={ix.flat_fallback_count()}")

@@ -23,6 +23,50 @@ __global__ __launch_bounds__(512) void k_chunks(const float4 *__restrict__ src, 
     }
     if (acc == 12345.678f) out[0] = acc;
 }
+// pattern C: like A, but the grid is split into `share` groups that read the SAME chunk sequence concurrently
+// (do concurrent readers of one stream share L2 / Infinity Cache, i.e. can two query batches ride one HBM pass?)
+template <int INFLIGHT>
+__global__ __launch_bounds__(512) void k_shared(const float4 *__restrict__ src, uint64_t n_kb, uint32_t chunk_kb, uint32_t share, float *out) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint32_t per = gridDim.x / share;            // workgroups per group
+    const uint32_t bid = blockIdx.x / share;           // adjacent block ids (different XCDs) share a chunk ...
+    const uint64_t stride = uint64_t(per) * nw;
+    float acc = 0.f;
+    uint64_t n_chunks = n_kb / chunk_kb;
+    for (uint64_t c = bid * nw + wave; c < n_chunks; c += stride) {
+        const float4 *p = src + c * chunk_kb * 64 + lane;
+        for (uint32_t i = 0; i < chunk_kb; i += INFLIGHT) {
+            float4 v[INFLIGHT];
+#pragma unroll
+            for (int j = 0; j < INFLIGHT; j++) v[j] = p[(i + j) * 64];
+#pragma unroll
+            for (int j = 0; j < INFLIGHT; j++) acc += v[j].x + v[j].y + v[j].z + v[j].w;
+        }
+    }
+    if (acc == 12345.678f) out[0] = acc;
+}
+template <int INFLIGHT>
+__global__ __launch_bounds__(512) void k_shared_xcd(const float4 *__restrict__ src, uint64_t n_kb, uint32_t chunk_kb, uint32_t share, float *out) {
+    // ... or block ids b and b + 8*k (same XCD under round-robin placement) share a chunk
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint32_t per = gridDim.x / share;
+    const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;       // slot within the XCD
+    const uint32_t bid = (slot / share) * 8 + xcd;                    // group id
+    const uint64_t stride = uint64_t(per) * nw;
+    float acc = 0.f;
+    uint64_t n_chunks = n_kb / chunk_kb;
+    for (uint64_t c = bid * nw + wave; c < n_chunks; c += stride) {
+        const float4 *p = src + c * chunk_kb * 64 + lane;
+        for (uint32_t i = 0; i < chunk_kb; i += INFLIGHT) {
+            float4 v[INFLIGHT];
+#pragma unroll
+            for (int j = 0; j < INFLIGHT; j++) v[j] = p[(i + j) * 64];
+#pragma unroll
+            for (int j = 0; j < INFLIGHT; j++) acc += v[j].x + v[j].y + v[j].z + v[j].w;
+        }
+    }
+    if (acc == 12345.678f) out[0] = acc;
+}
 // pattern B: grid-stride linear (adjacent waves read adjacent KBs)
 template <int INFLIGHT>
 __global__ __launch_bounds__(512) void k_linear(const float4 *__restrict__ src, uint64_t n_kb, float *out) {
@@ -66,6 +110,15 @@ int main() {
             snprintf(nm, 128, "linear inflight4 grid%d nt%d", grid, nt);
             timeit(nm, [&]() { hipLaunchKernelGGL(k_linear<4>, dim3(grid), dim3(nt), 0, 0, src, n_kb, out); });
         }
+    }
+    for (int share : {1, 2, 4}) {
+        char nm[128];
+        snprintf(nm, 128, "shared x%d (adjacent ids) grid256 nt512 [unique bytes]", share);
+        timeit(nm, [&]() { hipLaunchKernelGGL(k_shared<10>, dim3(256), dim3(512), 0, 0, src, n_kb, 120, share, out); });
+        snprintf(nm, 128, "shared x%d (same XCD) grid256 nt512 [unique bytes]", share);
+        timeit(nm, [&]() { hipLaunchKernelGGL(k_shared_xcd<10>, dim3(256), dim3(512), 0, 0, src, n_kb, 120, share, out); });
+        snprintf(nm, 128, "shared x%d (same XCD) grid512 nt256 [unique bytes]", share);
+        timeit(nm, [&]() { hipLaunchKernelGGL(k_shared_xcd<10>, dim3(512), dim3(256), 0, 0, src, n_kb, 120, share, out); });
     }
     // high-occupancy linear
     timeit("linear inflight4 grid2048 nt256", [&]() { hipLaunchKernelGGL(k_linear<4>, dim3(2048), dim3(256), 0, 0, src, n_kb, out); });
