@@ -382,9 +382,17 @@ struct Scratch {
 struct Builder {
     HNSWState &h;
     const float *rows;
-    const float *cache;  // dist_cache per row (dot for L2, norm for Cosine)
+    const float *sq;  // dot(x,x) per row; dist_cache = sq (L2Sqr) or sqrt(sq) (Cosine), distance/mod.rs:31-36
     uint64_t dim;
     int dist;
+    struct CacheView {
+        const float *sq;
+        int dist;
+        float operator[](uint64_t i) const { return dist == 0 ? sq[i] : std::sqrt(sq[i]); }
+    };
+    CacheView cache{nullptr, 0};
+    Builder(HNSWState &hh, const float *r, const float *s, uint64_t d, int ds)
+        : h(hh), rows(r), sq(s), dim(d), dist(ds), cache{s, ds} {}
 
     float dot(const float *a, const float *b) const {
         float acc = 0.0f;
@@ -620,15 +628,6 @@ void hnsw_config(HNSWState &h, uint64_t M, uint64_t efc) {  // IndexBuilder::new
     h.inv_log_m = 1.0f / std::log((float)h.m);
 }
 
-std::vector<float> host_cache(Index &ix) {
-    std::vector<float> c(ix.n);
-    ix.use_device();
-    if (ix.n) VDB_HIP(hipMemcpy(c.data(), ix.d_sq.p, ix.n * sizeof(float), hipMemcpyDeviceToHost));
-    if (ix.dist == 1)
-        for (auto &v : c) v = std::sqrt(v);  // Cosine caches vec_norm (distance/mod.rs:31-36)
-    return c;
-}
-
 void reset_graph(HNSWState &h) {
     h.level0.clear();
     h.len0.clear();
@@ -658,8 +657,7 @@ void hnsw_build(Index &ix, uint64_t M, uint64_t ef_construction, uint64_t seed, 
     hnsw_config(h, M, ef_construction);
     h.rng_state = seed;
     const float *rows = ix.host_rows();
-    std::vector<float> cache = host_cache(ix);
-    Builder b{h, rows, cache.data(), ix.dim, ix.dist};
+    Builder b(h, rows, ix.h_sq.data(), ix.dim, ix.dist);
     uint64_t n = ix.n;
     std::vector<uint64_t> levels(n);
     for (uint64_t i = 0; i < n; i++) levels[i] = rand_level(h.rng_state, h.inv_log_m);
@@ -722,9 +720,7 @@ void hnsw_insert_rows(Index &ix, const float *rows, uint64_t count) {
     Scratch s;
     for (uint64_t i = 0; i < count; i++) {
         ix.add_rows(rows + i * ix.dim, 1, false);
-        const float *hr = ix.host_rows();
-        std::vector<float> cache = host_cache(ix);
-        Builder b{h, hr, cache.data(), ix.dim, ix.dist};
+        Builder b(h, ix.host_rows(), ix.h_sq.data(), ix.dim, ix.dist);  // both mirrors may have been reallocated
         b.add(ix.n - 1, rand_level(h.rng_state, h.inv_log_m), s);
     }
     h.dev_dirty = true;

@@ -74,6 +74,7 @@ void Index::add_rows(const float *rows, uint64_t count, bool on_device) {
         if (v > xsq_max && std::isfinite(v)) xsq_max = v;
         if (v > 0.0f && v < xsq_min_pos) xsq_min_pos = v;
     }
+    h_sq.insert(h_sq.end(), sq.begin(), sq.end());
     {
         std::lock_guard<std::mutex> g(host_mu);
         if (on_device) {
@@ -109,6 +110,8 @@ void Index::swap_remove(uint64_t i) {
             h_rows.resize(last * dim);
         }
     }
+    if (i < last) h_sq[i] = h_sq[last];
+    h_sq.resize(last);
     n = last;
     // xsq_max stays an upper bound (certification only needs a bound)
 }

@@ -114,6 +114,7 @@ struct Index {
     uint64_t id_offset = 0;
     DevBuf d_rows, d_sq;
     DevBuf d_tiled;  // MFMA-fragment-ordered mirror of d_rows (k_mfma.hip), only when mfma_supported(dim)
+    std::vector<float> h_sq;  // host mirror of d_sq (4 B/row), kept in step by add_rows / swap_remove
     float xsq_max = 0.0f;
     float xsq_min_pos = 3.4e38f;  // smallest positive row |x|^2 seen (cosine certification: clamp check)
     // lazily materialised host mirror of the rows (needed by the host-side builders and vdb_index_row)
