@@ -282,7 +282,7 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     launch_flat_mfma_filter(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>(), (uint32_t)nbatch, d_sq.as<float>(),
                             cosine, d_tau, d_cand, d_hits, CAND_CAP, d_sync, num_cu, s);
     prof_end(ws);
-    launch_topk_merge(d_cand, 1, CAND_CAP, (uint32_t)nq, kprime, ws.keys_a.as<uint64_t>(), s);
+    launch_topk_merge_counted(d_cand, CAND_CAP, d_hits, (uint32_t)nq, kprime, ws.keys_a.as<uint64_t>(), s);
     VDB_HIP(hipMemsetAsync(ws.keys_b.p, 0xff, nq * capp * sizeof(uint64_t), s));
     launch_rerank(d_rows.as<float>(), (uint32_t)dim, d_q, (uint32_t)nq, cosine ? MET_COSINE : MET_L2_DIRECT, d_sq.as<float>(),
                   ws.qsq.as<float>(), ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), kprime, capp, s);

@@ -128,6 +128,25 @@ __global__ __launch_bounds__(64) void k_topk_merge(const uint64_t *__restrict__ 
     wl.store(out + uint64_t(q) * (64 * R));
 }
 
+// level 2 over one candidate list per query whose valid length is min(cnt[q], cap) (the tail is PAIR_NONE)
+template <int R>
+__global__ __launch_bounds__(64) void k_topk_merge_counted(const uint64_t *__restrict__ lists, uint32_t cap,
+                                                           const uint32_t *__restrict__ cnt, uint32_t k,
+                                                           uint64_t *__restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t q = blockIdx.x;
+    WaveList<R> wl;
+    wl.init(k);
+    const uint64_t *src = lists + uint64_t(q) * cap;
+    uint32_t total = cnt[q] < cap ? cnt[q] : cap;
+    uint32_t rounds = (total + 63) / 64;
+    for (uint32_t it = 0; it < rounds; it++) {
+        uint32_t i = it * 64 + lane;
+        wl.offer(i < total ? src[i] : PAIR_NONE);
+    }
+    wl.store(out + uint64_t(q) * (64 * R));
+}
+
 template <int R>
 static void topk_dense_r(const float *keys, uint64_t ld, uint64_t n, uint32_t nq, uint32_t k, uint64_t *lists,
                          hipStream_t s) {
@@ -178,6 +197,16 @@ void launch_topk_dense(const float *keys, uint64_t ld, uint64_t n, uint32_t nq, 
     VDB_REQUIRE(k >= 1, "top-k: k must be >= 1");
     uint32_t cap = topk_capacity(k);
 #define CALL(R) topk_dense_r<R>(keys, ld, n, nq, k, lists, s)
+    VDB_DISPATCH_R(cap, CALL)
+#undef CALL
+}
+
+void launch_topk_merge_counted(const uint64_t *lists, uint32_t cap_in, const uint32_t *cnt, uint32_t nq, uint32_t k,
+                               uint64_t *out, hipStream_t s) {
+    if (nq == 0) return;
+    VDB_REQUIRE(k >= 1, "top-k: k must be >= 1");
+    uint32_t cap = topk_capacity(k);
+#define CALL(R) hipLaunchKernelGGL((k_topk_merge_counted<R>), dim3(nq), dim3(64), 0, s, lists, cap_in, cnt, k, out)
     VDB_DISPATCH_R(cap, CALL)
 #undef CALL
 }

@@ -54,35 +54,88 @@ __global__ void k_pq_lut(const float *__restrict__ Q, uint32_t dim, const float 
 // ds_read_b32 gather by code value is conflict-free whatever the codes are.
 // LUT_IN_LDS = false: tables too large for LDS (8-bit codes with large m) are read through L1/L2.
 // ---------------------------------------------------------------------------------------------------
-template <int BQ, int NBITS, bool LUT_IN_LDS>
-__global__ __launch_bounds__(1024) void k_pq_adc(const uint8_t *__restrict__ codes, uint64_t n, uint32_t enc_dim,
-                                                uint32_t m, const float *__restrict__ lut_g,
-                                                const float *__restrict__ cent_cache_g, int cosine,
-                                                const float *__restrict__ qsq, uint32_t nq,
-                                                float *__restrict__ out, uint64_t ld) {
+// MODE 0 (dense): out[b*ld + j] for the visited rows (row blocks of blockDim.x rows, every `blk_step`-th block;
+//                 j = dense position among the visited rows; +inf for rows >= n).  blk_step = 1 is the plain scan,
+//                 blk_step > 1 the strided sample whose ef-th smallest value per query bounds the global one.
+// MODE 1 (filter): all rows; pairs with adc <= tau[b] are parked in an LDS buffer and handed to cand[b][..] when
+//                 the workgroup is done (one global atomic per query per workgroup) -- no dense N x B matrix, no
+//                 separate top-ef pass over it.  ADC values are exact, so {adc <= tau} is a superset of the exact
+//                 top-ef and the select that follows is the reference's (adc, idx) order.
+struct AdcArgs {
+    const uint8_t *codes;
+    uint64_t n;
+    uint32_t enc_dim, m;
+    const float *lut;         // [BQ][m*kc]
+    const float *cent_cache;  // [m*kc]
+    const float *qsq;         // [BQ]
+    uint32_t nq;              // valid queries of this pass (<= BQ)
+    int cosine;
+    uint32_t blk_step;
+    float *out;               // MODE 0
+    uint64_t ld;
+    const float *tau;         // MODE 1: [BQ]
+    uint64_t *cand;           //         [BQ][cap]
+    uint32_t *cnt;            //         [BQ]
+    uint32_t cap;
+    uint32_t nq_total;        // queries of the whole launch; blockIdx.y selects the sub-batch of BQ queries
+};
+constexpr uint32_t ADC_WGBUF = 2048;  // LDS hit buffer entries per workgroup (MODE 1)
+
+template <int BQ, int NBITS, bool LUT_IN_LDS, int MODE>
+__global__ __launch_bounds__(1024) void k_pq_adc(AdcArgs a) {
+    {   // sub-batch blockIdx.y: BQ consecutive queries of the launch
+        const uint32_t q0 = blockIdx.y * BQ;
+        a.nq = a.nq_total - q0 < (uint32_t)BQ ? a.nq_total - q0 : (uint32_t)BQ;
+        a.lut += uint64_t(q0) * a.m * (1u << NBITS);
+        a.qsq += q0;
+        if (MODE == 0) {
+            a.out += uint64_t(q0) * a.ld;
+        } else {
+            a.tau += q0;
+            a.cand += uint64_t(q0) * a.cap;
+            a.cnt += q0;
+        }
+    }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr uint32_t KC = 1u << NBITS;
+    const uint32_t m = a.m, enc_dim = a.enc_dim;
+    const uint64_t n = a.n;
+    const int cosine = a.cosine;
     const uint32_t lsz = m * KC;
     const float *lut[BQ];
-    const float *ccache = cent_cache_g;
+    const float *ccache = a.cent_cache;
+    uint32_t lds_floats = 0;
     if (LUT_IN_LDS) {
         // entry-major, query-minor: the BQ values of one (group, code) entry are adjacent, so one ds_read_b128
         // (BQ = 4) serves all queries of the pass -- half the LDS cycles of four ds_read_b32 gathers.  Distinct
         // codes of a group still land in distinct banks (16 entries x 16 B = all 64 banks).
         for (uint32_t i = threadIdx.x; i < lsz * BQ; i += blockDim.x) {
             uint32_t b = i / lsz, e = i % lsz;
-            smem[e * BQ + b] = b < nq ? lut_g[i] : 0.0f;
+            smem[e * BQ + b] = b < a.nq ? a.lut[i] : 0.0f;
         }
         if (cosine)
-            for (uint32_t i = threadIdx.x; i < lsz; i += blockDim.x) smem[lsz * BQ + i] = cent_cache_g[i];
-        __syncthreads();
+            for (uint32_t i = threadIdx.x; i < lsz; i += blockDim.x) smem[lsz * BQ + i] = a.cent_cache[i];
         ccache = smem + lsz * BQ;
+        lds_floats = lsz * BQ + (cosine ? lsz : 0);
     } else {
 #pragma unroll
-        for (int b = 0; b < BQ; b++) lut[b] = lut_g + (b < (int)nq ? b : 0) * uint64_t(lsz);
+        for (int b = 0; b < BQ; b++) lut[b] = a.lut + (b < (int)a.nq ? b : 0) * uint64_t(lsz);
     }
-    for (uint64_t row = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; row < n; row += uint64_t(gridDim.x) * blockDim.x) {
-        const uint8_t *cr = codes + row * enc_dim;
+    // hit buffer behind the tables (MODE 1)
+    uint64_t *hit_key = reinterpret_cast<uint64_t *>(smem + ((lds_floats + 3) & ~3u));
+    uint32_t *hit_q = reinterpret_cast<uint32_t *>(hit_key + ADC_WGBUF);
+    uint32_t *hit_n = hit_q + ADC_WGBUF;  // [0] entries, [1..BQ] per-query counts, [1+BQ..2BQ] bases
+    if (MODE == 1 && threadIdx.x < 1 + 2 * BQ) hit_n[threadIdx.x] = 0;
+    float tau[BQ];
+#pragma unroll
+    for (int b = 0; b < BQ; b++) tau[b] = (MODE == 1 && b < (int)a.nq) ? a.tau[b] : -INFINITY;
+    __syncthreads();
+
+    const uint64_t nblk = (n + blockDim.x - 1) / blockDim.x;
+    for (uint64_t vb = blockIdx.x; vb * a.blk_step < nblk; vb += gridDim.x) {
+        const uint64_t row = vb * a.blk_step * blockDim.x + threadIdx.x;
+        const bool valid = row < n;
+        const uint8_t *cr = a.codes + (valid ? row : n - 1) * enc_dim;
         float sum[BQ];
 #pragma unroll
         for (int b = 0; b < BQ; b++) sum[b] = 0.0f;
@@ -159,16 +212,45 @@ __global__ __launch_bounds__(1024) void k_pq_adc(const uint8_t *__restrict__ cod
         }
 #pragma unroll
         for (int b = 0; b < BQ; b++) {
-            if (b >= (int)nq) break;
+            if (b >= (int)a.nq) break;
             float d = sum[b];
             if (cosine) {  // pq_table.rs:294-299
                 float norm0 = sqrtf(cdp);
-                float norm1 = sqrtf(qsq[b]);
+                float norm1 = sqrtf(a.qsq[b]);
                 float den = fmaxf(norm0 * norm1, 1e-10f);
                 float r = sum[b] / den;
                 d = 1.0f - r;
             }
-            out[uint64_t(b) * ld + row] = d;
+            if (MODE == 0) {
+                a.out[uint64_t(b) * a.ld + vb * blockDim.x + threadIdx.x] = valid ? d : INFINITY;
+            } else if (valid && d <= tau[b]) {
+                uint32_t pos = atomicAdd(hit_n, 1u);
+                if (pos < ADC_WGBUF) {
+                    hit_key[pos] = pair_key(d, uint32_t(row));
+                    hit_q[pos] = b;
+                } else {
+                    atomicAdd(&a.cnt[b], a.cap + 1);  // mark the query as overflowed (-> dense path)
+                }
+            }
+        }
+    }
+    if (MODE == 1) {
+        __syncthreads();
+        uint32_t total = hit_n[0];
+        if (total > ADC_WGBUF) total = ADC_WGBUF;
+        // ranks: each thread walks its strided entries (total <= 2048)
+        for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
+            uint32_t r_ = atomicAdd(&hit_n[1 + hit_q[i]], 1u);
+            hit_q[i] |= r_ << 8;  // park the rank beside the query id (BQ <= 4, rank < 2048)
+        }
+        __syncthreads();
+        if (threadIdx.x < BQ && hit_n[1 + threadIdx.x] > 0)
+            hit_n[1 + BQ + threadIdx.x] = atomicAdd(&a.cnt[threadIdx.x], hit_n[1 + threadIdx.x]);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
+            uint32_t q = hit_q[i] & 0xff, r_ = hit_q[i] >> 8;
+            uint32_t slot = hit_n[1 + BQ + q] + r_;
+            if (slot < a.cap) a.cand[uint64_t(q) * a.cap + slot] = hit_key[i];
         }
     }
 }
@@ -519,31 +601,42 @@ void pq_build(Index &ix, uint64_t n_bits, uint64_t m, uint64_t train_n, uint64_t
 }
 
 // ---- FlatIndex::knn_pq (flat_index.rs:84-104) --------------------------------------------------------
-template <int BQ, int NBITS>
-static void adc_launch(Index &ix, Workspace &ws, const float *lut, const float *qsq, uint32_t nb, float *out,
-                       uint64_t ld) {
+template <int BQ, int NBITS, int MODE>
+static void adc_launch_m(Index &ix, Workspace &ws, AdcArgs a) {
     PQState &pq = ix.pq;
     size_t lsz = pq.m * pq.kc * sizeof(float);
-    size_t need = lsz * BQ + (ix.dist == 1 ? lsz : 0);
-    bool in_lds = need <= 150 * 1024;
-    int cosine = ix.dist == 1 ? 1 : 0;
+    size_t tables = lsz * BQ + (ix.dist == 1 ? lsz : 0);
+    bool in_lds = tables <= 120 * 1024;
+    size_t lds = (in_lds ? ((tables + 15) & ~size_t(15)) : 0) + (MODE == 1 ? ADC_WGBUF * 12 + (1 + 2 * BQ) * 4 + 16 : 0);
     // LUTs in LDS: one 1024-thread workgroup per CU (16 waves keep the LDS gather pipe busy); else 8 x 256
     uint32_t nt = in_lds ? 1024 : 256;
-    uint32_t grid = (uint32_t)std::min<uint64_t>((ix.n + nt - 1) / nt, uint64_t(ix.num_cu) * (in_lds ? 1 : 8));
+    uint64_t nblk = ((ix.n + nt - 1) / nt + a.blk_step - 1) / a.blk_step;
+    uint32_t grid = (uint32_t)std::min<uint64_t>(nblk, uint64_t(ix.num_cu) * (in_lds ? 1 : 8));
+    if (grid == 0 || a.nq_total == 0) return;
+    dim3 g(grid, (a.nq_total + BQ - 1) / BQ);
     if (in_lds) {
         static bool attr = false;
         if (!attr) {
-            VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pq_adc<BQ, NBITS, true>),
+            VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pq_adc<BQ, NBITS, true, MODE>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr = true;
         }
-        hipLaunchKernelGGL((k_pq_adc<BQ, NBITS, true>), dim3(grid), dim3(nt), need, ws.stream,
-                           pq.d_codes.as<uint8_t>(), ix.n, (uint32_t)pq.enc_dim, (uint32_t)pq.m, lut,
-                           pq.d_cent_cache.as<float>(), cosine, qsq, nb, out, ld);
+        hipLaunchKernelGGL((k_pq_adc<BQ, NBITS, true, MODE>), g, dim3(nt), lds, ws.stream, a);
     } else {
-        hipLaunchKernelGGL((k_pq_adc<BQ, NBITS, false>), dim3(grid), dim3(nt), 0, ws.stream,
-                           pq.d_codes.as<uint8_t>(), ix.n, (uint32_t)pq.enc_dim, (uint32_t)pq.m, lut,
-                           pq.d_cent_cache.as<float>(), cosine, qsq, nb, out, ld);
+        hipLaunchKernelGGL((k_pq_adc<BQ, NBITS, false, MODE>), g, dim3(nt), lds, ws.stream, a);
+    }
+}
+
+template <int MODE>
+static void adc_launch(Index &ix, Workspace &ws, uint32_t BQ, const AdcArgs &a) {
+    if (ix.pq.n_bits == 4) {
+        if (BQ == 4) adc_launch_m<4, 4, MODE>(ix, ws, a);
+        else if (BQ == 2) adc_launch_m<2, 4, MODE>(ix, ws, a);
+        else adc_launch_m<1, 4, MODE>(ix, ws, a);
+    } else {
+        if (BQ == 4) adc_launch_m<4, 8, MODE>(ix, ws, a);
+        else if (BQ == 2) adc_launch_m<2, 8, MODE>(ix, ws, a);
+        else adc_launch_m<1, 8, MODE>(ix, ws, a);
     }
 }
 
@@ -591,43 +684,104 @@ void flat_knn_pq_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq,
     launch_row_sqnorm(d_q, nq, (uint32_t)ix.dim, ws.qsq.as<float>(), s);
     pq_make_luts(ix, ws, d_q, nq);
 
-    const uint64_t ld = (n + 63) & ~63ull;
-    const uint32_t nl = topk_num_lists(n);
     const uint32_t cape = topk_capacity(efk), capk = topk_capacity(ksel);
     const uint32_t lsz = (uint32_t)(pq.m * pq.kc);
     // queries per pass: as many lookup tables as fit beside each other in LDS (<= 4)
     size_t lbytes = size_t(lsz) * sizeof(float);
-    uint32_t BQ = lbytes * 4 + (ix.dist == 1 ? lbytes : 0) <= 150 * 1024 ? 4 : (lbytes * 2 + (ix.dist == 1 ? lbytes : 0) <= 150 * 1024 ? 2 : 1);
-    // ADC distances of a group of GQ queries are kept dense so that the top-ef select and its merge run with
-    // GQ x (N/8192) waves -- a 4-query launch would leave the GPU mostly idle
-    uint64_t GQ = std::min<uint64_t>(64, (size_t(512) << 20) / (ld * sizeof(float)));
-    GQ = std::max<uint64_t>(BQ, GQ / BQ * BQ);
-    ws.dense.reserve(GQ * ld * sizeof(float));
-    ws.lists.reserve(GQ * nl * cape * sizeof(uint64_t));
+    const size_t cbytes = ix.dist == 1 ? lbytes : 0;
+    uint32_t BQ = lbytes * 4 + cbytes <= 120 * 1024 ? 4 : (lbytes * 2 + cbytes <= 120 * 1024 ? 2 : 1);
+    const uint32_t nt = lbytes * BQ + cbytes <= 120 * 1024 ? 1024 : 256;  // rows per row block (= workgroup size)
     ws.keys_a.reserve(nq * cape * sizeof(uint64_t));
     ws.keys_b.reserve(nq * cape * sizeof(uint64_t));
     ws.keys_c.reserve(nq * capk * sizeof(uint64_t));
-    for (uint64_t g0 = 0; g0 < nq; g0 += GQ) {
-        const uint64_t gn = std::min<uint64_t>(GQ, nq - g0);
-        for (uint64_t q0 = g0; q0 < g0 + gn; q0 += BQ) {
-            uint32_t nb = (uint32_t)std::min<uint64_t>(BQ, g0 + gn - q0);
-            const float *lut = ws.lut.as<float>() + q0 * lsz;
-            const float *qs = ws.qsq.as<float>() + q0;
-            float *dst = ws.dense.as<float>() + (q0 - g0) * ld;
-            ix.prof_begin(ws, "pq_adc", double(n) * pq.enc_dim);
-            if (pq.n_bits == 4) {
-                if (BQ == 4) adc_launch<4, 4>(ix, ws, lut, qs, nb, dst, ld);
-                else if (BQ == 2) adc_launch<2, 4>(ix, ws, lut, qs, nb, dst, ld);
-                else adc_launch<1, 4>(ix, ws, lut, qs, nb, dst, ld);
-            } else {
-                if (BQ == 4) adc_launch<4, 8>(ix, ws, lut, qs, nb, dst, ld);
-                else if (BQ == 2) adc_launch<2, 8>(ix, ws, lut, qs, nb, dst, ld);
-                else adc_launch<1, 8>(ix, ws, lut, qs, nb, dst, ld);
-            }
+
+    AdcArgs base{};
+    base.codes = pq.d_codes.as<uint8_t>();
+    base.n = n;
+    base.enc_dim = (uint32_t)pq.enc_dim;
+    base.m = (uint32_t)pq.m;
+    base.cent_cache = pq.d_cent_cache.as<float>();
+    base.cosine = ix.dist == 1 ? 1 : 0;
+    base.blk_step = 1;
+
+    // dense path for one group of queries: every ADC distance, then the wave select (also the overflow fallback)
+    auto dense_group = [&](uint64_t g0, uint64_t gn) {
+        const uint64_t ld = (n + nt + 63) & ~63ull;
+        const uint32_t nl = topk_num_lists(n);
+        ws.dense.reserve(gn * ld * sizeof(float));
+        ws.lists.reserve(gn * nl * cape * sizeof(uint64_t));
+        {
+            AdcArgs a = base;
+            a.nq_total = (uint32_t)gn;
+            a.lut = ws.lut.as<float>() + g0 * lsz;
+            a.qsq = ws.qsq.as<float>() + g0;
+            a.out = ws.dense.as<float>();
+            a.ld = ld;
+            ix.prof_begin(ws, "pq_adc", double((gn + BQ - 1) / BQ) * double(n) * pq.enc_dim);
+            adc_launch<0>(ix, ws, BQ, a);
             ix.prof_end(ws);
         }
         launch_topk_dense(ws.dense.as<float>(), ld, n, (uint32_t)gn, efk, ws.lists.as<uint64_t>(), s);
         launch_topk_merge(ws.lists.as<uint64_t>(), nl, cape, (uint32_t)gn, efk, ws.keys_a.as<uint64_t>() + g0 * cape, s);
+    };
+
+    const uint64_t nblk = (n + nt - 1) / nt;
+    const uint32_t step = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, nblk / 16));
+    const uint64_t n_s = (nblk + step - 1) / step * nt;  // sampled rows (incl. padding past n)
+    const bool fused = n_s >= 2 * uint64_t(efk) && n >= 65536;
+    if (!fused) {
+        const uint64_t GQ = std::max<uint64_t>(BQ, std::min<uint64_t>(64, (size_t(512) << 20) / ((n + nt + 64) * sizeof(float))) / BQ * BQ);
+        for (uint64_t g0 = 0; g0 < nq; g0 += GQ) dense_group(g0, std::min<uint64_t>(GQ, nq - g0));
+    } else {
+        // fused path: tau[q] from a strided row-block sample, then one filtered scan per BQ queries
+        const uint64_t ld_s = (n_s + 63) & ~63ull;
+        const uint32_t nl_s = topk_num_lists(n_s);
+        const uint32_t cap = (uint32_t)std::min<uint64_t>(65536, std::max<uint64_t>(4096, 4ull * efk * step));
+        const uint64_t GQ = 64;
+        ws.dense.reserve(GQ * ld_s * sizeof(float));
+        ws.lists.reserve(std::max<size_t>(GQ * nl_s * cape, GQ * size_t(cap)) * sizeof(uint64_t));
+        ws.misc.reserve(nq * (sizeof(float) + sizeof(uint32_t)));
+        float *d_tau = ws.misc.as<float>();
+        uint32_t *d_hits = reinterpret_cast<uint32_t *>(d_tau + nq);
+        VDB_HIP(hipMemsetAsync(d_hits, 0, nq * sizeof(uint32_t), s));
+        for (uint64_t g0 = 0; g0 < nq; g0 += GQ) {
+            const uint64_t gn = std::min<uint64_t>(GQ, nq - g0);
+            {
+                AdcArgs a = base;
+                a.nq_total = (uint32_t)gn;
+                a.lut = ws.lut.as<float>() + g0 * lsz;
+                a.qsq = ws.qsq.as<float>() + g0;
+                a.blk_step = step;
+                a.out = ws.dense.as<float>();
+                a.ld = ld_s;
+                adc_launch<0>(ix, ws, BQ, a);
+            }
+            launch_topk_dense(ws.dense.as<float>(), ld_s, n_s, (uint32_t)gn, efk, ws.lists.as<uint64_t>(), s);
+            launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, cape, (uint32_t)gn, efk, ws.keys_a.as<uint64_t>() + g0 * cape, s);
+            launch_extract_tau(ws.keys_a.as<uint64_t>() + g0 * cape, cape, (uint32_t)gn, efk, d_tau + g0, s);
+            uint64_t *d_cand = ws.lists.as<uint64_t>();  // the sample lists are dead now
+            VDB_HIP(hipMemsetAsync(d_cand, 0xff, gn * size_t(cap) * sizeof(uint64_t), s));
+            {
+                AdcArgs a = base;
+                a.nq_total = (uint32_t)gn;
+                a.lut = ws.lut.as<float>() + g0 * lsz;
+                a.qsq = ws.qsq.as<float>() + g0;
+                a.tau = d_tau + g0;
+                a.cand = d_cand;
+                a.cnt = d_hits + g0;
+                a.cap = cap;
+                ix.prof_begin(ws, "pq_adc", double((gn + BQ - 1) / BQ) * double(n) * pq.enc_dim);
+                adc_launch<1>(ix, ws, BQ, a);
+                ix.prof_end(ws);
+            }
+            launch_topk_merge_counted(d_cand, cap, d_hits + g0, (uint32_t)gn, efk, ws.keys_a.as<uint64_t>() + g0 * cape, s);
+        }
+        // queries whose candidate list overflowed (or whose workgroup buffer filled) are redone densely
+        std::vector<uint32_t> hits(nq);
+        VDB_HIP(hipMemcpyAsync(hits.data(), d_hits, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        VDB_HIP(hipStreamSynchronize(s));
+        for (uint64_t q = 0; q < nq; q++)
+            if (hits[q] > cap) dense_group(q, 1);
     }
     // exact distances of the ADC shortlist in ADC order, then the reference's re-sort
     VDB_HIP(hipMemsetAsync(ws.keys_b.p, 0xff, nq * cape * sizeof(uint64_t), s));

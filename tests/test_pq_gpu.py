@@ -100,6 +100,27 @@ def test_pq_resort_ties(mods):
             assert np.array_equal(gd, od)
 
 
+@pytest.mark.parametrize("dist,kind", [("l2sqr", 0), ("cosine", 1)])
+def test_fused_threshold_path(mods, dist, kind):
+    """n >= 65536 takes the sampled-threshold + in-kernel filter path of the ADC scan (pq.hip); duplicated rows
+    put exact ADC ties at the cut."""
+    vdb, O = mods
+    base = gist_like(70000, dim=96, seed=11)
+    base[60000:60050] = base[100:150]  # equal codes -> equal ADC distances
+    qs = gist_like(10, dim=96, seed=12)
+    ix = vdb.GpuIndex(96, dist)
+    ix.batch_add(base)
+    ix.pq_build(n_bits=4, m=32, train_n=2000, max_iter=4, seed=5)
+    pq, opq = _oracle_pq(O, ix, base, kind)
+    assert np.array_equal(pq["codes"], opq.codes)
+    for k, ef in ((10, 10), (10, 128), (5, 1000)):
+        idx, d, cnt = ix.knn_pq(qs, k, ef)
+        for q in range(qs.shape[0]):
+            oi, od = O.flat_knn_pq(base, opq, qs[q], k, ef, kind)
+            assert idx[q].tolist() == oi.tolist(), (k, ef, q)
+            assert np.array_equal(d[q], od), (k, ef, q)
+
+
 def test_gistlike_knn_pq_large(mods):
     vdb, O = mods
     base = gist_like(30000, seed=1806)
