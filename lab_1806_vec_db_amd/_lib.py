@@ -71,10 +71,23 @@ class VdbError(RuntimeError):
     """Recoverable failure reported by libvdbhip (the reference raises PyRuntimeError, pyo3/mod.rs:65,85)."""
 
 
+def _preload_torch_runtime():
+    """PyTorch-ROCm wheels bundle their own libhsa-runtime64 / libamdhip64, and two HSA runtimes do not coexist in
+    one process: whichever initialises second sees no GPUs ("No HIP GPUs are available").  Importing torch first
+    (library load only, no GPU initialisation) lets libvdbhip.so's libhsa-runtime64.so.1 dependency resolve to the
+    copy torch already mapped, so the process has a single runtime whatever the later call order is.  Without
+    torch installed nothing happens -- the library itself does not need it."""
+    import importlib.util
+
+    if importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
+
+
 def load():
     global _lib
     if _lib is not None:
         return _lib
+    _preload_torch_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -63,7 +63,7 @@ void Index::add_rows(const float *rows, uint64_t count, bool on_device) {
         // refresh the fragment-ordered mirror for every 16-row tile that received rows
         uint64_t tiles_new = ((n + count + 15) / 16 + 3) & ~3ull;  // rounded up so a 64-row item never leaves the buffer
         uint64_t tiles_old = n / 16;                                // the partially filled tile is rewritten
-        uint64_t tile_bytes = 16 * row_bytes;
+        uint64_t tile_bytes = 16 * size_t(mfma_dim_pad((uint32_t)dim)) * sizeof(float);
         d_tiled.grow(tiles_new * tile_bytes, tiles_old * tile_bytes, s);
         launch_tile_rows(d_rows.as<float>(), n + count, (uint32_t)dim, tiles_old, tiles_new, d_tiled.as<float>(), s);
     }

@@ -36,8 +36,10 @@ namespace vdb {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-size_t mfma_qfrag_floats(uint32_t dim) { return size_t(dim) * MFMA_B; }
-bool mfma_supported(uint32_t dim) { return dim >= 64 && (dim % 64) == 0 && size_t(dim) * MFMA_B * 4 <= 128 * 1024; }
+// the mirror and the Q images are zero-padded to a multiple of 64 columns, so every dim <= 1024 qualifies
+uint32_t mfma_dim_pad(uint32_t dim) { return (dim + 63) & ~63u; }
+size_t mfma_qfrag_floats(uint32_t dim) { return size_t(mfma_dim_pad(dim)) * MFMA_B; }
+bool mfma_supported(uint32_t dim) { return dim >= 1 && size_t(mfma_dim_pad(dim)) * MFMA_B * 4 <= 128 * 1024; }
 constexpr int MFMA_RT = 2;              // 16-row tiles per wave item
 constexpr uint32_t MFMA_WGBUF = 3072;   // per-workgroup LDS hit buffer entries (MODE_FILTER): 36 KB beside the 120 KB Q image
 uint64_t mfma_row_pad() { return 64; }  // rows of padding the kernel may touch past n (xsq reads)
@@ -73,12 +75,26 @@ __device__ __forceinline__ void split8(const float4 &a, const float4 &b, uint4 &
                     l[6] | (uint32_t(l[7]) << 16));
 }
 
+// 8 consecutive columns [col, col+8) of a row of `dim` floats, zero past the row end (the padding columns)
+__device__ __forceinline__ void load8_padded(const float *row, uint32_t dim, uint32_t col, float4 &a, float4 &b) {
+    if ((dim & 3) == 0 && col + 8 <= dim) {
+        a = *reinterpret_cast<const float4 *>(row + col);
+        b = *reinterpret_cast<const float4 *>(row + col + 4);
+        return;
+    }
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = col + i < dim ? row[col + i] : 0.0f;
+    a = make_float4(v[0], v[1], v[2], v[3]);
+    b = make_float4(v[4], v[5], v[6], v[7]);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // rows [16*tile0, 16*tile1) of the row-major VecSet -> fragment-ordered split-bf16 mirror (rows >= n: zero)
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_tile_rows(const float *__restrict__ X, uint64_t n, uint32_t dim,
                                                    uint64_t tile0, uint64_t tile1, uint4 *__restrict__ T) {
-    const uint32_t KB = dim / 32;
+    const uint32_t KB = ((dim + 63) & ~63u) / 32;
     uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;  // (tile, kb, lane)
     uint64_t total = (tile1 - tile0) * KB * 64;
     if (i >= total) return;
@@ -89,10 +105,7 @@ __global__ __launch_bounds__(256) void k_tile_rows(const float *__restrict__ X, 
     uint64_t row = tile * 16 + (l & 15);
     uint32_t col = kb * 32 + 8 * (l >> 4);
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    if (row < n) {
-        a = *reinterpret_cast<const float4 *>(X + row * dim + col);
-        b = *reinterpret_cast<const float4 *>(X + row * dim + col + 4);
-    }
+    if (row < n) load8_padded(X + row * dim, dim, col, a, b);
     uint4 hi, lo;
     split8(a, b, hi, lo);
     T[((tile * KB + kb) * 2 + 0) * 64 + l] = hi;
@@ -102,7 +115,7 @@ __global__ __launch_bounds__(256) void k_tile_rows(const float *__restrict__ X, 
 void launch_tile_rows(const float *X, uint64_t n, uint32_t dim, uint64_t tile0, uint64_t tile1, float *T,
                       hipStream_t s) {
     if (tile1 <= tile0) return;
-    uint64_t total = (tile1 - tile0) * (dim / 32) * 64;
+    uint64_t total = (tile1 - tile0) * (mfma_dim_pad(dim) / 32) * 64;
     hipLaunchKernelGGL(k_tile_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, X, n, dim, tile0, tile1,
                        reinterpret_cast<uint4 *>(T));
 }
@@ -110,17 +123,14 @@ void launch_tile_rows(const float *X, uint64_t n, uint32_t dim, uint64_t tile0, 
 // Q [nq][dim] -> per batch of 32 queries a B-operand image [kb][half][hi|lo][lane] (queries >= nq: zero)
 __global__ void k_mfma_pack_queries(const float *__restrict__ Q, uint32_t nq, uint32_t dim, uint4 *__restrict__ qfrag) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // (kb, half, lane)
-    uint32_t KB = dim / 32;
+    uint32_t KB = ((dim + 63) & ~63u) / 32;
     if (i >= KB * 128) return;
     qfrag += uint64_t(blockIdx.y) * KB * 256;
     uint32_t l = i & 63, h = (i >> 6) & 1, kb = i >> 7;
     uint32_t q = blockIdx.y * MFMA_B + h * 16 + (l & 15);
     uint32_t c = kb * 32 + 8 * (l >> 4);
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    if (q < nq) {
-        a = *reinterpret_cast<const float4 *>(Q + size_t(q) * dim + c);
-        b = *reinterpret_cast<const float4 *>(Q + size_t(q) * dim + c + 4);
-    }
+    if (q < nq) load8_padded(Q + size_t(q) * dim, dim, c, a, b);
     uint4 hi, lo;
     split8(a, b, hi, lo);
     qfrag[((kb * 2 + h) * 2 + 0) * 64 + l] = hi;
@@ -128,7 +138,7 @@ __global__ void k_mfma_pack_queries(const float *__restrict__ Q, uint32_t nq, ui
 }
 
 void launch_mfma_pack_queries(const float *Q, uint32_t nq, uint32_t dim, float *qfrag, hipStream_t s) {
-    uint32_t total = (dim / 32) * 128;
+    uint32_t total = (mfma_dim_pad(dim) / 32) * 128;
     uint32_t nbatch = (nq + MFMA_B - 1) / MFMA_B;
     if (nbatch == 0) return;
     hipLaunchKernelGGL(k_mfma_pack_queries, dim3((total + 255) / 256, nbatch), dim3(256), 0, s, Q, nq, dim,
@@ -483,14 +493,14 @@ uint64_t mfma_sample_rows(uint64_t n) {
 
 static MfmaArgs mfma_args(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t nbatch,
                           const float *xsq, int cosine) {
-    VDB_REQUIRE(mfma_supported(dim), "flat_mfma: dim must be a multiple of 64 with 32*dim*4 <= 128 KiB");
+    VDB_REQUIRE(mfma_supported(dim), "flat_mfma: dim (padded to a multiple of 64) must be <= 1024");
     VDB_REQUIRE(n < (1ull << 32), "flat_mfma: too many rows for one shard");
     MfmaArgs a{};
     a.XT = reinterpret_cast<const uint4 *>(XT);
     a.qfrag = reinterpret_cast<const uint4 *>(qfrag);
     a.xsq = xsq;
     a.n = n;
-    a.dim = dim;
+    a.dim = mfma_dim_pad(dim);  // the kernel only sees the padded mirror / images
     a.n_items = mfma_num_items(n);
     a.nbatch = nbatch;
     a.cosine = cosine;

@@ -80,6 +80,7 @@ size_t mfma_sync_words(uint32_t nbatch, int num_cu);
 uint64_t mfma_sample_rows(uint64_t n);
 uint32_t mfma_sample_step(uint64_t n);
 size_t mfma_qfrag_floats(uint32_t dim);
+uint32_t mfma_dim_pad(uint32_t dim);  // columns of the mirror / Q images (dim rounded up to 64, zero filled)
 void mfma_set_variant(int v);  // tuning hook (0 = default)
 void mfma_set_share(int v);    // query batches (of 32) that ride one HBM pass through XCD-local L2 sharing (1, 2, 4, 8)
 uint32_t mfma_share();
