@@ -201,7 +201,7 @@ static void host_search(Index &ix, const float *queries, uint64_t nq, uint64_t k
         }
         std::vector<uint64_t> cnt(nb);
         VDB_HIP(hipMemcpyAsync(cnt.data(), ws->out_cnt.p, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-        VDB_HIP(hipStreamSynchronize(s));
+        VDB_SYNC(s);
         ix.prof_collect(*ws);
         if (out_count) std::memcpy(out_count + q0, cnt.data(), nb * sizeof(uint64_t));
     }
@@ -233,10 +233,10 @@ int vdb_flat_knn_device(vdb_index *idx, const void *d_queries, uint64_t nq, uint
     ix.use_device();
     WsLease ws(ix);
     // order after whatever produced the queries on the caller's stream
-    VDB_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    VDB_SYNC(static_cast<hipStream_t>(stream));
     ix.flat_knn_device(*ws, static_cast<const float *>(d_queries), nq, k, static_cast<uint64_t *>(d_out_idx),
                        static_cast<float *>(d_out_dist), static_cast<uint64_t *>(d_out_count));
-    VDB_HIP(hipStreamSynchronize(ws->stream));
+    VDB_SYNC(ws->stream);
     ix.prof_collect(*ws);
     VDB_API_END
 }
@@ -466,7 +466,7 @@ int vdb_merge_topk_device(vdb_index *idx, const void *d_dists, const void *d_ids
     Index &ix = idx->ix;
     ix.use_device();
     WsLease ws(ix);
-    VDB_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    VDB_SYNC(static_cast<hipStream_t>(stream));
     uint32_t cap = topk_capacity((uint32_t)k);
     ws->lists.reserve(nq * n_shards * cap * sizeof(uint64_t));
     ws->keys_c.reserve(nq * cap * sizeof(uint64_t));
@@ -478,7 +478,7 @@ int vdb_merge_topk_device(vdb_index *idx, const void *d_dists, const void *d_ids
     launch_finalize(ws->keys_c.as<uint64_t>(), cap, (uint32_t)nq, (uint32_t)k, (uint32_t)k, 0,
                     static_cast<uint64_t *>(d_out_idx), static_cast<float *>(d_out_dist),
                     static_cast<uint64_t *>(d_out_count), ws->stream);
-    VDB_HIP(hipStreamSynchronize(ws->stream));
+    VDB_SYNC(ws->stream);
     VDB_API_END
 }
 

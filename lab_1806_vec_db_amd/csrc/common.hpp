@@ -22,6 +22,15 @@ struct Error : std::runtime_error {
                                       ":" + std::to_string(__LINE__) + ")");                            \
     } while (0)
 
+// hipLaunchKernelGGL reports a rejected launch (bad grid, LDS over the limit ...) only through the sticky last-error
+// slot.  Every synchronisation point of the library goes through here, so a rejected launch surfaces as an error
+// of the call that issued it instead of as stale output buffers.
+#define VDB_SYNC(stream)                            \
+    do {                                            \
+        VDB_HIP(hipStreamSynchronize(stream));      \
+        VDB_HIP(hipGetLastError());                 \
+    } while (0)
+
 #define VDB_REQUIRE(cond, msg)                          \
     do {                                                \
         if (!(cond)) throw ::vdb::Error(1, (msg));      \

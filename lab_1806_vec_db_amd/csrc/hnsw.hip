@@ -876,7 +876,7 @@ void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, ui
     }
     unsigned char hostbuf[64];
     VDB_HIP(hipMemcpyAsync(hostbuf, ws.flags.p, 64, hipMemcpyDeviceToHost, s));
-    VDB_HIP(hipStreamSynchronize(s));
+    VDB_SYNC(s);
     uint32_t e;
     std::memcpy(&e, hostbuf, 4);
     unsigned long long st[2];

@@ -69,7 +69,7 @@ void Index::add_rows(const float *rows, uint64_t count, bool on_device) {
     }
     std::vector<float> sq(count);
     VDB_HIP(hipMemcpyAsync(sq.data(), d_sq.as<float>() + n, count * sizeof(float), hipMemcpyDeviceToHost, s));
-    VDB_HIP(hipStreamSynchronize(s));
+    VDB_SYNC(s);
     for (float v : sq) {
         if (v > xsq_max && std::isfinite(v)) xsq_max = v;
         if (v > 0.0f && v < xsq_min_pos) xsq_min_pos = v;
@@ -102,7 +102,7 @@ void Index::swap_remove(uint64_t i) {
         launch_tile_rows(d_rows.as<float>(), last, (uint32_t)dim, i / 16, i / 16 + 1, d_tiled.as<float>(), s);
         launch_tile_rows(d_rows.as<float>(), last, (uint32_t)dim, last / 16, last / 16 + 1, d_tiled.as<float>(), s);
     }
-    VDB_HIP(hipStreamSynchronize(s));
+    VDB_SYNC(s);
     {
         std::lock_guard<std::mutex> g(host_mu);
         if (host_valid) {
@@ -248,8 +248,9 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     // phase 3: shortlist = k' smallest appended pairs per query
     const uint32_t capp = topk_capacity(kprime);
     const uint32_t capk = topk_capacity(ksel);
-    const uint64_t nbatch = (nq + MFMA_B - 1) / MFMA_B;
-    const uint64_t nq_pad = nbatch * MFMA_B;
+    const uint64_t bq = mfma_batch((uint32_t)dim);  // queries per workgroup batch (32, or 16 for 1024 < dim <= 2048)
+    const uint64_t nbatch = (nq + bq - 1) / bq;
+    const uint64_t nq_pad = nbatch * bq;
     const uint64_t n_s = mfma_sample_rows(n);
     const uint64_t ld_s = (n_s + 63) & ~63ull;
     const uint32_t nl_s = topk_num_lists(n_s);
@@ -293,7 +294,7 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     launch_finalize(ws.keys_c.as<uint64_t>(), capk, (uint32_t)nq, ksel, (uint32_t)k, id_offset, d_idx, d_dist, d_cnt, s);
     std::vector<uint8_t> flags(nq);
     VDB_HIP(hipMemcpyAsync(flags.data(), ws.flags.p, nq, hipMemcpyDeviceToHost, s));
-    VDB_HIP(hipStreamSynchronize(s));
+    VDB_SYNC(s);
     // uncertified queries: gather them, redo them 8 per corpus pass with the exact scan, scatter the results
     std::vector<uint64_t> redo;
     for (uint64_t q = 0; q < nq; q++)
@@ -319,7 +320,7 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
         VDB_HIP(hipMemcpyAsync(d_dist + redo[j] * k, rd.as<float>() + j * k, k * sizeof(float), hipMemcpyDeviceToDevice, s));
         VDB_HIP(hipMemcpyAsync(d_cnt + redo[j], rc.as<uint64_t>() + j, sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
     }
-    VDB_HIP(hipStreamSynchronize(s));  // rq..rc are freed on return
+    VDB_SYNC(s);  // rq..rc are freed on return
 }
 
 }  // namespace vdb

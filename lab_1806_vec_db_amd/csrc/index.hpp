@@ -42,7 +42,7 @@ struct DevBuf {
         VDB_HIP(hipMalloc(&np, want));
         if (keep) {
             VDB_HIP(hipMemcpyAsync(np, p, keep, hipMemcpyDeviceToDevice, s));
-            VDB_HIP(hipStreamSynchronize(s));
+            VDB_SYNC(s);
         }
         if (p) (void)hipFree(p);
         p = np;

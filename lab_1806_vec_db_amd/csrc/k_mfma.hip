@@ -38,8 +38,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // the mirror and the Q images are zero-padded to a multiple of 64 columns, so every dim <= 1024 qualifies
 uint32_t mfma_dim_pad(uint32_t dim) { return (dim + 63) & ~63u; }
-size_t mfma_qfrag_floats(uint32_t dim) { return size_t(mfma_dim_pad(dim)) * MFMA_B; }
-bool mfma_supported(uint32_t dim) { return dim >= 1 && size_t(mfma_dim_pad(dim)) * MFMA_B * 4 <= 128 * 1024; }
+// queries per workgroup batch: the Q image (batch x dim_pad x 4 B) must fit 128 KB of LDS: 32 queries up to
+// dim 1024, 16 queries (one MFMA query half) up to dim 2048, beyond that the exact scan serves the index
+uint32_t mfma_batch(uint32_t dim) {
+    uint32_t p = mfma_dim_pad(dim);
+    return dim == 0 ? 0 : (p <= 1024 ? 32 : (p <= 2048 ? 16 : 0));
+}
+size_t mfma_qfrag_floats(uint32_t dim) { return size_t(mfma_dim_pad(dim)) * mfma_batch(dim); }
+bool mfma_supported(uint32_t dim) { return mfma_batch(dim) != 0; }
 constexpr int MFMA_RT = 2;              // 16-row tiles per wave item
 constexpr uint32_t MFMA_WGBUF = 3072;   // per-workgroup LDS hit buffer entries (MODE_FILTER): 36 KB beside the 120 KB Q image
 uint64_t mfma_row_pad() { return 64; }  // rows of padding the kernel may touch past n (xsq reads)
@@ -121,27 +127,30 @@ void launch_tile_rows(const float *X, uint64_t n, uint32_t dim, uint64_t tile0, 
 }
 
 // Q [nq][dim] -> per batch of 32 queries a B-operand image [kb][half][hi|lo][lane] (queries >= nq: zero)
-__global__ void k_mfma_pack_queries(const float *__restrict__ Q, uint32_t nq, uint32_t dim, uint4 *__restrict__ qfrag) {
+__global__ void k_mfma_pack_queries(const float *__restrict__ Q, uint32_t nq, uint32_t dim, uint32_t NH,
+                                    uint4 *__restrict__ qfrag) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // (kb, half, lane)
     uint32_t KB = ((dim + 63) & ~63u) / 32;
-    if (i >= KB * 128) return;
-    qfrag += uint64_t(blockIdx.y) * KB * 256;
-    uint32_t l = i & 63, h = (i >> 6) & 1, kb = i >> 7;
-    uint32_t q = blockIdx.y * MFMA_B + h * 16 + (l & 15);
+    if (i >= KB * NH * 64) return;
+    qfrag += uint64_t(blockIdx.y) * KB * NH * 128;
+    uint32_t l = i & 63, h = (i >> 6) % NH, kb = (i >> 6) / NH;
+    uint32_t q = blockIdx.y * 16 * NH + h * 16 + (l & 15);
     uint32_t c = kb * 32 + 8 * (l >> 4);
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     if (q < nq) load8_padded(Q + size_t(q) * dim, dim, c, a, b);
     uint4 hi, lo;
     split8(a, b, hi, lo);
-    qfrag[((kb * 2 + h) * 2 + 0) * 64 + l] = hi;
-    qfrag[((kb * 2 + h) * 2 + 1) * 64 + l] = lo;
+    qfrag[((kb * NH + h) * 2 + 0) * 64 + l] = hi;
+    qfrag[((kb * NH + h) * 2 + 1) * 64 + l] = lo;
 }
 
 void launch_mfma_pack_queries(const float *Q, uint32_t nq, uint32_t dim, float *qfrag, hipStream_t s) {
-    uint32_t total = (mfma_dim_pad(dim) / 32) * 128;
-    uint32_t nbatch = (nq + MFMA_B - 1) / MFMA_B;
+    const uint32_t bq = mfma_batch(dim), NH = bq / 16;
+    VDB_REQUIRE(bq != 0, "flat_mfma: unsupported dim");
+    uint32_t total = (mfma_dim_pad(dim) / 32) * NH * 64;
+    uint32_t nbatch = (nq + bq - 1) / bq;
     if (nbatch == 0) return;
-    hipLaunchKernelGGL(k_mfma_pack_queries, dim3((total + 255) / 256, nbatch), dim3(256), 0, s, Q, nq, dim,
+    hipLaunchKernelGGL(k_mfma_pack_queries, dim3((total + 255) / 256, nbatch), dim3(256), 0, s, Q, nq, dim, NH,
                        reinterpret_cast<uint4 *>(qfrag));
 }
 
@@ -177,13 +186,15 @@ struct MfmaArgs {
     uint32_t debug;
     uint32_t *sync;      // MODE_FILTER, share > 1: arrival counters [groups][passes], zeroed before the launch
     uint32_t *isync;     // MODE_FILTER, share > 1: per-item arrival counters [groups*8 waves][passes], zeroed likewise
+    uint32_t wgbuf;      // MODE_FILTER: entries of the per-workgroup LDS hit buffer (<= MFMA_WGBUF, set by the launcher)
     uint32_t share;      // MODE_FILTER: workgroups per XCD group that ride one HBM pass with different query batches
     int cosine;          // keys for DistanceAlgorithm::Cosine: -S/|x| (ranks like 1 - S/(|x||q|) for a fixed query)
 };
 
-template <int PD, int MODE>
+template <int PD, int MODE, int NH>
 __global__ __launch_bounds__(512, 1) void k_flat_mfma(MfmaArgs a) {
     constexpr int NT = 512, RT = MFMA_RT;
+    constexpr uint32_t BQ = 16 * NH;  // queries per workgroup batch
     constexpr uint32_t NW = NT / 64;
     const uint4 *__restrict__ XT = a.XT;
     const float *__restrict__ xsq = a.xsq;
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_mfma(MfmaArgs a) {
     const uint32_t n_visit = (a.n_items + a.item_step - 1) / a.item_step;  // items one pass visits
     extern __shared__ __attribute__((aligned(16))) uint4 qs[];  // [KB][2 halves][hi|lo][64], then the hit buffer
     const uint32_t KB = dim / 32;
-    const uint32_t qn = KB * 256;  // uint4 in one Q image
+    const uint32_t qn = KB * NH * 128;  // uint4 in one Q image
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // per-workgroup hit buffer (MODE_FILTER): pairs that pass the threshold are parked in LDS and handed to the
     // global per-query candidate lists once per batch, when the workgroup has finished streaming.  Measured
@@ -201,8 +212,8 @@ __global__ __launch_bounds__(512, 1) void k_flat_mfma(MfmaArgs a) {
     // atomics per query counter in the kernel's tail (0.667 ms); flushing per 8 hits is worse (0.712 ms).
     // Here each workgroup reserves its range with ONE atomic per query (256 per counter per pass).
     uint64_t *hit_key = reinterpret_cast<uint64_t *>(qs + qn);
-    uint32_t *hit_q = reinterpret_cast<uint32_t *>(hit_key + MFMA_WGBUF);
-    uint32_t *hit_n = hit_q + MFMA_WGBUF;  // [0] entries, [1..32] per-query counts, [33..64] per-query bases
+    uint32_t *hit_q = reinterpret_cast<uint32_t *>(hit_key + a.wgbuf);
+    uint32_t *hit_n = hit_q + a.wgbuf;  // [0] entries, [1..32] per-query counts, [33..64] per-query bases
 
     const uint32_t r = lane & 15, g = lane >> 4;
     // XCD-shared passes (MODE_FILTER, share = S > 1): measured with tools/stream_probe.hip, S workgroups on the SAME
@@ -263,11 +274,11 @@ __global__ __launch_bounds__(512, 1) void k_flat_mfma(MfmaArgs a) {
             }
         }
         __syncthreads();
-        float tau[2] = {0.f, 0.f};
-        if (MODE == MODE_FILTER) {
-            tau[0] = a.tau[b * MFMA_B + r];
-            tau[1] = a.tau[b * MFMA_B + 16 + r];
-            if (a.debug & 1) tau[0] = tau[1] = -INFINITY;  // timing experiment: no hits
+        float tau[NH];
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            tau[h] = MODE == MODE_FILTER ? a.tau[b * BQ + h * 16 + r] : 0.0f;
+            if (MODE == MODE_FILTER && (a.debug & 1)) tau[h] = -INFINITY;  // timing experiment: no hits
         }
 
         // The X stream is one continuous sequence of (item, k-block) pairs per wave; a cursor runs PD k-blocks
@@ -329,29 +340,28 @@ __global__ __launch_bounds__(512, 1) void k_flat_mfma(MfmaArgs a) {
             // round trip of the ring per item.)  constant address space + uniform address => s_load_dwordx8.
             typedef const __attribute__((address_space(4))) float *cfloat_p;
             cfloat_p xs_item = (cfloat_p)(xsq + uint64_t(__builtin_amdgcn_readfirstlane(item)) * a.item_step * (16 * RT));
-            f32x4 acc[RT][2];
+            f32x4 acc[RT][NH];
 #pragma unroll
-            for (int t = 0; t < RT; t++) {
-                acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
+            for (int t = 0; t < RT; t++)
+#pragma unroll
+                for (int h = 0; h < NH; h++) acc[t][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
             for (uint32_t k0 = 0; k0 < KB; k0 += R) {
 #pragma unroll
                 for (int p = 0; p < R; p++) {
                     fetch(ring[(p + R - 1) % R]);
                     const uint32_t kb = k0 + p;
-                    bf16x8 qh[2], ql[2];
+                    bf16x8 qh[NH], ql[NH];
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        qh[h] = __builtin_bit_cast(bf16x8, qs[((kb * 2 + h) * 2 + 0) * 64 + lane]);
-                        ql[h] = __builtin_bit_cast(bf16x8, qs[((kb * 2 + h) * 2 + 1) * 64 + lane]);
+                    for (int h = 0; h < NH; h++) {
+                        qh[h] = __builtin_bit_cast(bf16x8, qs[((kb * NH + h) * 2 + 0) * 64 + lane]);
+                        ql[h] = __builtin_bit_cast(bf16x8, qs[((kb * NH + h) * 2 + 1) * 64 + lane]);
                     }
 #pragma unroll
                     for (int t = 0; t < RT; t++) {
                         const bf16x8 xh = __builtin_bit_cast(bf16x8, ring[p][t][0]);
                         const bf16x8 xl = __builtin_bit_cast(bf16x8, ring[p][t][1]);
 #pragma unroll
-                        for (int h = 0; h < 2; h++) {
+                        for (int h = 0; h < NH; h++) {
                             acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, qh[h], acc[t][h], 0, 0, 0);
                             acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, ql[h], acc[t][h], 0, 0, 0);
                             acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, qh[h], acc[t][h], 0, 0, 0);
@@ -367,7 +377,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_mfma(MfmaArgs a) {
             for (int t = 0; t < RT; t++) {
                 const uint64_t rb = row0 + t * 16 + 4 * g;
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
+                for (int h = 0; h < NH; h++) {
                     float key[4];
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
@@ -386,18 +396,18 @@ __global__ __launch_bounds__(512, 1) void k_flat_mfma(MfmaArgs a) {
                         kv.z = rb + 2 < n ? key[2] : INFINITY;
                         kv.w = rb + 3 < n ? key[3] : INFINITY;
                         const uint64_t col = uint64_t(item) * (16 * RT) + t * 16 + 4 * g;  // dense position in the sample
-                        *reinterpret_cast<float4 *>(a.out + (uint64_t(b) * MFMA_B + h * 16 + r) * a.ld + col) = kv;
+                        *reinterpret_cast<float4 *>(a.out + (uint64_t(b) * BQ + h * 16 + r) * a.ld + col) = kv;
                     } else {
                         const uint32_t q = h * 16 + r;
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
                             if (key[e] <= tau[h] && rb + e < n) {  // rare: ~k' * sample step hits per query in total
                                 uint32_t pos = atomicAdd(hit_n, 1u);  // LDS atomic: waits on lgkmcnt only
-                                if (pos < MFMA_WGBUF) {
+                                if (pos < a.wgbuf) {
                                     hit_key[pos] = pair_key(key[e], uint32_t(rb + e));
                                     hit_q[pos] = q;
                                 } else {  // buffer full: mark the query as overflowed (-> exact fallback)
-                                    atomicAdd(&a.cnt[b * MFMA_B + q], a.cap + 1);
+                                    atomicAdd(&a.cnt[b * BQ + q], a.cap + 1);
                                 }
                             }
                         }
@@ -409,7 +419,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_mfma(MfmaArgs a) {
         __syncthreads();                   // every wave has left the item loop: qs and the hit buffer are quiescent
         if (MODE == MODE_FILTER) {
             uint32_t total = hit_n[0];
-            if (total > MFMA_WGBUF) total = MFMA_WGBUF;
+            if (total > a.wgbuf) total = a.wgbuf;
             constexpr uint32_t NJ = (MFMA_WGBUF + NT - 1) / NT;
             uint32_t rank[NJ];
 #pragma unroll
@@ -418,8 +428,8 @@ __global__ __launch_bounds__(512, 1) void k_flat_mfma(MfmaArgs a) {
                 rank[j] = i < total ? atomicAdd(&hit_n[1 + hit_q[i]], 1u) : 0u;  // rank inside (workgroup, query)
             }
             __syncthreads();
-            if (threadIdx.x < 32 && hit_n[1 + threadIdx.x] > 0)  // reserve this workgroup's range: one atomic per query
-                hit_n[33 + threadIdx.x] = atomicAdd(&a.cnt[b * MFMA_B + threadIdx.x], hit_n[1 + threadIdx.x]);
+            if (threadIdx.x < BQ && hit_n[1 + threadIdx.x] > 0)  // reserve this workgroup's range: one atomic per query
+                hit_n[33 + threadIdx.x] = atomicAdd(&a.cnt[b * BQ + threadIdx.x], hit_n[1 + threadIdx.x]);
             __syncthreads();
 #pragma unroll
             for (uint32_t j = 0; j < NJ; j++) {
@@ -427,7 +437,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_mfma(MfmaArgs a) {
                 if (i < total) {
                     uint32_t q = hit_q[i];
                     uint32_t slot = hit_n[33 + q] + rank[j];
-                    if (slot < a.cap) a.cand[(uint64_t(b) * MFMA_B + q) * a.cap + slot] = hit_key[i];
+                    if (slot < a.cap) a.cand[(uint64_t(b) * BQ + q) * a.cap + slot] = hit_key[i];
                 }
             }
             __syncthreads();
@@ -435,12 +445,16 @@ __global__ __launch_bounds__(512, 1) void k_flat_mfma(MfmaArgs a) {
     }
 }
 
-template <int PD, int MODE>
+template <int PD, int MODE, int NH>
 static void flat_mfma_launch(const MfmaArgs &a, int num_cu, hipStream_t s) {
-    size_t lds = size_t(a.dim) * MFMA_B * sizeof(float) + size_t(MFMA_WGBUF) * 12 + 80 * 4 + 16;
+    // LDS: Q image + hit buffer (12 B per entry) + counters; the hit buffer takes what the Q image leaves of 160 KB
+    const size_t q_bytes = size_t(a.dim) * 16 * NH * sizeof(float), fixed = 80 * 4 + 16;
+    VDB_REQUIRE(q_bytes + fixed + 64 * 12 <= 160 * 1024, "flat mfma: Q image does not fit LDS");
+    uint32_t wgbuf = (uint32_t)std::min<size_t>(MFMA_WGBUF, ((160 * 1024 - q_bytes - fixed) / 12) & ~size_t(63));
+    size_t lds = q_bytes + size_t(wgbuf) * 12 + fixed;
     static bool attr_done = false;
     if (!attr_done) {
-        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_mfma<PD, MODE>),
+        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_mfma<PD, MODE, NH>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
@@ -449,6 +463,7 @@ static void flat_mfma_launch(const MfmaArgs &a, int num_cu, hipStream_t s) {
     uint32_t grid = (uint32_t)num_cu;
     uint32_t need = (n_visit + NW - 1) / NW;
     MfmaArgs b = a;
+    b.wgbuf = wgbuf;
     if (MODE == MODE_FILTER && b.share > 1) {
         // sharing needs whole XCD groups: grid a multiple of 8*share, every group with work, >= share batches
         uint32_t unit = 8 * b.share;
@@ -461,22 +476,28 @@ static void flat_mfma_launch(const MfmaArgs &a, int num_cu, hipStream_t s) {
     if (b.share <= 1 && need < grid) grid = need;
     if (grid == 0 || b.nbatch == 0) return;
     dim3 g(grid, MODE == MODE_SAMPLE ? b.nbatch : 1);
-    hipLaunchKernelGGL((k_flat_mfma<PD, MODE>), g, dim3(512), lds, s, b);
+    hipLaunchKernelGGL((k_flat_mfma<PD, MODE, NH>), g, dim3(512), lds, s, b);
+    VDB_HIP(hipGetLastError());
 }
 
-template <int MODE>
-static void flat_mfma_dispatch(const MfmaArgs &a, int num_cu, hipStream_t s) {
+template <int MODE, int NH>
+static void flat_mfma_dispatch_nh(const MfmaArgs &a, int num_cu, hipStream_t s) {
     uint32_t KB = a.dim / 32;  // the ring size R = PD+1 must divide KB
     if (KB % 6 == 0 && (g_mfma_variant & 15) == 2)
-        flat_mfma_launch<2, MODE>(a, num_cu, s);
-    else if (KB % 6 == 0 && (g_mfma_variant & 15) == 1)
-        flat_mfma_launch<1, MODE>(a, num_cu, s);
+        flat_mfma_launch<2, MODE, NH>(a, num_cu, s);
     else if (KB % 6 == 0)
-        flat_mfma_launch<5, MODE>(a, num_cu, s);
+        flat_mfma_launch<5, MODE, NH>(a, num_cu, s);
     else if (KB % 4 == 0)
-        flat_mfma_launch<3, MODE>(a, num_cu, s);
+        flat_mfma_launch<3, MODE, NH>(a, num_cu, s);
     else
-        flat_mfma_launch<1, MODE>(a, num_cu, s);
+        flat_mfma_launch<1, MODE, NH>(a, num_cu, s);
+}
+template <int MODE>
+static void flat_mfma_dispatch(const MfmaArgs &a, int num_cu, hipStream_t s) {
+    if (a.dim <= 1024)
+        flat_mfma_dispatch_nh<MODE, 2>(a, num_cu, s);
+    else
+        flat_mfma_dispatch_nh<MODE, 1>(a, num_cu, s);
 }
 
 uint32_t mfma_num_items(uint64_t n) { return (uint32_t)((n + 16 * MFMA_RT - 1) / (16 * MFMA_RT)); }
@@ -493,7 +514,7 @@ uint64_t mfma_sample_rows(uint64_t n) {
 
 static MfmaArgs mfma_args(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t nbatch,
                           const float *xsq, int cosine) {
-    VDB_REQUIRE(mfma_supported(dim), "flat_mfma: dim (padded to a multiple of 64) must be <= 1024");
+    VDB_REQUIRE(mfma_supported(dim), "flat_mfma: dim (padded to a multiple of 64) must be <= 2048");
     VDB_REQUIRE(n < (1ull << 32), "flat_mfma: too many rows for one shard");
     MfmaArgs a{};
     a.XT = reinterpret_cast<const uint4 *>(XT);

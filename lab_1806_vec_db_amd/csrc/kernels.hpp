@@ -60,7 +60,7 @@ void launch_sort_pairs(const float *dist, uint64_t n, uint64_t *tmp_keys, uint64
                        hipStream_t s);
 
 // ---- k_mfma.hip ----------------------------------------------------------------------------
-constexpr uint32_t MFMA_B = 32;  // queries per corpus pass
+uint32_t mfma_batch(uint32_t dim);  // queries per workgroup batch: 32 (dim <= 1024), 16 (dim <= 2048), 0 = unsupported
 // Q [nq][dim] -> ceil(nq/32) fragment-ordered split-bf16 images of mfma_qfrag_floats(dim) floats each
 void launch_mfma_pack_queries(const float *Q, uint32_t nq, uint32_t dim, float *qfrag, hipStream_t s);
 // fragment-ordered mirror of rows: tiles [tile0, tile1) of 16 rows each; T holds ceil(n/16) tiles rounded up to 4

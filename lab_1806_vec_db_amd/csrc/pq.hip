@@ -457,7 +457,7 @@ static void pq_encode_all(Index &ix) {
                        ix.d_rows.as<float>(), ix.n, (uint32_t)ix.dim, pq.d_centroids.as<float>(),
                        pq.d_cent_cache.as<float>(), pq.d_gstart.as<uint64_t>(), (uint32_t)pq.m, (uint32_t)pq.kc,
                        (uint32_t)pq.n_bits, ix.dist == 1 ? 1 : 0, (uint32_t)pq.enc_dim, pq.d_codes.as<uint8_t>());
-    VDB_HIP(hipStreamSynchronize(ws->stream));
+    VDB_SYNC(ws->stream);
 }
 
 void pq_attach(Index &ix, uint64_t n_bits, uint64_t m, const float *centroids, const uint8_t *codes) {
@@ -779,7 +779,7 @@ void flat_knn_pq_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq,
         // queries whose candidate list overflowed (or whose workgroup buffer filled) are redone densely
         std::vector<uint32_t> hits(nq);
         VDB_HIP(hipMemcpyAsync(hits.data(), d_hits, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        VDB_HIP(hipStreamSynchronize(s));
+        VDB_SYNC(s);
         for (uint64_t q = 0; q < nq; q++)
             if (hits[q] > cap) dense_group(q, 1);
     }

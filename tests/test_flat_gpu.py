@@ -73,7 +73,7 @@ def test_flat_index_test_restated(mods, gist_base):
     _check(idx, d, oi, od)
 
 
-@pytest.mark.parametrize("dim", [4, 13, 32, 64, 96, 100, 960])
+@pytest.mark.parametrize("dim", [4, 13, 32, 64, 96, 100, 960, 1088, 1536, 2048, 2100])
 @pytest.mark.parametrize("dist", ["l2sqr", "cosine"])
 def test_dims_and_edges(mods, dim, dist):
     vdb, O = mods
@@ -160,6 +160,22 @@ def test_gistlike_mfma_parity(mods, n, dist, kind):
     np.testing.assert_array_equal(idx, idx2)
     np.testing.assert_array_equal(d, d2)
     print("fallbacks:", ix.flat_fallback_count())
+
+
+@pytest.mark.parametrize("dist,kind", [("l2sqr", 0), ("cosine", 1)])
+def test_dim1536_mfma_16_query_batches(mods, dist, kind):
+    """1024 < dim <= 2048: the Q image of 32 queries no longer fits LDS, batches are 16 queries (k_mfma.hip)."""
+    vdb, O = mods
+    rng = np.random.default_rng(1536)
+    base = rng.standard_normal((30000, 1536)).astype(np.float32)
+    qs = rng.standard_normal((37, 1536)).astype(np.float32)
+    ix = vdb.GpuIndex(1536, dist)
+    ix.batch_add(base)
+    idx, d, cnt = ix.flat_knn(qs, 10)  # auto mode: n >= 16384 -> MFMA path
+    oi, od, _ = O.flat_knn_batch(base, qs, 10, kind, nthreads=8)
+    for q in range(qs.shape[0]):
+        _check(idx[q], d[q], oi[q], od[q])
+    assert ix.flat_fallback_count() == 0
 
 
 def test_cosine_degenerate_norms_mfma(mods):
