@@ -141,6 +141,24 @@ int vdb_merge_topk_device(vdb_index *idx, const void *d_dists, const void *d_ids
                           uint64_t n_shards, uint64_t nq, uint64_t k, void *d_out_idx, void *d_out_dist,
                           void *d_out_count, void *stream);
 
+/* ---- row-sharded FlatIndex::knn_pq -------------------------------------------
+ * pq_resort (candidate_pair.rs:102-108) replays ResultSet::add in the GLOBAL (ADC distance, id) order, so the
+ * exchange carries, per shard and query, max(ef,k) pair keys twice: the ADC key row (ascending) and the exact-distance
+ * key of the same row at the same position.  A pair key is orderable(f32) << 32 | global row id (id_offset + local
+ * row, < 2^32); ~0 pads rows shorter than max(ef,k).  Layout [nq][max(ef,k)] u64 each. */
+int vdb_flat_knn_pq_shard(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef,
+                          uint64_t *out_adc_keys, uint64_t *out_exact_keys);
+int vdb_flat_knn_pq_shard_device(vdb_index *idx, const void *d_queries, uint64_t nq, uint64_t dim, uint64_t k,
+                                 uint64_t ef, void *d_out_adc_keys, void *d_out_exact_keys, void *stream);
+/* merge of the all-gathered rows ([n_shards][nq][efk], efk = max(ef,k)) to the global ADC top-efk, then the
+ * reference's re-sort (flat_index.rs:100-103): out [nq][k] ascending exact distances, global ids.  Host utility. */
+int vdb_pq_merge_resort(const uint64_t *adc_keys, const uint64_t *exact_keys, uint64_t n_shards, uint64_t nq,
+                        uint64_t efk, uint64_t k, uint64_t *out_idx, float *out_dist, uint64_t *out_count);
+/* same on the index's GPU; returns synchronised */
+int vdb_pq_merge_resort_device(vdb_index *idx, const void *d_adc_keys, const void *d_exact_keys, uint64_t n_shards,
+                               uint64_t nq, uint64_t efk, uint64_t k, void *d_out_idx, void *d_out_dist,
+                               void *d_out_count, void *stream);
+
 /* ---- measurement hooks -------------------------------------------------------------------
  * When enabled, the dominant kernels are bracketed by HIP events on their own stream and the
  * elapsed time is accumulated per kernel name ("flat_mfma", "flat_exact", "pq_adc", "hnsw"). */

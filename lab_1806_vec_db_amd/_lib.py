@@ -48,6 +48,10 @@ SIGNATURES = {
     "vdb_pq_info": [vp, u64p, u64p, u64p],
     "vdb_pq_export": [vp, f32p, u8p],
     "vdb_flat_knn_pq": [vp, f32p, u64, u64, u64, u64, u64p, f32p, u64p],
+    "vdb_flat_knn_pq_shard": [vp, f32p, u64, u64, u64, u64, u64p, u64p],
+    "vdb_flat_knn_pq_shard_device": [vp, vp, u64, u64, u64, u64, vp, vp, vp],
+    "vdb_pq_merge_resort": [u64p, u64p, u64, u64, u64, u64, u64p, f32p, u64p],
+    "vdb_pq_merge_resort_device": [vp, vp, vp, u64, u64, u64, u64, vp, vp, vp, vp],
     "vdb_hnsw_build": [vp, u64, u64, u64, u64, C.c_int],
     "vdb_hnsw_attach": [vp, u64, u64, u32p, u64p, u64p, u32p, u64p, C.c_int, u64, u64],
     "vdb_hnsw_clear": [vp],

@@ -329,6 +329,107 @@ int vdb_flat_knn_pq(vdb_index *idx, const float *queries, uint64_t nq, uint64_t 
     VDB_API_END
 }
 
+// ---- row-sharded knn_pq ------------------------------------------------------------------
+int vdb_flat_knn_pq_shard(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef,
+                          uint64_t *out_adc_keys, uint64_t *out_exact_keys) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    Index &ix = idx->ix;
+    check_query_args(ix, queries, nq, dim, out_adc_keys, out_exact_keys);
+    VDB_REQUIRE(ix.pq.present, "knn_pq needs a PQ table (vdb_pq_build / vdb_pq_attach)");
+    VDB_REQUIRE(nq <= 32768, "at most 32768 queries per shard call");
+    if (nq == 0) return VDB_OK;
+    const uint64_t efg = std::max(ef, k);
+    ix.use_device();
+    WsLease ws(ix);
+    hipStream_t s = ws->stream;
+    ws->q.reserve(nq * ix.dim * sizeof(float));
+    ws->out_idx.reserve(2 * nq * std::max<uint64_t>(efg, 1) * sizeof(uint64_t));
+    uint64_t *d_adc = ws->out_idx.as<uint64_t>(), *d_exact = d_adc + nq * efg;
+    VDB_HIP(hipMemcpyAsync(ws->q.p, queries, nq * ix.dim * sizeof(float), hipMemcpyHostToDevice, s));
+    flat_knn_pq_shard_device(ix, *ws, ws->q.as<float>(), nq, k, ef, d_adc, d_exact);
+    VDB_HIP(hipMemcpyAsync(out_adc_keys, d_adc, nq * efg * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    VDB_HIP(hipMemcpyAsync(out_exact_keys, d_exact, nq * efg * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    VDB_SYNC(s);
+    ix.prof_collect(*ws);
+    VDB_API_END
+}
+
+int vdb_flat_knn_pq_shard_device(vdb_index *idx, const void *d_queries, uint64_t nq, uint64_t dim, uint64_t k,
+                                 uint64_t ef, void *d_out_adc_keys, void *d_out_exact_keys, void *stream) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    Index &ix = idx->ix;
+    check_query_args(ix, d_queries, nq, dim, d_out_adc_keys, d_out_exact_keys);
+    VDB_REQUIRE(ix.pq.present, "knn_pq needs a PQ table (vdb_pq_build / vdb_pq_attach)");
+    VDB_REQUIRE(nq <= 32768, "at most 32768 queries per shard call");
+    if (nq == 0) return VDB_OK;
+    ix.use_device();
+    WsLease ws(ix);
+    VDB_SYNC(static_cast<hipStream_t>(stream));
+    flat_knn_pq_shard_device(ix, *ws, static_cast<const float *>(d_queries), nq, k, ef,
+                             static_cast<uint64_t *>(d_out_adc_keys), static_cast<uint64_t *>(d_out_exact_keys));
+    VDB_SYNC(ws->stream);
+    ix.prof_collect(*ws);
+    VDB_API_END
+}
+
+// host merge (no GPU needed): S rows per query sorted by ADC key -> global ADC top-efk -> ResultSet::add replay over
+// the exact keys in that order (candidate_pair.rs:61-74,102-108)
+int vdb_pq_merge_resort(const uint64_t *adc_keys, const uint64_t *exact_keys, uint64_t n_shards, uint64_t nq,
+                        uint64_t efk, uint64_t k, uint64_t *out_idx, float *out_dist, uint64_t *out_count) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(nq == 0 || (adc_keys && exact_keys && out_idx && out_dist), "null argument");
+    VDB_REQUIRE(efk >= k, "pq merge: efk = max(ef, k) must be >= k");
+    std::vector<std::pair<uint64_t, uint64_t>> all;
+    std::vector<uint64_t> set;  // the ResultSet, ascending pair keys
+    for (uint64_t q = 0; q < nq; q++) {
+        all.clear();
+        for (uint64_t s = 0; s < n_shards; s++)
+            for (uint64_t j = 0; j < efk; j++) {
+                uint64_t a = adc_keys[(s * nq + q) * efk + j];
+                if (a != PAIR_NONE) all.push_back({a, exact_keys[(s * nq + q) * efk + j]});
+            }
+        std::sort(all.begin(), all.end());
+        if (all.size() > efk) all.resize(efk);
+        set.clear();
+        for (auto &pr : all) {
+            uint64_t e = pr.second;
+            if (k == 0) break;
+            if (set.size() >= k) {
+                if (uint32_t(e >> 32) >= uint32_t(set.back() >> 32)) continue;  // not strictly closer than the worst
+                set.pop_back();
+            }
+            set.insert(std::lower_bound(set.begin(), set.end(), e), e);
+        }
+        for (uint64_t j = 0; j < k; j++) {
+            bool ok = j < set.size();
+            out_idx[q * k + j] = ok ? uint64_t(uint32_t(set[j])) : 0;
+            out_dist[q * k + j] = ok ? f32_from_orderable(uint32_t(set[j] >> 32)) : 0.0f;
+        }
+        if (out_count) out_count[q] = set.size();
+    }
+    VDB_API_END
+}
+
+int vdb_pq_merge_resort_device(vdb_index *idx, const void *d_adc_keys, const void *d_exact_keys, uint64_t n_shards,
+                               uint64_t nq, uint64_t efk, uint64_t k, void *d_out_idx, void *d_out_dist,
+                               void *d_out_count, void *stream) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx && d_adc_keys && d_exact_keys && d_out_idx && d_out_dist && d_out_count, "null argument");
+    VDB_REQUIRE(nq <= 65535 && n_shards >= 1 && n_shards <= 1024, "too many queries or shards for one call");
+    Index &ix = idx->ix;
+    ix.use_device();
+    WsLease ws(ix);
+    VDB_SYNC(static_cast<hipStream_t>(stream));
+    pq_merge_resort_device(ix, *ws, static_cast<const uint64_t *>(d_adc_keys),
+                           static_cast<const uint64_t *>(d_exact_keys), n_shards, nq, efk, k,
+                           static_cast<uint64_t *>(d_out_idx), static_cast<float *>(d_out_dist),
+                           static_cast<uint64_t *>(d_out_count));
+    VDB_SYNC(ws->stream);
+    VDB_API_END
+}
+
 // ---- HNSW -----------------------------------------------------------------------------------------
 int vdb_hnsw_build(vdb_index *idx, uint64_t M, uint64_t ef_construction, uint64_t seed, uint64_t batch,
                    int nthreads) {

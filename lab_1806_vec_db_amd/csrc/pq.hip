@@ -662,29 +662,18 @@ void pq_resort_launch(const uint64_t *exact_keys, uint32_t ncand, uint32_t ldc, 
     }
 }
 
-void flat_knn_pq_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef,
-                        uint64_t *d_idx, float *d_dist, uint64_t *d_cnt) {
+// ADC scan of the whole code table (pq_table.rs:239-301 through flat_index.rs:96-100): per query the efk smallest
+// (ADC distance, row) pairs, sorted by the CandidatePair order, land in ws.keys_a [nq][topk_capacity(efk)];
+// ws.qsq holds the query norms afterwards.
+static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint32_t efk) {
     hipStream_t s = ws.stream;
     PQState &pq = ix.pq;
-    if (nq == 0) return;
-    if (k == 0 || ix.n == 0) {
-        VDB_HIP(hipMemsetAsync(d_cnt, 0, nq * sizeof(uint64_t), s));
-        return;
-    }
     const uint64_t n = ix.n;
-    const uint64_t efk64 = std::min<uint64_t>(std::max(ef, k), n);  // ResultSet::new(ef.max(k)) flat_index.rs:96
-    const uint64_t ksel64 = std::min<uint64_t>(k, n);
-    VDB_REQUIRE(efk64 <= 1024, "knn_pq: min(max(ef, k), len) must be <= 1024 in this build");
-    const uint32_t efk = (uint32_t)efk64, ksel = (uint32_t)ksel64;
-    if (k > ksel) {
-        VDB_HIP(hipMemsetAsync(d_idx, 0, nq * k * sizeof(uint64_t), s));
-        VDB_HIP(hipMemsetAsync(d_dist, 0, nq * k * sizeof(float), s));
-    }
     ws.qsq.reserve(nq * sizeof(float));
     launch_row_sqnorm(d_q, nq, (uint32_t)ix.dim, ws.qsq.as<float>(), s);
     pq_make_luts(ix, ws, d_q, nq);
 
-    const uint32_t cape = topk_capacity(efk), capk = topk_capacity(ksel);
+    const uint32_t cape = topk_capacity(efk);
     const uint32_t lsz = (uint32_t)(pq.m * pq.kc);
     // queries per pass: as many lookup tables as fit beside each other in LDS (<= 4)
     size_t lbytes = size_t(lsz) * sizeof(float);
@@ -693,7 +682,6 @@ void flat_knn_pq_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq,
     const uint32_t nt = lbytes * BQ + cbytes <= 120 * 1024 ? 1024 : 256;  // rows per row block (= workgroup size)
     ws.keys_a.reserve(nq * cape * sizeof(uint64_t));
     ws.keys_b.reserve(nq * cape * sizeof(uint64_t));
-    ws.keys_c.reserve(nq * capk * sizeof(uint64_t));
 
     AdcArgs base{};
     base.codes = pq.d_codes.as<uint8_t>();
@@ -783,14 +771,143 @@ void flat_knn_pq_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq,
         for (uint64_t q = 0; q < nq; q++)
             if (hits[q] > cap) dense_group(q, 1);
     }
-    // exact distances of the ADC shortlist in ADC order, then the reference's re-sort
+}
+
+// exact distances of the ADC shortlist, in ADC order (the operand order of pq_resort, candidate_pair.rs:102-108):
+// ws.keys_a -> ws.keys_b
+static void pq_exact_of_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint32_t efk) {
+    hipStream_t s = ws.stream;
+    const uint32_t cape = topk_capacity(efk);
     VDB_HIP(hipMemsetAsync(ws.keys_b.p, 0xff, nq * cape * sizeof(uint64_t), s));
     launch_rerank(ix.d_rows.as<float>(), (uint32_t)ix.dim, d_q, (uint32_t)nq, ix.dist == 0 ? MET_L2_DIRECT : MET_COSINE,
                   ix.d_sq.as<float>(), ws.qsq.as<float>(), ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), efk,
                   cape, s);
+}
+
+void flat_knn_pq_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef,
+                        uint64_t *d_idx, float *d_dist, uint64_t *d_cnt) {
+    hipStream_t s = ws.stream;
+    if (nq == 0) return;
+    if (k == 0 || ix.n == 0) {
+        VDB_HIP(hipMemsetAsync(d_cnt, 0, nq * sizeof(uint64_t), s));
+        return;
+    }
+    const uint64_t n = ix.n;
+    const uint64_t efk64 = std::min<uint64_t>(std::max(ef, k), n);  // ResultSet::new(ef.max(k)) flat_index.rs:96
+    const uint64_t ksel64 = std::min<uint64_t>(k, n);
+    VDB_REQUIRE(efk64 <= 1024, "knn_pq: min(max(ef, k), len) must be <= 1024 in this build");
+    const uint32_t efk = (uint32_t)efk64, ksel = (uint32_t)ksel64;
+    if (k > ksel) {
+        VDB_HIP(hipMemsetAsync(d_idx, 0, nq * k * sizeof(uint64_t), s));
+        VDB_HIP(hipMemsetAsync(d_dist, 0, nq * k * sizeof(float), s));
+    }
+    const uint32_t cape = topk_capacity(efk), capk = topk_capacity(ksel);
+    pq_adc_shortlist(ix, ws, d_q, nq, efk);
+    pq_exact_of_shortlist(ix, ws, d_q, nq, efk);
+    ws.keys_c.reserve(nq * capk * sizeof(uint64_t));
     pq_resort_launch(ws.keys_b.as<uint64_t>(), efk, cape, (uint32_t)nq, ksel, ws.keys_c.as<uint64_t>(), s);
     launch_finalize(ws.keys_c.as<uint64_t>(), capk, (uint32_t)nq, ksel, (uint32_t)k, ix.id_offset, d_idx, d_dist,
                     d_cnt, s);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Row-sharded PQ-Flat.  pq_resort replays the candidates in GLOBAL (ADC, id) order, so a shard cannot
+// finish the re-sort alone.  Each shard exports its own ADC top-max(ef,k) as two key rows per query, both carrying
+// the GLOBAL row id in the low word: the ADC key (sorted ascending) and, at the same position, the exact-distance
+// key.  After one all-gather every rank merges the S sorted rows by ADC key, keeps the first max(ef,k), and replays
+// ResultSet::add over the exact keys in that order -- the same operand sequence the unsharded scan produces,
+// because the global ADC top-ef is contained in the union of the per-shard ADC top-ef lists.
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_pq_export_keys(const uint64_t *__restrict__ adc, const uint64_t *__restrict__ exact, uint32_t ld,
+                                 uint32_t efk_local, uint32_t efk_out, uint64_t id_offset,
+                                 uint64_t *__restrict__ out_adc, uint64_t *__restrict__ out_exact) {
+    const uint32_t q = blockIdx.x;
+    for (uint32_t j = threadIdx.x; j < efk_out; j += blockDim.x) {
+        uint64_t a = PAIR_NONE, e = PAIR_NONE;
+        if (j < efk_local) {
+            a = adc[uint64_t(q) * ld + j];
+            e = exact[uint64_t(q) * ld + j];
+            if (a != PAIR_NONE) {
+                a += id_offset;  // local row < 2^32 - id_offset (checked by the launcher): no carry into the distance
+                e += id_offset;
+            } else {
+                e = PAIR_NONE;
+            }
+        }
+        out_adc[uint64_t(q) * efk_out + j] = a;
+        out_exact[uint64_t(q) * efk_out + j] = e;
+    }
+}
+
+void flat_knn_pq_shard_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef,
+                              uint64_t *d_adc_keys, uint64_t *d_exact_keys) {
+    hipStream_t s = ws.stream;
+    if (nq == 0) return;
+    const uint64_t efg = std::max(ef, k);
+    VDB_REQUIRE(efg >= 1 && efg <= 1024, "knn_pq shard: max(ef, k) must be in 1..1024 in this build");
+    VDB_REQUIRE(ix.id_offset + ix.n <= (1ull << 32), "knn_pq shard: global row ids must fit 32 bits");
+    if (ix.n == 0) {
+        VDB_HIP(hipMemsetAsync(d_adc_keys, 0xff, nq * efg * sizeof(uint64_t), s));
+        VDB_HIP(hipMemsetAsync(d_exact_keys, 0xff, nq * efg * sizeof(uint64_t), s));
+        return;
+    }
+    const uint32_t efk = (uint32_t)std::min<uint64_t>(efg, ix.n);
+    pq_adc_shortlist(ix, ws, d_q, nq, efk);
+    pq_exact_of_shortlist(ix, ws, d_q, nq, efk);
+    hipLaunchKernelGGL(k_pq_export_keys, dim3((unsigned)nq), dim3(256), 0, s, ws.keys_a.as<uint64_t>(),
+                       ws.keys_b.as<uint64_t>(), topk_capacity(efk), efk, (uint32_t)efg, ix.id_offset, d_adc_keys,
+                       d_exact_keys);
+}
+
+// merge of S per-shard rows: an entry's position in the merged order is the number of entries with a smaller ADC key
+// (keys are unique: global ids), found by one binary search per shard row.
+__global__ __launch_bounds__(256) void k_pq_shard_merge(const uint64_t *__restrict__ adc,
+                                                        const uint64_t *__restrict__ exact, uint32_t n_shards,
+                                                        uint32_t nq, uint32_t efg, uint64_t *__restrict__ merged) {
+    const uint32_t q = blockIdx.x;
+    for (uint32_t j = threadIdx.x; j < efg; j += blockDim.x) merged[uint64_t(q) * efg + j] = PAIR_NONE;
+    __syncthreads();
+    const uint32_t total = n_shards * efg;
+    for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
+        const uint32_t sh = e / efg, j = e - sh * efg;
+        const uint64_t key = adc[(uint64_t(sh) * nq + q) * efg + j];
+        if (key == PAIR_NONE) continue;
+        uint32_t rank = j;  // entries of the own (sorted) row before this one
+        for (uint32_t t = 0; t < n_shards && rank < efg; t++) {
+            if (t == sh) continue;
+            const uint64_t *row = adc + (uint64_t(t) * nq + q) * efg;
+            uint32_t lo = 0, hi = efg;
+            while (lo < hi) {  // first position with row[pos] >= key (PAIR_NONE pads the tail)
+                uint32_t mid = (lo + hi) >> 1;
+                if (row[mid] < key) lo = mid + 1;
+                else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < efg) merged[uint64_t(q) * efg + rank] = exact[(uint64_t(sh) * nq + q) * efg + j];
+    }
+}
+
+void pq_merge_resort_device(Index &ix, Workspace &ws, const uint64_t *d_adc, const uint64_t *d_exact,
+                            uint64_t n_shards, uint64_t nq, uint64_t efg, uint64_t k, uint64_t *d_idx, float *d_dist,
+                            uint64_t *d_cnt) {
+    hipStream_t s = ws.stream;
+    if (nq == 0) return;
+    if (k == 0) {
+        VDB_HIP(hipMemsetAsync(d_cnt, 0, nq * sizeof(uint64_t), s));
+        return;
+    }
+    VDB_REQUIRE(efg >= k && efg <= 1024, "pq merge: need k <= max(ef, k) <= 1024");
+    const uint32_t capk = topk_capacity((uint32_t)k);
+    ws.keys_b.reserve(nq * efg * sizeof(uint64_t));
+    ws.keys_c.reserve(nq * capk * sizeof(uint64_t));
+    hipLaunchKernelGGL(k_pq_shard_merge, dim3((unsigned)nq), dim3(256), 0, s, d_adc, d_exact, (uint32_t)n_shards,
+                       (uint32_t)nq, (uint32_t)efg, ws.keys_b.as<uint64_t>());
+    pq_resort_launch(ws.keys_b.as<uint64_t>(), (uint32_t)efg, (uint32_t)efg, (uint32_t)nq, (uint32_t)k,
+                     ws.keys_c.as<uint64_t>(), s);
+    VDB_HIP(hipMemsetAsync(d_idx, 0, nq * k * sizeof(uint64_t), s));
+    VDB_HIP(hipMemsetAsync(d_dist, 0, nq * k * sizeof(float), s));
+    launch_finalize(ws.keys_c.as<uint64_t>(), capk, (uint32_t)nq, (uint32_t)k, (uint32_t)k, 0, d_idx, d_dist, d_cnt, s);
 }
 
 }  // namespace vdb

@@ -11,6 +11,13 @@ void pq_clear(Index &ix);
 void flat_knn_pq_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef,
                         uint64_t *d_idx, float *d_dist, uint64_t *d_cnt);
 
+// row-sharded knn_pq: per-shard export of the ADC shortlist, and the merge + pq_resort replay
+void flat_knn_pq_shard_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef,
+                              uint64_t *d_adc_keys, uint64_t *d_exact_keys);
+void pq_merge_resort_device(Index &ix, Workspace &ws, const uint64_t *d_adc, const uint64_t *d_exact,
+                            uint64_t n_shards, uint64_t nq, uint64_t efg, uint64_t k, uint64_t *d_idx, float *d_dist,
+                            uint64_t *d_cnt);
+
 // ---- HNSW (index_algorithm/hnsw_index.rs) ----
 void hnsw_build(Index &ix, uint64_t M, uint64_t ef_construction, uint64_t seed, uint64_t batch, int nthreads);
 void hnsw_attach(Index &ix, uint64_t M, uint64_t ef_construction, const uint32_t *level0, const uint64_t *len0,

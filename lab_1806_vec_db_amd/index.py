@@ -164,6 +164,28 @@ class GpuIndex:
         L.check(self._lib.vdb_merge_topk_device(self._h, L.vp(d_dists), L.vp(d_ids), L.vp(d_counts), n_shards, nq, k,
                                                 L.vp(out_idx), L.vp(out_dist), L.vp(out_cnt), L.vp(stream)))
 
+    # -- row-sharded knn_pq: local ADC shortlist as pair-key rows, merged after the all-gather ------
+    def knn_pq_shard(self, queries, k: int, ef: int):
+        """This shard's ADC top-max(ef,k): (adc_keys, exact_keys), each [nq, max(ef,k)] uint64 with GLOBAL ids."""
+        q = _f32(queries)
+        q = q.reshape(1, -1) if q.ndim == 1 else q
+        efk = max(int(ef), int(k))
+        adc = np.full((q.shape[0], efk), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+        ex = np.full((q.shape[0], efk), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+        L.check(self._lib.vdb_flat_knn_pq_shard(self._h, _ptr(q, L.f32p), q.shape[0], q.shape[1], int(k), int(ef),
+                                                _ptr(adc, L.u64p), _ptr(ex, L.u64p)))
+        return adc, ex
+
+    def knn_pq_shard_device(self, q_ptr: int, nq: int, k: int, ef: int, out_adc_ptr: int, out_exact_ptr: int,
+                            stream: int = 0):
+        L.check(self._lib.vdb_flat_knn_pq_shard_device(self._h, L.vp(q_ptr), int(nq), self.dim, int(k), int(ef),
+                                                       L.vp(out_adc_ptr), L.vp(out_exact_ptr), L.vp(stream)))
+
+    def pq_merge_resort_device(self, d_adc: int, d_exact: int, n_shards: int, nq: int, efk: int, k: int,
+                               out_idx: int, out_dist: int, out_cnt: int, stream: int = 0):
+        L.check(self._lib.vdb_pq_merge_resort_device(self._h, L.vp(d_adc), L.vp(d_exact), n_shards, nq, efk, k,
+                                                     L.vp(out_idx), L.vp(out_dist), L.vp(out_cnt), L.vp(stream)))
+
     def set_flat_mode(self, mode: int):
         L.check(self._lib.vdb_flat_set_mode(self._h, int(mode)))
 
@@ -272,4 +294,17 @@ def merge_topk(dists: np.ndarray, ids: np.ndarray, counts: np.ndarray, k: int):
     oc = np.zeros(nq, dtype=np.uint64)
     L.check(L.load().vdb_merge_topk(_ptr(d, L.f32p), _ptr(i, L.u64p), _ptr(c, L.u64p), S, nq, k, _ptr(oi, L.u64p),
                                     _ptr(od, L.f32p), _ptr(oc, L.u64p)))
+    return oi, od, oc
+
+
+def pq_merge_resort(adc_keys: np.ndarray, exact_keys: np.ndarray, k: int):
+    """Merge per-shard ADC shortlists [S][nq][efk] (pair keys, see vdbhip.h) and replay pq_resort."""
+    a = np.ascontiguousarray(adc_keys, dtype=np.uint64)
+    e = np.ascontiguousarray(exact_keys, dtype=np.uint64)
+    S, nq, efk = a.shape
+    oi = np.zeros((nq, k), dtype=np.uint64)
+    od = np.zeros((nq, k), dtype=np.float32)
+    oc = np.zeros(nq, dtype=np.uint64)
+    L.check(L.load().vdb_pq_merge_resort(_ptr(a, L.u64p), _ptr(e, L.u64p), S, nq, efk, k, _ptr(oi, L.u64p),
+                                         _ptr(od, L.f32p), _ptr(oc, L.u64p)))
     return oi, od, oc

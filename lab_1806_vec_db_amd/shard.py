@@ -57,3 +57,40 @@ def allgather_merge(local_idx, local_dist, local_cnt, k: int, group=None, gpu_in
 
     oi, od, oc = merge_topk(g_dist.numpy(), g_idx.numpy().astype(np.uint64), g_cnt.numpy().astype(np.uint64), k)
     return (torch.from_numpy(oi.astype(np.int64)), torch.from_numpy(od), torch.from_numpy(oc.astype(np.int64)))
+
+
+def allgather_merge_pq(adc_keys, exact_keys, k: int, group=None, gpu_index=None):
+    """Row-sharded FlatIndex::knn_pq (flat_index.rs:84-104): adc_keys / exact_keys are this rank's
+    [nq, max(ef,k)] pair-key rows (GpuIndex.knn_pq_shard[_device]; torch int64 views of the u64 keys).
+
+    pq_resort replays ResultSet::add in the GLOBAL (ADC, id) order (candidate_pair.rs:102-108), so the exact
+    re-sort cannot finish per shard: ONE all-gather moves both key rows ([nq, efk] x 2 x 8 B per rank), then every
+    rank merges to the global ADC top-efk and replays the re-sort.  Returns (idx, dist, cnt) like allgather_merge.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    nq, efk = adc_keys.shape
+    mine = torch.stack((adc_keys.contiguous(), exact_keys.contiguous()))  # [2, nq, efk] int64
+    if world > 1:
+        gathered = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1), group=group)
+    else:
+        gathered = mine.unsqueeze(0)
+    g_adc = gathered[:, 0].contiguous()
+    g_ex = gathered[:, 1].contiguous()
+    if adc_keys.is_cuda:
+        if gpu_index is None:
+            raise ValueError("allgather_merge_pq on CUDA tensors needs the rank's GpuIndex")
+        o_idx = torch.empty((nq, k), dtype=torch.int64, device=adc_keys.device)
+        o_dist = torch.empty((nq, k), dtype=torch.float32, device=adc_keys.device)
+        o_cnt = torch.empty((nq,), dtype=torch.int64, device=adc_keys.device)
+        torch.cuda.current_stream().synchronize()
+        gpu_index.pq_merge_resort_device(g_adc.data_ptr(), g_ex.data_ptr(), world, nq, efk, k, o_idx.data_ptr(),
+                                         o_dist.data_ptr(), o_cnt.data_ptr())
+        return o_idx, o_dist, o_cnt
+    from .index import pq_merge_resort
+
+    oi, od, oc = pq_merge_resort(g_adc.numpy().view(np.uint64), g_ex.numpy().view(np.uint64), k)
+    return (torch.from_numpy(oi.astype(np.int64)), torch.from_numpy(od), torch.from_numpy(oc.astype(np.int64)))

@@ -82,6 +82,8 @@ def lib():
     L.orc_pq_lookup.argtypes = [C.c_void_p, _f32p, _f32p]
     L.orc_pq_adc.restype = C.c_float
     L.orc_pq_adc.argtypes = [C.c_void_p, _u8p, _f32p, C.c_float]
+    L.orc_pq_adc_all.restype = None
+    L.orc_pq_adc_all.argtypes = [C.c_void_p, sz, _f32p, _f32p]
     L.orc_flat_knn_pq.restype = sz
     L.orc_flat_knn_pq.argtypes = [_f32p, sz, sz, C.c_int, C.c_void_p, _f32p, sz, sz, _u64p, _f32p]
     L.orc_kmeans.restype = None
@@ -246,6 +248,13 @@ class PQ:
         code = np.ascontiguousarray(code, dtype=np.uint8)
         return float(lib().orc_pq_adc(self.h, _p(code, _u8p), _p(lut, _f32p), qc))
 
+    def adc_all(self, q, n):
+        """ADC distance of each of the n encoded rows (pq_table.rs:239-301), in row order."""
+        q = _f32(q)
+        out = np.zeros(n, dtype=np.float32)
+        lib().orc_pq_adc_all(self.h, n, _p(q, _f32p), _p(out, _f32p))
+        return out
+
     def __del__(self):
         try:
             lib().orc_pq_free(self.h)
@@ -261,6 +270,16 @@ def flat_knn_pq(base, pq: PQ, query, k, ef, kind=L2SQR):
     c = lib().orc_flat_knn_pq(_p(base, _f32p), n, dim, kind, pq.h, _p(query, _f32p), k, ef, _p(idx, _u64p),
                               _p(d, _f32p))
     return idx[:c].copy(), d[:c].copy()
+
+
+def pair_keys(d, ids):
+    """CandidatePair total order (candidate_pair.rs:36-41; ordered-float: NaN greatest, -0 == +0) as one u64 per
+    pair: order-preserving u32 image of the f32 distance in the high word, the id in the low word."""
+    d = (np.asarray(d, dtype=np.float32) + np.float32(0.0)).astype(np.float32)
+    u = d.view(np.uint32).copy()
+    u[np.isnan(d)] = 0x7FC00000
+    o = np.where(u & 0x80000000, ~u, u | np.uint32(0x80000000)).astype(np.uint64)
+    return (o << np.uint64(32)) | np.asarray(ids, dtype=np.uint64)
 
 
 def kmeans(rows, c0, c1, k, max_iter=20, tol=1e-6, kind=L2SQR, seed=42):

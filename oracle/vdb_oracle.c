@@ -529,6 +529,14 @@ static float flat_exact(void *c, uint64_t idx) {
     return orc_dist(f->dist, f->query, f->base + idx * f->dim, f->dim);
 }
 
+/* ADC distance of every encoded row (the operand stream of flat_index.rs:97-100), for shard-merge tests */
+void orc_pq_adc_all(const orc_pq *pq, size_t n, const float *query, float *out) {
+    float *lut = (float *)malloc(pq->m * pq->k * sizeof(float));
+    float qc = orc_pq_lookup(pq, query, lut);
+    for (size_t i = 0; i < n; i++) out[i] = orc_pq_adc(pq, pq->codes + i * pq->enc_dim, lut, qc);
+    free(lut);
+}
+
 /* flat_index.rs:84-104 */
 size_t orc_flat_knn_pq(const float *base, size_t n, size_t dim, int dist, const orc_pq *pq,
                        const float *query, size_t k, size_t ef, uint64_t *out_idx, float *out_dist) {

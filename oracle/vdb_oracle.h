@@ -79,6 +79,7 @@ float orc_pq_lookup(const orc_pq *pq, const float *query, float *lut);
 /* ADC :239-301 */
 float orc_pq_adc(const orc_pq *pq, const uint8_t *code, const float *lut, float q_cache);
 /* FlatIndex::knn_pq flat_index.rs:84-104 */
+void orc_pq_adc_all(const orc_pq *pq, size_t n, const float *query, float *out);
 size_t orc_flat_knn_pq(const float *base, size_t n, size_t dim, int dist, const orc_pq *pq,
                        const float *query, size_t k, size_t ef, uint64_t *out_idx, float *out_dist);
 /* k-means (k_means.rs:61-162) with an explicit splitmix64 stream -- RNG unpinned.

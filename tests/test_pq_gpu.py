@@ -121,6 +121,60 @@ def test_fused_threshold_path(mods, dist, kind):
             assert np.array_equal(d[q], od), (k, ef, q)
 
 
+@pytest.mark.parametrize("dist,kind", [("l2sqr", 0), ("cosine", 1)])
+@pytest.mark.parametrize("n,shards", [(70000 * 3, 3), (5000, 2), (37, 4)])
+def test_row_sharded_knn_pq(mods, dist, kind, n, shards):
+    """PQ codes shard by rows, centroids replicated; the per-shard ADC top-ef rows are merged in (adc, id)
+    order and only then re-sorted (candidate_pair.rs:102-108).  Host merge and GPU merge must both equal the
+    unsharded search."""
+    import torch
+    vdb, O = mods
+    from lab_1806_vec_db_amd.index import pq_merge_resort
+    from lab_1806_vec_db_amd.shard import shard_bounds
+    dim = 48
+    base = gist_like(n, dim=dim, seed=21)
+    base[n - 3:] = base[:3]  # equal codes on different shards: ADC ties across the shard boundary
+    qs = gist_like(9, dim=dim, seed=22)
+    whole = vdb.GpuIndex(dim, dist)
+    whole.batch_add(base)
+    whole.pq_build(n_bits=4, m=16, train_n=min(n, 2000), max_iter=4, seed=5)
+    pq = whole.pq_export()
+    parts = []
+    for r in range(shards):
+        r0, r1 = shard_bounds(n, shards, r)
+        ix = vdb.GpuIndex(dim, dist)
+        ix.set_id_offset(r0)
+        ix.batch_add(base[r0:r1])
+        ix.pq_attach(4, 16, pq["centroids"], None)  # centroids replicated, codes encoded per shard
+        parts.append(ix)
+    opq = O.PQ.from_centroids(dim, 16, 4, kind, pq["centroids"])
+    opq.encode_all(base)
+    for k, ef in ((10, 100), (10, 10), (3, 1000), (20, 5)):
+        rows = [ix.knn_pq_shard(qs, k, ef) for ix in parts]
+        adc = np.stack([r[0] for r in rows])
+        ex = np.stack([r[1] for r in rows])
+        hi, hd, hc = pq_merge_resort(adc, ex, k)
+        d_adc = torch.from_numpy(adc.view(np.int64)).cuda()
+        d_ex = torch.from_numpy(ex.view(np.int64)).cuda()
+        nq, efk = qs.shape[0], max(k, ef)
+        o_idx = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        o_dist = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        o_cnt = torch.empty((nq,), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        parts[0].pq_merge_resort_device(d_adc.data_ptr(), d_ex.data_ptr(), shards, nq, efk, k, o_idx.data_ptr(),
+                                        o_dist.data_ptr(), o_cnt.data_ptr())
+        gi, gd, gc = o_idx.cpu().numpy(), o_dist.cpu().numpy(), o_cnt.cpu().numpy()
+        wi, wd, wc = whole.knn_pq(qs, k, ef)
+        for q in range(nq):
+            oi, od = O.flat_knn_pq(base, opq, qs[q], k, ef, kind)
+            c = len(oi)
+            assert int(hc[q]) == c and int(gc[q]) == c and int(wc[q]) == c
+            assert hi[q, :c].tolist() == oi.tolist(), (k, ef, q)
+            assert gi[q, :c].tolist() == oi.tolist(), (k, ef, q)
+            assert wi[q, :c].tolist() == oi.tolist(), (k, ef, q)
+            assert np.array_equal(hd[q, :c], od) and np.array_equal(gd[q, :c], od)
+
+
 def test_gistlike_knn_pq_large(mods):
     vdb, O = mods
     base = gist_like(30000, seed=1806)
