@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--cpu-queries", type=int, default=512,
                     help="queries timed on the CPU oracle and parity-checked (0 = skip); 512 = ~12 s on 16 cores")
+    ap.add_argument("--workload", choices=["flat", "pq_flat", "hnsw"], default="flat",
+                    help="flat = the headline (BASELINE metric); pq_flat / hnsw = the other SURVEY 8d configs")
+    ap.add_argument("--ef", type=int, default=0, help="pq_flat: ADC shortlist (default 100); hnsw: search ef (default 128)")
     ap.add_argument("--mode", type=int, default=0, help="flat mode: 0 auto, 1 exact scan, 2 MFMA forced")
     ap.add_argument("--dump", type=str, default="", help="rank 0 saves the last step's results to this .npz (tests)")
     args = ap.parse_args()
@@ -68,7 +71,8 @@ def main():
     import torch.distributed as dist
 
     import lab_1806_vec_db_amd as vdb
-    from lab_1806_vec_db_amd.shard import allgather_merge, shard_bounds
+    from lab_1806_vec_db_amd.shard import (allgather_concat, allgather_merge, allgather_merge_pq, replica_query_slice,
+                                           shard_bounds)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -89,11 +93,15 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    wl = args.workload
+    if wl == "hnsw" and args.rows == 1_000_000:
+        args.rows = 100_000  # the serial-insert host builder (hnsw_index.rs:493-572 order) needs minutes per 100k rows
+    ef = args.ef or (100 if wl == "pq_flat" else 128)
     n, dim, nq, k = args.rows, args.dim, args.nq, args.k
     # identical corpus on every rank (same seed), each keeps its row block
     base = gist_like_gpu(torch, n, dim, 1806, device)
     queries = gist_like_gpu(torch, nq, dim, 1807, device)
-    r0, r1 = shard_bounds(n, world, rank)
+    r0, r1 = shard_bounds(n, world, rank) if wl != "hnsw" else (0, n)  # HNSW: full replica per GPU
     shard = base[r0:r1].contiguous()
     torch.cuda.synchronize()
 
@@ -104,6 +112,20 @@ def main():
     host_base = None
     if rank == 0 and world == 1 and args.cpu_queries > 0:
         host_base = base.cpu().numpy()
+    if wl == "pq_flat":
+        # config/bench_pq_hnsw.toml:16-23: n_bits 4, m = dim/3, k_means_size 10000, max_iter 20, tol 1e-6.  Every rank
+        # trains on the same first 10000 rows (same seed) -> identical centroids; codes are encoded per shard on the GPU.
+        m = dim // 3
+        tr = vdb.GpuIndex(dim, "l2sqr", device=local_rank)
+        tr.add_device(base.data_ptr(), min(n, 10000))
+        tr.pq_build(n_bits=4, m=m, train_n=0, max_iter=20, tol=1e-6, seed=42)
+        cent = tr.pq_export()["centroids"]
+        del tr
+        ix.pq_attach(4, m, cent, None)
+    elif wl == "hnsw":
+        t_b = time.perf_counter()
+        ix.hnsw_build(M=16, ef_construction=200, seed=42, batch=64, nthreads=min(len(os.sched_getaffinity(0)), 16))
+        build_s = time.perf_counter() - t_b
     del base, shard
     torch.cuda.empty_cache()
 
@@ -111,11 +133,35 @@ def main():
     o_dist = torch.zeros((nq, k), dtype=torch.float32, device=device)
     o_cnt = torch.zeros((nq,), dtype=torch.int64, device=device)
 
+    host_xchg = backend != "nccl" and world > 1
+    efk = max(ef, k)
+    if wl == "pq_flat" and world > 1:
+        s_adc = torch.zeros((nq, efk), dtype=torch.int64, device=device)
+        s_ex = torch.zeros((nq, efk), dtype=torch.int64, device=device)
+    q0, q1 = replica_query_slice(nq, world, rank)
+
     def step():
-        ix.flat_knn_device(queries.data_ptr(), nq, k, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr())
-        if backend != "nccl" and world > 1:
-            return allgather_merge(o_idx.cpu(), o_dist.cpu(), o_cnt.cpu(), k)
-        return allgather_merge(o_idx, o_dist, o_cnt, k, gpu_index=ix)
+        if wl == "flat":
+            ix.flat_knn_device(queries.data_ptr(), nq, k, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr())
+            if host_xchg:
+                return allgather_merge(o_idx.cpu(), o_dist.cpu(), o_cnt.cpu(), k)
+            return allgather_merge(o_idx, o_dist, o_cnt, k, gpu_index=ix)
+        if wl == "pq_flat":
+            if world == 1:
+                ix.knn_pq_device(queries.data_ptr(), nq, k, ef, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr())
+                return o_idx, o_dist, o_cnt
+            ix.knn_pq_shard_device(queries.data_ptr(), nq, k, ef, s_adc.data_ptr(), s_ex.data_ptr())
+            if host_xchg:
+                return allgather_merge_pq(s_adc.cpu(), s_ex.cpu(), k)
+            return allgather_merge_pq(s_adc, s_ex, k, gpu_index=ix)
+        # hnsw: replicas, each rank answers its block of the queries, blocks are concatenated
+        if q1 > q0:
+            ix.hnsw_knn_device(queries[q0:q1].data_ptr(), q1 - q0, k, ef, o_idx.data_ptr(), o_dist.data_ptr(),
+                               o_cnt.data_ptr())
+        li, ld, lc = o_idx[: q1 - q0], o_dist[: q1 - q0], o_cnt[: q1 - q0]
+        if host_xchg:
+            return allgather_concat(li.cpu(), ld.cpu(), lc.cpu(), nq)
+        return allgather_concat(li, ld, lc, nq)
 
     def fence():
         torch.cuda.synchronize()
@@ -139,10 +185,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kernel = "flat_mfma" if ix.prof_get("flat_mfma")["launches"] else "flat_exact"
+    if wl == "flat":
+        kernel = "flat_mfma" if ix.prof_get("flat_mfma")["launches"] else "flat_exact"
+    else:
+        kernel = "pq_adc" if wl == "pq_flat" else "hnsw"
     p = ix.prof_get(kernel)
     roofline = None
-    if p["launches"]:
+    if p["launches"] and wl != "flat":
+        # pq_adc: code bytes of one scan = rows x ceil(m*n_bits/8), one scan serves 4 queries (LUTs side by side in
+        # LDS); hnsw: n_dist x (dim*4 + 4) + n_expanded x max_m0*4 counted by the kernel
+        avg_ms = p["ms"] / p["launches"]
+        bytes_per_launch = p["bytes"] / p["launches"]
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
+                    "avg_launch_ms": round(avg_ms, 4), "launches": p["launches"], "bytes_per_launch": bytes_per_launch}
+    elif p["launches"]:
         avg_ms = p["ms"] / p["launches"]
         bytes_per_launch = p["bytes"] / p["launches"]  # shard_rows * dim * 4
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
@@ -170,38 +228,78 @@ def main():
     if args.dump:
         np.savez(args.dump, idx=res[0].cpu().numpy(), dist=res[1].cpu().numpy(), cnt=res[2].cpu().numpy())
     qps = nq * args.steps / elapsed
+    names = {"flat": ("Flat brute force", "flat_knn_gist1m"), "pq_flat": (f"PQ-Flat 4-bit m={dim // 3}, ADC ef={ef}", "pq_flat_knn_gist1m"),
+             "hnsw": (f"HNSW M=16 efc=200, ef={ef}", f"hnsw_knn_gistlike_{n}")}[wl]
+    par = {"flat": f"row-shard x{world}", "pq_flat": f"row-shard x{world}", "hnsw": f"replica x{world}, queries split"}[wl]
     out = {
-        "metric": "queries/sec at recall@10, Gist1M d=960 (Flat brute force, L2Sqr, k=10)",
+        "metric": f"queries/sec at recall@10, Gist1M d=960 ({names[0]}, L2Sqr, k=10)",
         "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "flat_knn_gist1m", "rows": n, "dim": dim, "queries_per_step": nq, "k": k,
-                   "dist": "L2Sqr", "queries_per_corpus_pass": 64,
-                   "parallelism": f"row-shard x{world}" if world > 1 else "single GPU"},
-        "roofline": roofline, "recall_at_10": None, "fallback_queries": ix.flat_fallback_count(),
+        "config": {"workload": names[1], "rows": n, "dim": dim, "queries_per_step": nq, "k": k, "dist": "L2Sqr",
+                   "parallelism": par if world > 1 else "single GPU"},
+        "roofline": roofline, "recall_at_10": None,
     }
+    if wl == "flat":
+        out["config"]["queries_per_corpus_pass"] = 64
+        out["fallback_queries"] = ix.flat_fallback_count()
+    else:
+        out["config"]["ef"] = ef
+    if wl == "hnsw":
+        nd, ne = ix.hnsw_last_stats()
+        out["config"]["host_build_s"] = round(build_s, 1)
+        out["hnsw_work_per_query"] = {"n_dist": round(nd / max(q1 - q0, 1), 1), "n_expanded": round(ne / max(q1 - q0, 1), 1)}
 
     # ---- CPU baseline + parity (rank 0, N=1 only) ------------------------------------------------------
     if host_base is not None:
+        from concurrent.futures import ThreadPoolExecutor
+
         from oracle import oracle as O
 
         O.build()
         ncpu = min(args.cpu_queries, nq)
         threads = min(len(os.sched_getaffinity(0)), 16)  # the GPU box's CPU share for one GPU
         hq = queries[:ncpu].cpu().numpy()
-        t0 = time.perf_counter()
-        ci, cd, cc = O.flat_knn_batch(host_base, hq, k, O.L2SQR, nthreads=threads)
-        cpu_s = time.perf_counter() - t0
         gi = res[0][:ncpu].cpu().numpy().astype(np.uint64)
         gd = res[1][:ncpu].cpu().numpy()
+        if wl == "flat":
+            t0 = time.perf_counter()
+            ci, cd, cc = O.flat_knn_batch(host_base, hq, k, O.L2SQR, nthreads=threads)
+            cpu_s = time.perf_counter() - t0
+            truth = ci
+            what = "FlatIndex::knn"
+        else:
+            # recall is against Flat ground truth (gen_gnd.rs:54-72), taken from the GPU Flat path of the same index
+            t_idx = torch.zeros((nq, k), dtype=torch.int64, device=device)
+            t_dist = torch.zeros((nq, k), dtype=torch.float32, device=device)
+            t_cnt = torch.zeros((nq,), dtype=torch.int64, device=device)
+            ix.flat_knn_device(queries.data_ptr(), nq, k, t_idx.data_ptr(), t_dist.data_ptr(), t_cnt.data_ptr())
+            truth = t_idx[:ncpu].cpu().numpy().astype(np.uint64)
+            if wl == "pq_flat":
+                pq = ix.pq_export()
+                opq = O.PQ.from_centroids(dim, pq["m"], pq["n_bits"], O.L2SQR, pq["centroids"])
+                opq.set_codes(pq["codes"])  # GPU-encoded codes (bit-equal to the oracle's encoder, tests/test_pq_gpu.py)
+                t0 = time.perf_counter()
+                with ThreadPoolExecutor(threads) as ex:  # ctypes releases the GIL: one query per thread
+                    r = list(ex.map(lambda q: O.flat_knn_pq(host_base, opq, hq[q], k, ef, O.L2SQR), range(ncpu)))
+                cpu_s = time.perf_counter() - t0
+                what = "FlatIndex::knn_pq"
+            else:
+                oh = O.HNSW.from_graph(host_base, O.L2SQR, 16, 200, ix.hnsw_export())
+                t0 = time.perf_counter()
+                with ThreadPoolExecutor(threads) as ex:
+                    r = list(ex.map(lambda q: oh.knn(hq[q], k, ef), range(ncpu)))
+                cpu_s = time.perf_counter() - t0
+                what = "HNSWIndex::knn_with_ef on the same graph"
+            ci = np.stack([np.pad(x[0], (0, k - len(x[0]))) for x in r]).astype(np.uint64)
+            cd = np.stack([np.pad(x[1], (0, k - len(x[1]))) for x in r]).astype(np.float32)
         idx_equal = bool(np.array_equal(gi, ci))
         dist_equal = bool(np.array_equal(gd, cd))
-        rec = float(np.mean([O.recall(ci[q], gi[q]) for q in range(ncpu)]))
-        out["recall_at_10"] = rec
+        out["recall_at_10"] = float(np.mean([O.recall(truth[q], gi[q]) for q in range(ncpu)]))
         out["parity"] = {"queries_checked": ncpu, "indices_identical": idx_equal, "distances_bit_exact": dist_equal}
         out["cpu_baseline"] = {"value": round(ncpu / cpu_s, 2), "unit": "queries/s", "cores": threads,
                                "kind": "port",
-                               "sample": f"{ncpu} of the {nq} queries against the full {n}x{dim} corpus, "
+                               "sample": f"{what}: {ncpu} of the {nq} queries against the full {n}x{dim} corpus, "
                                          f"one query per thread (mirrors rayon par_iter, examples/bench.rs:414-416)"}
     print(json.dumps(out))
     if world > 1:

@@ -106,6 +106,10 @@ int vdb_pq_export(const vdb_index *idx, float *centroids, uint8_t *codes);
 int vdb_flat_knn_pq(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef,
                     uint64_t *out_idx, float *out_dist, uint64_t *out_count);
 
+/* device-pointer variant (queries / outputs on the index's GPU); returns synchronised */
+int vdb_flat_knn_pq_device(vdb_index *idx, const void *d_queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef,
+                           void *d_out_idx, void *d_out_dist, void *d_out_count, void *stream);
+
 /* ---- HNSWIndex (index_algorithm/hnsw_index.rs) -----------------------------------------
  * Graph layout (fields :98-141): level0 = n x max_m0 u32 (max_m0 = 2*min(M,10000)), len0[n];
  * vec_level[n]; upper = CSR over nodes, node v level L>=1 at ((sum_{u<v} vec_level[u]) + L-1)*m,
@@ -127,6 +131,9 @@ int vdb_hnsw_knn(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim
 /* HNSWIndex::knn_pq (:672-697) */
 int vdb_hnsw_knn_pq(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef,
                     uint64_t *out_idx, float *out_dist, uint64_t *out_count);
+/* device-pointer variant of knn_with_ef (use_pq = 0) / knn_pq (use_pq = 1); returns synchronised */
+int vdb_hnsw_knn_device(vdb_index *idx, const void *d_queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef,
+                        int use_pq, void *d_out_idx, void *d_out_dist, void *d_out_count, void *stream);
 /* per-call work counters of the last vdb_hnsw_knn on this index (SURVEY 8d bytes/query) */
 int vdb_hnsw_last_stats(const vdb_index *idx, uint64_t *n_dist, uint64_t *n_expanded);
 

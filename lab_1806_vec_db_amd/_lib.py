@@ -48,6 +48,8 @@ SIGNATURES = {
     "vdb_pq_info": [vp, u64p, u64p, u64p],
     "vdb_pq_export": [vp, f32p, u8p],
     "vdb_flat_knn_pq": [vp, f32p, u64, u64, u64, u64, u64p, f32p, u64p],
+    "vdb_flat_knn_pq_device": [vp, vp, u64, u64, u64, u64, vp, vp, vp, vp],
+    "vdb_hnsw_knn_device": [vp, vp, u64, u64, u64, u64, C.c_int, vp, vp, vp, vp],
     "vdb_flat_knn_pq_shard": [vp, f32p, u64, u64, u64, u64, u64p, u64p],
     "vdb_flat_knn_pq_shard_device": [vp, vp, u64, u64, u64, u64, vp, vp, vp],
     "vdb_pq_merge_resort": [u64p, u64p, u64, u64, u64, u64, u64p, f32p, u64p],

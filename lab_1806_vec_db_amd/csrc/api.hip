@@ -221,23 +221,28 @@ int vdb_flat_knn(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim
     VDB_API_END
 }
 
-int vdb_flat_knn_device(vdb_index *idx, const void *d_queries, uint64_t nq, uint64_t dim, uint64_t k,
-                        void *d_out_idx, void *d_out_dist, void *d_out_count, void *stream) {
-    VDB_API_BEGIN
-    VDB_REQUIRE(idx, "null index");
-    Index &ix = idx->ix;
+// device-pointer front end shared by all searches (queries and outputs already on the index's GPU)
+static void device_search(Index &ix, const void *d_queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef,
+                          void *d_out_idx, void *d_out_dist, void *d_out_count, void *stream, dev_search_fn fn) {
     check_query_args(ix, d_queries, nq, dim, d_out_idx, d_out_dist);
     VDB_REQUIRE(nq == 0 || d_out_count, "null out_count");
     VDB_REQUIRE(nq <= 32768, "at most 32768 queries per device call");
-    if (nq == 0) return VDB_OK;
+    if (nq == 0) return;
     ix.use_device();
     WsLease ws(ix);
     // order after whatever produced the queries on the caller's stream
     VDB_SYNC(static_cast<hipStream_t>(stream));
-    ix.flat_knn_device(*ws, static_cast<const float *>(d_queries), nq, k, static_cast<uint64_t *>(d_out_idx),
-                       static_cast<float *>(d_out_dist), static_cast<uint64_t *>(d_out_count));
+    fn(ix, *ws, static_cast<const float *>(d_queries), nq, k, ef, static_cast<uint64_t *>(d_out_idx),
+       static_cast<float *>(d_out_dist), static_cast<uint64_t *>(d_out_count));
     VDB_SYNC(ws->stream);
     ix.prof_collect(*ws);
+}
+
+int vdb_flat_knn_device(vdb_index *idx, const void *d_queries, uint64_t nq, uint64_t dim, uint64_t k,
+                        void *d_out_idx, void *d_out_dist, void *d_out_count, void *stream) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    device_search(idx->ix, d_queries, nq, dim, k, 0, d_out_idx, d_out_dist, d_out_count, stream, flat_dev);
     VDB_API_END
 }
 
@@ -326,6 +331,15 @@ int vdb_flat_knn_pq(vdb_index *idx, const float *queries, uint64_t nq, uint64_t 
     check_query_args(idx->ix, queries, nq, dim, out_idx, out_dist);
     VDB_REQUIRE(idx->ix.pq.present, "knn_pq needs a PQ table (vdb_pq_build / vdb_pq_attach)");
     host_search(idx->ix, queries, nq, k, ef, out_idx, out_dist, out_count, flat_pq_dev);
+    VDB_API_END
+}
+
+int vdb_flat_knn_pq_device(vdb_index *idx, const void *d_queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef,
+                           void *d_out_idx, void *d_out_dist, void *d_out_count, void *stream) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    VDB_REQUIRE(idx->ix.pq.present, "knn_pq needs a PQ table (vdb_pq_build / vdb_pq_attach)");
+    device_search(idx->ix, d_queries, nq, dim, k, ef, d_out_idx, d_out_dist, d_out_count, stream, flat_pq_dev);
     VDB_API_END
 }
 
@@ -514,6 +528,17 @@ int vdb_hnsw_knn_pq(vdb_index *idx, const float *queries, uint64_t nq, uint64_t 
     VDB_REQUIRE(idx->ix.hnsw.present, "knn_pq needs an HNSW graph");
     VDB_REQUIRE(idx->ix.pq.present, "knn_pq needs a PQ table");
     host_search(idx->ix, queries, nq, k, ef, out_idx, out_dist, out_count, hnsw_pq_dev);
+    VDB_API_END
+}
+int vdb_hnsw_knn_device(vdb_index *idx, const void *d_queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef,
+                        int use_pq, void *d_out_idx, void *d_out_dist, void *d_out_count, void *stream) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    VDB_REQUIRE(idx->ix.hnsw.present, "knn_with_ef needs an HNSW graph (vdb_hnsw_build / vdb_hnsw_attach)");
+    VDB_REQUIRE(!use_pq || idx->ix.pq.present, "knn_pq needs a PQ table");
+    if (ef == 0) ef = idx->ix.hnsw.default_ef;
+    device_search(idx->ix, d_queries, nq, dim, k, ef, d_out_idx, d_out_dist, d_out_count, stream,
+                  use_pq ? hnsw_pq_dev : hnsw_dev);
     VDB_API_END
 }
 int vdb_hnsw_last_stats(const vdb_index *idx, uint64_t *n_dist, uint64_t *n_expanded) {

@@ -883,6 +883,12 @@ void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, ui
     std::memcpy(st, hostbuf + 16, 16);
     h.last_n_dist = st[0];
     h.last_n_expanded = st[1];
+    if (!ws.pending.empty()) {
+        // algorithmic bytes are data-dependent: n_dist row fetches (+ cached norm) and n_expanded link rows,
+        // known only now -- credited to the call's last launch record
+        const double row_bytes = use_pq ? double(pq.enc_dim) : double(ix.dim) * sizeof(float) + sizeof(float);
+        ws.pending.back().bytes += double(st[0]) * row_bytes + double(st[1]) * double(h.max_m0) * sizeof(uint32_t);
+    }
     VDB_REQUIRE(e == 0, "hnsw search: candidate pool overflow (more than 2048 live candidates; degenerate duplicates)");
 }
 

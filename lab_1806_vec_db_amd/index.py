@@ -159,6 +159,17 @@ class GpuIndex:
         L.check(self._lib.vdb_flat_knn_device(self._h, L.vp(q_ptr), int(nq), self.dim, int(k), L.vp(out_idx_ptr),
                                               L.vp(out_dist_ptr), L.vp(out_cnt_ptr), L.vp(stream)))
 
+    def knn_pq_device(self, q_ptr: int, nq: int, k: int, ef: int, out_idx_ptr: int, out_dist_ptr: int,
+                      out_cnt_ptr: int, stream: int = 0):
+        L.check(self._lib.vdb_flat_knn_pq_device(self._h, L.vp(q_ptr), int(nq), self.dim, int(k), int(ef),
+                                                 L.vp(out_idx_ptr), L.vp(out_dist_ptr), L.vp(out_cnt_ptr),
+                                                 L.vp(stream)))
+
+    def hnsw_knn_device(self, q_ptr: int, nq: int, k: int, ef: int, out_idx_ptr: int, out_dist_ptr: int,
+                        out_cnt_ptr: int, use_pq: bool = False, stream: int = 0):
+        L.check(self._lib.vdb_hnsw_knn_device(self._h, L.vp(q_ptr), int(nq), self.dim, int(k), int(ef), int(use_pq),
+                                              L.vp(out_idx_ptr), L.vp(out_dist_ptr), L.vp(out_cnt_ptr), L.vp(stream)))
+
     def merge_topk_device(self, d_dists: int, d_ids: int, d_counts: int, n_shards: int, nq: int, k: int,
                           out_idx: int, out_dist: int, out_cnt: int, stream: int = 0):
         L.check(self._lib.vdb_merge_topk_device(self._h, L.vp(d_dists), L.vp(d_ids), L.vp(d_counts), n_shards, nq, k,

@@ -94,3 +94,39 @@ def allgather_merge_pq(adc_keys, exact_keys, k: int, group=None, gpu_index=None)
 
     oi, od, oc = pq_merge_resort(g_adc.numpy().view(np.uint64), g_ex.numpy().view(np.uint64), k)
     return (torch.from_numpy(oi.astype(np.int64)), torch.from_numpy(od), torch.from_numpy(oc.astype(np.int64)))
+
+
+def replica_query_slice(nq: int, world: int, rank: int) -> tuple[int, int]:
+    """HNSW does not shard (edges cross any row partition): every GPU holds a full replica and serves the
+    contiguous query block [rank*ceil(nq/world), ...) -- no data-path collective."""
+    return shard_bounds(nq, world, rank)
+
+
+def allgather_concat(local_idx, local_dist, local_cnt, nq: int, group=None):
+    """Replica mode: rank r computed rows replica_query_slice(nq, world, r) of the answer; every rank receives all nq
+    rows.  The blocks are padded to ceil(nq/world) rows so one fixed-size all-gather suffices."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local_idx, local_dist, local_cnt
+    per = -(-nq // world)
+    k = local_idx.shape[1]
+
+    def pad(t, shape):
+        out = torch.zeros(shape, dtype=t.dtype, device=t.device)
+        out[: t.shape[0]] = t
+        return out
+
+    parts = (pad(local_idx, (per, k)).view(torch.uint8).reshape(-1), pad(local_dist, (per, k)).view(torch.uint8).reshape(-1),
+             pad(local_cnt, (per,)).view(torch.uint8).reshape(-1))
+    sizes = [p.numel() for p in parts]
+    mine = torch.cat(parts)
+    gathered = torch.empty((world, mine.numel()), dtype=torch.uint8, device=mine.device)
+    dist.all_gather_into_tensor(gathered.view(-1), mine, group=group)
+    o0, o1 = sizes[0], sizes[0] + sizes[1]
+    g_idx = gathered[:, :o0].contiguous().view(local_idx.dtype).view(world * per, k)[:nq]
+    g_dist = gathered[:, o0:o1].contiguous().view(local_dist.dtype).view(world * per, k)[:nq]
+    g_cnt = gathered[:, o1:].contiguous().view(local_cnt.dtype).view(world * per)[:nq]
+    return g_idx, g_dist, g_cnt

@@ -13,10 +13,10 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _run(world, dump, port):
+def _run(world, dump, port, extra=()):
     env = dict(os.environ, VDB_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     args = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--rows", "60000", "--nq", "96", "--cpu-queries",
-            "0", "--dump", dump]
+            "0", "--dump", dump] + list(extra)
     if world == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
     else:
@@ -39,3 +39,18 @@ def test_sharded_bench_equals_single(tmp_path):
         assert np.array_equal(a["idx"], b["idx"])
         assert np.array_equal(a["dist"], b["dist"])
         assert np.array_equal(a["cnt"], b["cnt"])
+
+
+@pytest.mark.parametrize("workload,rows,dim", [("pq_flat", "70000", "96"), ("hnsw", "3000", "48")])
+def test_sharded_other_workloads_equal_single(tmp_path, workload, rows, dim):
+    """pq_flat: row shards + ADC-order merge + re-sort; hnsw: replicas with split queries."""
+    extra = ["--workload", workload, "--rows", rows, "--dim", dim]
+    r1 = _run(1, str(tmp_path / "w1.npz"), 29621, extra)
+    assert r1["n_gpus"] == 1 and r1["roofline"]["launches"] > 0 and r1["roofline"]["bytes_per_launch"] > 0
+    a = np.load(tmp_path / "w1.npz")
+    r = _run(2, str(tmp_path / "w2.npz"), 29622, extra)
+    assert r["n_gpus"] == 2
+    b = np.load(tmp_path / "w2.npz")
+    assert np.array_equal(a["idx"], b["idx"])
+    assert np.array_equal(a["dist"], b["dist"])
+    assert np.array_equal(a["cnt"], b["cnt"])
