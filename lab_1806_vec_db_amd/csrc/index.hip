@@ -61,7 +61,7 @@ void Index::add_rows(const float *rows, uint64_t count, bool on_device) {
     launch_row_sqnorm(dst, count, (uint32_t)dim, d_sq.as<float>() + n, s);
     if (mfma_supported((uint32_t)dim)) {
         // refresh the fragment-ordered mirror for every 16-row tile that received rows
-        uint64_t tiles_new = ((n + count + 15) / 16 + 3) & ~3ull;  // rounded up so a 64-row item never leaves the buffer
+        uint64_t tiles_new = ((n + count + 15) / 16 + 11) / 12 * 12;  // whole 64-row items (k_flat_mfma) and whole 2/3-tile units (k_flat_gemm)
         uint64_t tiles_old = n / 16;                                // the partially filled tile is rewritten
         uint64_t tile_bytes = 16 * size_t(mfma_dim_pad((uint32_t)dim)) * sizeof(float);
         d_tiled.grow(tiles_new * tile_bytes, tiles_old * tile_bytes, s);
@@ -249,8 +249,13 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     const uint32_t capp = topk_capacity(kprime);
     const uint32_t capk = topk_capacity(ksel);
     const uint64_t bq = mfma_batch((uint32_t)dim);  // queries per workgroup batch (32, or 16 for 1024 < dim <= 2048)
-    const uint64_t nbatch = (nq + bq - 1) / bq;
-    const uint64_t nq_pad = nbatch * bq;
+    // more than 64 queries: the filter pass runs as k_flat_gemm, 128 queries per corpus pass (k_gemm.hip); the
+    // sample pass keeps the small-batch kernel, so the padded query count is a multiple of both batch sizes
+    const bool gemm = flat_gemm_mode == 2 || (flat_gemm_mode == 0 && nq > 64);
+    const uint64_t gq = gemm_group();
+    const uint64_t ngroups = gemm ? (nq + gq - 1) / gq : 0;
+    const uint64_t nq_pad = gemm ? ngroups * gq : (nq + bq - 1) / bq * bq;
+    const uint64_t nbatch = nq_pad / bq;
     const uint64_t n_s = mfma_sample_rows(n);
     const uint64_t ld_s = (n_s + 63) & ~63ull;
     const uint32_t nl_s = topk_num_lists(n_s);
@@ -267,21 +272,33 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     ws.flags.reserve(nq_pad);
     float *d_tau = ws.misc.as<float>();
     uint32_t *d_hits = reinterpret_cast<uint32_t *>(d_tau + nq_pad);
-    launch_mfma_pack_queries(d_q, (uint32_t)nq, (uint32_t)dim, ws.qfrag.as<float>(), s);
+    launch_mfma_pack_queries(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, ws.qfrag.as<float>(), s);
+    if (gemm) {
+        ws.qfrag_g.reserve(nq_pad * size_t(mfma_dim_pad((uint32_t)dim)) * sizeof(float));
+        launch_mfma_pack_queries_nh(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, 8, ws.qfrag_g.as<float>(), s);
+    }
     launch_flat_mfma_sample(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>(), (uint32_t)nbatch, d_sq.as<float>(),
                             cosine, ws.dense.as<float>(), ld_s, num_cu, s);
     launch_topk_dense(ws.dense.as<float>(), ld_s, n_s, (uint32_t)nq_pad, kprime, ws.lists.as<uint64_t>(), s);
     launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, capp, (uint32_t)nq_pad, kprime, ws.keys_a.as<uint64_t>(), s);
     launch_extract_tau(ws.keys_a.as<uint64_t>(), capp, (uint32_t)nq_pad, kprime, d_tau, s);
+    // padding queries are zero vectors: under Cosine every row ties at key 0 = tau and would flood the hit buffers of
+    // the real queries that share their workgroup batch; tau = -inf lets nothing through
+    if (nq_pad > nq)
+        VDB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_tau + nq), (int)0xFF800000u, nq_pad - nq, s));
     uint64_t *d_cand = ws.lists.as<uint64_t>();  // the sample lists are dead now
     VDB_HIP(hipMemsetAsync(d_cand, 0xff, nq_pad * size_t(CAND_CAP) * sizeof(uint64_t), s));
     uint32_t *d_sync = d_hits + nq_pad;
     VDB_HIP(hipMemsetAsync(d_hits, 0, (nq_pad + sync_words) * sizeof(uint32_t), s));
     // algorithmic bytes: one corpus pass (N*d*4) serves 32*share queries (bytes/query = N*d*4 / B)
-    const uint64_t hbm_passes = (nbatch + mfma_share() - 1) / mfma_share();
+    const uint64_t hbm_passes = gemm ? ngroups : (nbatch + mfma_share() - 1) / mfma_share();
     prof_begin(ws, "flat_mfma", double(hbm_passes) * double(n) * dim * sizeof(float));
-    launch_flat_mfma_filter(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>(), (uint32_t)nbatch, d_sq.as<float>(),
-                            cosine, d_tau, d_cand, d_hits, CAND_CAP, d_sync, num_cu, s);
+    if (gemm)
+        launch_flat_gemm_filter(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag_g.as<float>(), (uint32_t)ngroups,
+                                d_sq.as<float>(), cosine, d_tau, d_cand, d_hits, CAND_CAP, flat_gemm_debug, num_cu, s);
+    else
+        launch_flat_mfma_filter(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>(), (uint32_t)nbatch,
+                                d_sq.as<float>(), cosine, d_tau, d_cand, d_hits, CAND_CAP, d_sync, num_cu, s);
     prof_end(ws);
     launch_topk_merge_counted(d_cand, CAND_CAP, d_hits, (uint32_t)nq, kprime, ws.keys_a.as<uint64_t>(), s);
     VDB_HIP(hipMemsetAsync(ws.keys_b.p, 0xff, nq * capp * sizeof(uint64_t), s));

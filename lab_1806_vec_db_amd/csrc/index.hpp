@@ -61,7 +61,7 @@ struct ProfEntry {
 // per-call scratch: one per concurrent reader (read-side calls are re-entrant, see vdbhip.h)
 struct Workspace {
     hipStream_t stream = nullptr;
-    DevBuf q, qsq, qfrag, dense, lists, keys_a, keys_b, keys_c, flags, out_idx, out_dist, out_cnt, lut, misc;
+    DevBuf q, qsq, qfrag, qfrag_g, dense, lists, keys_a, keys_b, keys_c, flags, out_idx, out_dist, out_cnt, lut, misc;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     struct Pending {
         std::string name;
@@ -122,6 +122,8 @@ struct Index {
     mutable bool host_valid = true;
     mutable std::mutex host_mu;
     int flat_mode = 0;
+    int flat_gemm_mode = 0;   // 0 auto (more than 64 queries per call), 1 off, 2 forced (k_gemm.hip)
+    int flat_gemm_debug = 0;
     std::atomic<uint64_t> fallback_count{0};
     PQState pq;
     HNSWState hnsw;

@@ -1,0 +1,304 @@
+// k_gemm.hip -- Flat brute force for LARGE query batches: 128 queries per HBM pass (second form).
+//
+// k_flat_mfma (k_mfma.hip) keeps the whole Q image of 32 queries in LDS and streams the corpus past it; every
+// workgroup therefore ingests 4 B of X per (row, column) for only 32 queries.  Measured on MI355X that per-CU
+// ingest, not HBM, becomes the limit once several batches share a pass through L2 (two batches: 0.69 ms per pass,
+// four: 1.15 ms; a CU takes in at most ~50-70 GB/s from L2).  This kernel turns the loop nest around so that a
+// byte of X entering a CU is used for 128 queries:
+//
+//   * a wave owns a UNIT of TW 16-row tiles and keeps the TW x 8 accumulator tiles (rows x 128 queries) in
+//     registers for the whole contraction;
+//   * the query group's B-operand image is cut into K-chunks of KC 32-column blocks (KC x 16 KB); the workgroup
+//     double-buffers the chunks in LDS (global -> registers -> LDS while the previous chunk is being multiplied,
+//     one barrier per chunk).  The chunks are re-read from L2 once per unit step (480 KB per 8 x TW x 16 rows),
+//     i.e. +33 % on-chip traffic at TW = 3 against 4x fewer X bytes per query;
+//   * X still never touches LDS: each fragment is read once, by one wave, straight from the fragment-ordered
+//     mirror into a register ring that runs KC-1 k-blocks ahead across chunk, unit and group boundaries
+//     (unconditional loads -> counted vmcnt, as in k_flat_mfma);
+//   * same split-bf16 arithmetic (xh*qh + xh*ql + xl*qh), same epilogue: keys <= tau[q] are parked in an LDS hit
+//     buffer and handed to the per-query candidate lists once per group.
+//
+// HBM traffic: one corpus pass (N x d x 4 B) per 128 queries.  The keys are approximate ranking keys exactly as in
+// k_flat_mfma; exactness comes from k_rerank + k_certify downstream (index.hip).
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace vdb {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr uint32_t GEMM_NH = 8;             // 16-query halves per group
+constexpr uint32_t GEMM_BQ = 16 * GEMM_NH;  // 128 queries per pass
+constexpr uint32_t GEMM_WGBUF = 3072;       // LDS hit buffer entries per workgroup and group
+static int g_gemm_tw = 3;
+void gemm_set_tw(int v) { g_gemm_tw = v == 2 ? 2 : 3; }
+uint32_t gemm_group() { return GEMM_BQ; }
+
+struct GemmArgs {
+    const uint4 *XT;     // fragment-ordered split-bf16 mirror (k_tile_rows)
+    const uint4 *qfrag;  // [ngroups][KB][8 halves][hi|lo][64] (k_mfma_pack_queries with NH = 8)
+    const float *xsq;
+    uint64_t n;
+    uint32_t KB, n_units, ngroups, steps;
+    const float *tau;  // [ngroups*128]
+    uint64_t *cand;    // [ngroups*128][cap]
+    uint32_t *cnt;     // [ngroups*128]
+    uint32_t cap;
+    int cosine;
+    uint32_t debug;
+};
+
+template <int TW, int KC>
+__global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
+    constexpr int NT = 512, NW = 8, NH = GEMM_NH, R = KC;
+    constexpr uint32_t CHUNK = KC * NH * 128;  // uint4 per Q chunk
+    constexpr int QST = CHUNK / NT;            // staged uint4 per thread
+    static_assert(CHUNK % NT == 0, "chunk must split evenly over the workgroup");
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];  // [2][CHUNK] Q chunks, then the hit buffer
+    uint64_t *hit_key = reinterpret_cast<uint64_t *>(smem + 2 * CHUNK);
+    uint32_t *hit_q = reinterpret_cast<uint32_t *>(hit_key + GEMM_WGBUF);
+    uint32_t *hit_n = hit_q + GEMM_WGBUF;  // [0] entries, [1..128] per-query counts, [129..256] per-query bases
+    float *tau_s = reinterpret_cast<float *>(hit_n + 1 + 2 * GEMM_BQ);  // [128] thresholds of the current group
+
+    // wave-uniform values are made visibly uniform (readfirstlane) so that addresses are SGPR base + 32-bit lane offset
+    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t r = lane & 15, g4 = lane >> 4;
+    const uint32_t nwaves = gridDim.x * NW, gw = blockIdx.x * NW + wave;
+    const uint32_t KB = a.KB, nchunk = KB / KC, steps = a.steps;
+    const uint64_t n = a.n;
+
+    // ---- X stream: k-block k of a unit is consumed from ring slot k % R while the loads for k-block k + PD land in
+    // the slot consumed one step earlier.  Past the unit's last k-blocks the loads run into the wave's NEXT unit
+    // (next step, or step 0 again for the next query group), so the ring never drains; the position where that
+    // happens is static (last chunk, p >= KC - PD), which keeps the chunk body free of branches.
+    constexpr int PD = R - 1;
+    auto unit_ptr = [&](uint32_t st) -> const char * {  // wave-uniform
+        if (st >= steps) st -= steps;  // the wave's unit sequence repeats for every query group
+        if (st >= steps) st = 0;
+        uint32_t u = st * nwaves + gw;
+        if (u >= a.n_units) u = a.n_units - 1;  // idle waves re-read the last unit (L2 hits, results masked)
+        return reinterpret_cast<const char *>(a.XT) + uint64_t(u) * TW * KB * 2048;
+    };
+    const char *cp_cur = unit_ptr(0), *cp_nxt = unit_ptr(1);
+    uint32_t voff[TW];  // this lane's byte offset inside a unit, per tile
+#pragma unroll
+    for (int t = 0; t < TW; t++) voff[t] = lane * 16 + t * KB * 2048;
+    uint4 ring[R][TW][2];
+    auto fetch_at = [&](uint4(&dst)[TW][2], const char *base, uint32_t kb) {
+        const char *sb = base + kb * 2048;  // scalar
+#pragma unroll
+        for (int t = 0; t < TW; t++) {
+            dst[t][0] = *reinterpret_cast<const uint4 *>(sb + voff[t]);
+            dst[t][1] = *reinterpret_cast<const uint4 *>(sb + voff[t] + 1024);
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < PD; p++) fetch_at(ring[p], cp_cur, p);
+
+    // ---- Q chunk staging: QP uint4 per thread and k-block, global -> registers at the top of the k-block (BEFORE
+    // its X loads, so that waiting for them later is a counted vmcnt that leaves the X loads in flight), registers ->
+    // the other LDS buffer at the bottom ----
+    constexpr int QP = QST / KC;
+    static_assert(QST % KC == 0, "staging must split evenly over the k-blocks of a chunk");
+    {
+        const uint4 *src = a.qfrag;
+#pragma unroll
+        for (int j = 0; j < QST; j++) smem[j * NT + threadIdx.x] = src[j * NT + threadIdx.x];
+    }
+    uint32_t buf = 0;
+    __syncthreads();
+
+    for (uint32_t grp = 0; grp < a.ngroups; grp++) {
+        const uint4 *qgrp = a.qfrag + uint64_t(grp) * nchunk * CHUNK;
+        if (threadIdx.x < 1 + 2 * GEMM_BQ) hit_n[threadIdx.x] = 0;  // ordered before the first append by the chunk barriers
+        if (threadIdx.x < GEMM_BQ)  // thresholds live in LDS, not in 8 registers per lane
+            tau_s[threadIdx.x] = (a.debug & 1) ? -INFINITY : a.tau[grp * GEMM_BQ + threadIdx.x];
+        for (uint32_t st = 0; st < steps; st++) {
+            const uint32_t u_raw = st * nwaves + gw;
+            const uint32_t u = u_raw < a.n_units ? u_raw : a.n_units - 1;
+            f32x4 acc[TW][NH];
+#pragma unroll
+            for (int t = 0; t < TW; t++)
+#pragma unroll
+                for (int h = 0; h < NH; h++) acc[t][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (uint32_t c = 0; c < nchunk; c++) {
+                // next chunk in consumption order: same group until its last step is done
+                const uint4 *nxt = (c + 1 < nchunk ? qgrp + uint64_t(c + 1) * CHUNK
+                                    : (st + 1 < steps ? qgrp : (grp + 1 < a.ngroups ? qgrp + uint64_t(nchunk) * CHUNK : a.qfrag)));
+                const uint32_t tid16 = threadIdx.x * 16;
+                uint4 *qdst = smem + (buf ^ 1) * CHUNK + threadIdx.x;
+                const uint4 *qcur = smem + buf * CHUNK + lane;
+                const bool last_c = c + 1 == nchunk;
+                bf16x8 qh_n = __builtin_bit_cast(bf16x8, qcur[0]);
+                bf16x8 ql_n = __builtin_bit_cast(bf16x8, qcur[64]);
+#pragma unroll
+                for (int p = 0; p < KC; p++) {
+                    static_assert(QP == 2, "two staged uint4 per thread and k-block");  // scalars: an array here stays in scratch
+                    const uint4 qs0 = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(nxt + (p * QP + 0) * NT) + tid16);
+                    const uint4 qs1 = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(nxt + (p * QP + 1) * NT) + tid16);
+                    {
+                        const uint32_t kf = c * KC + p + PD;  // k-block the cursor is at
+                        const bool wrap = p >= KC - PD && last_c;
+                        fetch_at(ring[(p + R - 1) % R], wrap ? cp_nxt : cp_cur, wrap ? kf - KB : kf);
+                    }
+                    // the machine scheduler otherwise sinks these loads next to their uses (measured: vmcnt(0) before every
+                    // staging ds_write, i.e. the whole X ring drained once per k-block) and pulls the B-fragment reads
+                    // back to just before their MFMAs; pin the issue order instead
+                    __builtin_amdgcn_sched_barrier(0);
+                    bf16x8 xh[TW], xl[TW];
+#pragma unroll
+                    for (int t = 0; t < TW; t++) {
+                        xh[t] = __builtin_bit_cast(bf16x8, ring[p][t][0]);
+                        xl[t] = __builtin_bit_cast(bf16x8, ring[p][t][1]);
+                    }
+#pragma unroll
+                    for (int h = 0; h < NH; h++) {
+                        const bf16x8 qh = qh_n, ql = ql_n;
+                        if (!(p == KC - 1 && h == NH - 1)) {  // B fragments one step ahead of their MFMAs
+                            const int pn = h + 1 < NH ? p : p + 1, hn = h + 1 < NH ? h + 1 : 0;
+                            qh_n = __builtin_bit_cast(bf16x8, qcur[((pn * NH + hn) * 2 + 0) * 64]);
+                            ql_n = __builtin_bit_cast(bf16x8, qcur[((pn * NH + hn) * 2 + 1) * 64]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int t = 0; t < TW; t++)
+                            acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[t], qh, acc[t][h], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < TW; t++)
+                            acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[t], ql, acc[t][h], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < TW; t++)
+                            acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl[t], qh, acc[t][h], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    qdst[(p * QP + 0) * NT] = qs0;
+                    qdst[(p * QP + 1) * NT] = qs1;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __syncthreads();
+                buf ^= 1;
+            }
+            cp_cur = cp_nxt;
+            cp_nxt = unit_ptr(st + 2);
+            // ---- epilogue: lane holds rows 4*g4..4*g4+3 of each tile for query r of each half ----
+            typedef const __attribute__((address_space(4))) float *cfloat_p;
+            cfloat_p xs_unit = (cfloat_p)(a.xsq + uint64_t(__builtin_amdgcn_readfirstlane(u)) * (16 * TW));
+            const uint64_t row0 = uint64_t(u_raw) * (16 * TW);  // the unclamped unit: idle waves are past n
+#pragma unroll
+            for (int t = 0; t < TW; t++) {
+                float xsv[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) xsv[i] = xs_unit[t * 16 + i];
+                float xv[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float x0 = xsv[0 + e], x1 = xsv[4 + e], x2 = xsv[8 + e], x3 = xsv[12 + e];
+                    const float x = g4 == 0 ? x0 : (g4 == 1 ? x1 : (g4 == 2 ? x2 : x3));
+                    // cosine keys -S/|x|; zero-norm rows: S = 0 and the reference distance is exactly 1 -> key 0
+                    xv[e] = a.cosine ? (x > 0.0f ? __frsqrt_rn(x) : 0.0f) : x;
+                }
+                const uint64_t rb = row0 + t * 16 + 4 * g4;
+#pragma unroll
+                for (int h = 0; h < NH; h++) {
+                    const float tau_h = tau_s[h * 16 + r];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float key = a.cosine ? -acc[t][h][e] * xv[e] : xv[e] - 2.0f * acc[t][h][e];
+                        if (key <= tau_h && rb + e < n) {  // rare: ~k' * sample step hits per query in total
+                            uint32_t pos = atomicAdd(hit_n, 1u);
+                            if (pos < GEMM_WGBUF) {
+                                hit_key[pos] = pair_key(key, uint32_t(rb + e));
+                                hit_q[pos] = h * 16 + r;
+                            } else {  // buffer full: mark the query as overflowed (-> exact fallback)
+                                atomicAdd(&a.cnt[grp * GEMM_BQ + h * 16 + r], a.cap + 1);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // ---- group end: hand the parked hits to the per-query candidate lists (one global atomic per query) ----
+        __syncthreads();
+        {
+            uint32_t total = hit_n[0];
+            if (total > GEMM_WGBUF) total = GEMM_WGBUF;
+            constexpr uint32_t NJ = (GEMM_WGBUF + NT - 1) / NT;
+            uint32_t rank[NJ];
+#pragma unroll
+            for (uint32_t j = 0; j < NJ; j++) {
+                uint32_t i = j * NT + threadIdx.x;
+                rank[j] = i < total ? atomicAdd(&hit_n[1 + hit_q[i]], 1u) : 0u;
+            }
+            __syncthreads();
+            if (threadIdx.x < GEMM_BQ && hit_n[1 + threadIdx.x] > 0)
+                hit_n[1 + GEMM_BQ + threadIdx.x] = atomicAdd(&a.cnt[grp * GEMM_BQ + threadIdx.x], hit_n[1 + threadIdx.x]);
+            __syncthreads();
+#pragma unroll
+            for (uint32_t j = 0; j < NJ; j++) {
+                uint32_t i = j * NT + threadIdx.x;
+                if (i < total) {
+                    uint32_t q = hit_q[i];
+                    uint32_t slot = hit_n[1 + GEMM_BQ + q] + rank[j];
+                    if (slot < a.cap) a.cand[(uint64_t(grp) * GEMM_BQ + q) * a.cap + slot] = hit_key[i];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int TW, int KC>
+static void flat_gemm_launch(const GemmArgs &a0, int num_cu, hipStream_t s) {
+    GemmArgs a = a0;
+    const uint64_t n_tiles = (a.n + 15) / 16;
+    a.n_units = (uint32_t)((n_tiles + TW - 1) / TW);
+    uint32_t grid = (uint32_t)num_cu;
+    const uint32_t need = (a.n_units + 7) / 8;
+    if (need < grid) grid = need;
+    if (grid == 0 || a.ngroups == 0) return;
+    a.steps = (a.n_units + grid * 8 - 1) / (grid * 8);
+    const size_t lds = size_t(2) * KC * GEMM_NH * 128 * sizeof(uint4) + size_t(GEMM_WGBUF) * 12 + (1 + 3 * GEMM_BQ) * 4 + 16;
+    static bool attr_done = false;
+    if (!attr_done) {
+        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_gemm<TW, KC>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_flat_gemm<TW, KC>), dim3(grid), dim3(512), lds, s, a);
+    VDB_HIP(hipGetLastError());
+}
+
+// rows past n up to a whole unit are read from the mirror (zero tiles) and from xsq (padding): see Index::add_rows
+void launch_flat_gemm_filter(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t ngroups,
+                             const float *xsq, int cosine, const float *tau, uint64_t *cand, uint32_t *cnt,
+                             uint32_t cap, int debug, int num_cu, hipStream_t s) {
+    if (n == 0 || ngroups == 0) return;
+    VDB_REQUIRE(n < (1ull << 32), "flat_gemm: too many rows for one shard");
+    GemmArgs a{};
+    a.XT = reinterpret_cast<const uint4 *>(XT);
+    a.qfrag = reinterpret_cast<const uint4 *>(qfrag);
+    a.xsq = xsq;
+    a.n = n;
+    a.KB = mfma_dim_pad(dim) / 32;
+    a.ngroups = ngroups;
+    a.tau = tau;
+    a.cand = cand;
+    a.cnt = cnt;
+    a.cap = cap;
+    a.cosine = cosine;
+    a.debug = (uint32_t)debug;
+    if (a.KB % 3 == 0) {
+        if (g_gemm_tw == 2)
+            flat_gemm_launch<2, 3>(a, num_cu, s);
+        else
+            flat_gemm_launch<3, 3>(a, num_cu, s);
+    } else {  // KB is even (columns padded to a multiple of 64)
+        if (g_gemm_tw == 2)
+            flat_gemm_launch<2, 2>(a, num_cu, s);
+        else
+            flat_gemm_launch<3, 2>(a, num_cu, s);
+    }
+}
+
+}  // namespace vdb

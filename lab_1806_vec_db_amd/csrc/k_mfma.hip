@@ -28,6 +28,8 @@
 // Q lives in LDS as the matching B-operand image [kb][query half][hi|lo][lane] (120 KB for d = 960):
 // every B fragment is one lane-linear, conflict-free ds_read_b128.  X never touches LDS: it is read
 // once, by exactly one wave, straight into VGPRs through a register ring (GEMV regime).
+#include <algorithm>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -144,14 +146,21 @@ __global__ void k_mfma_pack_queries(const float *__restrict__ Q, uint32_t nq, ui
     qfrag[((kb * NH + h) * 2 + 1) * 64 + l] = lo;
 }
 
-void launch_mfma_pack_queries(const float *Q, uint32_t nq, uint32_t dim, float *qfrag, hipStream_t s) {
-    const uint32_t bq = mfma_batch(dim), NH = bq / 16;
-    VDB_REQUIRE(bq != 0, "flat_mfma: unsupported dim");
+// images for batches of 16*NH queries (NH = 8: the 128-query groups of k_gemm.hip)
+void launch_mfma_pack_queries_nh(const float *Q, uint32_t nq, uint32_t nq_cover, uint32_t dim, uint32_t NH, float *qfrag,
+                                 hipStream_t s) {
+    const uint32_t bq = 16 * NH;
     uint32_t total = (mfma_dim_pad(dim) / 32) * NH * 64;
-    uint32_t nbatch = (nq + bq - 1) / bq;
+    uint32_t nbatch = (std::max(nq, nq_cover) + bq - 1) / bq;  // queries in [nq, nq_cover) get zero images
     if (nbatch == 0) return;
     hipLaunchKernelGGL(k_mfma_pack_queries, dim3((total + 255) / 256, nbatch), dim3(256), 0, s, Q, nq, dim, NH,
                        reinterpret_cast<uint4 *>(qfrag));
+}
+
+void launch_mfma_pack_queries(const float *Q, uint32_t nq, uint32_t nq_cover, uint32_t dim, float *qfrag, hipStream_t s) {
+    const uint32_t bq = mfma_batch(dim);
+    VDB_REQUIRE(bq != 0, "flat_mfma: unsupported dim");
+    launch_mfma_pack_queries_nh(Q, nq, nq_cover, dim, bq / 16, qfrag, s);
 }
 
 // ---------------------------------------------------------------------------------------------------

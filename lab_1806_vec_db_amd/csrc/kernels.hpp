@@ -62,7 +62,7 @@ void launch_sort_pairs(const float *dist, uint64_t n, uint64_t *tmp_keys, uint64
 // ---- k_mfma.hip ----------------------------------------------------------------------------
 uint32_t mfma_batch(uint32_t dim);  // queries per workgroup batch: 32 (dim <= 1024), 16 (dim <= 2048), 0 = unsupported
 // Q [nq][dim] -> ceil(nq/32) fragment-ordered split-bf16 images of mfma_qfrag_floats(dim) floats each
-void launch_mfma_pack_queries(const float *Q, uint32_t nq, uint32_t dim, float *qfrag, hipStream_t s);
+void launch_mfma_pack_queries(const float *Q, uint32_t nq, uint32_t nq_cover, uint32_t dim, float *qfrag, hipStream_t s);
 // fragment-ordered mirror of rows: tiles [tile0, tile1) of 16 rows each; T holds ceil(n/16) tiles rounded up to 4
 void launch_tile_rows(const float *X, uint64_t n, uint32_t dim, uint64_t tile0, uint64_t tile1, float *T,
                       hipStream_t s);
@@ -77,6 +77,15 @@ void launch_flat_mfma_filter(const float *XT, uint64_t n, uint32_t dim, const fl
                              const float *xsq, int cosine, const float *tau, uint64_t *cand, uint32_t *cnt,
                              uint32_t cap, uint32_t *sync /* mfma_sync_words() zeroed words */, int num_cu, hipStream_t s);
 size_t mfma_sync_words(uint32_t nbatch, int num_cu);
+// k_gemm.hip: the same filter for groups of gemm_group() = 128 queries per corpus pass; qfrag = images packed with
+// launch_mfma_pack_queries_nh(.., 8, ..), tau / cand / cnt indexed by the global query number as above
+void launch_flat_gemm_filter(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t ngroups,
+                             const float *xsq, int cosine, const float *tau, uint64_t *cand, uint32_t *cnt,
+                             uint32_t cap, int debug, int num_cu, hipStream_t s);
+uint32_t gemm_group();
+void gemm_set_tw(int v);
+void launch_mfma_pack_queries_nh(const float *Q, uint32_t nq, uint32_t nq_cover, uint32_t dim, uint32_t NH, float *qfrag,
+                                 hipStream_t s);
 uint64_t mfma_sample_rows(uint64_t n);
 uint32_t mfma_sample_step(uint64_t n);
 size_t mfma_qfrag_floats(uint32_t dim);
