@@ -40,7 +40,7 @@ struct GemmArgs {
     const uint4 *qfrag;  // [ngroups][KB][8 halves][hi|lo][64] (k_mfma_pack_queries with NH = 8)
     const float *xsq;
     uint64_t n;
-    uint32_t KB, n_units, ngroups, steps;
+    uint32_t KB, n_units, ngroups;
     const float *tau;  // [ngroups*128]
     uint64_t *cand;    // [ngroups*128][cap]
     uint32_t *cnt;     // [ngroups*128]
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t r = lane & 15, g4 = lane >> 4;
     const uint32_t nwaves = gridDim.x * NW, gw = blockIdx.x * NW + wave;
-    const uint32_t KB = a.KB, nchunk = KB / KC, steps = a.steps;
+    const uint32_t KB = a.KB, nchunk = KB / KC;
     const uint64_t n = a.n;
 
     // ---- X stream: k-block k of a unit is consumed from ring slot k % R while the loads for k-block k + PD land in
@@ -73,14 +73,36 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
     // (next step, or step 0 again for the next query group), so the ring never drains; the position where that
     // happens is static (last chunk, p >= KC - PD), which keeps the chunk body free of branches.
     constexpr int PD = R - 1;
-    auto unit_ptr = [&](uint32_t st) -> const char * {  // wave-uniform
-        if (st >= steps) st -= steps;  // the wave's unit sequence repeats for every query group
-        if (st >= steps) st = 0;
-        uint32_t u = st * nwaves + gw;
+    // Units are dealt round-robin: step s < S0 gives wave gw unit s*nwaves + gw.  The n_units % nwaves units that are
+    // left do not fill another step of the whole chip; they go to a window of workgroups that ROTATES with the query
+    // group, so that over the launch every workgroup gets about the same number of steps (1M rows, TW = 3: 10.17
+    // units per wave; 11 steps everywhere would idle 7.5 % of the launch) -- workgroups move on to the next group
+    // without a grid-wide barrier, only the per-workgroup totals matter.  With fewer units than waves (S0 = 0) every
+    // workgroup runs the single partial step.
+    const uint32_t S0 = a.n_units / nwaves, rem = a.n_units - S0 * nwaves;
+    const uint32_t rem_wg = (rem + NW - 1) / NW;  // workgroups in the window
+    auto rot_of = [&](uint32_t grp) -> uint32_t { return S0 == 0 ? 0u : (grp * rem_wg) % gridDim.x; };
+    auto steps_of = [&](uint32_t grp) -> uint32_t {
+        if (rem == 0) return S0;
+        if (S0 == 0) return 1;
+        const uint32_t slot = (blockIdx.x + gridDim.x - rot_of(grp)) % gridDim.x;  // position inside the window
+        return S0 + (slot < rem_wg ? 1u : 0u);
+    };
+    auto unit_of = [&](uint32_t grp, uint32_t st) -> uint32_t {  // may be >= n_units (idle wave of the window's tail)
+        if (st < S0) return st * nwaves + gw;
+        const uint32_t slot = (blockIdx.x + gridDim.x - rot_of(grp)) % gridDim.x;
+        return S0 * nwaves + slot * NW + wave;
+    };
+    auto unit_ptr = [&](uint32_t u) -> const char * {  // wave-uniform
         if (u >= a.n_units) u = a.n_units - 1;  // idle waves re-read the last unit (L2 hits, results masked)
         return reinterpret_cast<const char *>(a.XT) + uint64_t(u) * TW * KB * 2048;
     };
-    const char *cp_cur = unit_ptr(0), *cp_nxt = unit_ptr(1);
+    // the unit after (grp, st) in this wave's sequence; past the last group it does not matter (loads only)
+    auto next_unit = [&](uint32_t grp, uint32_t st) -> uint32_t {
+        if (st + 1 < steps_of(grp)) return unit_of(grp, st + 1);
+        return unit_of(grp + 1 < a.ngroups ? grp + 1 : 0, 0);
+    };
+    const char *cp_cur = unit_ptr(unit_of(0, 0)), *cp_nxt = unit_ptr(next_unit(0, 0));
     uint32_t voff[TW];  // this lane's byte offset inside a unit, per tile
 #pragma unroll
     for (int t = 0; t < TW; t++) voff[t] = lane * 16 + t * KB * 2048;
@@ -114,8 +136,9 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
         if (threadIdx.x < 1 + 2 * GEMM_BQ) hit_n[threadIdx.x] = 0;  // ordered before the first append by the chunk barriers
         if (threadIdx.x < GEMM_BQ)  // thresholds live in LDS, not in 8 registers per lane
             tau_s[threadIdx.x] = (a.debug & 1) ? -INFINITY : a.tau[grp * GEMM_BQ + threadIdx.x];
+        const uint32_t steps = steps_of(grp);
         for (uint32_t st = 0; st < steps; st++) {
-            const uint32_t u_raw = st * nwaves + gw;
+            const uint32_t u_raw = unit_of(grp, st);
             const uint32_t u = u_raw < a.n_units ? u_raw : a.n_units - 1;
             f32x4 acc[TW][NH];
 #pragma unroll
@@ -180,7 +203,11 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
                 buf ^= 1;
             }
             cp_cur = cp_nxt;
-            cp_nxt = unit_ptr(st + 2);
+            {   // cp_cur now points at the unit after (grp, st); cp_nxt at the one after that
+                const bool last = st + 1 >= steps;
+                const uint32_t g1 = last ? (grp + 1 < a.ngroups ? grp + 1 : 0) : grp, s1 = last ? 0 : st + 1;
+                cp_nxt = unit_ptr(next_unit(g1, s1));
+            }
             // ---- epilogue: lane holds rows 4*g4..4*g4+3 of each tile for query r of each half ----
             typedef const __attribute__((address_space(4))) float *cfloat_p;
             cfloat_p xs_unit = (cfloat_p)(a.xsq + uint64_t(__builtin_amdgcn_readfirstlane(u)) * (16 * TW));
@@ -257,7 +284,6 @@ static void flat_gemm_launch(const GemmArgs &a0, int num_cu, hipStream_t s) {
     const uint32_t need = (a.n_units + 7) / 8;
     if (need < grid) grid = need;
     if (grid == 0 || a.ngroups == 0) return;
-    a.steps = (a.n_units + grid * 8 - 1) / (grid * 8);
     const size_t lds = size_t(2) * KC * GEMM_NH * 128 * sizeof(uint4) + size_t(GEMM_WGBUF) * 12 + (1 + 3 * GEMM_BQ) * 4 + 16;
     static bool attr_done = false;
     if (!attr_done) {
