@@ -204,9 +204,12 @@ def main():
         avg_ms = p["ms"] / p["launches"]
         bytes_per_launch = p["bytes"] / p["launches"]  # shard_rows * dim * 4
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        # queries one corpus pass serves: 128 (k_flat_gemm) when a call carries more than 64 queries, else 2 x 32
+        # (k_flat_mfma, XCD-shared passes) -- the rule of Index::flat_knn_device
+        qpp = 128 if nq > 64 else 64
         traffic = None  # HBM bytes per launch from the committed PMC passes (same kernel, same shard size only)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_flat_mfma.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_flat_gemm.json" if qpp == 128 else "pmc_flat_mfma.json")))
             passes = round(bytes_per_launch / pmc["algorithmic_bytes_per_pass"])  # HBM passes in one launch
             if kernel == "flat_mfma" and abs(pmc["algorithmic_bytes_per_pass"] * passes - bytes_per_launch) < 1:
                 traffic = pmc["hbm_bytes_per_pass"] * passes
@@ -217,8 +220,7 @@ def main():
                     "avg_launch_ms": round(avg_ms, 4), "launches": p["launches"],
                     "bytes_per_launch": bytes_per_launch,
                     "units_per_launch": f"{round(bytes_per_launch / ((r1 - r0) * dim * 4))} corpus passes x {r1 - r0} rows "
-                                        f"x {dim} x 4 B; one pass serves 64 queries (two 32-query batches share it "
-                                        f"through the XCD's L2)"}
+                                        f"x {dim} x 4 B; one pass serves {qpp} queries"}
 
     if rank != 0:
         if world > 1:
@@ -241,7 +243,7 @@ def main():
         "roofline": roofline, "recall_at_10": None,
     }
     if wl == "flat":
-        out["config"]["queries_per_corpus_pass"] = 64
+        out["config"]["queries_per_corpus_pass"] = 128 if nq > 64 else 64
         out["fallback_queries"] = ix.flat_fallback_count()
     else:
         out["config"]["ef"] = ef
