@@ -279,9 +279,13 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     }
     launch_flat_mfma_sample(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>(), (uint32_t)nbatch, d_sq.as<float>(),
                             cosine, ws.dense.as<float>(), ld_s, num_cu, s);
-    launch_topk_dense(ws.dense.as<float>(), ld_s, n_s, (uint32_t)nq_pad, kprime, ws.lists.as<uint64_t>(), s);
-    launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, capp, (uint32_t)nq_pad, kprime, ws.keys_a.as<uint64_t>(), s);
-    launch_extract_tau(ws.keys_a.as<uint64_t>(), capp, (uint32_t)nq_pad, kprime, d_tau, s);
+    if (n_s <= select_tau_max_n()) {  // tau only needs the k'-th smallest sampled key, not a sorted sample shortlist
+        launch_select_tau(ws.dense.as<float>(), ld_s, (uint32_t)n_s, (uint32_t)nq_pad, kprime, d_tau, s);
+    } else {
+        launch_topk_dense(ws.dense.as<float>(), ld_s, n_s, (uint32_t)nq_pad, kprime, ws.lists.as<uint64_t>(), s);
+        launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, capp, (uint32_t)nq_pad, kprime, ws.keys_a.as<uint64_t>(), s);
+        launch_extract_tau(ws.keys_a.as<uint64_t>(), capp, (uint32_t)nq_pad, kprime, d_tau, s);
+    }
     // padding queries are zero vectors: under Cosine every row ties at key 0 = tau and would flood the hit buffers of
     // the real queries that share their workgroup batch; tau = -inf lets nothing through
     if (nq_pad > nq)

@@ -483,6 +483,13 @@ static void flat_mfma_launch(const MfmaArgs &a, int num_cu, hipStream_t s) {
         }
     }
     if (b.share <= 1 && need < grid) grid = need;
+    if (MODE == MODE_SAMPLE && b.nbatch > 0) {
+        // every workgroup first loads its batch's whole Q image (up to 128 KB): with one item per wave that load IS the
+        // pass (measured 157 us for 32 batches x 33 workgroups at 125k rows).  One chip-full of workgroups in total,
+        // each walking several sampled items, reads each image ~8 times instead of ~33.
+        uint32_t per_batch = ((uint32_t)num_cu + b.nbatch - 1) / b.nbatch;
+        if (per_batch < grid) grid = per_batch;
+    }
     if (grid == 0 || b.nbatch == 0) return;
     dim3 g(grid, MODE == MODE_SAMPLE ? b.nbatch : 1);
     hipLaunchKernelGGL((k_flat_mfma<PD, MODE, NH>), g, dim3(512), lds, s, b);

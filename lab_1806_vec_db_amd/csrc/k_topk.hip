@@ -16,7 +16,8 @@
 
 namespace vdb {
 
-uint32_t topk_num_lists(uint64_t n) { return n == 0 ? 1u : (uint32_t)((n + TOPK_CHUNK - 1) / TOPK_CHUNK); }
+uint32_t topk_chunk(uint64_t) { return 8192u; }  // finer chunks cost more fill-phase insertions than they gain in parallelism (measured)
+uint32_t topk_num_lists(uint64_t n) { return n == 0 ? 1u : (uint32_t)((n + topk_chunk(n) - 1) / topk_chunk(n)); }
 uint32_t topk_capacity(uint32_t k) {
     uint32_t r = 1;
     while (64u * r < k) r *= 2;
@@ -79,7 +80,8 @@ struct WaveList {
 // level 1: grid = (ceil(nlists/4), nq), block = 256 (4 waves, one list each)
 template <int R>
 __global__ __launch_bounds__(256) void k_topk_dense(const float *__restrict__ keys, uint64_t ld, uint64_t n,
-                                                    uint32_t k, uint32_t nlists, uint64_t *__restrict__ lists) {
+                                                    uint32_t k, uint32_t nlists, uint32_t chunk,
+                                                    uint64_t *__restrict__ lists) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t list = blockIdx.x * 4 + wave;
     const uint32_t q = blockIdx.y;
@@ -87,8 +89,8 @@ __global__ __launch_bounds__(256) void k_topk_dense(const float *__restrict__ ke
     WaveList<R> wl;
     wl.init(k);
     const float *kq = keys + uint64_t(q) * ld;
-    uint64_t begin = uint64_t(list) * TOPK_CHUNK;
-    uint64_t end = begin + TOPK_CHUNK < n ? begin + TOPK_CHUNK : n;
+    uint64_t begin = uint64_t(list) * chunk;
+    uint64_t end = begin + chunk < n ? begin + chunk : n;
     const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(keys) & 15) == 0);
     for (uint64_t base = begin; base < end; base += 256) {
         uint64_t i0 = base + uint64_t(lane) * 4;
@@ -107,6 +109,76 @@ __global__ __launch_bounds__(256) void k_topk_dense(const float *__restrict__ ke
         }
     }
     wl.store(lists + (uint64_t(q) * nlists + list) * (64 * R));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// tau[q] = the kth smallest of n keys of row q (as a float value), by radix select on the order-preserving u32 image
+// of the keys held in LDS: three histogram passes (11 + 11 + 10 bits).  This is all the sampled-threshold step of the
+// Flat path needs from its key sample -- a sorted shortlist of the sample (k_topk_dense + k_topk_merge, 120 us at
+// nq = 1000) is not.  One workgroup per query; n <= SELECT_MAX_N.  Fewer than kth keys -> +inf.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t SELECT_MAX_N = 16384;
+uint32_t select_tau_max_n() { return SELECT_MAX_N; }
+
+__global__ __launch_bounds__(256) void k_select_tau(const float *__restrict__ keys, uint64_t ld, uint32_t n, uint32_t kth,
+                                                    float *__restrict__ tau) {
+    extern __shared__ uint32_t sel_smem[];
+    uint32_t *o = sel_smem;        // [n] orderable keys
+    uint32_t *hist = o + n;        // [2048]
+    uint32_t *part = hist + 2048;  // [256] partial sums, then [0] = chosen bin, [1] = keys below it
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const float *kq = keys + uint64_t(q) * ld;
+    for (uint32_t i = tid; i < n; i += 256) o[i] = f32_orderable(kq[i]);
+    uint32_t prefix = 0, mask = 0, want = kth;  // looking for the want-th smallest among keys with (o & mask) == prefix
+    bool found = n >= kth && kth >= 1;
+    const int shifts[3] = {21, 10, 0};
+    const uint32_t widths[3] = {2048, 2048, 1024};
+#pragma unroll
+    for (int pass = 0; pass < 3; pass++) {
+        const int sh = shifts[pass];
+        const uint32_t nb = widths[pass];
+        for (uint32_t i = tid; i < 2048; i += 256) hist[i] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += 256) {
+            uint32_t v = o[i];
+            if ((v & mask) == prefix) atomicAdd(&hist[(v >> sh) & (nb - 1)], 1u);
+        }
+        __syncthreads();
+        const uint32_t per = nb / 256;  // bins per thread: 8 or 4
+        uint32_t sum = 0;
+        for (uint32_t j = 0; j < per; j++) sum += hist[tid * per + j];
+        part[tid] = sum;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t cum = 0, t = 0;
+            while (t < 255 && cum + part[t] < want) cum += part[t++];
+            uint32_t b = t * per;
+            while (b < t * per + per - 1 && cum + hist[b] < want) cum += hist[b++];
+            part[0] = b;
+            part[1] = cum;
+        }
+        __syncthreads();
+        const uint32_t b = part[0];
+        want -= part[1];
+        prefix |= b << sh;
+        mask |= (nb - 1) << sh;
+        __syncthreads();
+    }
+    if (tid == 0) tau[q] = found ? f32_from_orderable(prefix) : INFINITY;
+}
+
+void launch_select_tau(const float *keys, uint64_t ld, uint32_t n, uint32_t nq, uint32_t kth, float *tau, hipStream_t s) {
+    if (nq == 0) return;
+    VDB_REQUIRE(n <= SELECT_MAX_N, "select_tau: sample too long");
+    size_t lds = (size_t(n) + 2048 + 256) * sizeof(uint32_t);
+    static bool attr_done = false;
+    if (!attr_done) {
+        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select_tau),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_select_tau, dim3(nq), dim3(256), lds, s, keys, ld, n, kth, tau);
+    VDB_HIP(hipGetLastError());
 }
 
 // level 2: one wave per query merges nlists*cap_in keys
@@ -151,7 +223,8 @@ template <int R>
 static void topk_dense_r(const float *keys, uint64_t ld, uint64_t n, uint32_t nq, uint32_t k, uint64_t *lists,
                          hipStream_t s) {
     uint32_t nl = topk_num_lists(n);
-    hipLaunchKernelGGL((k_topk_dense<R>), dim3((nl + 3) / 4, nq), dim3(256), 0, s, keys, ld, n, k, nl, lists);
+    hipLaunchKernelGGL((k_topk_dense<R>), dim3((nl + 3) / 4, nq), dim3(256), 0, s, keys, ld, n, k, nl,
+                       topk_chunk(n), lists);
 }
 template <int R>
 static void topk_merge_r(const uint64_t *lists, uint32_t nlists, uint32_t cap_in, uint32_t nq, uint32_t k,
