@@ -112,10 +112,14 @@ __global__ __launch_bounds__(256) void k_topk_dense(const float *__restrict__ ke
 }
 
 // ---------------------------------------------------------------------------------------------------
-// tau[q] = the kth smallest of n keys of row q (as a float value), by radix select on the order-preserving u32 image
-// of the keys held in LDS: three histogram passes (11 + 11 + 10 bits).  This is all the sampled-threshold step of the
-// Flat path needs from its key sample -- a sorted shortlist of the sample (k_topk_dense + k_topk_merge, 120 us at
-// nq = 1000) is not.  One workgroup per query; n <= SELECT_MAX_N.  Fewer than kth keys -> +inf.
+// tau[q] = the kth smallest of n keys of row q (as a float value), by a range-adaptive radix select on the
+// order-preserving u32 image of the keys held in LDS.  This is all the sampled-threshold step of the Flat path needs
+// from its key sample -- a sorted shortlist of the sample (k_topk_dense + k_topk_merge, 120 us at nq = 1000) is not.
+// Distances of one query sit in a narrow band, so fixed bit fields put the whole sample into one or two histogram
+// bins (measured: 95 us of serialised LDS atomics); instead every pass spreads the CURRENT value range [lo, hi]
+// over up to 2048 equal power-of-two bins and narrows it to the bin holding the wanted rank, until the range is at most 2048 values
+// wide and the histogram is exact (<= 4 passes for 32-bit keys).  +inf (rows past n) and NaN keys sort last and only
+// count.  One workgroup per query; n <= SELECT_MAX_N.  Fewer than kth finite keys -> +inf.
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t SELECT_MAX_N = 16384;
 uint32_t select_tau_max_n() { return SELECT_MAX_N; }
@@ -125,52 +129,110 @@ __global__ __launch_bounds__(256) void k_select_tau(const float *__restrict__ ke
     extern __shared__ uint32_t sel_smem[];
     uint32_t *o = sel_smem;        // [n] orderable keys
     uint32_t *hist = o + n;        // [2048]
-    uint32_t *part = hist + 2048;  // [256] partial sums, then [0] = chosen bin, [1] = keys below it
+    uint32_t *part = hist + 2048;  // [256] partial sums / reduction scratch; [256..257] results
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const float *kq = keys + uint64_t(q) * ld;
-    for (uint32_t i = tid; i < n; i += 256) o[i] = f32_orderable(kq[i]);
-    uint32_t prefix = 0, mask = 0, want = kth;  // looking for the want-th smallest among keys with (o & mask) == prefix
-    bool found = n >= kth && kth >= 1;
-    const int shifts[3] = {21, 10, 0};
-    const uint32_t widths[3] = {2048, 2048, 1024};
+    const uint32_t O_INF = 0xFF800000u;  // f32_orderable(+inf); NaN is above it
+    uint32_t mn = 0xFFFFFFFFu, mx = 0, fin = 0;
+    for (uint32_t i = tid; i < n; i += 256) {
+        uint32_t v = f32_orderable(kq[i]);
+        o[i] = v;
+        if (v < O_INF) {
+            mn = v < mn ? v : mn;
+            mx = v > mx ? v : mx;
+            fin++;
+        }
+    }
+    // block reduction of (min, max, count): wave shuffles, then the 4 wave results through LDS
 #pragma unroll
-    for (int pass = 0; pass < 3; pass++) {
-        const int sh = shifts[pass];
-        const uint32_t nb = widths[pass];
+    for (int d = 32; d > 0; d >>= 1) {
+        uint32_t a = __shfl_xor(mn, d), b = __shfl_xor(mx, d), c = __shfl_xor(fin, d);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+        fin += c;
+    }
+    if ((tid & 63) == 0) {
+        part[(tid >> 6) * 3 + 0] = mn;
+        part[(tid >> 6) * 3 + 1] = mx;
+        part[(tid >> 6) * 3 + 2] = fin;
+    }
+    __syncthreads();
+    uint32_t lo = part[0], hi = part[1], n_fin = part[2];
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+        lo = part[w * 3] < lo ? part[w * 3] : lo;
+        hi = part[w * 3 + 1] > hi ? part[w * 3 + 1] : hi;
+        n_fin += part[w * 3 + 2];
+    }
+    __syncthreads();
+    if (kth == 0 || kth > n_fin) {  // uniform
+        if (tid == 0) tau[q] = INFINITY;
+        return;
+    }
+    uint32_t want = kth;
+    for (int pass = 0; pass < 5; pass++) {  // the range shrinks >= 1024x per pass
+        // bins of 2^sh values: the smallest shift that maps [lo, hi] into 2048 bins (no division in the key loop)
+        const uint32_t span = hi - lo;  // width - 1
+        const int sh = span < 2048 ? 0 : (32 - __builtin_clz(span)) - 11;
+        const bool exact = sh == 0;
         for (uint32_t i = tid; i < 2048; i += 256) hist[i] = 0;
         __syncthreads();
         for (uint32_t i = tid; i < n; i += 256) {
             uint32_t v = o[i];
-            if ((v & mask) == prefix) atomicAdd(&hist[(v >> sh) & (nb - 1)], 1u);
+            if (v >= lo && v <= hi) {
+                atomicAdd(&hist[(v - lo) >> sh], 1u);
+            }
         }
         __syncthreads();
-        const uint32_t per = nb / 256;  // bins per thread: 8 or 4
         uint32_t sum = 0;
-        for (uint32_t j = 0; j < per; j++) sum += hist[tid * per + j];
+        for (uint32_t j = 0; j < 8; j++) sum += hist[tid * 8 + j];
         part[tid] = sum;
         __syncthreads();
-        if (tid == 0) {
-            uint32_t cum = 0, t = 0;
-            while (t < 255 && cum + part[t] < want) cum += part[t++];
-            uint32_t b = t * per;
-            while (b < t * per + per - 1 && cum + hist[b] < want) cum += hist[b++];
-            part[0] = b;
-            part[1] = cum;
+        if (tid < 64) {  // first wave: scan of the 256 partial sums (4 per lane), then the 8 bins of the crossing one
+            uint32_t p4[4], mine = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                p4[j] = part[tid * 4 + j];
+                mine += p4[j];
+            }
+            uint32_t incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t up = __shfl_up(incl, d);
+                if ((int)tid >= d) incl += up;
+            }
+            const uint64_t reach = __ballot(incl >= want);  // want <= keys in range, so some lane reaches it
+            const uint32_t first = reach ? (uint32_t)__builtin_ctzll(reach) : 63u;
+            if (tid == first) {
+                uint32_t cum = incl - mine, t = 0;
+                while (t < 3 && cum + p4[t] < want) cum += p4[t++];
+                uint32_t b = (tid * 4 + t) * 8;
+                const uint32_t bend = b + 7;
+                while (b < bend && cum + hist[b] < want) cum += hist[b++];
+                part[256] = b;
+                part[257] = cum;
+            }
         }
         __syncthreads();
-        const uint32_t b = part[0];
-        want -= part[1];
-        prefix |= b << sh;
-        mask |= (nb - 1) << sh;
+        const uint32_t b = part[256];
+        want -= part[257];
         __syncthreads();
+        if (exact) {
+            if (tid == 0) tau[q] = f32_from_orderable(lo + b);
+            return;
+        }
+        const uint32_t nlo = lo + (b << sh);  // values of bin b
+        const uint32_t nhi = nlo + ((1u << sh) - 1);
+        lo = nlo;
+        hi = nhi < hi && nhi >= nlo ? nhi : hi;
     }
-    if (tid == 0) tau[q] = found ? f32_from_orderable(prefix) : INFINITY;
+    if (tid == 0) tau[q] = f32_from_orderable(hi);  // not reached: 2^32 / 1024^3 < 2048
 }
 
 void launch_select_tau(const float *keys, uint64_t ld, uint32_t n, uint32_t nq, uint32_t kth, float *tau, hipStream_t s) {
     if (nq == 0) return;
     VDB_REQUIRE(n <= SELECT_MAX_N, "select_tau: sample too long");
-    size_t lds = (size_t(n) + 2048 + 256) * sizeof(uint32_t);
+    size_t lds = (size_t(n) + 2048 + 258) * sizeof(uint32_t);
     static bool attr_done = false;
     if (!attr_done) {
         VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select_tau),
