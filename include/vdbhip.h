@@ -72,7 +72,10 @@ int vdb_index_set_id_offset(vdb_index *idx, uint64_t offset);
 /* calc_dist (pyo3/mod.rs:43-48): one distance, evaluated on the GPU in reference order */
 int vdb_calc_dist(int device_id, const float *a, const float *b, uint64_t n, int dist, float *out);
 
-/* ---- FlatIndex::knn (flat_index.rs:48-57), batched over nq queries -------------------- */
+/* ---- FlatIndex::knn (flat_index.rs:48-57), batched over nq queries --------------------
+ * Any k: up to min(k, len) = 1024 results come from the register-resident select, beyond that from a full
+ * (distance, index) radix sort per query.  More than 64 queries in one call are served 128 per corpus pass
+ * (k_flat_gemm), fewer 2 x 32 per pass (k_flat_mfma); results do not depend on the batching. */
 int vdb_flat_knn(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, uint64_t k,
                  uint64_t *out_idx, float *out_dist, uint64_t *out_count);
 /* device-resident queries and outputs (out_idx u64[nq*k], out_dist f32[nq*k], out_count u64[nq]);
