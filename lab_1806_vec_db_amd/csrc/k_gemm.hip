@@ -27,6 +27,7 @@ namespace vdb {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr uint32_t GEMM_NH = 8;             // 16-query halves per group
 constexpr uint32_t GEMM_BQ = 16 * GEMM_NH;  // 128 queries per pass
@@ -81,28 +82,24 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
     // workgroup runs the single partial step.
     const uint32_t S0 = a.n_units / nwaves, rem = a.n_units - S0 * nwaves;
     const uint32_t rem_wg = (rem + NW - 1) / NW;  // workgroups in the window
-    auto rot_of = [&](uint32_t grp) -> uint32_t { return S0 == 0 ? 0u : (grp * rem_wg) % gridDim.x; };
-    auto steps_of = [&](uint32_t grp) -> uint32_t {
+    // slot = this workgroup's position relative to the window's start; the window moves by rem_wg per group
+    const uint32_t rw = S0 == 0 ? 0u : rem_wg;
+    auto adv = [&](uint32_t slot) -> uint32_t { return slot >= rw ? slot - rw : slot + gridDim.x - rw; };
+    auto steps_of = [&](uint32_t slot) -> uint32_t {
         if (rem == 0) return S0;
         if (S0 == 0) return 1;
-        const uint32_t slot = (blockIdx.x + gridDim.x - rot_of(grp)) % gridDim.x;  // position inside the window
         return S0 + (slot < rem_wg ? 1u : 0u);
     };
-    auto unit_of = [&](uint32_t grp, uint32_t st) -> uint32_t {  // may be >= n_units (idle wave of the window's tail)
-        if (st < S0) return st * nwaves + gw;
-        const uint32_t slot = (blockIdx.x + gridDim.x - rot_of(grp)) % gridDim.x;
-        return S0 * nwaves + slot * NW + wave;
+    auto unit_of = [&](uint32_t slot, uint32_t st) -> uint32_t {  // may be >= n_units (idle wave of the window's tail)
+        return st < S0 ? st * nwaves + gw : S0 * nwaves + slot * NW + wave;
     };
     auto unit_ptr = [&](uint32_t u) -> const char * {  // wave-uniform
         if (u >= a.n_units) u = a.n_units - 1;  // idle waves re-read the last unit (L2 hits, results masked)
         return reinterpret_cast<const char *>(a.XT) + uint64_t(u) * TW * KB * 2048;
     };
-    // the unit after (grp, st) in this wave's sequence; past the last group it does not matter (loads only)
-    auto next_unit = [&](uint32_t grp, uint32_t st) -> uint32_t {
-        if (st + 1 < steps_of(grp)) return unit_of(grp, st + 1);
-        return unit_of(grp + 1 < a.ngroups ? grp + 1 : 0, 0);
-    };
-    const char *cp_cur = unit_ptr(unit_of(0, 0)), *cp_nxt = unit_ptr(next_unit(0, 0));
+    uint32_t slot_cur = blockIdx.x, slot_nxt = adv(slot_cur);  // of the current and of the next query group
+    const char *cp_cur = unit_ptr(unit_of(slot_cur, 0)),
+               *cp_nxt = unit_ptr(1 < steps_of(slot_cur) ? unit_of(slot_cur, 1) : unit_of(slot_nxt, 0));
     uint32_t voff[TW];  // this lane's byte offset inside a unit, per tile
 #pragma unroll
     for (int t = 0; t < TW; t++) voff[t] = lane * 16 + t * KB * 2048;
@@ -136,9 +133,9 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
         if (threadIdx.x < 1 + 2 * GEMM_BQ) hit_n[threadIdx.x] = 0;  // ordered before the first append by the chunk barriers
         if (threadIdx.x < GEMM_BQ)  // thresholds live in LDS, not in 8 registers per lane
             tau_s[threadIdx.x] = (a.debug & 1) ? -INFINITY : a.tau[grp * GEMM_BQ + threadIdx.x];
-        const uint32_t steps = steps_of(grp);
+        const uint32_t steps = steps_of(slot_cur);
         for (uint32_t st = 0; st < steps; st++) {
-            const uint32_t u_raw = unit_of(grp, st);
+            const uint32_t u_raw = unit_of(slot_cur, st);
             const uint32_t u = u_raw < a.n_units ? u_raw : a.n_units - 1;
             f32x4 acc[TW][NH];
 #pragma unroll
@@ -203,10 +200,16 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
                 buf ^= 1;
             }
             cp_cur = cp_nxt;
-            {   // cp_cur now points at the unit after (grp, st); cp_nxt at the one after that
-                const bool last = st + 1 >= steps;
-                const uint32_t g1 = last ? (grp + 1 < a.ngroups ? grp + 1 : 0) : grp, s1 = last ? 0 : st + 1;
-                cp_nxt = unit_ptr(next_unit(g1, s1));
+            {   // cp_cur now points at the unit after (grp, st); cp_nxt at the one after that (past the last group the
+                // sequence just continues: those loads are never used)
+                uint32_t un;
+                if (st + 2 < steps)
+                    un = unit_of(slot_cur, st + 2);
+                else if (st + 1 < steps)
+                    un = unit_of(slot_nxt, 0);
+                else
+                    un = 1 < steps_of(slot_nxt) ? unit_of(slot_nxt, 1) : unit_of(adv(slot_nxt), 0);
+                cp_nxt = unit_ptr(un);
             }
             // ---- epilogue: lane holds rows 4*g4..4*g4+3 of each tile for query r of each half ----
             typedef const __attribute__((address_space(4))) float *cfloat_p;
@@ -226,19 +229,37 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
                     xv[e] = a.cosine ? (x > 0.0f ? __frsqrt_rn(x) : 0.0f) : x;
                 }
                 const uint64_t rb = row0 + t * 16 + 4 * g4;
+                // The common case (no key of the 4 rows passes) must be cheap and small: the 24 (tile, half) pairs are
+                // tested through one min each (packed mul/add, same unfused rounding as the sample pass so that tau
+                // stays an upper bound); the append code is a rolled loop.  All 8 waves reach their epilogues
+                // together, so these cycles are not hidden behind a partner wave's MFMAs.
+                const f32x2 xv01 = {xv[0], xv[1]}, xv23 = {xv[2], xv[3]};
 #pragma unroll
                 for (int h = 0; h < NH; h++) {
                     const float tau_h = tau_s[h * 16 + r];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const float key = a.cosine ? -acc[t][h][e] * xv[e] : xv[e] - 2.0f * acc[t][h][e];
-                        if (key <= tau_h && rb + e < n) {  // rare: ~k' * sample step hits per query in total
-                            uint32_t pos = atomicAdd(hit_n, 1u);
-                            if (pos < GEMM_WGBUF) {
-                                hit_key[pos] = pair_key(key, uint32_t(rb + e));
-                                hit_q[pos] = h * 16 + r;
-                            } else {  // buffer full: mark the query as overflowed (-> exact fallback)
-                                atomicAdd(&a.cnt[grp * GEMM_BQ + h * 16 + r], a.cap + 1);
+                    const f32x2 a01 = {acc[t][h][0], acc[t][h][1]}, a23 = {acc[t][h][2], acc[t][h][3]};
+                    f32x2 k01, k23;
+                    if (a.cosine) {
+                        k01 = -a01 * xv01;
+                        k23 = -a23 * xv23;
+                    } else {
+                        const f32x2 two = {2.0f, 2.0f};
+                        k01 = xv01 - two * a01;
+                        k23 = xv23 - two * a23;
+                    }
+                    const float kmin = fminf(fminf(k01.x, k01.y), fminf(k23.x, k23.y));  // NaN keys never pass
+                    if (kmin <= tau_h) {  // rare: ~k' * sample step hits per query in total
+#pragma nounroll
+                        for (int e = 0; e < 4; e++) {
+                            const float key = e == 0 ? k01.x : (e == 1 ? k01.y : (e == 2 ? k23.x : k23.y));
+                            if (key <= tau_h && rb + e < n) {
+                                uint32_t pos = atomicAdd(hit_n, 1u);
+                                if (pos < GEMM_WGBUF) {
+                                    hit_key[pos] = pair_key(key, uint32_t(rb + e));
+                                    hit_q[pos] = h * 16 + r;
+                                } else {  // buffer full: mark the query as overflowed (-> exact fallback)
+                                    atomicAdd(&a.cnt[grp * GEMM_BQ + h * 16 + r], a.cap + 1);
+                                }
                             }
                         }
                     }
@@ -272,6 +293,8 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
             }
             __syncthreads();
         }
+        slot_cur = slot_nxt;
+        slot_nxt = adv(slot_nxt);
     }
 }
 
