@@ -256,7 +256,9 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     const uint64_t ngroups = gemm ? (nq + gq - 1) / gq : 0;
     const uint64_t nq_pad = gemm ? ngroups * gq : (nq + bq - 1) / bq * bq;
     const uint64_t nbatch = nq_pad / bq;
-    const uint64_t n_s = mfma_sample_rows(n);
+    uint32_t s_step = 1, s_rank = kprime;  // threshold sample: every s_step-th item, tau = s_rank-th smallest sampled key
+    mfma_sample_plan(n, kprime, &s_step, &s_rank);
+    const uint64_t n_s = mfma_sample_rows(n, s_step);
     const uint64_t ld_s = (n_s + 63) & ~63ull;
     const uint32_t nl_s = topk_num_lists(n_s);
     constexpr uint32_t CAND_CAP = 8192;
@@ -278,13 +280,13 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
         launch_mfma_pack_queries_nh(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, 8, ws.qfrag_g.as<float>(), s);
     }
     launch_flat_mfma_sample(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>(), (uint32_t)nbatch, d_sq.as<float>(),
-                            cosine, ws.dense.as<float>(), ld_s, num_cu, s);
+                            cosine, s_step, ws.dense.as<float>(), ld_s, num_cu, s);
     if (n_s <= select_tau_max_n()) {  // tau only needs the k'-th smallest sampled key, not a sorted sample shortlist
-        launch_select_tau(ws.dense.as<float>(), ld_s, (uint32_t)n_s, (uint32_t)nq_pad, kprime, d_tau, s);
+        launch_select_tau(ws.dense.as<float>(), ld_s, (uint32_t)n_s, (uint32_t)nq_pad, s_rank, d_tau, s);
     } else {
-        launch_topk_dense(ws.dense.as<float>(), ld_s, n_s, (uint32_t)nq_pad, kprime, ws.lists.as<uint64_t>(), s);
-        launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, capp, (uint32_t)nq_pad, kprime, ws.keys_a.as<uint64_t>(), s);
-        launch_extract_tau(ws.keys_a.as<uint64_t>(), capp, (uint32_t)nq_pad, kprime, d_tau, s);
+        launch_topk_dense(ws.dense.as<float>(), ld_s, n_s, (uint32_t)nq_pad, s_rank, ws.lists.as<uint64_t>(), s);
+        launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, capp, (uint32_t)nq_pad, s_rank, ws.keys_a.as<uint64_t>(), s);
+        launch_extract_tau(ws.keys_a.as<uint64_t>(), capp, (uint32_t)nq_pad, s_rank, d_tau, s);
     }
     // padding queries are zero vectors: under Cosine every row ties at key 0 = tau and would flood the hit buffers of
     // the real queries that share their workgroup batch; tau = -inf lets nothing through
@@ -311,7 +313,7 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     launch_topk_merge(ws.keys_b.as<uint64_t>(), 1, capp, (uint32_t)nq, ksel, ws.keys_c.as<uint64_t>(), s);
     launch_certify(ws.keys_c.as<uint64_t>(), capk, ws.keys_a.as<uint64_t>(), capp, (uint32_t)nq, ksel, kprime, n,
                    ws.qsq.as<float>(), xsq_max, xsq_min_pos, cosine, (uint32_t)dim, ws.flags.as<uint8_t>(), s);
-    launch_flag_overflow(d_hits, CAND_CAP, (uint32_t)nq, ws.flags.as<uint8_t>(), s);
+    launch_flag_overflow(d_hits, CAND_CAP, kprime, (uint32_t)nq, ws.flags.as<uint8_t>(), s);
     launch_finalize(ws.keys_c.as<uint64_t>(), capk, (uint32_t)nq, ksel, (uint32_t)k, id_offset, d_idx, d_dist, d_cnt, s);
     std::vector<uint8_t> flags(nq);
     VDB_HIP(hipMemcpyAsync(flags.data(), ws.flags.p, nq, hipMemcpyDeviceToHost, s));

@@ -381,15 +381,17 @@ void launch_extract_tau(const uint64_t *sorted, uint32_t ld, uint32_t nq, uint32
     hipLaunchKernelGGL(k_extract_tau, dim3((nq + 63) / 64), dim3(64), 0, s, sorted, ld, nq, kprime, tau);
 }
 
-// flags[q] |= 1 when the filter pass dropped candidates of query q (more hits than slots)
-__global__ void k_flag_overflow(const uint32_t *__restrict__ cnt, uint32_t cap, uint32_t nq, uint8_t *__restrict__ flags) {
+// flags[q] |= 1 when the filter pass dropped candidates of query q (more hits than slots) or returned fewer than the
+// k' the shortlist needs (possible only with a thinned threshold sample, see mfma_sample_plan)
+__global__ void k_flag_overflow(const uint32_t *__restrict__ cnt, uint32_t cap, uint32_t min_hits, uint32_t nq,
+                                uint8_t *__restrict__ flags) {
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
-    if (cnt[q] > cap) flags[q] = 1;
+    if (cnt[q] > cap || cnt[q] < min_hits) flags[q] = 1;
 }
-void launch_flag_overflow(const uint32_t *cnt, uint32_t cap, uint32_t nq, uint8_t *flags, hipStream_t s) {
+void launch_flag_overflow(const uint32_t *cnt, uint32_t cap, uint32_t min_hits, uint32_t nq, uint8_t *flags, hipStream_t s) {
     if (nq == 0) return;
-    hipLaunchKernelGGL(k_flag_overflow, dim3((nq + 63) / 64), dim3(64), 0, s, cnt, cap, nq, flags);
+    hipLaunchKernelGGL(k_flag_overflow, dim3((nq + 63) / 64), dim3(64), 0, s, cnt, cap, min_hits, nq, flags);
 }
 
 void launch_certify(const uint64_t *exact_sorted, uint32_t lde, const uint64_t *approx_sorted, uint32_t lda,

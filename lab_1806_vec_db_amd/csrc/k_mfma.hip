@@ -517,14 +517,35 @@ static void flat_mfma_dispatch(const MfmaArgs &a, int num_cu, hipStream_t s) {
 }
 
 uint32_t mfma_num_items(uint64_t n) { return (uint32_t)((n + 16 * MFMA_RT - 1) / (16 * MFMA_RT)); }
-// every `step`-th item is sampled; at least 256 items (8192 rows) when the corpus has that many
-uint32_t mfma_sample_step(uint64_t n) {
-    uint32_t items = mfma_num_items(n);
-    uint32_t step = items / 256;
-    return step < 1 ? 1 : (step > 64 ? 64 : step);
+// Threshold sample: every `step`-th item (32 rows) is scored and tau = the `rank`-th smallest sampled key.  Expected
+// rows with key <= tau over the whole shard: step * rank, aimed at ~2048 per query (candidate lists hold 8192).
+//  - rank = k': tau is an upper bound of the k'-th smallest key of ALL rows (the sample is a subset), so the filter
+//    pass is guaranteed to return at least k' rows;
+//  - large shards (step >= 32) use rank = max(8, k'/4) on a 4x thinner sample: a quarter of the sample-pass and
+//    selection work for the same expected hit count.  The k'-hit guarantee becomes a probability (P[hits < k'] is
+//    below 1e-100 at 256 * 8 expected hits), so it is CHECKED: a query with fewer than k' hits is redone by the exact
+//    scan like any other uncertified query.
+void mfma_sample_plan(uint64_t n, uint32_t kprime, uint32_t *step_out, uint32_t *rank_out) {
+    const uint32_t items = mfma_num_items(n), target = 2048;
+    uint32_t rank = kprime < 1 ? 1 : kprime;
+    uint32_t step = items / 256;  // >= 256 sampled items (8192 rows) when the shard has them
+    step = step < 1 ? 1 : step;
+    uint32_t cap = target / rank < 1 ? 1 : target / rank;
+    if (step > cap) step = cap;
+    if (step >= 32 && items / (4 * step) >= 64) {  // thin the sample 4x, lower the rank 4x
+        uint32_t r4 = kprime / 4 < 8 ? 8 : kprime / 4;
+        if (r4 < rank) {
+            rank = r4;
+            step *= 4;
+            cap = target / rank < 1 ? 1 : target / rank;
+            if (step > cap) step = cap;
+        }
+    }
+    *step_out = step;
+    *rank_out = rank;
 }
-uint64_t mfma_sample_rows(uint64_t n) {
-    uint32_t items = mfma_num_items(n), step = mfma_sample_step(n);
+uint64_t mfma_sample_rows(uint64_t n, uint32_t step) {
+    uint32_t items = mfma_num_items(n);
     return uint64_t((items + step - 1) / step) * 16 * MFMA_RT;
 }
 
@@ -545,12 +566,13 @@ static MfmaArgs mfma_args(const float *XT, uint64_t n, uint32_t dim, const float
 }
 
 void launch_flat_mfma_sample(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t nbatch,
-                             const float *xsq, int cosine, float *out, uint64_t ld, int num_cu, hipStream_t s) {
+                             const float *xsq, int cosine, uint32_t step, float *out, uint64_t ld, int num_cu,
+                             hipStream_t s) {
     if (n == 0 || nbatch == 0) return;
     MfmaArgs a = mfma_args(XT, n, dim, qfrag, nbatch, xsq, cosine);
-    VDB_REQUIRE((ld & 3) == 0 && ld >= mfma_sample_rows(n), "flat_mfma: ld must cover the sample");
+    VDB_REQUIRE(step >= 1 && (ld & 3) == 0 && ld >= mfma_sample_rows(n, step), "flat_mfma: ld must cover the sample");
     VDB_REQUIRE(nbatch <= 65535, "flat_mfma: too many query batches");
-    a.item_step = mfma_sample_step(n);
+    a.item_step = step;
     a.out = out;
     a.ld = ld;
     flat_mfma_dispatch<MODE_SAMPLE>(a, num_cu, s);

@@ -34,7 +34,8 @@ void launch_certify(const uint64_t *exact_sorted, uint32_t lde, const uint64_t *
                     float xsq_min_pos, int cosine, uint32_t dim, uint8_t *flags, hipStream_t s);
 
 void launch_extract_tau(const uint64_t *sorted, uint32_t ld, uint32_t nq, uint32_t kprime, float *tau, hipStream_t s);
-void launch_flag_overflow(const uint32_t *cnt, uint32_t cap, uint32_t nq, uint8_t *flags, hipStream_t s);
+void launch_flag_overflow(const uint32_t *cnt, uint32_t cap, uint32_t min_hits, uint32_t nq, uint8_t *flags,
+                          hipStream_t s);
 
 // ---- k_topk.hip ----------------------------------------------------------------------------
 // rows per level-1 list
@@ -72,10 +73,11 @@ void launch_mfma_pack_queries(const float *Q, uint32_t nq, uint32_t nq_cover, ui
 void launch_tile_rows(const float *X, uint64_t n, uint32_t dim, uint64_t tile0, uint64_t tile1, float *T,
                       hipStream_t s);
 // approximate keys key(i,q) = xsq[i] - 2*dot(x_i, q); XT = fragment-ordered mirror; qfrag = nbatch images.
-// sample: keys of a strided sample of rows, dense: out[q*ld + j], j < mfma_sample_rows(n) (+inf past n)
+// sample: keys of a strided sample of rows, dense: out[q*ld + j], j < mfma_sample_rows(n, step) (+inf past n)
 // cosine != 0: keys are -dot(x_i,q)/|x_i| (0 for zero rows), which rank like the cosine distance
 void launch_flat_mfma_sample(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t nbatch,
-                             const float *xsq, int cosine, float *out, uint64_t ld, int num_cu, hipStream_t s);
+                             const float *xsq, int cosine, uint32_t step, float *out, uint64_t ld, int num_cu,
+                             hipStream_t s);
 // filter: ONE launch walks all nbatch passes; pair keys of all rows with key <= tau[q] land in cand[q][0..cap)
 // (cnt[q] counts every hit, so cnt[q] > cap means candidates were dropped)
 void launch_flat_mfma_filter(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t nbatch,
@@ -91,8 +93,8 @@ uint32_t gemm_group();
 void gemm_set_tw(int v);
 void launch_mfma_pack_queries_nh(const float *Q, uint32_t nq, uint32_t nq_cover, uint32_t dim, uint32_t NH, float *qfrag,
                                  hipStream_t s);
-uint64_t mfma_sample_rows(uint64_t n);
-uint32_t mfma_sample_step(uint64_t n);
+void mfma_sample_plan(uint64_t n, uint32_t kprime, uint32_t *step, uint32_t *rank);
+uint64_t mfma_sample_rows(uint64_t n, uint32_t step);
 size_t mfma_qfrag_floats(uint32_t dim);
 uint32_t mfma_dim_pad(uint32_t dim);  // columns of the mirror / Q images (dim rounded up to 64, zero filled)
 void mfma_set_variant(int v);  // tuning hook (0 = default)
