@@ -43,16 +43,32 @@ __device__ __forceinline__ float epilogue(int metric, float acc, float xsq, floa
 // ---------------------------------------------------------------------------------------------
 // row squared norms (dist_cache, distance/mod.rs:31-36): one thread per row, sequential fold
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_row_sqnorm(const float *__restrict__ X, uint64_t n, uint32_t dim,
-                                                    float *__restrict__ sq) {
-    uint64_t r = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+template <int BS>
+__global__ __launch_bounds__(BS) void k_row_sqnorm(const float *__restrict__ X, uint64_t n, uint32_t dim,
+                                                   float *__restrict__ sq) {
+    uint64_t r = uint64_t(blockIdx.x) * BS + threadIdx.x;
     if (r >= n) return;
     const float *x = X + r * dim;
     float acc = 0.0f;
     if ((dim & 3) == 0) {
+        // the fold is a strict chain, the loads are not: 8 x 16 B per lane in flight (a lane walks its own row, so
+        // every load is a separate line; latency, not bandwidth, is what this kernel waits for)
         const float4 *x4 = reinterpret_cast<const float4 *>(x);
-#pragma unroll 4
-        for (uint32_t j = 0; j < dim / 4; j++) {
+        const uint32_t nv = dim / 4;
+        uint32_t j = 0;
+        for (; j + 8 <= nv; j += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = x4[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                acc = fold1<FOLD_DOT>(acc, v[u].x, v[u].x);
+                acc = fold1<FOLD_DOT>(acc, v[u].y, v[u].y);
+                acc = fold1<FOLD_DOT>(acc, v[u].z, v[u].z);
+                acc = fold1<FOLD_DOT>(acc, v[u].w, v[u].w);
+            }
+        }
+        for (; j < nv; j++) {
             float4 v = x4[j];
             acc = fold1<FOLD_DOT>(acc, v.x, v.x);
             acc = fold1<FOLD_DOT>(acc, v.y, v.y);
@@ -67,7 +83,10 @@ __global__ __launch_bounds__(256) void k_row_sqnorm(const float *__restrict__ X,
 
 void launch_row_sqnorm(const float *X, uint64_t n, uint32_t dim, float *sq, hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_row_sqnorm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, X, n, dim, sq);
+    if (n <= 16384)  // query batches: one wave per workgroup spreads the rows over more CUs
+        hipLaunchKernelGGL(k_row_sqnorm<64>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, X, n, dim, sq);
+    else
+        hipLaunchKernelGGL(k_row_sqnorm<256>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, X, n, dim, sq);
 }
 
 // ---------------------------------------------------------------------------------------------

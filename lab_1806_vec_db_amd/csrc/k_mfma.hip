@@ -525,6 +525,8 @@ uint32_t mfma_num_items(uint64_t n) { return (uint32_t)((n + 16 * MFMA_RT - 1) /
 //    selection work for the same expected hit count.  The k'-hit guarantee becomes a probability (P[hits < k'] is
 //    below 1e-100 at 256 * 8 expected hits), so it is CHECKED: a query with fewer than k' hits is redone by the exact
 //    scan like any other uncertified query.
+static int g_sample_thin = 1;
+void mfma_set_sample_thin(int v) { g_sample_thin = v; }
 void mfma_sample_plan(uint64_t n, uint32_t kprime, uint32_t *step_out, uint32_t *rank_out) {
     const uint32_t items = mfma_num_items(n), target = 2048;
     uint32_t rank = kprime < 1 ? 1 : kprime;
@@ -532,7 +534,7 @@ void mfma_sample_plan(uint64_t n, uint32_t kprime, uint32_t *step_out, uint32_t 
     step = step < 1 ? 1 : step;
     uint32_t cap = target / rank < 1 ? 1 : target / rank;
     if (step > cap) step = cap;
-    if (step >= 32 && items / (4 * step) >= 64) {  // thin the sample 4x, lower the rank 4x
+    if (g_sample_thin && step >= 32 && items / (4 * step) >= 64) {  // thin the sample 4x, lower the rank 4x
         uint32_t r4 = kprime / 4 < 8 ? 8 : kprime / 4;
         if (r4 < rank) {
             rank = r4;

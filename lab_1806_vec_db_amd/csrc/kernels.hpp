@@ -93,6 +93,7 @@ uint32_t gemm_group();
 void gemm_set_tw(int v);
 void launch_mfma_pack_queries_nh(const float *Q, uint32_t nq, uint32_t nq_cover, uint32_t dim, uint32_t NH, float *qfrag,
                                  hipStream_t s);
+void mfma_set_sample_thin(int v);
 void mfma_sample_plan(uint64_t n, uint32_t kprime, uint32_t *step, uint32_t *rank);
 uint64_t mfma_sample_rows(uint64_t n, uint32_t step);
 size_t mfma_qfrag_floats(uint32_t dim);
