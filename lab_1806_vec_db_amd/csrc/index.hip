@@ -293,7 +293,6 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     if (nq_pad > nq)
         VDB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_tau + nq), (int)0xFF800000u, nq_pad - nq, s));
     uint64_t *d_cand = ws.lists.as<uint64_t>();  // the sample lists are dead now
-    VDB_HIP(hipMemsetAsync(d_cand, 0xff, nq_pad * size_t(CAND_CAP) * sizeof(uint64_t), s));
     uint32_t *d_sync = d_hits + nq_pad;
     VDB_HIP(hipMemsetAsync(d_hits, 0, (nq_pad + sync_words) * sizeof(uint32_t), s));
     // algorithmic bytes: one corpus pass (N*d*4) serves 32*share queries (bytes/query = N*d*4 / B)

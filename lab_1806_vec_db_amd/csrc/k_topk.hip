@@ -272,7 +272,9 @@ __global__ __launch_bounds__(64) void k_topk_merge_counted(const uint64_t *__res
     WaveList<R> wl;
     wl.init(k);
     const uint64_t *src = lists + uint64_t(q) * cap;
-    uint32_t total = cnt[q] < cap ? cnt[q] : cap;
+    // cnt > cap: candidates were dropped (or a workgroup hit buffer filled) and the slots are not all written; the query
+    // is redone by its caller, so an empty list is the safe output (no stale slot is ever interpreted as a row id)
+    uint32_t total = cnt[q] <= cap ? cnt[q] : 0;
     uint32_t rounds = (total + 63) / 64;
     // the offers are a serial chain, the loads are not: keep 4 rounds of keys in flight (one wave per query, so the
     // load latency is otherwise paid once per round: 63 us for ~2000 candidates x 1000 queries)

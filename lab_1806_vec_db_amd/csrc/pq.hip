@@ -748,7 +748,6 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
             launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, cape, (uint32_t)gn, efk, ws.keys_a.as<uint64_t>() + g0 * cape, s);
             launch_extract_tau(ws.keys_a.as<uint64_t>() + g0 * cape, cape, (uint32_t)gn, efk, d_tau + g0, s);
             uint64_t *d_cand = ws.lists.as<uint64_t>();  // the sample lists are dead now
-            VDB_HIP(hipMemsetAsync(d_cand, 0xff, gn * size_t(cap) * sizeof(uint64_t), s));
             {
                 AdcArgs a = base;
                 a.nq_total = (uint32_t)gn;
