@@ -151,6 +151,21 @@ int vdb_merge_topk_device(vdb_index *idx, const void *d_dists, const void *d_ids
                           uint64_t n_shards, uint64_t nq, uint64_t k, void *d_out_idx, void *d_out_dist,
                           void *d_out_count, void *stream);
 
+/* ---- IVFIndex (index_algorithm/ivf_index.rs) ------------------------------
+ * from_vec_set (:66-118): k-means over all columns on train_n sampled rows (0 = all; host, RNG = splitmix64(seed),
+ * parity unpinned), then every row joins its nearest centroid (k_means.rs:40-57: CandidatePair order) -- computed on
+ * the GPU in reference arithmetic, bit-exact given the centroids.  Writes to the index (add) drop the clusters. */
+int vdb_ivf_build(vdb_index *idx, uint64_t k_clusters, uint64_t train_n, uint64_t max_iter, float tol, uint64_t seed);
+/* centroids: k_clusters x dim; assign: cluster of every row (n values) or NULL -> computed as above */
+int vdb_ivf_attach(vdb_index *idx, uint64_t k_clusters, const float *centroids, const uint64_t *assign);
+int vdb_ivf_clear(vdb_index *idx);
+int vdb_ivf_info(const vdb_index *idx, int *present, uint64_t *k_clusters, uint64_t *default_n_probes);
+int vdb_ivf_export(vdb_index *idx, float *centroids, uint64_t *assign);
+/* IVFIndex::knn_with_ef (:143-154), ef = n_probes (0 -> default_n_probes = 4, :108): probes by find_n_nearest
+ * (k_means.rs:174-190), then ResultSet::add over the probed clusters in probe order, rows ascending */
+int vdb_ivf_knn(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t n_probes,
+                uint64_t *out_idx, float *out_dist, uint64_t *out_count);
+
 /* ---- row-sharded FlatIndex::knn_pq -------------------------------------------
  * pq_resort (candidate_pair.rs:102-108) replays ResultSet::add in the GLOBAL (ADC distance, id) order, so the
  * exchange carries, per shard and query, max(ef,k) pair keys twice: the ADC key row (ascending) and the exact-distance

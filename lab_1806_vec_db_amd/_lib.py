@@ -54,6 +54,12 @@ SIGNATURES = {
     "vdb_flat_knn_pq_shard_device": [vp, vp, u64, u64, u64, u64, vp, vp, vp],
     "vdb_pq_merge_resort": [u64p, u64p, u64, u64, u64, u64, u64p, f32p, u64p],
     "vdb_pq_merge_resort_device": [vp, vp, vp, u64, u64, u64, u64, vp, vp, vp, vp],
+    "vdb_ivf_build": [vp, u64, u64, u64, C.c_float, u64],
+    "vdb_ivf_attach": [vp, u64, f32p, u64p],
+    "vdb_ivf_clear": [vp],
+    "vdb_ivf_info": [vp, intp, u64p, u64p],
+    "vdb_ivf_export": [vp, f32p, u64p],
+    "vdb_ivf_knn": [vp, f32p, u64, u64, u64, u64, u64p, f32p, u64p],
     "vdb_hnsw_build": [vp, u64, u64, u64, u64, C.c_int],
     "vdb_hnsw_attach": [vp, u64, u64, u32p, u64p, u64p, u32p, u64p, C.c_int, u64, u64],
     "vdb_hnsw_clear": [vp],

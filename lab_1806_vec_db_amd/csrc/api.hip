@@ -102,6 +102,7 @@ int vdb_index_row(const vdb_index *idx, uint64_t i, float *out) {
 
 static void add_common(Index &ix, const float *rows, uint64_t n, uint64_t *first_id, bool on_device) {
     VDB_REQUIRE(rows || n == 0, "null rows");
+    if (ix.ivf.present && n) ivf_clear(ix);  // IVFIndex has no add (built from_vec_set only): the clusters go stale
     if (first_id) *first_id = ix.n;
     if (ix.hnsw.present) {
         // DynamicIndex::add on the HNSW arm (dynamic_index.rs:47-52): HNSWIndex::add per row
@@ -135,6 +136,7 @@ int vdb_index_swap_remove(vdb_index *idx, uint64_t i) {
     VDB_REQUIRE(idx, "null index");
     VDB_REQUIRE(!idx->ix.hnsw.present, "swap_remove needs a Flat index (clear the HNSW graph first)");
     VDB_REQUIRE(!idx->ix.pq.present, "swap_remove invalidates the PQ table: clear it first");
+    VDB_REQUIRE(!idx->ix.ivf.present, "swap_remove invalidates the IVF clusters: clear them first");
     idx->ix.swap_remove(i);
     VDB_API_END
 }
@@ -449,6 +451,54 @@ int vdb_pq_merge_resort_device(vdb_index *idx, const void *d_adc_keys, const voi
                            static_cast<uint64_t *>(d_out_idx), static_cast<float *>(d_out_dist),
                            static_cast<uint64_t *>(d_out_count));
     VDB_SYNC(ws->stream);
+    VDB_API_END
+}
+
+// ---- IVF (index_algorithm/ivf_index.rs) --------------------------------------------------------------
+int vdb_ivf_build(vdb_index *idx, uint64_t k_clusters, uint64_t train_n, uint64_t max_iter, float tol, uint64_t seed) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    ivf_build(idx->ix, k_clusters, train_n, max_iter, tol, seed);
+    VDB_API_END
+}
+int vdb_ivf_attach(vdb_index *idx, uint64_t k_clusters, const float *centroids, const uint64_t *assign) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    ivf_attach(idx->ix, k_clusters, centroids, assign);
+    VDB_API_END
+}
+int vdb_ivf_clear(vdb_index *idx) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    ivf_clear(idx->ix);
+    VDB_API_END
+}
+int vdb_ivf_info(const vdb_index *idx, int *present, uint64_t *k_clusters, uint64_t *default_n_probes) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    if (present) *present = idx->ix.ivf.present ? 1 : 0;
+    if (k_clusters) *k_clusters = idx->ix.ivf.k;
+    if (default_n_probes) *default_n_probes = idx->ix.ivf.default_n_probes;
+    VDB_API_END
+}
+int vdb_ivf_export(vdb_index *idx, float *centroids, uint64_t *assign) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    ivf_export(idx->ix, centroids, assign);
+    VDB_API_END
+}
+static void ivf_dev(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t n_probes,
+                    uint64_t *d_idx, float *d_dist, uint64_t *d_cnt) {
+    ivf_knn_device(ix, ws, d_q, nq, k, n_probes, d_idx, d_dist, d_cnt);
+}
+int vdb_ivf_knn(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t n_probes,
+                uint64_t *out_idx, float *out_dist, uint64_t *out_count) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    check_query_args(idx->ix, queries, nq, dim, out_idx, out_dist);
+    VDB_REQUIRE(idx->ix.ivf.present, "knn needs an IVF index (vdb_ivf_build / vdb_ivf_attach)");
+    if (n_probes == 0) n_probes = idx->ix.ivf.default_n_probes;
+    host_search(idx->ix, queries, nq, k, n_probes, out_idx, out_dist, out_count, ivf_dev);
     VDB_API_END
 }
 

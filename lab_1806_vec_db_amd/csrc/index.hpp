@@ -105,6 +105,18 @@ struct HNSWState {
     std::atomic<uint64_t> last_n_dist{0}, last_n_expanded{0};
 };
 
+struct Index;
+// IVFIndex (ivf_index.rs:34-47): centroids as a small Flat index of their own, clusters as CSR over row ids
+struct IVFState {
+    bool present = false;
+    uint64_t k = 0, default_n_probes = 4;  // :108
+    std::shared_ptr<Index> cent;           // k x dim centroids (find_n_nearest = Flat knn over them)
+    std::vector<uint64_t> assign;          // cluster of every row
+    std::vector<uint32_t> offsets;         // k+1
+    std::vector<uint32_t> sizes_desc;      // cluster sizes, descending (bounds the candidates of n probes)
+    DevBuf d_offsets, d_members;           // u32 [k+1], u32 [n] (ascending id inside a cluster)
+};
+
 struct Index {
     int device = 0;
     int num_cu = 256;
@@ -127,6 +139,7 @@ struct Index {
     std::atomic<uint64_t> fallback_count{0};
     PQState pq;
     HNSWState hnsw;
+    IVFState ivf;
 
     std::mutex ws_mu;
     std::vector<std::unique_ptr<Workspace>> ws_free;

@@ -1,0 +1,194 @@
+// ivf.hip -- IVFIndex (index_algorithm/ivf_index.rs) on the GPU: SURVEY 8(f-4), "a trivially related probe-list scan".
+//
+// Reference semantics restated:
+//  * build (ivf_index.rs:66-118): k-means over all columns (optionally on a random sample), then every row goes to
+//    its nearest centroid under the CandidatePair order (k_means.rs:40-57,166-170); cluster c lists its rows in
+//    ascending id (:95-100).  The assignment is integer work -> bit-exact given the centroids: it runs as an exact
+//    top-1 Flat search of the rows against the centroid set (strict-order distances, ties -> lower centroid).
+//  * search (:143-154): probes = find_n_nearest(query, n_probes) = ResultSet over all centroids in index order, i.e.
+//    Flat knn over the centroids; the members of the probed clusters are offered to ResultSet::add cluster by
+//    cluster in probe order.  `add` replaces only on a strictly smaller DISTANCE (candidate_pair.rs:61-74), so on
+//    exact ties at the cut the earlier-offered row stays: the scan is an ordered replay, not a lexicographic top-k.
+//    Here: (1) probes by the Flat path of the centroid index, (2) the candidate ids of a query are laid out in offer
+//    order, (3) k_rerank computes their exact distances, (4) k_pq_resort replays ResultSet::add over that order
+//    (the same replay FlatIndex::knn_pq uses).
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#include "pq_hnsw.hpp"
+
+namespace vdb {
+
+void ivf_clear(Index &ix) {
+    ix.ivf.present = false;
+    ix.ivf.cent.reset();
+    ix.ivf.assign.clear();
+    ix.ivf.offsets.clear();
+    ix.ivf.sizes_desc.clear();
+    ix.ivf.d_offsets.release();
+    ix.ivf.d_members.release();
+}
+
+// cluster of every row: exact top-1 search of the rows (as queries) against the centroid index
+static void ivf_assign_rows(Index &ix, std::vector<uint64_t> &assign) {
+    Index &cent = *ix.ivf.cent;
+    const uint64_t n = ix.n;
+    assign.resize(n);
+    WsLease ws(cent);
+    hipStream_t s = ws->stream;
+    constexpr uint64_t CHUNK = 8192;
+    ws->out_idx.reserve(CHUNK * sizeof(uint64_t));
+    ws->out_dist.reserve(CHUNK * sizeof(float));
+    ws->out_cnt.reserve(CHUNK * sizeof(uint64_t));
+    for (uint64_t r0 = 0; r0 < n; r0 += CHUNK) {
+        const uint64_t nb = std::min<uint64_t>(CHUNK, n - r0);
+        cent.flat_knn_device(*ws, ix.d_rows.as<float>() + r0 * ix.dim, nb, 1, ws->out_idx.as<uint64_t>(),
+                             ws->out_dist.as<float>(), ws->out_cnt.as<uint64_t>());
+        VDB_HIP(hipMemcpyAsync(assign.data() + r0, ws->out_idx.p, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        VDB_SYNC(s);
+    }
+}
+
+static void ivf_install(Index &ix, uint64_t k, const float *centroids, const uint64_t *assign) {
+    VDB_REQUIRE(k >= 1, "The number of centroids should be greater than 0.");  // k_means.rs:45-48
+    VDB_REQUIRE(ix.n < (1ull << 32), "ivf: too many rows");
+    ivf_clear(ix);
+    IVFState &iv = ix.ivf;
+    iv.k = k;
+    iv.cent = std::make_shared<Index>(ix.device, ix.dim, ix.dist);
+    iv.cent->flat_mode = 1;  // exact scan: the centroid set is small and ties must resolve like ResultSet::add
+    iv.cent->add_rows(centroids, k, false);
+    if (assign) {
+        iv.assign.assign(assign, assign + ix.n);
+        for (uint64_t i = 0; i < ix.n; i++) VDB_REQUIRE(iv.assign[i] < k, "ivf: cluster id out of range");
+    } else {
+        ivf_assign_rows(ix, iv.assign);
+    }
+    // CSR: counting sort keeps ids ascending inside a cluster (ivf_index.rs:98-100 pushes rows in id order)
+    iv.offsets.assign(k + 1, 0);
+    for (uint64_t i = 0; i < ix.n; i++) iv.offsets[iv.assign[i] + 1]++;
+    iv.sizes_desc.assign(iv.offsets.begin() + 1, iv.offsets.end());
+    std::sort(iv.sizes_desc.begin(), iv.sizes_desc.end(), std::greater<uint32_t>());
+    for (uint64_t c = 0; c < k; c++) iv.offsets[c + 1] += iv.offsets[c];
+    std::vector<uint32_t> members(ix.n), cursor(iv.offsets.begin(), iv.offsets.end() - 1);
+    for (uint64_t i = 0; i < ix.n; i++) members[cursor[iv.assign[i]]++] = (uint32_t)i;
+    iv.d_offsets.reserve((k + 1) * sizeof(uint32_t));
+    iv.d_members.reserve(std::max<uint64_t>(ix.n, 1) * sizeof(uint32_t));
+    VDB_HIP(hipMemcpy(iv.d_offsets.p, iv.offsets.data(), (k + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (ix.n) VDB_HIP(hipMemcpy(iv.d_members.p, members.data(), ix.n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    iv.present = true;
+}
+
+void ivf_attach(Index &ix, uint64_t k_clusters, const float *centroids, const uint64_t *assign) {
+    VDB_REQUIRE(centroids, "null centroids");
+    ix.use_device();
+    ivf_install(ix, k_clusters, centroids, assign);
+}
+
+// IVFIndex::from_vec_set (ivf_index.rs:66-118): sample (vec_set.rs:154-163), k-means, assignment
+void ivf_build(Index &ix, uint64_t k_clusters, uint64_t train_n, uint64_t max_iter, float tol, uint64_t seed) {
+    VDB_REQUIRE(ix.n > 0, "Cannot build an IVF index for an empty table");
+    VDB_REQUIRE(k_clusters >= 1, "The number of centroids should be greater than 0.");
+    ix.use_device();
+    const float *rows = ix.host_rows();
+    const size_t n = ix.n, dim = ix.dim;
+    std::vector<float> sample;
+    const float *train = rows;
+    size_t nt = n;
+    uint64_t rng = seed;
+    if (train_n && train_n < n) {
+        std::vector<size_t> perm(n);
+        std::iota(perm.begin(), perm.end(), size_t(0));
+        sample.resize(train_n * dim);
+        for (size_t i = 0; i < train_n; i++) {
+            size_t j = i + host_splitmix64(rng) % (n - i);
+            std::swap(perm[i], perm[j]);
+            std::memcpy(&sample[i * dim], rows + perm[i] * dim, dim * sizeof(float));
+        }
+        train = sample.data();
+        nt = train_n;
+    }
+    std::vector<float> cent(k_clusters * dim);
+    host_kmeans(train, nt, dim, 0, dim, k_clusters, max_iter, tol, ix.dist, rng, cent.data());
+    ivf_install(ix, k_clusters, cent.data(), nullptr);
+}
+
+void ivf_export(Index &ix, float *centroids, uint64_t *assign) {
+    VDB_REQUIRE(ix.ivf.present, "no IVF index");
+    if (centroids) std::memcpy(centroids, ix.ivf.cent->host_rows(), ix.ivf.k * ix.dim * sizeof(float));
+    if (assign) std::memcpy(assign, ix.ivf.assign.data(), ix.n * sizeof(uint64_t));
+}
+
+// candidate ids of query q in offer order: clusters in probe order, rows ascending inside a cluster; PAIR_NONE pads
+__global__ __launch_bounds__(256) void k_ivf_candidates(const uint64_t *__restrict__ probe_idx,
+                                                        const uint64_t *__restrict__ probe_cnt, uint32_t n_probes,
+                                                        const uint32_t *__restrict__ offsets,
+                                                        const uint32_t *__restrict__ members, uint32_t ld,
+                                                        uint64_t *__restrict__ cand) {
+    const uint32_t q = blockIdx.x;
+    uint64_t *row = cand + uint64_t(q) * ld;
+    uint32_t base = 0;
+    const uint32_t np = (uint32_t)probe_cnt[q];
+    for (uint32_t p = 0; p < np; p++) {  // block-uniform
+        const uint32_t c = (uint32_t)probe_idx[uint64_t(q) * n_probes + p];
+        const uint32_t b = offsets[c], e = offsets[c + 1];
+        for (uint32_t j = threadIdx.x; j < e - b; j += blockDim.x) row[base + j] = members[b + j];
+        base += e - b;
+    }
+    for (uint32_t j = base + threadIdx.x; j < ld; j += blockDim.x) row[j] = PAIR_NONE;
+}
+
+void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t n_probes,
+                    uint64_t *d_idx, float *d_dist, uint64_t *d_cnt) {
+    hipStream_t s = ws.stream;
+    IVFState &iv = ix.ivf;
+    if (nq == 0) return;
+    VDB_REQUIRE(n_probes > 0, "The number of probes should be greater than 0.");  // k_means.rs:175-178
+    if (k == 0 || ix.n == 0) {
+        VDB_HIP(hipMemsetAsync(d_cnt, 0, nq * sizeof(uint64_t), s));
+        return;
+    }
+    VDB_REQUIRE(k <= 1024, "ivf knn: k must be <= 1024 in this build");
+    const uint64_t np = std::min<uint64_t>(n_probes, iv.k);
+    VDB_REQUIRE(np <= 1024, "ivf knn: at most 1024 probes in this build");
+    // (1) probes: Flat knn over the centroids on the centroid index's own workspace and stream
+    DevBuf &pidx = ws.lut, &pcnt = ws.flags;  // scratch not used by the Flat exact path of another index
+    pidx.reserve(nq * np * (sizeof(uint64_t) + sizeof(float)));
+    pcnt.reserve(nq * sizeof(uint64_t));
+    uint64_t *d_pidx = pidx.as<uint64_t>();
+    float *d_pdist = reinterpret_cast<float *>(d_pidx + nq * np);
+    {
+        WsLease cws(*iv.cent);
+        VDB_SYNC(s);  // d_q may have been produced on this workspace's stream
+        iv.cent->flat_knn_device(*cws, d_q, nq, np, d_pidx, d_pdist, pcnt.as<uint64_t>());
+        VDB_SYNC(cws->stream);
+    }
+    // (2) candidate lists; the np largest clusters bound every query's candidate count
+    uint64_t bound = 0;
+    for (uint64_t j = 0; j < np; j++) bound += iv.sizes_desc[j];
+    if (bound == 0) {
+        VDB_HIP(hipMemsetAsync(d_cnt, 0, nq * sizeof(uint64_t), s));
+        return;
+    }
+    const uint32_t ld = (uint32_t)((bound + 63) & ~63ull);
+    const uint32_t ksel = (uint32_t)std::min<uint64_t>(k, bound), capk = topk_capacity(ksel);
+    ws.keys_a.reserve(nq * ld * sizeof(uint64_t));
+    ws.keys_b.reserve(nq * ld * sizeof(uint64_t));
+    ws.keys_c.reserve(nq * capk * sizeof(uint64_t));
+    ws.qsq.reserve(nq * sizeof(float));
+    launch_row_sqnorm(d_q, nq, (uint32_t)ix.dim, ws.qsq.as<float>(), s);
+    hipLaunchKernelGGL(k_ivf_candidates, dim3((unsigned)nq), dim3(256), 0, s, d_pidx, pcnt.as<uint64_t>(), (uint32_t)np,
+                       iv.d_offsets.as<uint32_t>(), iv.d_members.as<uint32_t>(), ld, ws.keys_a.as<uint64_t>());
+    // (3) exact distances in offer order, (4) ResultSet::add replay, sorted output (into_sorted_vec, :153)
+    launch_rerank(ix.d_rows.as<float>(), (uint32_t)ix.dim, d_q, (uint32_t)nq, ix.dist == 0 ? MET_L2_DIRECT : MET_COSINE,
+                  ix.d_sq.as<float>(), ws.qsq.as<float>(), ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), ld, ld, s);
+    pq_resort_launch(ws.keys_b.as<uint64_t>(), ld, ld, (uint32_t)nq, ksel, ws.keys_c.as<uint64_t>(), s);
+    if (k > ksel) {
+        VDB_HIP(hipMemsetAsync(d_idx, 0, nq * k * sizeof(uint64_t), s));
+        VDB_HIP(hipMemsetAsync(d_dist, 0, nq * k * sizeof(float), s));
+    }
+    launch_finalize(ws.keys_c.as<uint64_t>(), capk, (uint32_t)nq, ksel, (uint32_t)k, ix.id_offset, d_idx, d_dist, d_cnt, s);
+}
+
+}  // namespace vdb

@@ -270,8 +270,14 @@ __global__ __launch_bounds__(64) void k_pq_resort(const uint64_t *__restrict__ e
 #pragma unroll
     for (int r = 0; r < R; r++) v[r] = PAIR_NONE;
     uint64_t tau = PAIR_NONE;
-    for (uint32_t j = 0; j < ncand; j++) {
-        uint64_t e = exact_keys[uint64_t(q) * ldc + j];  // wave-uniform
+    // the replay is serial, the loads are not: one coalesced load fetches the next 64 keys (lane = position), the
+    // offers then take them lane by lane (ncand runs into the thousands for IVF probe lists)
+    for (uint32_t j0 = 0; j0 < ncand; j0 += 64) {
+      const uint64_t mine = j0 + lane < ncand ? exact_keys[uint64_t(q) * ldc + j0 + lane] : PAIR_NONE;
+      if (__ballot(mine != PAIR_NONE) == 0) continue;
+      const uint32_t jn = ncand - j0 < 64 ? ncand - j0 : 64;
+      for (uint32_t jj = 0; jj < jn; jj++) {
+        uint64_t e = __shfl(mine, jj);  // wave-uniform
         if (e == PAIR_NONE) continue;
         if (uint32_t(e >> 32) >= uint32_t(tau >> 32)) continue;  // full and not strictly closer
         bool placed = false;
@@ -294,6 +300,7 @@ __global__ __launch_bounds__(64) void k_pq_resort(const uint64_t *__restrict__ e
         for (int r = 0; r < R; r++)
             if ((p >> 6) == (uint32_t)r) t = __shfl(v[r], p & 63);
         tau = t;
+      }
     }
 #pragma unroll
     for (int r = 0; r < R; r++) out[uint64_t(q) * (64 * R) + r * 64 + lane] = v[r];
@@ -558,6 +565,12 @@ static void kmeans_group(const float *train, size_t nt, size_t dim, size_t c0, s
 }
 
 // PQTable::from_vec_set (pq_table.rs:141-191): sample, per-group k-means on the host, encode on the GPU
+void host_kmeans(const float *train, size_t nt, size_t dim, size_t c0, size_t c1, size_t k, size_t max_iter, float tol,
+                 int dist, uint64_t seed, float *cent) {
+    kmeans_group(train, nt, dim, c0, c1, k, max_iter, tol, dist, seed, cent);
+}
+uint64_t host_splitmix64(uint64_t &s) { return splitmix64(s); }
+
 void pq_build(Index &ix, uint64_t n_bits, uint64_t m, uint64_t train_n, uint64_t max_iter, float tol,
               uint64_t seed) {
     VDB_REQUIRE(n_bits == 4 || n_bits == 8, "n_bits must be 4 or 8 in PQTable.");

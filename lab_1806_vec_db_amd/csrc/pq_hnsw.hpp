@@ -18,6 +18,21 @@ void pq_merge_resort_device(Index &ix, Workspace &ws, const uint64_t *d_adc, con
                             uint64_t n_shards, uint64_t nq, uint64_t efg, uint64_t k, uint64_t *d_idx, float *d_dist,
                             uint64_t *d_cnt);
 
+// host k-means over columns [c0, c1) (k_means.rs:61-162; RNG = splitmix64, parity unpinned), k x (c1-c0) centroids out
+void host_kmeans(const float *train, size_t nt, size_t dim, size_t c0, size_t c1, size_t k, size_t max_iter, float tol,
+                 int dist, uint64_t seed, float *cent);
+uint64_t host_splitmix64(uint64_t &s);
+void pq_resort_launch(const uint64_t *exact_keys, uint32_t ncand, uint32_t ldc, uint32_t nq, uint32_t k,
+                      uint64_t *out, hipStream_t s);
+
+// ---- IVF (index_algorithm/ivf_index.rs) ----
+void ivf_attach(Index &ix, uint64_t k_clusters, const float *centroids, const uint64_t *assign);
+void ivf_build(Index &ix, uint64_t k_clusters, uint64_t train_n, uint64_t max_iter, float tol, uint64_t seed);
+void ivf_clear(Index &ix);
+void ivf_export(Index &ix, float *centroids, uint64_t *assign);
+void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t n_probes,
+                    uint64_t *d_idx, float *d_dist, uint64_t *d_cnt);
+
 // ---- HNSW (index_algorithm/hnsw_index.rs) ----
 void hnsw_build(Index &ix, uint64_t M, uint64_t ef_construction, uint64_t seed, uint64_t batch, int nthreads);
 void hnsw_attach(Index &ix, uint64_t M, uint64_t ef_construction, const uint32_t *level0, const uint64_t *len0,

@@ -281,6 +281,38 @@ class GpuIndex:
         L.check(self._lib.vdb_hnsw_last_stats(self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
+    # -- IVF (index_algorithm/ivf_index.rs) ---------------------------------------------------------------------
+    def ivf_build(self, k: int, train_n: int = 0, max_iter: int = 20, tol: float = 1e-6, seed: int = 42):
+        """IVFIndex::from_vec_set with IVFConfig{k, k_means_size, k_means_max_iter, k_means_tol} (ivf_index.rs:19-31)."""
+        L.check(self._lib.vdb_ivf_build(self._h, int(k), int(train_n), int(max_iter), float(tol), int(seed)))
+
+    def ivf_attach(self, centroids, assign=None):
+        c = _f32(centroids)
+        a = None if assign is None else np.ascontiguousarray(assign, dtype=np.uint64)
+        L.check(self._lib.vdb_ivf_attach(self._h, c.shape[0], _ptr(c.ravel(), L.f32p), _ptr(a, L.u64p)))
+
+    def ivf_clear(self):
+        L.check(self._lib.vdb_ivf_clear(self._h))
+
+    def ivf_info(self):
+        p, k, d = C.c_int(), C.c_uint64(), C.c_uint64()
+        L.check(self._lib.vdb_ivf_info(self._h, C.byref(p), C.byref(k), C.byref(d)))
+        return {"present": bool(p.value), "k": int(k.value), "default_n_probes": int(d.value)}
+
+    def has_ivf(self) -> bool:
+        return self.ivf_info()["present"]
+
+    def ivf_export(self):
+        info = self.ivf_info()
+        cent = np.zeros((info["k"], self.dim), dtype=np.float32)
+        assign = np.zeros(len(self), dtype=np.uint64)
+        L.check(self._lib.vdb_ivf_export(self._h, _ptr(cent, L.f32p), _ptr(assign, L.u64p)))
+        return {"centroids": cent, "assign": assign}
+
+    def ivf_knn(self, queries, k: int, n_probes: int = 0):
+        """IVFIndex::knn_with_ef (ef = n_probes; 0 -> default 4)."""
+        return self._search(self._lib.vdb_ivf_knn, queries, k, n_probes)
+
     # -- measurement ---------------------------------------------------------------------------------------------
     def prof_enable(self, on: bool = True):
         L.check(self._lib.vdb_prof_enable(self._h, 1 if on else 0))

@@ -84,6 +84,10 @@ def lib():
     L.orc_pq_adc.argtypes = [C.c_void_p, _u8p, _f32p, C.c_float]
     L.orc_pq_adc_all.restype = None
     L.orc_pq_adc_all.argtypes = [C.c_void_p, sz, _f32p, _f32p]
+    L.orc_assign_nearest.restype = None
+    L.orc_assign_nearest.argtypes = [_f32p, sz, sz, C.c_int, _f32p, sz, _u64p]
+    L.orc_ivf_knn.restype = sz
+    L.orc_ivf_knn.argtypes = [_f32p, sz, C.c_int, _f32p, sz, _u64p, _u64p, _f32p, sz, sz, _u64p, _f32p]
     L.orc_flat_knn_pq.restype = sz
     L.orc_flat_knn_pq.argtypes = [_f32p, sz, sz, C.c_int, C.c_void_p, _f32p, sz, sz, _u64p, _f32p]
     L.orc_kmeans.restype = None
@@ -289,6 +293,33 @@ def kmeans(rows, c0, c1, k, max_iter=20, tol=1e-6, kind=L2SQR, seed=42):
     st = np.array([seed], dtype=np.uint64)
     lib().orc_kmeans(_p(rows, _f32p), n, dim, c0, c1, k, max_iter, tol, kind, _p(st, _u64p), _p(out, _f32p))
     return out
+
+
+# ---- IVF ----------------------------------------------------------------
+class IVF:
+    """oracle IVFIndex (ivf_index.rs:34-47) for given centroids: clusters by find_nearest, search by probes."""
+
+    def __init__(self, base, centroids, kind=L2SQR):
+        self.base = _f32(base)
+        self.cents = _f32(centroids)
+        self.kind = kind
+        n, dim = self.base.shape
+        k = self.cents.shape[0]
+        self.assign = np.zeros(n, dtype=np.uint64)
+        lib().orc_assign_nearest(_p(self.base, _f32p), n, dim, kind, _p(self.cents, _f32p), k, _p(self.assign, _u64p))
+        order = np.argsort(self.assign, kind="stable")  # ascending id inside a cluster (ivf_index.rs:98-100)
+        self.members = order.astype(np.uint64)
+        counts = np.bincount(self.assign.astype(np.int64), minlength=k)
+        self.offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+
+    def knn(self, query, k, n_probes=4):
+        query = _f32(query)
+        idx = np.zeros(max(k, 1), dtype=np.uint64)
+        d = np.zeros(max(k, 1), dtype=np.float32)
+        c = lib().orc_ivf_knn(_p(self.base, _f32p), self.base.shape[1], self.kind, _p(self.cents, _f32p),
+                              self.cents.shape[0], _p(self.offsets, _u64p), _p(self.members, _u64p),
+                              _p(query, _f32p), k, n_probes, _p(idx, _u64p), _p(d, _f32p))
+        return idx[:c].copy(), d[:c].copy()
 
 
 # ---- HNSW ---------------------------------------------------------------

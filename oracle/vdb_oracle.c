@@ -378,6 +378,47 @@ void orc_kmeans(const float *rows, size_t n, size_t dim, size_t c0, size_t c1, s
     free(sel);
 }
 
+/* k_means.rs:166-170 (find_nearest, no column selection) for every row: the cluster assignment of
+ * IVFIndex::from_vec_set (ivf_index.rs:92-100) */
+void orc_assign_nearest(const float *base, size_t n, size_t dim, int dist, const float *cents, size_t k, uint64_t *out) {
+    for (size_t i = 0; i < n; i++) out[i] = find_nearest_base(base + i * dim, cents, k, dim, dist);
+}
+
+/* ===================================================================== *
+ * index_algorithm/ivf_index.rs
+ * ===================================================================== */
+/* IVFIndex::knn_with_ef (ivf_index.rs:143-154): find_n_nearest (k_means.rs:174-190) picks the probes, the members of
+ * the probed clusters are offered to ResultSet::add cluster by cluster in ascending id (:95-100 builds them so).
+ * offsets: k_clusters+1, members: n ids grouped by cluster. */
+size_t orc_ivf_knn(const float *base, size_t dim, int dist, const float *cents, size_t k_clusters,
+                   const uint64_t *offsets, const uint64_t *members, const float *query, size_t k, size_t n_probes,
+                   uint64_t *out_idx, float *out_dist) {
+    rset probes;
+    rset_init(&probes, n_probes);
+    for (size_t c = 0; c < k_clusters; c++) {
+        pair_t p = {orc_dist(dist, query, cents + c * dim, dim), c};
+        rset_add(&probes, p);
+    }
+    rset r;
+    rset_init(&r, k);
+    for (size_t j = 0; j < probes.n; j++) {
+        size_t c = (size_t)probes.v[j].i;
+        for (uint64_t t = offsets[c]; t < offsets[c + 1]; t++) {
+            uint64_t i = members[t];
+            pair_t p = {orc_dist(dist, base + i * dim, query, dim), i};
+            rset_add(&r, p);
+        }
+    }
+    size_t cnt = r.n;
+    for (size_t j = 0; j < cnt; j++) {
+        out_idx[j] = r.v[j].i;
+        out_dist[j] = r.v[j].d;
+    }
+    rset_free(&r);
+    rset_free(&probes);
+    return cnt;
+}
+
 /* ===================================================================== *
  * distance/pq_table.rs
  * ===================================================================== */

@@ -90,6 +90,12 @@ void orc_kmeans(const float *rows, size_t n, size_t dim, size_t c0, size_t c1, s
 orc_pq *orc_pq_train(const float *base, size_t n, size_t dim, size_t m, size_t n_bits, int dist,
                      size_t k_means_size /*0 = all*/, size_t max_iter, float tol, uint64_t seed);
 
+/* ---- ivf_index.rs ------------------------------------------------------ */
+void orc_assign_nearest(const float *base, size_t n, size_t dim, int dist, const float *cents, size_t k, uint64_t *out);
+size_t orc_ivf_knn(const float *base, size_t dim, int dist, const float *cents, size_t k_clusters,
+                   const uint64_t *offsets, const uint64_t *members, const float *query, size_t k, size_t n_probes,
+                   uint64_t *out_idx, float *out_dist);
+
 /* ---- hnsw_index.rs ---------------------------------------------------- */
 typedef struct {
     uint64_t dim, m, max_m0, ef_construction, default_ef; /* :75-96, :493-506 */

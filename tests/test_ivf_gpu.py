@@ -1,0 +1,93 @@
+"""GPU parity: IVFIndex (index_algorithm/ivf_index.rs) through the C ABI vs the CPU oracle.
+
+Centroids are RNG-dependent in the reference (parity unpinned) and therefore an INPUT: built once by the library,
+exported, and handed to the oracle.  Given the centroids, the cluster assignment (integer work) and the search results
+(indices and distance bits, including the ResultSet::add replay order on ties) must be identical.
+"""
+import numpy as np
+import pytest
+
+from conftest import gist_like
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import lab_1806_vec_db_amd as vdb
+    from oracle import oracle as O
+    return vdb, O
+
+
+def test_ivf_index_test_restated(mods, gist_base):
+    """ivf_index.rs:161-234: gist_1000 clipped to 12 dims, k = 7 clusters trained on len/10 rows, L2Sqr; knn(row 200,
+    6) with the default 4 probes must return the same indices as FlatIndex, ascending distances."""
+    vdb, O = mods
+    base = np.ascontiguousarray(gist_base[:, :12])
+    ix = vdb.GpuIndex(12, "l2sqr")
+    ix.batch_add(base)
+    ix.ivf_build(7, train_n=len(base) // 10, max_iter=20, tol=1e-6, seed=42)
+    assert ix.has_ivf() and ix.ivf_info() == {"present": True, "k": 7, "default_n_probes": 4}
+    gi, gd = ix.ivf_knn(base[200], 6)
+    fi, fd = ix.flat_knn(base[200], 6)
+    assert gi.tolist() == fi.tolist()
+    assert len(gi) == 6 and np.all(np.diff(gd) >= 0)
+    # and it equals the oracle's IVF on the same centroids
+    ex = ix.ivf_export()
+    iv = O.IVF(base, ex["centroids"], 0)
+    assert np.array_equal(ex["assign"], iv.assign), "GPU cluster assignment differs from find_nearest"
+    oi, od = iv.knn(base[200], 6, 4)
+    assert gi.tolist() == oi.tolist() and np.array_equal(gd, od)
+
+
+@pytest.mark.parametrize("dist,kind", [("l2sqr", 0), ("cosine", 1)])
+def test_ivf_parity_with_ties(mods, dist, kind):
+    vdb, O = mods
+    rng = np.random.default_rng(17)
+    n, dim = 6000, 48
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    base[5000:5040] = base[100:140]  # exact duplicates: equal distances, usually in the same cluster, sometimes not
+    base[5100] = base[7] * np.float32(1.0)  # and a lone duplicate
+    qs = rng.standard_normal((25, dim)).astype(np.float32)
+    qs[:5] = base[100:105] + np.float32(0.01)  # queries next to duplicated rows: ties at the cut
+    ix = vdb.GpuIndex(dim, dist)
+    ix.batch_add(base)
+    ix.ivf_build(23, train_n=1000, max_iter=10, seed=5)
+    ex = ix.ivf_export()
+    iv = O.IVF(base, ex["centroids"], kind)
+    assert np.array_equal(ex["assign"], iv.assign)
+    for k, n_probes in ((1, 1), (10, 4), (10, 0), (40, 3), (7, 23), (5, 100), (1000, 2)):
+        idx, d, cnt = ix.ivf_knn(qs, k, n_probes)
+        for q in range(qs.shape[0]):
+            oi, od = iv.knn(qs[q], k, n_probes if n_probes else 4)
+            c = int(cnt[q])
+            assert c == len(oi), (k, n_probes, q)
+            assert idx[q, :c].tolist() == oi.tolist(), (k, n_probes, q)
+            assert np.array_equal(d[q, :c], od), (k, n_probes, q)
+
+
+def test_ivf_attach_external_and_invalidation(mods):
+    """Reference-built indices come as centroids + clusters (bincode): attach both; writes drop the index."""
+    vdb, O = mods
+    base = gist_like(3000, dim=96, seed=3)
+    cents = O.kmeans(base[:500], 0, 96, 9, 8, 1e-6, 0, 7)
+    iv = O.IVF(base, cents, 0)
+    ix = vdb.GpuIndex(96, "l2sqr")
+    ix.batch_add(base)
+    ix.ivf_attach(cents, iv.assign)
+    qs = gist_like(8, dim=96, seed=4)
+    idx, d, cnt = ix.ivf_knn(qs, 10, 2)
+    for q in range(8):
+        oi, od = iv.knn(qs[q], 10, 2)
+        assert idx[q].tolist() == oi.tolist() and np.array_equal(d[q], od)
+    # attach without clusters: assignment on the GPU
+    ix.ivf_attach(cents)
+    assert np.array_equal(ix.ivf_export()["assign"], iv.assign)
+    with pytest.raises(vdb.VdbError):
+        ix.ivf_attach(cents, np.full(3000, 9, dtype=np.uint64))  # cluster id out of range
+    ix.add(base[0])
+    assert not ix.has_ivf()
+    with pytest.raises(vdb.VdbError):
+        ix.ivf_knn(qs[0], 3)
+    with pytest.raises(vdb.VdbError):
+        ix.ivf_build(0)
