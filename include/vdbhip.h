@@ -72,6 +72,14 @@ int vdb_index_set_id_offset(vdb_index *idx, uint64_t offset);
 /* calc_dist (pyo3/mod.rs:43-48): one distance, evaluated on the GPU in reference order */
 int vdb_calc_dist(int device_id, const float *a, const float *b, uint64_t n, int dist, float *out);
 
+/* ---- u8 scalar (DistanceScalar for u8, distance/mod.rs:79-95) ---------------------------
+ * Every u8 element is converted with `as f32` (exact) before the f32 folds, so a VecSet<u8> index equals the f32
+ * index of the converted rows bit for bit; these entry points convert and forward (rows are held as f32 in HBM). */
+int vdb_calc_dist_u8(int device_id, const uint8_t *a, const uint8_t *b, uint64_t n, int dist, float *out);
+int vdb_index_add_u8(vdb_index *idx, const uint8_t *rows, uint64_t n, uint64_t *first_id);
+int vdb_flat_knn_u8(vdb_index *idx, const uint8_t *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t *out_idx,
+                    float *out_dist, uint64_t *out_count);
+
 /* ---- FlatIndex::knn (flat_index.rs:48-57), batched over nq queries --------------------
  * Any k: up to min(k, len) = 1024 results come from the register-resident select, beyond that from a full
  * (distance, index) radix sort per query.  More than 64 queries in one call are served 128 per corpus pass

@@ -4,6 +4,6 @@ Only the hot path lives here: csrc/ (hand-written gfx950 HIP kernels + the C ABI
 the host-side mirror of the reference's index / VecDB surface.  There is no CPU fallback.
 """
 from ._lib import COSINE, L2SQR, VdbError  # noqa: F401
-from .index import GpuIndex, calc_dist, merge_topk  # noqa: F401
+from .index import GpuIndex, calc_dist, calc_dist_u8, merge_topk  # noqa: F401
 
-__all__ = ["GpuIndex", "calc_dist", "merge_topk", "VdbError", "L2SQR", "COSINE"]
+__all__ = ["GpuIndex", "calc_dist", "calc_dist_u8", "merge_topk", "VdbError", "L2SQR", "COSINE"]

@@ -54,6 +54,9 @@ SIGNATURES = {
     "vdb_flat_knn_pq_shard_device": [vp, vp, u64, u64, u64, u64, vp, vp, vp],
     "vdb_pq_merge_resort": [u64p, u64p, u64, u64, u64, u64, u64p, f32p, u64p],
     "vdb_pq_merge_resort_device": [vp, vp, vp, u64, u64, u64, u64, vp, vp, vp, vp],
+    "vdb_calc_dist_u8": [C.c_int, u8p, u8p, u64, C.c_int, C.POINTER(C.c_float)],
+    "vdb_index_add_u8": [vp, u8p, u64, u64p],
+    "vdb_flat_knn_u8": [vp, u8p, u64, u64, u64, u64p, f32p, u64p],
     "vdb_ivf_build": [vp, u64, u64, u64, C.c_float, u64],
     "vdb_ivf_attach": [vp, u64, f32p, u64p],
     "vdb_ivf_clear": [vp],

@@ -168,6 +168,32 @@ int vdb_calc_dist(int device_id, const float *a, const float *b, uint64_t n, int
     VDB_API_END
 }
 
+// ---- u8 scalar (distance/mod.rs:79-95) -----------------------------------------------------------------
+// DistanceScalar for u8 converts every element with `as f32` (exact for 0..255) and then runs the f32 folds, so a
+// VecSet<u8> index behaves exactly like the f32 index of the converted rows: the u8 entry points convert and forward.
+static std::vector<float> widen_u8(const uint8_t *p, uint64_t count) {
+    std::vector<float> out(count);
+    for (uint64_t i = 0; i < count; i++) out[i] = (float)p[i];
+    return out;
+}
+int vdb_calc_dist_u8(int device_id, const uint8_t *a, const uint8_t *b, uint64_t n, int dist, float *out) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(a && b && out, "null argument");
+    VDB_REQUIRE(n > 0 && n < (1u << 24), "bad length");
+    std::vector<float> fa = widen_u8(a, n), fb = widen_u8(b, n);
+    int rc = vdb_calc_dist(device_id, fa.data(), fb.data(), n, dist, out);
+    if (rc != VDB_OK) return rc;
+    VDB_API_END
+}
+int vdb_index_add_u8(vdb_index *idx, const uint8_t *rows, uint64_t n, uint64_t *first_id) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    VDB_REQUIRE(rows || n == 0, "null rows");
+    std::vector<float> f = widen_u8(rows, n * idx->ix.dim);
+    add_common(idx->ix, f.data(), n, first_id, false);
+    VDB_API_END
+}
+
 // ---- Flat ----------------------------------------------------------------------------------------
 static void check_query_args(const Index &ix, const void *queries, uint64_t nq, uint64_t dim, const void *out_idx,
                              const void *out_dist) {
@@ -238,6 +264,17 @@ static void device_search(Index &ix, const void *d_queries, uint64_t nq, uint64_
        static_cast<float *>(d_out_dist), static_cast<uint64_t *>(d_out_count));
     VDB_SYNC(ws->stream);
     ix.prof_collect(*ws);
+}
+
+int vdb_flat_knn_u8(vdb_index *idx, const uint8_t *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t *out_idx,
+                    float *out_dist, uint64_t *out_count) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    VDB_REQUIRE(nq == 0 || queries, "null argument");
+    std::vector<float> f = widen_u8(queries, nq * dim);
+    check_query_args(idx->ix, f.data(), nq, dim, out_idx, out_dist);
+    host_search(idx->ix, f.data(), nq, k, 0, out_idx, out_dist, out_count, flat_dev);
+    VDB_API_END
 }
 
 int vdb_flat_knn_device(vdb_index *idx, const void *d_queries, uint64_t nq, uint64_t dim, uint64_t k,

@@ -30,11 +30,9 @@ void ivf_clear(Index &ix) {
     ix.ivf.d_members.release();
 }
 
-// cluster of every row: exact top-1 search of the rows (as queries) against the centroid index
-static void ivf_assign_rows(Index &ix, std::vector<uint64_t> &assign) {
-    Index &cent = *ix.ivf.cent;
-    const uint64_t n = ix.n;
-    assign.resize(n);
+// nearest centroid of n device-resident rows (k_means.rs:40-57): exact top-1 search of the rows, as queries, against
+// a Flat index over the centroids -- strict-order distances, ties to the lower centroid index
+static void assign_nearest(Index &cent, const float *d_rows, uint64_t n, uint64_t dim, uint64_t *out) {
     WsLease ws(cent);
     hipStream_t s = ws->stream;
     constexpr uint64_t CHUNK = 8192;
@@ -43,11 +41,15 @@ static void ivf_assign_rows(Index &ix, std::vector<uint64_t> &assign) {
     ws->out_cnt.reserve(CHUNK * sizeof(uint64_t));
     for (uint64_t r0 = 0; r0 < n; r0 += CHUNK) {
         const uint64_t nb = std::min<uint64_t>(CHUNK, n - r0);
-        cent.flat_knn_device(*ws, ix.d_rows.as<float>() + r0 * ix.dim, nb, 1, ws->out_idx.as<uint64_t>(),
-                             ws->out_dist.as<float>(), ws->out_cnt.as<uint64_t>());
-        VDB_HIP(hipMemcpyAsync(assign.data() + r0, ws->out_idx.p, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        cent.flat_knn_device(*ws, d_rows + r0 * dim, nb, 1, ws->out_idx.as<uint64_t>(), ws->out_dist.as<float>(),
+                             ws->out_cnt.as<uint64_t>());
+        VDB_HIP(hipMemcpyAsync(out + r0, ws->out_idx.p, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         VDB_SYNC(s);
     }
+}
+static void ivf_assign_rows(Index &ix, std::vector<uint64_t> &assign) {
+    assign.resize(ix.n);
+    assign_nearest(*ix.ivf.cent, ix.d_rows.as<float>(), ix.n, ix.dim, assign.data());
 }
 
 static void ivf_install(Index &ix, uint64_t k, const float *centroids, const uint64_t *assign) {
@@ -110,7 +112,20 @@ void ivf_build(Index &ix, uint64_t k_clusters, uint64_t train_n, uint64_t max_it
         nt = train_n;
     }
     std::vector<float> cent(k_clusters * dim);
-    host_kmeans(train, nt, dim, 0, dim, k_clusters, max_iter, tol, ix.dist, rng, cent.data());
+    // Lloyd's assignment step on the GPU (k_means.rs:117-120): nt x k x dim strict-order distances per
+    // iteration; seeding, the centroid update and the convergence test stay on the host
+    DevBuf d_train;
+    d_train.reserve(nt * dim * sizeof(float));
+    VDB_HIP(hipMemcpy(d_train.p, train, nt * dim * sizeof(float), hipMemcpyHostToDevice));
+    std::vector<uint64_t> a64(nt);
+    KMeansAssignFn on_gpu = [&](const float *c, uint32_t *assign) {
+        Index tmp(ix.device, ix.dim, ix.dist);
+        tmp.flat_mode = 1;
+        tmp.add_rows(c, k_clusters, false);
+        assign_nearest(tmp, d_train.as<float>(), nt, dim, a64.data());
+        for (size_t i = 0; i < nt; i++) assign[i] = (uint32_t)a64[i];
+    };
+    host_kmeans(train, nt, dim, 0, dim, k_clusters, max_iter, tol, ix.dist, rng, cent.data(), on_gpu);
     ivf_install(ix, k_clusters, cent.data(), nullptr);
 }
 

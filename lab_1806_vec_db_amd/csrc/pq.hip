@@ -501,7 +501,7 @@ static size_t nearest_centroid(const float *v, const float *cents, size_t k, siz
 }
 
 static void kmeans_group(const float *train, size_t nt, size_t dim, size_t c0, size_t c1, size_t k, size_t max_iter,
-                         float tol, int dist, uint64_t seed, float *cent) {
+                         float tol, int dist, uint64_t seed, float *cent, const KMeansAssignFn &assign_fn = nullptr) {
     size_t gd = c1 - c0;
     std::vector<float> sel(nt * gd);
     for (size_t i = 0; i < nt; i++) std::memcpy(&sel[i * gd], train + i * dim + c0, gd * sizeof(float));
@@ -542,11 +542,15 @@ static void kmeans_group(const float *train, size_t nt, size_t dim, size_t c0, s
     // Lloyd (k_means.rs:95-162)
     std::vector<float> sums(k * gd);
     std::vector<size_t> cnt(k);
+    std::vector<uint32_t> asg(assign_fn ? nt : 0);
     for (size_t it = 0; it < max_iter; it++) {
         std::fill(sums.begin(), sums.end(), 0.0f);
         std::fill(cnt.begin(), cnt.end(), 0);
+        // assignment step (k_means.rs:117-120): on the GPU when the caller provides it (same (distance, index) minimum,
+        // same strict-order distances, so the same clusters as the host loop); the sums stay in row order
+        if (assign_fn) assign_fn(cent, asg.data());
         for (size_t i = 0; i < nt; i++) {
-            size_t c = nearest_centroid(&sel[i * gd], cent, k, gd, dist);
+            size_t c = assign_fn ? asg[i] : nearest_centroid(&sel[i * gd], cent, k, gd, dist);
             cnt[c]++;
             for (size_t j = 0; j < gd; j++) sums[c * gd + j] += sel[i * gd + j];
         }
@@ -566,8 +570,8 @@ static void kmeans_group(const float *train, size_t nt, size_t dim, size_t c0, s
 
 // PQTable::from_vec_set (pq_table.rs:141-191): sample, per-group k-means on the host, encode on the GPU
 void host_kmeans(const float *train, size_t nt, size_t dim, size_t c0, size_t c1, size_t k, size_t max_iter, float tol,
-                 int dist, uint64_t seed, float *cent) {
-    kmeans_group(train, nt, dim, c0, c1, k, max_iter, tol, dist, seed, cent);
+                 int dist, uint64_t seed, float *cent, const KMeansAssignFn &assign_fn) {
+    kmeans_group(train, nt, dim, c0, c1, k, max_iter, tol, dist, seed, cent, assign_fn);
 }
 uint64_t host_splitmix64(uint64_t &s) { return splitmix64(s); }
 

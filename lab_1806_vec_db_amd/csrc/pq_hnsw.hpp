@@ -1,5 +1,7 @@
 // pq_hnsw.hpp -- PQ (pq.hip) and HNSW (hnsw.hip, hnsw_build.cpp) entry points used by api.hip.
 #pragma once
+#include <functional>
+
 #include "index.hpp"
 
 namespace vdb {
@@ -19,8 +21,10 @@ void pq_merge_resort_device(Index &ix, Workspace &ws, const uint64_t *d_adc, con
                             uint64_t *d_cnt);
 
 // host k-means over columns [c0, c1) (k_means.rs:61-162; RNG = splitmix64, parity unpinned), k x (c1-c0) centroids out
+// assign_fn (optional): cluster of every training row for the given k centroids (the Lloyd assignment step)
+using KMeansAssignFn = std::function<void(const float *cent, uint32_t *assign)>;
 void host_kmeans(const float *train, size_t nt, size_t dim, size_t c0, size_t c1, size_t k, size_t max_iter, float tol,
-                 int dist, uint64_t seed, float *cent);
+                 int dist, uint64_t seed, float *cent, const KMeansAssignFn &assign_fn = nullptr);
 uint64_t host_splitmix64(uint64_t &s);
 void pq_resort_launch(const uint64_t *exact_keys, uint32_t ncand, uint32_t ldc, uint32_t nq, uint32_t k,
                       uint64_t *out, hipStream_t s);

@@ -44,6 +44,17 @@ def calc_dist(a, b, dist="cosine", device: int = 0) -> float:
     return float(out.value)
 
 
+def calc_dist_u8(a, b, dist="cosine", device: int = 0) -> float:
+    """DistanceAdapter<[u8],[u8]> (distance/mod.rs:79-95,106-113): u8 elements widened exactly, f32 folds."""
+    kind = parse_dist(dist)
+    a = np.ascontiguousarray(a, dtype=np.uint8).ravel()
+    b = np.ascontiguousarray(b, dtype=np.uint8).ravel()
+    n = min(a.size, b.size)
+    out = C.c_float(0)
+    L.check(L.load().vdb_calc_dist_u8(device, _ptr(a, L.u8p), _ptr(b, L.u8p), n, kind, C.byref(out)))
+    return float(out.value)
+
+
 class GpuIndex:
     """One HBM-resident VecSet<f32> with optional PQ table and HNSW graph (DynamicIndex + PQTable)."""
 
@@ -108,6 +119,27 @@ class GpuIndex:
 
     def swap_remove(self, i: int):
         L.check(self._lib.vdb_index_swap_remove(self._h, int(i)))
+
+    def batch_add_u8(self, rows) -> int:
+        """VecSet<u8> rows (widened exactly on the way in, distance/mod.rs:79-95)."""
+        r = np.ascontiguousarray(rows, dtype=np.uint8)
+        r = r.reshape(1, -1) if r.ndim == 1 else r
+        if r.shape[1] != self.dim:
+            raise L.VdbError(f"dimension mismatch: index dim {self.dim}, got {r.shape[1]}")
+        first = C.c_uint64()
+        L.check(self._lib.vdb_index_add_u8(self._h, _ptr(r, L.u8p), r.shape[0], C.byref(first)))
+        return int(first.value)
+
+    def flat_knn_u8(self, queries, k: int):
+        q = np.ascontiguousarray(queries, dtype=np.uint8)
+        q = q.reshape(1, -1) if q.ndim == 1 else q
+        nq, dim = q.shape
+        idx = np.zeros((nq, max(k, 1)), dtype=np.uint64)
+        dist = np.zeros((nq, max(k, 1)), dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.uint64)
+        L.check(self._lib.vdb_flat_knn_u8(self._h, _ptr(q, L.u8p), nq, dim, int(k), _ptr(idx, L.u64p),
+                                          _ptr(dist, L.f32p), _ptr(cnt, L.u64p)))
+        return idx[:, :k], dist[:, :k], cnt
 
     def set_id_offset(self, off: int):
         L.check(self._lib.vdb_index_set_id_offset(self._h, int(off)))

@@ -312,3 +312,24 @@ def test_calc_dist(mods):
     a, b = rng.standard_normal(960).astype(np.float32), rng.standard_normal(960).astype(np.float32)
     for name, kind in (("l2sqr", 0), ("cosine", 1)):
         assert vdb.calc_dist(a, b, name) == O.dist(kind, a, b)
+
+
+def test_u8_scalar_path(mods):
+    """DistanceScalar for u8 (distance/mod.rs:79-95): the KAT of :145-150 and a u8 Flat index against the oracle."""
+    vdb, O = mods
+    assert abs(vdb.calc_dist_u8([1, 2, 3], [2, 4, 6], "cosine") - 0.0) < 1e-6
+    rng = np.random.default_rng(8)
+    a = rng.integers(0, 256, 300, dtype=np.uint8)
+    b = rng.integers(0, 256, 300, dtype=np.uint8)
+    for dist, kind in (("l2sqr", 0), ("cosine", 1)):
+        assert np.float32(vdb.calc_dist_u8(a, b, dist)) == np.float32(O.dist_u8(kind, a, b))
+    base = rng.integers(0, 256, (500, 32), dtype=np.uint8)
+    qs = rng.integers(0, 256, (6, 32), dtype=np.uint8)
+    for dist, kind in (("l2sqr", 0), ("cosine", 1)):
+        ix = vdb.GpuIndex(32, dist)
+        ix.batch_add_u8(base)
+        idx, d, cnt = ix.flat_knn_u8(qs, 7)
+        for q in range(6):
+            ref = sorted((np.float32(O.dist_u8(kind, base[i], qs[q])), i) for i in range(500))[:7]
+            assert idx[q].tolist() == [i for _, i in ref]
+            assert np.array_equal(d[q], np.array([x for x, _ in ref], dtype=np.float32))
