@@ -89,8 +89,9 @@ def test_dims_and_edges(mods, dim, dist):
     ix.batch_add(base[300:])  # growth path
     assert len(ix) == 777
     np.testing.assert_array_equal(ix[776], base[776])
-    for mode in (1, 2):
+    for mode, gemm in ((1, 0), (2, 1), (2, 2)):  # exact scan; MFMA small-batch kernel; 128-query kernel forced
         ix.set_flat_mode(mode)
+        ix.set_param("flat_gemm", gemm)
         for k in (1, 10, 65, 777, 1000):
             idx, dd, cnt = ix.flat_knn(qs, k)
             assert (cnt == min(k, 777)).all()
