@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_topk_dense(const float *__restrict__ ke
 // wide and the histogram is exact (<= 4 passes for 32-bit keys).  +inf (rows past n) and NaN keys sort last and only
 // count.  One workgroup per query; n <= SELECT_MAX_N.  Fewer than kth finite keys -> +inf.
 // ---------------------------------------------------------------------------------------------------
-constexpr uint32_t SELECT_MAX_N = 16384;
+constexpr uint32_t SELECT_MAX_N = 32768;
 uint32_t select_tau_max_n() { return SELECT_MAX_N; }
 
 __global__ __launch_bounds__(256) void k_select_tau(const float *__restrict__ keys, uint64_t ld, uint32_t n, uint32_t kth,
@@ -236,7 +236,7 @@ void launch_select_tau(const float *keys, uint64_t ld, uint32_t n, uint32_t nq, 
     static bool attr_done = false;
     if (!attr_done) {
         VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select_tau),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
         attr_done = true;
     }
     hipLaunchKernelGGL(k_select_tau, dim3(nq), dim3(256), lds, s, keys, ld, n, kth, tau);

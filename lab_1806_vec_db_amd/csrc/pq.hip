@@ -78,8 +78,47 @@ struct AdcArgs {
     uint32_t *cnt;            //         [BQ]
     uint32_t cap;
     uint32_t nq_total;        // queries of the whole launch; blockIdx.y selects the sub-batch of BQ queries
+    int fast;                 // batched-lookup inner loop (tuning switch, vdb_set_param "pq_adc_fast")
 };
+static int g_adc_fast = 1;
+void pq_set_adc_fast(int v) { g_adc_fast = v; }
 constexpr uint32_t ADC_WGBUF = 2048;  // LDS hit buffer entries per workgroup (MODE 1)
+
+// One code row of the Gist1M-shaped table (4-bit codes, every nibble a group, 16-B code words) against 4 lookup tables
+// held entry-major / query-minor in LDS: 8 independent ds_read_b128 per code word half, then the strict-order adds
+// (two packed adds per lookup serve the 4 queries).  A separate, non-inlined function: inside k_pq_adc the register
+// allocator shares 128 VGPRs with every other path of that kernel and spills the loaded entries to scratch.
+template <bool COS>
+__device__ __noinline__ float4 adc_row_fast(const uint4 *cw, uint32_t nwords, const char *lbase, const char *cbase,
+                                            float &cdp_out) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t s01 = {0.0f, 0.0f}, s23 = {0.0f, 0.0f};
+    float cdp = 0.0f;
+    uint4 v = cw[0];
+    for (uint32_t w = 0; w < nwords; w++) {
+        const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+        if (w + 1 < nwords) v = cw[w + 1];  // next code word while this one is looked up
+#pragma unroll
+        for (int wi = 0; wi < 4; wi++) {
+            float4 t[8];
+            float cc[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {  // nibble j of the word = group 32w + 8wi + j (low nibble of a byte first)
+                const uint32_t off = (w * 32 + 8 * wi + j) * 256 + (((words[wi] >> (4 * j)) & 0xf) << 4);
+                t[j] = *reinterpret_cast<const float4 *>(lbase + off);
+                if (COS) cc[j] = *reinterpret_cast<const float *>(cbase + (off >> 2));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                s01 += (f32x2_t){t[j].x, t[j].y};
+                s23 += (f32x2_t){t[j].z, t[j].w};
+                if (COS) cdp = cdp + cc[j];
+            }
+        }
+    }
+    cdp_out = cdp;
+    return make_float4(s01.x, s01.y, s23.x, s23.y);
+}
 
 template <int BQ, int NBITS, bool LUT_IN_LDS, int MODE>
 __global__ __launch_bounds__(1024) void k_pq_adc(AdcArgs a) {
@@ -163,7 +202,24 @@ __global__ __launch_bounds__(1024) void k_pq_adc(AdcArgs a) {
             }
             if (cosine) cdp = cdp + ccache[at];
         };
-        if ((enc_dim & 15) == 0) {  // 16 code bytes per load
+        if (LUT_IN_LDS && BQ == 4 && NBITS == 4 && a.fast && (enc_dim & 15) == 0 && m == 2 * enc_dim) {
+            // Fast path (the Gist1M table: m = 320, 4 bit, 160-B code rows): every nibble is a group, so no bound checks,
+            // and the 8 lookups of a code word are issued together -- addresses first, then 8 independent
+            // ds_read_b128, then the strict-order adds.  (The generic path below waits for each lookup before it
+            // issues the next and branches per nibble: measured 24.6 us per query and 1M rows against an LDS-gather
+            // floor of ~8 us.)
+            float4 r4;
+            if (cosine)
+                r4 = adc_row_fast<true>(reinterpret_cast<const uint4 *>(cr), enc_dim / 16, reinterpret_cast<const char *>(smem),
+                                        reinterpret_cast<const char *>(ccache), cdp);
+            else
+                r4 = adc_row_fast<false>(reinterpret_cast<const uint4 *>(cr), enc_dim / 16, reinterpret_cast<const char *>(smem),
+                                         nullptr, cdp);
+            sum[0] = r4.x;
+            sum[1 % BQ] = r4.y;
+            sum[2 % BQ] = r4.z;
+            sum[3 % BQ] = r4.w;
+        } else if ((enc_dim & 15) == 0) {  // 16 code bytes per load
             const uint4 *cw = reinterpret_cast<const uint4 *>(cr);
             for (uint32_t w = 0; w < enc_dim / 16; w++) {
                 const uint4 v = cw[w];
@@ -708,6 +764,7 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
     base.cent_cache = pq.d_cent_cache.as<float>();
     base.cosine = ix.dist == 1 ? 1 : 0;
     base.blk_step = 1;
+    base.fast = g_adc_fast;
 
     // dense path for one group of queries: every ADC distance, then the wave select (also the overflow fallback)
     auto dense_group = [&](uint64_t g0, uint64_t gn) {
@@ -761,9 +818,13 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
                 a.ld = ld_s;
                 adc_launch<0>(ix, ws, BQ, a);
             }
-            launch_topk_dense(ws.dense.as<float>(), ld_s, n_s, (uint32_t)gn, efk, ws.lists.as<uint64_t>(), s);
-            launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, cape, (uint32_t)gn, efk, ws.keys_a.as<uint64_t>() + g0 * cape, s);
-            launch_extract_tau(ws.keys_a.as<uint64_t>() + g0 * cape, cape, (uint32_t)gn, efk, d_tau + g0, s);
+            if (n_s <= select_tau_max_n()) {  // tau = efk-th smallest sampled ADC value: a selection, not a sort
+                launch_select_tau(ws.dense.as<float>(), ld_s, (uint32_t)n_s, (uint32_t)gn, efk, d_tau + g0, s);
+            } else {
+                launch_topk_dense(ws.dense.as<float>(), ld_s, n_s, (uint32_t)gn, efk, ws.lists.as<uint64_t>(), s);
+                launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, cape, (uint32_t)gn, efk, ws.keys_a.as<uint64_t>() + g0 * cape, s);
+                launch_extract_tau(ws.keys_a.as<uint64_t>() + g0 * cape, cape, (uint32_t)gn, efk, d_tau + g0, s);
+            }
             uint64_t *d_cand = ws.lists.as<uint64_t>();  // the sample lists are dead now
             {
                 AdcArgs a = base;
