@@ -334,3 +334,43 @@ def test_u8_scalar_path(mods):
             ref = sorted((np.float32(O.dist_u8(kind, base[i], qs[q])), i) for i in range(500))[:7]
             assert idx[q].tolist() == [i for _, i in ref]
             assert np.array_equal(d[q], np.array([x for x, _ in ref], dtype=np.float32))
+
+
+@pytest.mark.parametrize("dist,kind", [("l2sqr", 0), ("cosine", 1)])
+def test_gemm_filter_adversarial_duplicates(mods, dist, kind):
+    """15000 copies of one row: a query near it gets more hits than a candidate list holds (and the workgroup hit
+    buffers fill).  Such queries must be flagged and redone by the exact scan, never answered from a truncated list;
+    the other queries of the same 128-query group may be flagged with them but must stay exact too."""
+    vdb, O = mods
+    rng = np.random.default_rng(99)
+    n, dim, nq = 40000, 64, 70
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    base[10000:25000] = base[7]
+    qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    qs[0] = base[7]
+    qs[1] = base[7] + np.float32(0.001)
+    ix = vdb.GpuIndex(dim, dist)
+    ix.batch_add(base)
+    ix.set_flat_mode(2)
+    idx, d, cnt = ix.flat_knn(qs, 10)
+    assert ix.flat_fallback_count() >= 2
+    oi, od, oc = O.flat_knn_batch(base, qs, 10, kind, nthreads=8)
+    for q in range(nq):
+        _check(idx[q], d[q], oi[q], od[q])
+
+
+def test_gemm_no_hit_detection(mods):
+    """flat_gemm_debug = 1 makes the filter pass return nothing: every query has fewer than k' hits, which must be
+    detected (the thinned threshold sample only makes k' hits overwhelmingly likely, not certain) and redone exactly."""
+    vdb, O = mods
+    base = gist_like(30000, dim=96, seed=41)
+    qs = gist_like(100, dim=96, seed=42)
+    ix = vdb.GpuIndex(96, "l2sqr")
+    ix.batch_add(base)
+    ix.set_flat_mode(2)
+    ix.set_param("flat_gemm_debug", 1)
+    idx, d, cnt = ix.flat_knn(qs, 10)
+    assert ix.flat_fallback_count() == 100
+    oi, od, oc = O.flat_knn_batch(base, qs, 10, 0, nthreads=8)
+    for q in range(100):
+        _check(idx[q], d[q], oi[q], od[q])
