@@ -21,7 +21,16 @@
 #include <mutex>
 #include <thread>
 
+#include <atomic>
+#include <functional>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include "pq_hnsw.hpp"
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #pragma clang fp contract(off)
 
@@ -379,6 +388,57 @@ struct Scratch {
     }
 };
 
+// ---- 8 strict-order dot products at once (host) ---------------------------------------------------------
+// The builder spends its time in dist_cached(): a left fold whose adds form one dependent chain per distance
+// (distance/mod.rs:72-74), so a scalar core retires one product-add per ~4 cycles.  Eight DIFFERENT distances
+// against one fixed vector are eight independent chains: one AVX2 lane each, products and sums rounded separately
+// exactly as in the scalar fold (mul then add, no FMA), so every result is bit-identical to dot().  Rows are
+// transposed 8 x 8 in registers (each row is read in 32-B pieces).
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static void dot8_avx2(const float *fixed, const float *const rows[8], uint64_t dim, float out[8]) {
+    __m256 acc = _mm256_setzero_ps();
+    uint64_t i = 0;
+    for (; i + 8 <= dim; i += 8) {
+        __m256 r0 = _mm256_loadu_ps(rows[0] + i), r1 = _mm256_loadu_ps(rows[1] + i);
+        __m256 r2 = _mm256_loadu_ps(rows[2] + i), r3 = _mm256_loadu_ps(rows[3] + i);
+        __m256 r4 = _mm256_loadu_ps(rows[4] + i), r5 = _mm256_loadu_ps(rows[5] + i);
+        __m256 r6 = _mm256_loadu_ps(rows[6] + i), r7 = _mm256_loadu_ps(rows[7] + i);
+        __m256 t0 = _mm256_unpacklo_ps(r0, r1), t1 = _mm256_unpackhi_ps(r0, r1);
+        __m256 t2 = _mm256_unpacklo_ps(r2, r3), t3 = _mm256_unpackhi_ps(r2, r3);
+        __m256 t4 = _mm256_unpacklo_ps(r4, r5), t5 = _mm256_unpackhi_ps(r4, r5);
+        __m256 t6 = _mm256_unpacklo_ps(r6, r7), t7 = _mm256_unpackhi_ps(r6, r7);
+        __m256 u0 = _mm256_shuffle_ps(t0, t2, 0x44), u1 = _mm256_shuffle_ps(t0, t2, 0xEE);
+        __m256 u2 = _mm256_shuffle_ps(t1, t3, 0x44), u3 = _mm256_shuffle_ps(t1, t3, 0xEE);
+        __m256 u4 = _mm256_shuffle_ps(t4, t6, 0x44), u5 = _mm256_shuffle_ps(t4, t6, 0xEE);
+        __m256 u6 = _mm256_shuffle_ps(t5, t7, 0x44), u7 = _mm256_shuffle_ps(t5, t7, 0xEE);
+        __m256 c[8];  // c[k] lane j = rows[j][i + k]
+        c[0] = _mm256_permute2f128_ps(u0, u4, 0x20);
+        c[1] = _mm256_permute2f128_ps(u1, u5, 0x20);
+        c[2] = _mm256_permute2f128_ps(u2, u6, 0x20);
+        c[3] = _mm256_permute2f128_ps(u3, u7, 0x20);
+        c[4] = _mm256_permute2f128_ps(u0, u4, 0x31);
+        c[5] = _mm256_permute2f128_ps(u1, u5, 0x31);
+        c[6] = _mm256_permute2f128_ps(u2, u6, 0x31);
+        c[7] = _mm256_permute2f128_ps(u3, u7, 0x31);
+        for (int k = 0; k < 8; k++) {
+            __m256 p = _mm256_mul_ps(_mm256_broadcast_ss(fixed + i + k), c[k]);
+            acc = _mm256_add_ps(acc, p);
+        }
+    }
+    alignas(32) float a[8];
+    _mm256_store_ps(a, acc);
+    for (; i < dim; i++)
+        for (int j = 0; j < 8; j++) {
+            float p = fixed[i] * rows[j][i];
+            a[j] = a[j] + p;
+        }
+    for (int j = 0; j < 8; j++) out[j] = a[j];
+}
+static const bool g_have_avx2 = __builtin_cpu_supports("avx2");
+#else
+static const bool g_have_avx2 = false;
+#endif
+
 struct Builder {
     HNSWState &h;
     const float *rows;
@@ -391,6 +451,7 @@ struct Builder {
         float operator[](uint64_t i) const { return dist == 0 ? sq[i] : std::sqrt(sq[i]); }
     };
     CacheView cache{nullptr, 0};
+    double t_search = 0, t_connect = 0;  // wall seconds of the parallel candidate phase / the serial linking phase
     Builder(HNSWState &hh, const float *r, const float *s, uint64_t d, int ds)
         : h(hh), rows(r), sq(s), dim(d), dist(ds), cache{s, ds} {}
 
@@ -413,6 +474,35 @@ struct Builder {
         return 1.0f - dot(a, b) / den;
     }
     float to_query(uint64_t idx, const float *q, float qc) const { return dist_cached(rows + idx * dim, q, cache[idx], qc); }
+    // dist_cached(rows[ids[j]], fixed) for j < cnt: the same values as to_query / inner one by one (every factor pair
+    // and every sum is rounded identically; the operands of each commutative step are merely swapped)
+    void dist_many(const float *fixed, float cfixed, const uint32_t *ids, size_t cnt, float *out) const {
+        size_t j = 0;
+#if defined(__x86_64__)
+        if (g_have_avx2) {
+            while (cnt - j >= 3) {  // groups of up to 8; a short group is padded with its first row
+                const size_t m = cnt - j < 8 ? cnt - j : 8;
+                const float *r[8];
+                for (size_t t = 0; t < 8; t++) r[t] = rows + uint64_t(ids[j + (t < m ? t : 0)]) * dim;
+                float d8[8];
+                dot8_avx2(fixed, r, dim, d8);
+                for (size_t t = 0; t < m; t++) {
+                    const float cb = cache[ids[j + t]];
+                    if (dist == 0) {
+                        float s2 = cb + cfixed;
+                        float t2 = 2.0f * d8[t];
+                        out[j + t] = s2 - t2;
+                    } else {
+                        float den = std::fmax(cb * cfixed, 1e-10f);
+                        out[j + t] = 1.0f - d8[t] / den;
+                    }
+                }
+                j += m;
+            }
+        }
+#endif
+        for (; j < cnt; j++) out[j] = dist_cached(rows + uint64_t(ids[j]) * dim, fixed, cache[ids[j]], cfixed);
+    }
     float inner(uint64_t a, uint64_t b) const { return dist_cached(rows + a * dim, rows + b * dim, cache[a], cache[b]); }
 
     const uint32_t *links(uint64_t v, uint64_t level, size_t &len) const {
@@ -450,11 +540,29 @@ struct Builder {
             if (!res.check_candidate(p)) break;
             size_t len;
             const uint32_t *lk = links(p.i, level, len);
+            // unvisited neighbours in link order, their distances 8 at a time, then the same add / push sequence
+            uint32_t fresh[256];
+            float fd[256];
+            size_t nf = 0;
             for (size_t j = 0; j < len; j++) {
                 uint64_t nb = lk[j];
                 if (s.stamp[nb] == s.epoch) continue;
                 s.stamp[nb] = s.epoch;
-                Pair np{to_query(nb, q, qc), nb};
+                fresh[nf++] = (uint32_t)nb;
+                if (nf == 256) {  // max_m0 <= 20000 in the reference; flush in blocks
+                    dist_many(q, qc, fresh, nf, fd);
+                    for (size_t t = 0; t < nf; t++) {
+                        Pair np{fd[t], fresh[t]};
+                        res.add(np);
+                        s.heap.push_back(np);
+                        std::push_heap(s.heap.begin(), s.heap.end(), cmp);
+                    }
+                    nf = 0;
+                }
+            }
+            dist_many(q, qc, fresh, nf, fd);
+            for (size_t t = 0; t < nf; t++) {
+                Pair np{fd[t], fresh[t]};
                 res.add(np);
                 s.heap.push_back(np);
                 std::push_heap(s.heap.begin(), s.heap.end(), cmp);
@@ -471,10 +579,11 @@ struct Builder {
                 bool flag = false;
                 size_t len;
                 const uint32_t *lk = links(cur, level, len);
+                std::vector<float> nd(len);
+                dist_many(q, qc, lk, len, nd.data());
                 for (size_t j = 0; j < len; j++) {
-                    float nd = to_query(lk[j], q, qc);
-                    if (nd < cur_d) {
-                        cur_d = nd;
+                    if (nd[j] < cur_d) {
+                        cur_d = nd[j];
                         cur = lk[j];
                         flag = true;
                     }
@@ -488,11 +597,14 @@ struct Builder {
     // ResultSet::heuristic (candidate_pair.rs:85-99)
     std::vector<uint32_t> heuristic(const RSet &set, size_t m) const {
         std::vector<uint32_t> out;
+        std::vector<float> dd(m);
         for (const Pair &p : set.v) {
             if (out.size() >= m) break;
             bool ok = true;
-            for (uint32_t t : out)
-                if (!(inner(p.i, t) >= p.d)) {
+            // all inner(p, t) of the selected t at once; the first failing one decides, as in the early-exit loop
+            dist_many(rows + p.i * dim, cache[p.i], out.data(), out.size(), dd.data());
+            for (size_t t = 0; t < out.size(); t++)
+                if (!(dd[t] >= p.d)) {
                     ok = false;
                     break;
                 }
@@ -512,7 +624,9 @@ struct Builder {
             return;
         }
         RSet set(limit + 1);
-        for (uint32_t t : l) set.add(Pair{inner(v, t), t});
+        std::vector<float> dv(l.size());
+        dist_many(rows + v * dim, cache[v], l.data(), l.size(), dv.data());
+        for (size_t t = 0; t < l.size(); t++) set.add(Pair{dv[t], l[t]});
         put_links(v, level, heuristic(set, limit));
     }
     // connect_new_links (hnsw_index.rs:226-239)
@@ -565,6 +679,7 @@ struct Builder {
         }
         for (uint64_t i = 0; i < nb; i++) push_init(first + i, levels[i]);
         const uint64_t enter_point = h.enter_point, enter_level = h.enter_level;
+        const auto t_begin = std::chrono::steady_clock::now();
         std::vector<std::vector<RSet>> cands(nb);
         auto work = [&](uint64_t i, Scratch &s) {
             uint64_t idx = first + i, level = h.vec_level[idx];
@@ -575,8 +690,13 @@ struct Builder {
             for (uint64_t l = top + 1; l-- > 0;) {
                 RSet c = search_on_level(cur, l, h.ef_construction, q, qc, s);
                 cur = c.v.front().i;
-                for (uint64_t r = 0; r < i; r++)  // rhs_idx < idx && vec_level[rhs] >= level (:431-437)
-                    if (h.vec_level[first + r] >= l) c.add(Pair{inner(idx, first + r), first + r});
+                // rhs_idx < idx && vec_level[rhs] >= level (:431-437)
+                std::vector<uint32_t> rhs;
+                for (uint64_t r = 0; r < i; r++)
+                    if (h.vec_level[first + r] >= l) rhs.push_back((uint32_t)(first + r));
+                std::vector<float> rd(rhs.size());
+                dist_many(q, qc, rhs.data(), rhs.size(), rd.data());
+                for (size_t r = 0; r < rhs.size(); r++) c.add(Pair{rd[r], rhs[r]});
                 cands[i].push_back(std::move(c));
             }
         };
@@ -592,12 +712,61 @@ struct Builder {
                 });
             for (auto &x : th) x.join();
         }
-        for (uint64_t i = 0; i < nb; i++) {
-            uint64_t idx = first + i, level = h.vec_level[idx];
-            uint64_t top = std::min(level, enter_level);
-            size_t slot = 0;
-            for (uint64_t l = top + 1; l-- > 0;) connect_new_links(idx, l, cands[i][slot++]);
+        const auto t_mid = std::chrono::steady_clock::now();
+        // Linking (hnsw_index.rs:446-450 runs connect_new_links node by node).  Everything it computes is a function of
+        // distances and of ONE link list at a time: heuristic(candidates) reads no graph state, put_links(v) writes
+        // list (v, level), arrange_links(t, level, v) reads and writes list (t, level) only.  So the serial order only
+        // matters per list: the selections run in parallel, then the events are grouped by (node, level) in their
+        // serial order and the groups run in parallel -- the same lists as the node-by-node loop, bit for bit
+        // (an earlier batch member can be a later member's neighbour, never the reverse, so a list's put comes first).
+        struct Ev {
+            uint64_t key;   // (list owner << 8) | level
+            uint32_t seq;   // position in the serial order
+            uint32_t v;     // new node
+            int32_t sel;    // >= 0: put_links(owner = v, selections[sel]); < 0: arrange_links(owner, level, v)
+        };
+        std::vector<std::pair<uint32_t, uint32_t>> jobs;  // (batch member, slot)
+        for (uint64_t i = 0; i < nb; i++)
+            for (size_t sl = 0; sl < cands[i].size(); sl++) jobs.emplace_back((uint32_t)i, (uint32_t)sl);
+        std::vector<std::vector<uint32_t>> selections(jobs.size());
+        auto run_parallel = [&](size_t count, const std::function<void(size_t)> &fn) {
+            if (nt == 1 || count < 2) {
+                for (size_t j = 0; j < count; j++) fn(j);
+                return;
+            }
+            std::atomic<size_t> next{0};
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; t++)
+                th.emplace_back([&]() {
+                    for (size_t j; (j = next.fetch_add(1)) < count;) fn(j);
+                });
+            for (auto &x : th) x.join();
+        };
+        run_parallel(jobs.size(), [&](size_t j) { selections[j] = heuristic(cands[jobs[j].first][jobs[j].second], h.m); });
+        std::vector<Ev> evs;
+        for (size_t j = 0; j < jobs.size(); j++) {  // jobs are in the serial order: node by node, top level first
+            const uint64_t idx = first + jobs[j].first, level = h.vec_level[idx];
+            const uint64_t l = std::min(level, enter_level) - jobs[j].second;
+            evs.push_back({(idx << 8) | l, (uint32_t)evs.size(), (uint32_t)idx, (int32_t)j});
+            for (uint32_t t : selections[j]) evs.push_back({(uint64_t(t) << 8) | l, (uint32_t)evs.size(), (uint32_t)idx, -1});
         }
+        std::sort(evs.begin(), evs.end(), [](const Ev &a, const Ev &b) { return a.key != b.key ? a.key < b.key : a.seq < b.seq; });
+        std::vector<size_t> gstart;
+        for (size_t e = 0; e < evs.size(); e++)
+            if (e == 0 || evs[e].key != evs[e - 1].key) gstart.push_back(e);
+        gstart.push_back(evs.size());
+        run_parallel(gstart.size() - 1, [&](size_t g) {
+            for (size_t e = gstart[g]; e < gstart[g + 1]; e++) {
+                const uint64_t owner = evs[e].key >> 8, l = evs[e].key & 0xff;
+                if (evs[e].sel >= 0)
+                    put_links(owner, l, selections[evs[e].sel]);
+                else
+                    arrange_links(owner, l, evs[e].v);
+            }
+        });
+        const auto t_end = std::chrono::steady_clock::now();
+        t_search += std::chrono::duration<double>(t_mid - t_begin).count();
+        t_connect += std::chrono::duration<double>(t_end - t_mid).count();
         for (uint64_t i = 0; i < nb; i++) {
             uint64_t idx = first + i;
             if (h.vec_level[idx] > h.enter_level) {
@@ -673,6 +842,9 @@ void hnsw_build(Index &ix, uint64_t M, uint64_t ef_construction, uint64_t seed, 
         b.add_batch(cur, next - cur, levels.data() + cur, nthreads, s);
         cur = next;
     }
+    if (std::getenv("VDB_HNSW_PROF"))
+        std::fprintf(stderr, "hnsw_build: n=%llu candidate phase %.1f s (%d threads), linking phase %.1f s\n",
+                     (unsigned long long)n, b.t_search, nthreads, b.t_connect);
     h.present = true;
     h.dev_dirty = true;
 }
