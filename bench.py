@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=1_000_000)
+    ap.add_argument("--rows", type=int, default=0, help="corpus rows (default: 1,000,000 = Gist1M)")
     ap.add_argument("--dim", type=int, default=960)
     ap.add_argument("--nq", type=int, default=1000)
     ap.add_argument("--k", type=int, default=10)
@@ -94,8 +94,8 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     wl = args.workload
-    if wl == "hnsw" and args.rows == 1_000_000:
-        args.rows = 100_000  # the serial-insert host builder (hnsw_index.rs:493-572 order) needs minutes per 100k rows
+    if args.rows <= 0:
+        args.rows = 1_000_000  # hnsw: the host builder (hnsw_index.rs:391-457 batches) takes ~3-4 min for this graph
     ef = args.ef or (100 if wl == "pq_flat" else 128)
     n, dim, nq, k = args.rows, args.dim, args.nq, args.k
     # identical corpus on every rank (same seed), each keeps its row block
