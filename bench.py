@@ -71,8 +71,8 @@ def main():
     import torch.distributed as dist
 
     import lab_1806_vec_db_amd as vdb
-    from lab_1806_vec_db_amd.shard import (allgather_concat, allgather_merge, allgather_merge_pq, replica_query_slice,
-                                           shard_bounds)
+    from lab_1806_vec_db_amd.shard import (ShardExchange, allgather_concat, allgather_merge, allgather_merge_pq,
+                                           replica_query_slice, shard_bounds)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -129,9 +129,9 @@ def main():
     del base, shard
     torch.cuda.empty_cache()
 
-    o_idx = torch.zeros((nq, k), dtype=torch.int64, device=device)
-    o_dist = torch.zeros((nq, k), dtype=torch.float32, device=device)
-    o_cnt = torch.zeros((nq,), dtype=torch.int64, device=device)
+    # the local results live in the send block of the per-step exchange (typed views, no packing)
+    ex = ShardExchange(nq, k, device, world if backend == "nccl" else 1)
+    o_idx, o_dist, o_cnt = ex.idx, ex.dist, ex.cnt
 
     host_xchg = backend != "nccl" and world > 1
     efk = max(ef, k)
@@ -145,7 +145,7 @@ def main():
             ix.flat_knn_device(queries.data_ptr(), nq, k, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr())
             if host_xchg:
                 return allgather_merge(o_idx.cpu(), o_dist.cpu(), o_cnt.cpu(), k)
-            return allgather_merge(o_idx, o_dist, o_cnt, k, gpu_index=ix)
+            return ex.exchange_merge(ix)
         if wl == "pq_flat":
             if world == 1:
                 ix.knn_pq_device(queries.data_ptr(), nq, k, ef, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr())

@@ -74,6 +74,7 @@ SIGNATURES = {
     "vdb_hnsw_last_stats": [vp, u64p, u64p],
     "vdb_merge_topk": [f32p, u64p, u64p, u64, u64, u64, u64p, f32p, u64p],
     "vdb_merge_topk_device": [vp, vp, vp, vp, u64, u64, u64, vp, vp, vp, vp],
+    "vdb_merge_topk_gathered": [vp, vp, u64, u64, u64, u64, u64, u64, u64, vp, vp, vp, vp],
     "vdb_prof_enable": [vp, C.c_int],
     "vdb_prof_reset": [vp],
     "vdb_prof_get": [vp, C.c_char_p, f64p, u64p, f64p],

@@ -678,15 +678,13 @@ int vdb_merge_topk(const float *dists, const uint64_t *ids, const uint64_t *coun
     VDB_API_END
 }
 
-// device-resident variant: inputs/outputs on the index's GPU, ids < 2^32; synchronous on return
-int vdb_merge_topk_device(vdb_index *idx, const void *d_dists, const void *d_ids, const void *d_counts,
-                          uint64_t n_shards, uint64_t nq, uint64_t k, void *d_out_idx, void *d_out_dist,
-                          void *d_out_count, void *stream) {
-    VDB_API_BEGIN
-    VDB_REQUIRE(idx && d_dists && d_ids && d_counts && d_out_idx && d_out_dist && d_out_count, "null argument");
+// device-resident variants: inputs/outputs on the index's GPU, ids < 2^32; synchronous on return
+static void merge_topk_dev(Index &ix, const void *d_dists, const void *d_ids, const void *d_counts, uint64_t stride_d,
+                           uint64_t stride_i, uint64_t stride_c, uint64_t n_shards, uint64_t nq, uint64_t k,
+                           void *d_out_idx, void *d_out_dist, void *d_out_count, void *stream) {
+    VDB_REQUIRE(d_dists && d_ids && d_counts && d_out_idx && d_out_dist && d_out_count, "null argument");
     VDB_REQUIRE(k >= 1 && k <= 1024, "k must be in 1..1024");
     VDB_REQUIRE(nq <= 65535 && n_shards <= 65535, "too many queries or shards for one call");
-    Index &ix = idx->ix;
     ix.use_device();
     WsLease ws(ix);
     VDB_SYNC(static_cast<hipStream_t>(stream));
@@ -694,14 +692,36 @@ int vdb_merge_topk_device(vdb_index *idx, const void *d_dists, const void *d_ids
     ws->lists.reserve(nq * n_shards * cap * sizeof(uint64_t));
     ws->keys_c.reserve(nq * cap * sizeof(uint64_t));
     launch_pack_pairs(static_cast<const float *>(d_dists), static_cast<const uint64_t *>(d_ids),
-                      static_cast<const uint64_t *>(d_counts), (uint32_t)n_shards, (uint32_t)nq, (uint32_t)k, cap,
-                      ws->lists.as<uint64_t>(), ws->stream);
+                      static_cast<const uint64_t *>(d_counts), stride_d, stride_i, stride_c, (uint32_t)n_shards,
+                      (uint32_t)nq, (uint32_t)k, cap, ws->lists.as<uint64_t>(), ws->stream);
     launch_topk_merge(ws->lists.as<uint64_t>(), (uint32_t)n_shards, cap, (uint32_t)nq, (uint32_t)k,
                       ws->keys_c.as<uint64_t>(), ws->stream);
     launch_finalize(ws->keys_c.as<uint64_t>(), cap, (uint32_t)nq, (uint32_t)k, (uint32_t)k, 0,
                     static_cast<uint64_t *>(d_out_idx), static_cast<float *>(d_out_dist),
                     static_cast<uint64_t *>(d_out_count), ws->stream);
     VDB_SYNC(ws->stream);
+}
+int vdb_merge_topk_device(vdb_index *idx, const void *d_dists, const void *d_ids, const void *d_counts,
+                          uint64_t n_shards, uint64_t nq, uint64_t k, void *d_out_idx, void *d_out_dist,
+                          void *d_out_count, void *stream) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    merge_topk_dev(idx->ix, d_dists, d_ids, d_counts, nq * k * sizeof(float), nq * k * sizeof(uint64_t),
+                   nq * sizeof(uint64_t), n_shards, nq, k, d_out_idx, d_out_dist, d_out_count, stream);
+    VDB_API_END
+}
+// same, reading the S per-rank blocks of ONE all-gather buffer in place: block s starts s*block_bytes after block 0 and
+// holds ids at off_ids, distances at off_dists, counts at off_counts (bytes; 8-byte aligned ids / counts)
+int vdb_merge_topk_gathered(vdb_index *idx, const void *d_gathered, uint64_t block_bytes, uint64_t off_ids,
+                            uint64_t off_dists, uint64_t off_counts, uint64_t n_shards, uint64_t nq, uint64_t k,
+                            void *d_out_idx, void *d_out_dist, void *d_out_count, void *stream) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx && d_gathered, "null argument");
+    VDB_REQUIRE((off_ids & 7) == 0 && (off_counts & 7) == 0 && (off_dists & 3) == 0 && (block_bytes & 7) == 0,
+                "misaligned block layout");
+    const char *g = static_cast<const char *>(d_gathered);
+    merge_topk_dev(idx->ix, g + off_dists, g + off_ids, g + off_counts, block_bytes, block_bytes, block_bytes, n_shards,
+                   nq, k, d_out_idx, d_out_dist, d_out_count, stream);
     VDB_API_END
 }
 

@@ -306,25 +306,32 @@ static void topk_merge_r(const uint64_t *lists, uint32_t nlists, uint32_t cap_in
 }
 
 // shard merge input: per-shard results (f32 distance, u64 global id < 2^32) -> pair-key lists [q][S][cap_in]
-__global__ void k_pack_pairs(const float *__restrict__ dists, const uint64_t *__restrict__ ids,
-                             const uint64_t *__restrict__ counts, uint32_t S, uint32_t nq, uint32_t k,
-                             uint32_t cap_in, uint64_t *__restrict__ lists) {
+// shard s's arrays start shard_stride BYTES after shard s-1's (the per-rank blocks of one all-gather buffer, or plain
+// [S][nq][k] arrays when the stride is nq*k elements)
+__global__ void k_pack_pairs(const char *__restrict__ dists, const char *__restrict__ ids,
+                             const char *__restrict__ counts, uint64_t stride_d, uint64_t stride_i, uint64_t stride_c,
+                             uint32_t S, uint32_t nq, uint32_t k, uint32_t cap_in, uint64_t *__restrict__ lists) {
     uint32_t q = blockIdx.x, s = blockIdx.y;
-    uint64_t c = counts[uint64_t(s) * nq + q];
+    const float *d = reinterpret_cast<const float *>(dists + s * stride_d);
+    const uint64_t *id = reinterpret_cast<const uint64_t *>(ids + s * stride_i);
+    uint64_t c = reinterpret_cast<const uint64_t *>(counts + s * stride_c)[q];
     for (uint32_t j = threadIdx.x; j < cap_in; j += blockDim.x) {
         uint64_t key = PAIR_NONE;
         if (j < k && j < c) {
-            uint64_t at = (uint64_t(s) * nq + q) * k + j;
-            key = pair_key(dists[at], uint32_t(ids[at]));
+            uint64_t at = uint64_t(q) * k + j;
+            key = pair_key(d[at], uint32_t(id[at]));
         }
         lists[(uint64_t(q) * S + s) * cap_in + j] = key;
     }
 }
 
-void launch_pack_pairs(const float *dists, const uint64_t *ids, const uint64_t *counts, uint32_t S, uint32_t nq,
-                       uint32_t k, uint32_t cap_in, uint64_t *lists, hipStream_t s) {
+void launch_pack_pairs(const float *dists, const uint64_t *ids, const uint64_t *counts, uint64_t stride_d,
+                       uint64_t stride_i, uint64_t stride_c, uint32_t S, uint32_t nq, uint32_t k, uint32_t cap_in,
+                       uint64_t *lists, hipStream_t s) {
     if (nq == 0 || S == 0) return;
-    hipLaunchKernelGGL(k_pack_pairs, dim3(nq, S), dim3(64), 0, s, dists, ids, counts, S, nq, k, cap_in, lists);
+    hipLaunchKernelGGL(k_pack_pairs, dim3(nq, S), dim3(64), 0, s, reinterpret_cast<const char *>(dists),
+                       reinterpret_cast<const char *>(ids), reinterpret_cast<const char *>(counts), stride_d, stride_i,
+                       stride_c, S, nq, k, cap_in, lists);
 }
 
 #define VDB_DISPATCH_R(cap, CALL)                                   \

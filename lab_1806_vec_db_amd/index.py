@@ -229,6 +229,12 @@ class GpuIndex:
         L.check(self._lib.vdb_pq_merge_resort_device(self._h, L.vp(d_adc), L.vp(d_exact), n_shards, nq, efk, k,
                                                      L.vp(out_idx), L.vp(out_dist), L.vp(out_cnt), L.vp(stream)))
 
+    def merge_topk_gathered(self, d_gathered: int, block_bytes: int, off_ids: int, off_dists: int, off_counts: int,
+                            n_shards: int, nq: int, k: int, out_idx: int, out_dist: int, out_cnt: int, stream: int = 0):
+        L.check(self._lib.vdb_merge_topk_gathered(self._h, L.vp(d_gathered), block_bytes, off_ids, off_dists, off_counts,
+                                                  n_shards, nq, k, L.vp(out_idx), L.vp(out_dist), L.vp(out_cnt),
+                                                  L.vp(stream)))
+
     def set_flat_mode(self, mode: int):
         L.check(self._lib.vdb_flat_set_mode(self._h, int(mode)))
 

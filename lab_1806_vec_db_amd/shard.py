@@ -130,3 +130,44 @@ def allgather_concat(local_idx, local_dist, local_cnt, nq: int, group=None):
     g_dist = gathered[:, o0:o1].contiguous().view(local_dist.dtype).view(world * per, k)[:nq]
     g_cnt = gathered[:, o1:].contiguous().view(local_cnt.dtype).view(world * per)[:nq]
     return g_idx, g_dist, g_cnt
+
+
+class ShardExchange:
+    """Persistent buffers for the per-step exchange of row-sharded Flat results on the GPU.
+
+    One rank's block = [nq*k ids i64 | nq*k distances f32 | pad | nq counts i64] in ONE uint8 tensor: the search
+    writes straight into typed views of it (no packing kernels), `all_gather_into_tensor` moves the block (one RCCL
+    collective per step), and `vdb_merge_topk_gathered` reads the S blocks of the receive buffer in place.
+    """
+
+    def __init__(self, nq: int, k: int, device, world: int):
+        import torch
+
+        self.nq, self.k, self.world = nq, k, world
+        self.off_ids = 0
+        self.off_dists = nq * k * 8
+        self.off_counts = (nq * k * 12 + 7) // 8 * 8
+        self.block = self.off_counts + nq * 8
+        self.send = torch.zeros(self.block, dtype=torch.uint8, device=device)
+        self.idx = self.send[self.off_ids:self.off_dists].view(torch.int64).view(nq, k)
+        self.dist = self.send[self.off_dists:self.off_dists + nq * k * 4].view(torch.float32).view(nq, k)
+        self.cnt = self.send[self.off_counts:self.block].view(torch.int64)
+        if world > 1:
+            self.recv = torch.empty(world * self.block, dtype=torch.uint8, device=device)
+            self.m_idx = torch.empty((nq, k), dtype=torch.int64, device=device)
+            self.m_dist = torch.empty((nq, k), dtype=torch.float32, device=device)
+            self.m_cnt = torch.empty((nq,), dtype=torch.int64, device=device)
+
+    def exchange_merge(self, gpu_index, group=None):
+        """After the local search has filled idx / dist / cnt: returns the merged (idx, dist, cnt) on every rank."""
+        if self.world == 1:
+            return self.idx, self.dist, self.cnt
+        import torch
+        import torch.distributed as dist
+
+        dist.all_gather_into_tensor(self.recv, self.send, group=group)
+        torch.cuda.current_stream().synchronize()
+        gpu_index.merge_topk_gathered(self.recv.data_ptr(), self.block, self.off_ids, self.off_dists, self.off_counts,
+                                      self.world, self.nq, self.k, self.m_idx.data_ptr(), self.m_dist.data_ptr(),
+                                      self.m_cnt.data_ptr())
+        return self.m_idx, self.m_dist, self.m_cnt

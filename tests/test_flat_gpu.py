@@ -374,3 +374,46 @@ def test_gemm_no_hit_detection(mods):
     oi, od, oc = O.flat_knn_batch(base, qs, 10, 0, nthreads=8)
     for q in range(100):
         _check(idx[q], d[q], oi[q], od[q])
+
+
+def test_merge_topk_gathered_blocks(mods):
+    """vdb_merge_topk_gathered reads the per-rank blocks of the all-gather buffer in place (ShardExchange layout); it
+    must equal the host merge of the same three shard results, cross-shard ties included."""
+    import torch
+    vdb, O = mods
+    from lab_1806_vec_db_amd.index import merge_topk
+    from lab_1806_vec_db_amd.shard import ShardExchange, shard_bounds
+    rng = np.random.default_rng(12)
+    n, dim, nq, k, S = 3001, 24, 37, 10, 3
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    base[2500] = base[3]  # duplicate across shards
+    qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    qs[0] = base[3]
+    dq = torch.from_numpy(qs).cuda()
+    blocks, parts = [], []
+    for r in range(S):
+        r0, r1 = shard_bounds(n, S, r)
+        ix = vdb.GpuIndex(dim, "l2sqr")
+        ix.batch_add(base[r0:r1])
+        ix.set_id_offset(r0)
+        ex = ShardExchange(nq, k, torch.device("cuda", 0), 1)
+        ix.flat_knn_device(dq.data_ptr(), nq, k, ex.idx.data_ptr(), ex.dist.data_ptr(), ex.cnt.data_ptr())
+        blocks.append(ex.send.clone())
+        parts.append((ex.idx.cpu().numpy().copy(), ex.dist.cpu().numpy().copy(), ex.cnt.cpu().numpy().copy()))
+        last = (ix, ex)
+    ix, ex = last
+    recv = torch.cat(blocks)
+    o_idx = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    o_dist = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    o_cnt = torch.empty((nq,), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ix.merge_topk_gathered(recv.data_ptr(), ex.block, ex.off_ids, ex.off_dists, ex.off_counts, S, nq, k,
+                           o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr())
+    hi, hd, hc = merge_topk(np.stack([p[1] for p in parts]), np.stack([p[0] for p in parts]).astype(np.uint64),
+                            np.stack([p[2] for p in parts]).astype(np.uint64), k)
+    assert np.array_equal(o_idx.cpu().numpy().astype(np.uint64), hi)
+    assert np.array_equal(o_dist.cpu().numpy(), hd)
+    assert np.array_equal(o_cnt.cpu().numpy().astype(np.uint64), hc)
+    for q in range(nq):
+        oi, od = O.flat_knn(base, qs[q], k)
+        assert hi[q].tolist() == oi.tolist() and np.array_equal(hd[q], od)
