@@ -306,14 +306,12 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
                                 d_sq.as<float>(), cosine, d_tau, d_cand, d_hits, CAND_CAP, d_sync, num_cu, s);
     prof_end(ws);
     launch_topk_merge_counted(d_cand, CAND_CAP, d_hits, (uint32_t)nq, kprime, ws.keys_a.as<uint64_t>(), s);
-    VDB_HIP(hipMemsetAsync(ws.keys_b.p, 0xff, nq * capp * sizeof(uint64_t), s));
     launch_rerank(d_rows.as<float>(), (uint32_t)dim, d_q, (uint32_t)nq, cosine ? MET_COSINE : MET_L2_DIRECT, d_sq.as<float>(),
-                  ws.qsq.as<float>(), ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), kprime, capp, s);
+                  ws.qsq.as<float>(), ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), kprime, capp, s);  // pads its rows
     launch_topk_merge(ws.keys_b.as<uint64_t>(), 1, capp, (uint32_t)nq, ksel, ws.keys_c.as<uint64_t>(), s);
-    launch_certify(ws.keys_c.as<uint64_t>(), capk, ws.keys_a.as<uint64_t>(), capp, (uint32_t)nq, ksel, kprime, n,
-                   ws.qsq.as<float>(), xsq_max, xsq_min_pos, cosine, (uint32_t)dim, ws.flags.as<uint8_t>(), s);
-    launch_flag_overflow(d_hits, CAND_CAP, kprime, (uint32_t)nq, ws.flags.as<uint8_t>(), s);
-    launch_finalize(ws.keys_c.as<uint64_t>(), capk, (uint32_t)nq, ksel, (uint32_t)k, id_offset, d_idx, d_dist, d_cnt, s);
+    launch_flat_finish(ws.keys_c.as<uint64_t>(), capk, ws.keys_a.as<uint64_t>(), capp, (uint32_t)nq, ksel, (uint32_t)k, kprime,
+                       n, ws.qsq.as<float>(), xsq_max, xsq_min_pos, cosine, (uint32_t)dim, d_hits, CAND_CAP, id_offset,
+                       ws.flags.as<uint8_t>(), d_idx, d_dist, d_cnt, s);
     std::vector<uint8_t> flags(nq);
     VDB_HIP(hipMemcpyAsync(flags.data(), ws.flags.p, nq, hipMemcpyDeviceToHost, s));
     VDB_SYNC(s);

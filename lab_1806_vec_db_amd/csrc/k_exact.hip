@@ -4,6 +4,8 @@
 // bit for bit: products and sums are separately rounded (mod.rs:72-77), accumulation is strictly
 // ascending in the dimension.  The file is compiled with -ffp-contract=off and the pragma below
 // repeats that, so no v_fma is formed from a*b+c.
+#include <algorithm>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -261,7 +263,10 @@ __global__ __launch_bounds__(64) void k_rerank(const float *__restrict__ X, uint
                                                uint32_t ncand, uint32_t ldc) {
     uint32_t q = blockIdx.y;
     uint32_t j = blockIdx.x * 64 + threadIdx.x;
-    if (j >= ncand) return;
+    if (j >= ncand) {
+        if (j < ldc) out[uint64_t(q) * ldc + j] = PAIR_NONE;  // padding of the row: no separate memset of `out`
+        return;
+    }
     uint64_t c = cand[uint64_t(q) * ldc + j];
     if (c == PAIR_NONE) {
         out[uint64_t(q) * ldc + j] = PAIR_NONE;
@@ -293,7 +298,7 @@ void launch_rerank(const float *X, uint32_t dim, const float *Q, uint32_t nq, in
                    const float *qsq, const uint64_t *cand, uint64_t *out, uint32_t ncand, uint32_t ldc,
                    hipStream_t s) {
     if (nq == 0 || ncand == 0) return;
-    dim3 grid((ncand + 63) / 64, nq), block(64);
+    dim3 grid((std::max(ncand, ldc) + 63) / 64, nq), block(64);  // the tail blocks only pad
     if (metric == MET_L2_DIRECT)
         hipLaunchKernelGGL((k_rerank<FOLD_L2>), grid, block, 0, s, X, dim, Q, metric, xsq, qsq, cand, out, ncand, ldc);
     else
@@ -411,6 +416,69 @@ __global__ void k_flag_overflow(const uint32_t *__restrict__ cnt, uint32_t cap, 
 void launch_flag_overflow(const uint32_t *cnt, uint32_t cap, uint32_t min_hits, uint32_t nq, uint8_t *flags, hipStream_t s) {
     if (nq == 0) return;
     hipLaunchKernelGGL(k_flag_overflow, dim3((nq + 63) / 64), dim3(64), 0, s, cnt, cap, min_hits, nq, flags);
+}
+
+// certification + overflow check + output formatting of the Flat MFMA pipeline in one launch (one block per query):
+// k_certify's test, k_flag_overflow's test and k_finalize's writes (three 5-us launches per step otherwise)
+__global__ __launch_bounds__(64) void k_flat_finish(const uint64_t *__restrict__ exact_sorted, uint32_t lde,
+                                                    const uint64_t *__restrict__ approx_sorted, uint32_t lda,
+                                                    uint32_t ksel, uint32_t kstride, uint32_t kprime, uint64_t n_rows,
+                                                    const float *__restrict__ qsq, float xsq_max, float xsq_min_pos,
+                                                    int cosine, uint32_t dim, const uint32_t *__restrict__ cnt,
+                                                    uint32_t cap, uint64_t id_offset, uint8_t *__restrict__ flags,
+                                                    uint64_t *__restrict__ out_idx, float *__restrict__ out_dist,
+                                                    uint64_t *__restrict__ out_count) {
+    const uint32_t q = blockIdx.x;
+    if (threadIdx.x == 0) {
+        uint8_t flag = 0;
+        if (n_rows > kprime) {
+            uint32_t kk = ksel < kprime ? ksel : kprime;
+            uint64_t ek = exact_sorted[uint64_t(q) * lde + (kk - 1)];
+            uint64_t ak = approx_sorted[uint64_t(q) * lda + (kprime - 1)];
+            if (ek == PAIR_NONE || ak == PAIR_NONE) {
+                flag = 1;  // fewer than k' hits (thinned sample) or an emptied overflow list
+            } else {
+                float dk = f32_from_orderable(uint32_t(ek >> 32));
+                float kappa = f32_from_orderable(uint32_t(ak >> 32));
+                float qs = qsq[q];
+                bool ok;
+                if (cosine) {
+                    float qn = sqrtf(qs);
+                    float E = 2.5f * float(dim + 8) * 5.9604645e-8f + 6e-5f;
+                    bool clamp_free = sqrtf(xsq_min_pos) * qn > 1e-9f;
+                    ok = clamp_free && dk < (1.0f + kappa / qn) - E;
+                } else {
+                    float nrm = sqrtf(xsq_max) + sqrtf(qs);
+                    float E = 2.5f * float(dim + 8) * 5.9604645e-8f * nrm * nrm + 5e-5f * sqrtf(xsq_max) * sqrtf(qs);
+                    ok = dk < (kappa + qs) - E;
+                }
+                flag = ok ? 0 : 1;
+            }
+        }
+        if (cnt[q] > cap || cnt[q] < (n_rows > kprime ? kprime : 0)) flag = 1;
+        flags[q] = flag;
+    }
+    uint32_t c = 0;
+    for (uint32_t j = threadIdx.x; j < ksel; j += blockDim.x) {
+        uint64_t e = exact_sorted[uint64_t(q) * lde + j];
+        bool ok = e != PAIR_NONE;
+        out_idx[uint64_t(q) * kstride + j] = ok ? uint64_t(uint32_t(e)) + id_offset : 0;
+        out_dist[uint64_t(q) * kstride + j] = ok ? f32_from_orderable(uint32_t(e >> 32)) : 0.0f;
+        c += ok;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+    if (threadIdx.x == 0 && out_count) out_count[q] = c;
+}
+void launch_flat_finish(const uint64_t *exact_sorted, uint32_t lde, const uint64_t *approx_sorted, uint32_t lda,
+                        uint32_t nq, uint32_t ksel, uint32_t kstride, uint32_t kprime, uint64_t n_rows, const float *qsq,
+                        float xsq_max, float xsq_min_pos, int cosine, uint32_t dim, const uint32_t *cnt, uint32_t cap,
+                        uint64_t id_offset, uint8_t *flags, uint64_t *out_idx, float *out_dist, uint64_t *out_count,
+                        hipStream_t s) {
+    if (nq == 0) return;
+    hipLaunchKernelGGL(k_flat_finish, dim3(nq), dim3(64), 0, s, exact_sorted, lde, approx_sorted, lda, ksel, kstride,
+                       kprime, n_rows, qsq, xsq_max, xsq_min_pos, cosine, dim, cnt, cap, id_offset, flags, out_idx,
+                       out_dist, out_count);
 }
 
 void launch_certify(const uint64_t *exact_sorted, uint32_t lde, const uint64_t *approx_sorted, uint32_t lda,
