@@ -282,7 +282,7 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     launch_flat_mfma_sample(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>(), (uint32_t)nbatch, d_sq.as<float>(),
                             cosine, s_step, ws.dense.as<float>(), ld_s, num_cu, s);
     if (n_s <= select_tau_max_n()) {  // tau only needs the k'-th smallest sampled key, not a sorted sample shortlist
-        launch_select_tau(ws.dense.as<float>(), ld_s, (uint32_t)n_s, (uint32_t)nq_pad, s_rank, d_tau, s);
+        launch_select_tau(ws.dense.as<float>(), ld_s, (uint32_t)n_s, (uint32_t)nq_pad, (uint32_t)nq, s_rank, d_tau, s);
     } else {
         launch_topk_dense(ws.dense.as<float>(), ld_s, n_s, (uint32_t)nq_pad, s_rank, ws.lists.as<uint64_t>(), s);
         launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, capp, (uint32_t)nq_pad, s_rank, ws.keys_a.as<uint64_t>(), s);
@@ -290,7 +290,7 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     }
     // padding queries are zero vectors: under Cosine every row ties at key 0 = tau and would flood the hit buffers of
     // the real queries that share their workgroup batch; tau = -inf lets nothing through
-    if (nq_pad > nq)
+    if (nq_pad > nq && n_s > select_tau_max_n())  // (k_select_tau does it itself)
         VDB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_tau + nq), (int)0xFF800000u, nq_pad - nq, s));
     uint64_t *d_cand = ws.lists.as<uint64_t>();  // the sample lists are dead now
     uint32_t *d_sync = d_hits + nq_pad;

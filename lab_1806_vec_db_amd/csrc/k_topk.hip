@@ -125,12 +125,16 @@ constexpr uint32_t SELECT_MAX_N = 32768;
 uint32_t select_tau_max_n() { return SELECT_MAX_N; }
 
 __global__ __launch_bounds__(256) void k_select_tau(const float *__restrict__ keys, uint64_t ld, uint32_t n, uint32_t kth,
-                                                    float *__restrict__ tau) {
+                                                    uint32_t nq_real, float *__restrict__ tau) {
     extern __shared__ uint32_t sel_smem[];
     uint32_t *o = sel_smem;        // [n] orderable keys
     uint32_t *hist = o + n;        // [2048]
     uint32_t *part = hist + 2048;  // [256] partial sums / reduction scratch; [256..257] results
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    if (q >= nq_real) {  // padding query of a batch: let nothing through (see Index::flat_knn_device)
+        if (tid == 0) tau[q] = -INFINITY;
+        return;
+    }
     const float *kq = keys + uint64_t(q) * ld;
     const uint32_t O_INF = 0xFF800000u;  // f32_orderable(+inf); NaN is above it
     uint32_t mn = 0xFFFFFFFFu, mx = 0, fin = 0;
@@ -229,7 +233,8 @@ __global__ __launch_bounds__(256) void k_select_tau(const float *__restrict__ ke
     if (tid == 0) tau[q] = f32_from_orderable(hi);  // not reached: 2^32 / 1024^3 < 2048
 }
 
-void launch_select_tau(const float *keys, uint64_t ld, uint32_t n, uint32_t nq, uint32_t kth, float *tau, hipStream_t s) {
+void launch_select_tau(const float *keys, uint64_t ld, uint32_t n, uint32_t nq, uint32_t nq_real, uint32_t kth, float *tau,
+                       hipStream_t s) {
     if (nq == 0) return;
     VDB_REQUIRE(n <= SELECT_MAX_N, "select_tau: sample too long");
     size_t lds = (size_t(n) + 2048 + 258) * sizeof(uint32_t);
@@ -239,7 +244,7 @@ void launch_select_tau(const float *keys, uint64_t ld, uint32_t n, uint32_t nq, 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
         attr_done = true;
     }
-    hipLaunchKernelGGL(k_select_tau, dim3(nq), dim3(256), lds, s, keys, ld, n, kth, tau);
+    hipLaunchKernelGGL(k_select_tau, dim3(nq), dim3(256), lds, s, keys, ld, n, kth, nq_real, tau);
     VDB_HIP(hipGetLastError());
 }
 

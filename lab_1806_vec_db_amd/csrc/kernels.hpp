@@ -49,7 +49,9 @@ void launch_flag_overflow(const uint32_t *cnt, uint32_t cap, uint32_t min_hits, 
 uint32_t topk_chunk(uint64_t n);
 uint32_t topk_num_lists(uint64_t n);
 // tau[q] = kth smallest of keys[q][0..n) (k_select_tau, n <= select_tau_max_n())
-void launch_select_tau(const float *keys, uint64_t ld, uint32_t n, uint32_t nq, uint32_t kth, float *tau, hipStream_t s);
+// queries >= nq_real (batch padding) get tau = -inf
+void launch_select_tau(const float *keys, uint64_t ld, uint32_t n, uint32_t nq, uint32_t nq_real, uint32_t kth, float *tau,
+                       hipStream_t s);
 uint32_t select_tau_max_n();
 uint32_t topk_capacity(uint32_t k);  // entries per list (multiple of 64, >= k)
 // level 1: dense f32 keys[q*ld + i], i in [0,n) -> lists[q][list][cap] sorted ascending pair keys

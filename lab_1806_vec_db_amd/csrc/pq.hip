@@ -819,7 +819,7 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
                 adc_launch<0>(ix, ws, BQ, a);
             }
             if (n_s <= select_tau_max_n()) {  // tau = efk-th smallest sampled ADC value: a selection, not a sort
-                launch_select_tau(ws.dense.as<float>(), ld_s, (uint32_t)n_s, (uint32_t)gn, efk, d_tau + g0, s);
+                launch_select_tau(ws.dense.as<float>(), ld_s, (uint32_t)n_s, (uint32_t)gn, (uint32_t)gn, efk, d_tau + g0, s);
             } else {
                 launch_topk_dense(ws.dense.as<float>(), ld_s, n_s, (uint32_t)gn, efk, ws.lists.as<uint64_t>(), s);
                 launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, cape, (uint32_t)gn, efk, ws.keys_a.as<uint64_t>() + g0 * cape, s);
