@@ -49,6 +49,30 @@ def gist_like_gpu(torch, n, dim, seed, device, chunk=131072):
     return out
 
 
+def gist_lowrank_gpu(torch, n, dim, seed, device, latent=32, chunk=131072):
+    """Same per-dimension mean / std / clipping / 4-decimal grid as gist_like_gpu, but 81 % of every coordinate's variance
+    comes from a `latent`-dimensional Gaussian factor shared through one fixed mixing matrix: neighbours are meaningfully
+    closer than random rows (as in real GIST descriptors), so graph / PQ recall is informative.  `--data lowrank`."""
+    stats = np.load(os.path.join(ROOT, "tests", "golden", "gist_dim_stats.npy"))
+    mu = torch.from_numpy(np.resize(stats[0], dim).astype(np.float32)).to(device)
+    sd = torch.from_numpy(np.resize(stats[1], dim).astype(np.float32)).to(device)
+    gw = torch.Generator(device=device)
+    gw.manual_seed(977)  # the mixing matrix is part of the distribution: same for base and queries
+    w = torch.randn((latent, dim), generator=gw, device=device, dtype=torch.float32) / float(np.sqrt(latent))
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = torch.empty((n, dim), dtype=torch.float32, device=device)
+    for r0 in range(0, n, chunk):
+        r1 = min(n, r0 + chunk)
+        z = torch.randn((r1 - r0, latent), generator=g, device=device, dtype=torch.float32)
+        e = torch.randn((r1 - r0, dim), generator=g, device=device, dtype=torch.float32)
+        x = (z @ w).mul_(0.9).add_(e.mul_(0.4359))
+        x.mul_(sd).add_(mu).abs_().clamp_(0.0, 0.8)
+        x.mul_(10000.0).round_().div_(10000.0)
+        out[r0:r1] = x
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,6 +87,9 @@ def main():
     ap.add_argument("--workload", choices=["flat", "pq_flat", "hnsw"], default="flat",
                     help="flat = the headline (BASELINE metric); pq_flat / hnsw = the other SURVEY 8d configs")
     ap.add_argument("--ef", type=int, default=0, help="pq_flat: ADC shortlist (default 100); hnsw: search ef (default 128)")
+    ap.add_argument("--data", choices=["gistlike", "lowrank"], default="gistlike",
+                    help="gistlike = per-dimension Gaussians (SURVEY 8d generator); lowrank = same marginals with a 32-d "
+                         "latent factor, for informative ANN recall")
     ap.add_argument("--mode", type=int, default=0, help="flat mode: 0 auto, 1 exact scan, 2 MFMA forced")
     ap.add_argument("--dump", type=str, default="", help="rank 0 saves the last step's results to this .npz (tests)")
     args = ap.parse_args()
@@ -99,8 +126,9 @@ def main():
     ef = args.ef or (100 if wl == "pq_flat" else 128)
     n, dim, nq, k = args.rows, args.dim, args.nq, args.k
     # identical corpus on every rank (same seed), each keeps its row block
-    base = gist_like_gpu(torch, n, dim, 1806, device)
-    queries = gist_like_gpu(torch, nq, dim, 1807, device)
+    gen = gist_like_gpu if args.data == "gistlike" else gist_lowrank_gpu
+    base = gen(torch, n, dim, 1806, device)
+    queries = gen(torch, nq, dim, 1807, device)
     r0, r1 = shard_bounds(n, world, rank) if wl != "hnsw" else (0, n)  # HNSW: full replica per GPU
     shard = base[r0:r1].contiguous()
     torch.cuda.synchronize()
@@ -237,7 +265,8 @@ def main():
         "metric": f"queries/sec at recall@10, Gist1M d=960 ({names[0]}, L2Sqr, k=10)",
         "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic" if args.data == "gistlike" else "synthetic (low-rank gist-like)",
         "config": {"workload": names[1], "rows": n, "dim": dim, "queries_per_step": nq, "k": k, "dist": "L2Sqr",
                    "parallelism": par if world > 1 else "single GPU"},
         "roofline": roofline, "recall_at_10": None,
