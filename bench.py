@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--workload", choices=["flat", "pq_flat", "hnsw"], default="flat",
                     help="flat = the headline (BASELINE metric); pq_flat / hnsw = the other SURVEY 8d configs")
     ap.add_argument("--ef", type=int, default=0, help="pq_flat: ADC shortlist (default 100); hnsw: search ef (default 128)")
+    ap.add_argument("--dist", choices=["l2sqr", "cosine"], default="l2sqr",
+                    help="l2sqr = the BASELINE metric; cosine = the reference's default table distance (pyo3/mod.rs:73)")
     ap.add_argument("--data", choices=["gistlike", "lowrank"], default="gistlike",
                     help="gistlike = per-dimension Gaussians (SURVEY 8d generator); lowrank = same marginals with a 32-d "
                          "latent factor, for informative ANN recall")
@@ -133,7 +135,7 @@ def main():
     shard = base[r0:r1].contiguous()
     torch.cuda.synchronize()
 
-    ix = vdb.GpuIndex(dim, "l2sqr", device=local_rank)
+    ix = vdb.GpuIndex(dim, args.dist, device=local_rank)
     ix.add_device(shard.data_ptr(), r1 - r0)
     ix.set_id_offset(r0)
     ix.set_flat_mode(args.mode)
@@ -144,7 +146,7 @@ def main():
         # config/bench_pq_hnsw.toml:16-23: n_bits 4, m = dim/3, k_means_size 10000, max_iter 20, tol 1e-6.  Every rank
         # trains on the same first 10000 rows (same seed) -> identical centroids; codes are encoded per shard on the GPU.
         m = dim // 3
-        tr = vdb.GpuIndex(dim, "l2sqr", device=local_rank)
+        tr = vdb.GpuIndex(dim, args.dist, device=local_rank)
         tr.add_device(base.data_ptr(), min(n, 10000))
         tr.pq_build(n_bits=4, m=m, train_n=0, max_iter=20, tol=1e-6, seed=42)
         cent = tr.pq_export()["centroids"]
@@ -258,16 +260,17 @@ def main():
     if args.dump:
         np.savez(args.dump, idx=res[0].cpu().numpy(), dist=res[1].cpu().numpy(), cnt=res[2].cpu().numpy())
     qps = nq * args.steps / elapsed
+    dname = "L2Sqr" if args.dist == "l2sqr" else "Cosine"
     names = {"flat": ("Flat brute force", "flat_knn_gist1m"), "pq_flat": (f"PQ-Flat 4-bit m={dim // 3}, ADC ef={ef}", "pq_flat_knn_gist1m"),
              "hnsw": (f"HNSW M=16 efc=200, ef={ef}", f"hnsw_knn_gistlike_{n}")}[wl]
     par = {"flat": f"row-shard x{world}", "pq_flat": f"row-shard x{world}", "hnsw": f"replica x{world}, queries split"}[wl]
     out = {
-        "metric": f"queries/sec at recall@10, Gist1M d=960 ({names[0]}, L2Sqr, k=10)",
+        "metric": f"queries/sec at recall@10, Gist1M d=960 ({names[0]}, {dname}, k=10)",
         "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic" if args.data == "gistlike" else "synthetic (low-rank gist-like)",
-        "config": {"workload": names[1], "rows": n, "dim": dim, "queries_per_step": nq, "k": k, "dist": "L2Sqr",
+        "config": {"workload": names[1], "rows": n, "dim": dim, "queries_per_step": nq, "k": k, "dist": dname,
                    "parallelism": par if world > 1 else "single GPU"},
         "roofline": roofline, "recall_at_10": None,
     }
@@ -288,6 +291,7 @@ def main():
         from oracle import oracle as O
 
         O.build()
+        okind = O.L2SQR if args.dist == "l2sqr" else O.COSINE
         ncpu = min(args.cpu_queries, nq)
         threads = min(len(os.sched_getaffinity(0)), 16)  # the GPU box's CPU share for one GPU
         hq = queries[:ncpu].cpu().numpy()
@@ -295,7 +299,7 @@ def main():
         gd = res[1][:ncpu].cpu().numpy()
         if wl == "flat":
             t0 = time.perf_counter()
-            ci, cd, cc = O.flat_knn_batch(host_base, hq, k, O.L2SQR, nthreads=threads)
+            ci, cd, cc = O.flat_knn_batch(host_base, hq, k, okind, nthreads=threads)
             cpu_s = time.perf_counter() - t0
             truth = ci
             what = "FlatIndex::knn"
@@ -308,15 +312,15 @@ def main():
             truth = t_idx[:ncpu].cpu().numpy().astype(np.uint64)
             if wl == "pq_flat":
                 pq = ix.pq_export()
-                opq = O.PQ.from_centroids(dim, pq["m"], pq["n_bits"], O.L2SQR, pq["centroids"])
+                opq = O.PQ.from_centroids(dim, pq["m"], pq["n_bits"], okind, pq["centroids"])
                 opq.set_codes(pq["codes"])  # GPU-encoded codes (bit-equal to the oracle's encoder, tests/test_pq_gpu.py)
                 t0 = time.perf_counter()
                 with ThreadPoolExecutor(threads) as ex:  # ctypes releases the GIL: one query per thread
-                    r = list(ex.map(lambda q: O.flat_knn_pq(host_base, opq, hq[q], k, ef, O.L2SQR), range(ncpu)))
+                    r = list(ex.map(lambda q: O.flat_knn_pq(host_base, opq, hq[q], k, ef, okind), range(ncpu)))
                 cpu_s = time.perf_counter() - t0
                 what = "FlatIndex::knn_pq"
             else:
-                oh = O.HNSW.from_graph(host_base, O.L2SQR, 16, 200, ix.hnsw_export())
+                oh = O.HNSW.from_graph(host_base, okind, 16, 200, ix.hnsw_export())
                 t0 = time.perf_counter()
                 with ThreadPoolExecutor(threads) as ex:
                     r = list(ex.map(lambda q: oh.knn(hq[q], k, ef), range(ncpu)))
