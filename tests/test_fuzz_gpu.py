@@ -1,0 +1,55 @@
+"""GPU: seeded random configurations of the Flat path (dim, rows, queries, k, distance, kernel choice, data scale)
+against the oracle -- the shapes nobody thought of.  Deterministic: the seeds are the test ids."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import lab_1806_vec_db_amd as vdb
+    from oracle import oracle as O
+    return vdb, O
+
+
+def _check(gi, gd, oi, od):
+    assert gi.tolist() == oi.tolist()
+    assert np.array_equal(gd, od)
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_flat_random_configuration(mods, seed):
+    vdb, O = mods
+    rng = np.random.default_rng(1000 + seed)
+    dim = int(rng.choice([3, 8, 17, 48, 64, 100, 128, 200, 384, 515, 960, 1024, 1100, 1536]))
+    n = int(rng.integers(40, 60000)) if dim <= 400 else int(rng.integers(40, 22000))
+    nq = int(rng.choice([1, 2, 31, 33, 64, 65, 127, 129, 200]))
+    k = int(rng.choice([1, 3, 10, 16, 33, 100]))
+    dist, kind = (("l2sqr", 0), ("cosine", 1))[int(rng.integers(0, 2))]
+    scale = float(rng.choice([1e-3, 1.0, 300.0]))
+    style = int(rng.integers(0, 3))
+    if style == 0:
+        base = rng.standard_normal((n, dim)).astype(np.float32)
+    elif style == 1:
+        base = np.abs(rng.standard_normal((n, dim)) * 0.05 + 0.07).astype(np.float32)
+    else:  # few distinct rows: many exact ties
+        proto = rng.standard_normal((7, dim)).astype(np.float32)
+        base = proto[rng.integers(0, 7, n)] + (rng.standard_normal((n, dim)) * (rng.integers(0, 2) * 1e-3)).astype(np.float32)
+    base = (base * np.float32(scale)).astype(np.float32)
+    qs = (base[rng.integers(0, n, nq)] + rng.standard_normal((nq, dim)).astype(np.float32) * np.float32(0.05 * scale)).astype(np.float32)
+    ix = vdb.GpuIndex(dim, dist)
+    ix.batch_add(base[: n // 2])
+    ix.batch_add(base[n // 2:])
+    mode = int(rng.choice([0, 1, 2]))
+    ix.set_flat_mode(mode)
+    ix.set_param("flat_gemm", int(rng.choice([0, 1, 2])))
+    try:
+        idx, d, cnt = ix.flat_knn(qs, k)
+    finally:
+        ix.set_param("flat_gemm", 0)
+    oi, od, oc = O.flat_knn_batch(base, qs, k, kind, nthreads=8)
+    for q in range(nq):
+        c = int(cnt[q])
+        assert c == int(oc[q]) == min(k, n)
+        _check(idx[q, :c], d[q, :c], oi[q, :c], od[q, :c])
