@@ -53,3 +53,62 @@ def test_flat_random_configuration(mods, seed):
         c = int(cnt[q])
         assert c == int(oc[q]) == min(k, n)
         _check(idx[q, :c], d[q, :c], oi[q, :c], od[q, :c])
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_pq_ivf_hnsw_random_configuration(mods, seed):
+    """PQ-Flat, IVF and HNSW on one random corpus: centroids / graph built by the library, handed to the oracle."""
+    vdb, O = mods
+    rng = np.random.default_rng(5000 + seed)
+    dim = int(rng.choice([12, 31, 64, 96, 130]))
+    n = int(rng.integers(300, 9000))
+    nq = int(rng.choice([1, 5, 40]))
+    k = int(rng.choice([1, 5, 10, 25]))
+    dist, kind = (("l2sqr", 0), ("cosine", 1))[int(rng.integers(0, 2))]
+    base = (rng.standard_normal((n, dim)) * rng.uniform(0.1, 3.0, dim)).astype(np.float32)
+    base[n - 5:] = base[:5]
+    qs = (base[rng.integers(0, n, nq)] + rng.standard_normal((nq, dim)).astype(np.float32) * np.float32(0.1)).astype(np.float32)
+    ix = vdb.GpuIndex(dim, dist)
+    ix.batch_add(base)
+    # PQ
+    n_bits = int(rng.choice([4, 8]))
+    m = int(rng.integers(1, min(dim, 40) + 1))
+    ef = int(rng.choice([k, 3 * k, 64, 300]))
+    ix.pq_build(n_bits=n_bits, m=m, train_n=min(n, 500), max_iter=3, seed=seed)
+    pq = ix.pq_export()
+    opq = O.PQ.from_centroids(dim, m, n_bits, kind, pq["centroids"])
+    opq.encode_all(base)
+    assert np.array_equal(pq["codes"], opq.codes)
+    idx, d, cnt = ix.knn_pq(qs, k, ef)
+    for q in range(nq):
+        oi, od = O.flat_knn_pq(base, opq, qs[q], k, ef, kind)
+        c = int(cnt[q])
+        assert c == len(oi)
+        _check(idx[q, :c], d[q, :c], oi, od)
+    # IVF
+    kc = int(rng.integers(1, 40))
+    npb = int(rng.choice([1, 2, 4, 9, 64]))
+    ix.ivf_build(kc, train_n=min(n, 400), max_iter=4, seed=seed)
+    ex = ix.ivf_export()
+    iv = O.IVF(base, ex["centroids"], kind)
+    assert np.array_equal(ex["assign"], iv.assign)
+    idx, d, cnt = ix.ivf_knn(qs, k, npb)
+    for q in range(nq):
+        oi, od = iv.knn(qs[q], k, npb)
+        c = int(cnt[q])
+        assert c == len(oi)
+        _check(idx[q, :c], d[q, :c], oi, od)
+    # HNSW (small graphs: the builder is serial below 1000 rows and batched above)
+    if n <= 4000:
+        M = int(rng.choice([4, 8, 16]))
+        efc = int(rng.choice([20, 60]))
+        batch = int(rng.choice([1, 16]))
+        ix.hnsw_build(M=M, ef_construction=efc, seed=seed, batch=batch, nthreads=4)
+        oh = O.HNSW.from_graph(base, kind, M, efc, ix.hnsw_export())
+        efs = int(rng.choice([k, 40, 200]))
+        idx, d, cnt = ix.knn_with_ef(qs, k, efs)
+        for q in range(nq):
+            oi, od = oh.knn(qs[q], k, efs)
+            c = int(cnt[q])
+            assert c == len(oi)
+            _check(idx[q, :c], d[q, :c], oi, od)
