@@ -312,8 +312,8 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     launch_flat_finish(ws.keys_c.as<uint64_t>(), capk, ws.keys_a.as<uint64_t>(), capp, (uint32_t)nq, ksel, (uint32_t)k, kprime,
                        n, ws.qsq.as<float>(), xsq_max, xsq_min_pos, cosine, (uint32_t)dim, d_hits, CAND_CAP, id_offset,
                        ws.flags.as<uint8_t>(), d_idx, d_dist, d_cnt, s);
-    std::vector<uint8_t> flags(nq);
-    VDB_HIP(hipMemcpyAsync(flags.data(), ws.flags.p, nq, hipMemcpyDeviceToHost, s));
+    const uint8_t *flags = static_cast<const uint8_t *>(ws.pinned(nq));
+    VDB_HIP(hipMemcpyAsync(ws.pinned(nq), ws.flags.p, nq, hipMemcpyDeviceToHost, s));
     VDB_SYNC(s);
     // uncertified queries: gather them, redo them 8 per corpus pass with the exact scan, scatter the results
     std::vector<uint64_t> redo;

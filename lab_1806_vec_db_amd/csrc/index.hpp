@@ -70,8 +70,23 @@ struct Workspace {
     };
     std::vector<Pending> pending;
     size_t ev_used = 0;
+    // pinned host staging for the small per-call read-backs (flags, counters): a D2H copy into pageable memory goes
+    // through the runtime's own staging buffer and costs an extra hop before the stream sync returns
+    void *h_pinned = nullptr;
+    size_t h_pinned_cap = 0;
+    void *pinned(size_t bytes) {
+        if (bytes > h_pinned_cap) {
+            if (h_pinned) (void)hipHostFree(h_pinned);
+            h_pinned = nullptr;
+            size_t want = bytes < (64u << 10) ? (64u << 10) : bytes;
+            VDB_HIP(hipHostMalloc(&h_pinned, want, hipHostMallocDefault));
+            h_pinned_cap = want;
+        }
+        return h_pinned;
+    }
     Workspace() { VDB_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); }
     ~Workspace() {
+        if (h_pinned) (void)hipHostFree(h_pinned);
         for (auto &e : ev_pool) {
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);
