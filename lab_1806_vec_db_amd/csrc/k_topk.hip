@@ -233,9 +233,68 @@ __global__ __launch_bounds__(256) void k_select_tau(const float *__restrict__ ke
     if (tid == 0) tau[q] = f32_from_orderable(hi);  // not reached: 2^32 / 1024^3 < 2048
 }
 
+// Cheap upper bound for small ranks: tau only has to be >= the kth smallest sampled key (a looser threshold lets a few
+// more rows through the filter, nothing else changes).  Every thread keeps the 2 smallest keys of its strided share;
+// the kth smallest of those 512 is the kth smallest of a SUBSET, hence >= the true one, and equal to it unless one
+// thread happened to own 3 of the kth smallest (kth = 32 of ~10^4 keys over 256 threads: rarely, and then off by one
+// rank).  One pass over the keys, no LDS image of them, no histograms: ~10 us instead of ~50-95 us at nq = 1000.
+__global__ __launch_bounds__(256) void k_select_tau_small(const float *__restrict__ keys, uint64_t ld, uint32_t n, uint32_t kth,
+                                                          uint32_t nq_real, float *__restrict__ tau) {
+    __shared__ uint32_t cand[512];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    if (q >= nq_real) {
+        if (tid == 0) tau[q] = -INFINITY;
+        return;
+    }
+    const float *kq = keys + uint64_t(q) * ld;
+    uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;  // m1 <= m2
+    for (uint32_t i0 = tid; i0 < n; i0 += 256 * 8) {  // 8 independent loads in flight per thread
+        float f[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            uint32_t i = i0 + u * 256;
+            f[u] = i < n ? kq[i] : INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            uint32_t v = f32_orderable(f[u]);
+            if (v < m2) {
+                m2 = v < m1 ? m1 : v;
+                m1 = v < m1 ? v : m1;
+            }
+        }
+    }
+    cand[2 * tid] = m1;
+    cand[2 * tid + 1] = m2;
+    __syncthreads();
+    // bitonic sort of the 512 candidates (256 compare-exchanges per stage, 45 stages), then element kth-1
+    for (uint32_t k = 2; k <= 512; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t i = ((tid & ~(j - 1)) << 1) | (tid & (j - 1));  // lower index of this thread's pair
+            const uint32_t p = i | j;
+            const uint32_t a = cand[i], b = cand[p];
+            const bool up = (i & k) == 0;
+            if ((a > b) == up) {
+                cand[i] = b;
+                cand[p] = a;
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        const uint32_t v = cand[kth - 1];
+        tau[q] = v >= 0xFF800000u ? INFINITY : f32_from_orderable(v);  // +inf / NaN / fewer than kth keys -> +inf
+    }
+}
+
 void launch_select_tau(const float *keys, uint64_t ld, uint32_t n, uint32_t nq, uint32_t nq_real, uint32_t kth, float *tau,
                        hipStream_t s) {
     if (nq == 0) return;
+    if (kth >= 1 && kth <= 64 && n >= 8 * 512) {  // small rank in a long sample: the subset bound
+        hipLaunchKernelGGL(k_select_tau_small, dim3(nq), dim3(256), 0, s, keys, ld, n, kth, nq_real, tau);
+        VDB_HIP(hipGetLastError());
+        return;
+    }
     VDB_REQUIRE(n <= SELECT_MAX_N, "select_tau: sample too long");
     size_t lds = (size_t(n) + 2048 + 258) * sizeof(uint32_t);
     static bool attr_done = false;
