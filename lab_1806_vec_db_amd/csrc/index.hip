@@ -258,7 +258,7 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     const uint64_t nbatch = nq_pad / bq;
     uint32_t s_step = 1, s_rank = kprime;  // threshold sample: every s_step-th item, tau = s_rank-th smallest sampled key
     mfma_sample_plan(n, kprime, &s_step, &s_rank);
-    const uint64_t n_s = mfma_sample_rows(n, s_step);
+    const uint64_t n_s = gemm ? gemm_sample_rows(n, s_step) : mfma_sample_rows(n, s_step);
     const uint64_t ld_s = (n_s + 63) & ~63ull;
     const uint32_t nl_s = topk_num_lists(n_s);
     constexpr uint32_t CAND_CAP = 8192;
@@ -274,13 +274,17 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     ws.flags.reserve(nq_pad);
     float *d_tau = ws.misc.as<float>();
     uint32_t *d_hits = reinterpret_cast<uint32_t *>(d_tau + nq_pad);
-    launch_mfma_pack_queries(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, ws.qfrag.as<float>(), s);
+    if (!gemm) launch_mfma_pack_queries(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, ws.qfrag.as<float>(), s);
     if (gemm) {
         ws.qfrag_g.reserve(nq_pad * size_t(mfma_dim_pad((uint32_t)dim)) * sizeof(float));
         launch_mfma_pack_queries_nh(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, 8, ws.qfrag_g.as<float>(), s);
     }
-    launch_flat_mfma_sample(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>(), (uint32_t)nbatch, d_sq.as<float>(),
-                            cosine, s_step, ws.dense.as<float>(), ld_s, num_cu, s);
+    if (gemm)  // the sample through the 128-query kernel too: same arithmetic as the filter, 4x fewer re-reads of the sample
+        launch_flat_gemm_sample(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag_g.as<float>(), (uint32_t)ngroups,
+                                d_sq.as<float>(), cosine, s_step, ws.dense.as<float>(), ld_s, num_cu, s);
+    else
+        launch_flat_mfma_sample(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>(), (uint32_t)nbatch,
+                                d_sq.as<float>(), cosine, s_step, ws.dense.as<float>(), ld_s, num_cu, s);
     if (n_s <= select_tau_max_n()) {  // tau only needs the k'-th smallest sampled key, not a sorted sample shortlist
         launch_select_tau(ws.dense.as<float>(), ld_s, (uint32_t)n_s, (uint32_t)nq_pad, (uint32_t)nq, s_rank, d_tau, s);
     } else {

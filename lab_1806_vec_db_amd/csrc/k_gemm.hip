@@ -42,6 +42,9 @@ struct GemmArgs {
     const float *xsq;
     uint64_t n;
     uint32_t KB, n_units, ngroups;
+    uint32_t unit_step;  // GEMM_SAMPLE: every unit_step-th unit is scored (n_units counts the sampled ones); else 1
+    float *out;          // GEMM_SAMPLE: dense keys out[q*ld + v*16*TW + row in unit] (+inf past n), v = sampled ordinal
+    uint64_t ld;
     const float *tau;  // [ngroups*128]
     uint64_t *cand;    // [ngroups*128][cap]
     uint32_t *cnt;     // [ngroups*128]
@@ -50,7 +53,12 @@ struct GemmArgs {
     uint32_t debug;
 };
 
-template <int TW, int KC>
+enum { GEMM_FILTER = 0, GEMM_SAMPLE = 1 };
+
+// GEMM_SAMPLE: blockIdx.y = query group, one step per workgroup over the sampled units, keys written densely -- the
+// threshold sample of the same queries with the same arithmetic as the filter pass (the small-batch kernel's sample
+// mode re-reads the sampled rows once per 32 queries; this one once per 128: 80 -> ~25 us at a 125k-row shard).
+template <int TW, int KC, int MODE>
 __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
     constexpr int NT = 512, NW = 8, NH = GEMM_NH, R = KC;
     constexpr uint32_t CHUNK = KC * NH * 128;  // uint4 per Q chunk
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
     };
     auto unit_ptr = [&](uint32_t u) -> const char * {  // wave-uniform
         if (u >= a.n_units) u = a.n_units - 1;  // idle waves re-read the last unit (L2 hits, results masked)
-        return reinterpret_cast<const char *>(a.XT) + uint64_t(u) * TW * KB * 2048;
+        return reinterpret_cast<const char *>(a.XT) + uint64_t(u) * a.unit_step * TW * KB * 2048;
     };
     uint32_t slot_cur = blockIdx.x, slot_nxt = adv(slot_cur);  // of the current and of the next query group
     const char *cp_cur = unit_ptr(unit_of(slot_cur, 0)),
@@ -121,17 +129,18 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
     constexpr int QP = QST / KC;
     static_assert(QST % KC == 0, "staging must split evenly over the k-blocks of a chunk");
     {
-        const uint4 *src = a.qfrag;
+        const uint4 *src = a.qfrag + (MODE == GEMM_SAMPLE ? uint64_t(blockIdx.y) * nchunk * CHUNK : 0);
 #pragma unroll
         for (int j = 0; j < QST; j++) smem[j * NT + threadIdx.x] = src[j * NT + threadIdx.x];
     }
     uint32_t buf = 0;
     __syncthreads();
 
-    for (uint32_t grp = 0; grp < a.ngroups; grp++) {
+    const uint32_t g_begin = MODE == GEMM_SAMPLE ? blockIdx.y : 0, g_end = MODE == GEMM_SAMPLE ? blockIdx.y + 1 : a.ngroups;
+    for (uint32_t grp = g_begin; grp < g_end; grp++) {
         const uint4 *qgrp = a.qfrag + uint64_t(grp) * nchunk * CHUNK;
-        if (threadIdx.x < 1 + 2 * GEMM_BQ) hit_n[threadIdx.x] = 0;  // ordered before the first append by the chunk barriers
-        if (threadIdx.x < GEMM_BQ)  // thresholds live in LDS, not in 8 registers per lane
+        if (MODE == GEMM_FILTER && threadIdx.x < 1 + 2 * GEMM_BQ) hit_n[threadIdx.x] = 0;  // ordered before the first append by the chunk barriers
+        if (MODE == GEMM_FILTER && threadIdx.x < GEMM_BQ)  // thresholds live in LDS, not in 8 registers per lane
             tau_s[threadIdx.x] = (a.debug & 1) ? -INFINITY : a.tau[grp * GEMM_BQ + threadIdx.x];
         const uint32_t steps = steps_of(slot_cur);
         for (uint32_t st = 0; st < steps; st++) {
@@ -213,8 +222,8 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
             }
             // ---- epilogue: lane holds rows 4*g4..4*g4+3 of each tile for query r of each half ----
             typedef const __attribute__((address_space(4))) float *cfloat_p;
-            cfloat_p xs_unit = (cfloat_p)(a.xsq + uint64_t(__builtin_amdgcn_readfirstlane(u)) * (16 * TW));
-            const uint64_t row0 = uint64_t(u_raw) * (16 * TW);  // the unclamped unit: idle waves are past n
+            cfloat_p xs_unit = (cfloat_p)(a.xsq + uint64_t(__builtin_amdgcn_readfirstlane(u)) * a.unit_step * (16 * TW));
+            const uint64_t row0 = uint64_t(u_raw) * a.unit_step * (16 * TW);  // the unclamped unit: idle waves are past n
 #pragma unroll
             for (int t = 0; t < TW; t++) {
                 float xsv[16];
@@ -236,7 +245,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
                 const f32x2 xv01 = {xv[0], xv[1]}, xv23 = {xv[2], xv[3]};
 #pragma unroll
                 for (int h = 0; h < NH; h++) {
-                    const float tau_h = tau_s[h * 16 + r];
+                    const float tau_h = MODE == GEMM_FILTER ? tau_s[h * 16 + r] : 0.0f;
                     const f32x2 a01 = {acc[t][h][0], acc[t][h][1]}, a23 = {acc[t][h][2], acc[t][h][3]};
                     f32x2 k01, k23;
                     if (a.cosine) {
@@ -246,6 +255,18 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
                         const f32x2 two = {2.0f, 2.0f};
                         k01 = xv01 - two * a01;
                         k23 = xv23 - two * a23;
+                    }
+                    if (MODE == GEMM_SAMPLE) {
+                        if (u_raw < a.n_units) {  // wave-uniform: waves past the last sampled unit write nothing
+                            float4 kv;
+                            kv.x = rb + 0 < n ? k01.x : INFINITY;
+                            kv.y = rb + 1 < n ? k01.y : INFINITY;
+                            kv.z = rb + 2 < n ? k23.x : INFINITY;
+                            kv.w = rb + 3 < n ? k23.y : INFINITY;
+                            const uint64_t col = uint64_t(u_raw) * (16 * TW) + t * 16 + 4 * g4;  // dense position in the sample
+                            *reinterpret_cast<float4 *>(a.out + (uint64_t(grp) * GEMM_BQ + h * 16 + r) * a.ld + col) = kv;
+                        }
+                        continue;
                     }
                     const float kmin = fminf(fminf(k01.x, k01.y), fminf(k23.x, k23.y));  // NaN keys never pass
                     if (kmin <= tau_h) {  // rare: ~k' * sample step hits per query in total
@@ -268,7 +289,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
         }
         // ---- group end: hand the parked hits to the per-query candidate lists (one global atomic per query) ----
         __syncthreads();
-        {
+        if (MODE == GEMM_FILTER) {
             uint32_t total = hit_n[0];
             if (total > GEMM_WGBUF) total = GEMM_WGBUF;
             constexpr uint32_t NJ = (GEMM_WGBUF + NT - 1) / NT;
@@ -298,31 +319,51 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
     }
 }
 
-template <int TW, int KC>
+template <int TW, int KC, int MODE>
 static void flat_gemm_launch(const GemmArgs &a0, int num_cu, hipStream_t s) {
     GemmArgs a = a0;
     const uint64_t n_tiles = (a.n + 15) / 16;
-    a.n_units = (uint32_t)((n_tiles + TW - 1) / TW);
-    uint32_t grid = (uint32_t)num_cu;
-    const uint32_t need = (a.n_units + 7) / 8;
-    if (need < grid) grid = need;
+    const uint32_t units_all = (uint32_t)((n_tiles + TW - 1) / TW);
+    uint32_t grid;
+    if (MODE == GEMM_SAMPLE) {
+        a.n_units = (units_all + a.unit_step - 1) / a.unit_step;  // sampled units: ordinal v scores unit v * unit_step
+        grid = (a.n_units + 7) / 8;                               // one step: a wave per sampled unit
+    } else {
+        a.unit_step = 1;
+        a.n_units = units_all;
+        grid = (uint32_t)num_cu;
+        const uint32_t need = (a.n_units + 7) / 8;
+        if (need < grid) grid = need;
+    }
     if (grid == 0 || a.ngroups == 0) return;
     const size_t lds = size_t(2) * KC * GEMM_NH * 128 * sizeof(uint4) + size_t(GEMM_WGBUF) * 12 + (1 + 3 * GEMM_BQ) * 4 + 16;
     static bool attr_done = false;
     if (!attr_done) {
-        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_gemm<TW, KC>),
+        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_gemm<TW, KC, MODE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_flat_gemm<TW, KC>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((k_flat_gemm<TW, KC, MODE>), dim3(grid, MODE == GEMM_SAMPLE ? a.ngroups : 1), dim3(512), lds, s, a);
     VDB_HIP(hipGetLastError());
 }
 
-// rows past n up to a whole unit are read from the mirror (zero tiles) and from xsq (padding): see Index::add_rows
-void launch_flat_gemm_filter(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t ngroups,
-                             const float *xsq, int cosine, const float *tau, uint64_t *cand, uint32_t *cnt,
-                             uint32_t cap, int debug, int num_cu, hipStream_t s) {
-    if (n == 0 || ngroups == 0) return;
+template <int MODE>
+static void flat_gemm_dispatch(const GemmArgs &a, int num_cu, hipStream_t s) {
+    if (a.KB % 3 == 0) {
+        if (g_gemm_tw == 2)
+            flat_gemm_launch<2, 3, MODE>(a, num_cu, s);
+        else
+            flat_gemm_launch<3, 3, MODE>(a, num_cu, s);
+    } else {  // KB is even (columns padded to a multiple of 64)
+        if (g_gemm_tw == 2)
+            flat_gemm_launch<2, 2, MODE>(a, num_cu, s);
+        else
+            flat_gemm_launch<3, 2, MODE>(a, num_cu, s);
+    }
+}
+
+static GemmArgs gemm_args(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t ngroups, const float *xsq,
+                          int cosine) {
     VDB_REQUIRE(n < (1ull << 32), "flat_gemm: too many rows for one shard");
     GemmArgs a{};
     a.XT = reinterpret_cast<const uint4 *>(XT);
@@ -331,23 +372,43 @@ void launch_flat_gemm_filter(const float *XT, uint64_t n, uint32_t dim, const fl
     a.n = n;
     a.KB = mfma_dim_pad(dim) / 32;
     a.ngroups = ngroups;
+    a.cosine = cosine;
+    a.unit_step = 1;
+    return a;
+}
+
+// rows past n up to a whole unit are read from the mirror (zero tiles) and from xsq (padding): see Index::add_rows
+void launch_flat_gemm_filter(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t ngroups,
+                             const float *xsq, int cosine, const float *tau, uint64_t *cand, uint32_t *cnt,
+                             uint32_t cap, int debug, int num_cu, hipStream_t s) {
+    if (n == 0 || ngroups == 0) return;
+    GemmArgs a = gemm_args(XT, n, dim, qfrag, ngroups, xsq, cosine);
     a.tau = tau;
     a.cand = cand;
     a.cnt = cnt;
     a.cap = cap;
-    a.cosine = cosine;
     a.debug = (uint32_t)debug;
-    if (a.KB % 3 == 0) {
-        if (g_gemm_tw == 2)
-            flat_gemm_launch<2, 3>(a, num_cu, s);
-        else
-            flat_gemm_launch<3, 3>(a, num_cu, s);
-    } else {  // KB is even (columns padded to a multiple of 64)
-        if (g_gemm_tw == 2)
-            flat_gemm_launch<2, 2>(a, num_cu, s);
-        else
-            flat_gemm_launch<3, 2>(a, num_cu, s);
-    }
+    flat_gemm_dispatch<GEMM_FILTER>(a, num_cu, s);
+}
+
+// rows of the threshold sample: every unit_step-th unit of 16*TW rows (the unit size follows flat_gemm_tw)
+uint64_t gemm_sample_rows(uint64_t n, uint32_t unit_step) {
+    const uint32_t tw = (uint32_t)g_gemm_tw;
+    const uint64_t units = ((n + 15) / 16 + tw - 1) / tw;
+    return (units + unit_step - 1) / unit_step * (16 * tw);
+}
+// dense keys of the sample for every query of every group: out[q*ld + j], j < gemm_sample_rows(n, unit_step), +inf past n
+void launch_flat_gemm_sample(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t ngroups,
+                             const float *xsq, int cosine, uint32_t unit_step, float *out, uint64_t ld, int num_cu,
+                             hipStream_t s) {
+    if (n == 0 || ngroups == 0) return;
+    VDB_REQUIRE(unit_step >= 1 && (ld & 3) == 0 && ld >= gemm_sample_rows(n, unit_step), "flat_gemm: ld must cover the sample");
+    VDB_REQUIRE(ngroups <= 65535, "flat_gemm: too many query groups");
+    GemmArgs a = gemm_args(XT, n, dim, qfrag, ngroups, xsq, cosine);
+    a.unit_step = unit_step;
+    a.out = out;
+    a.ld = ld;
+    flat_gemm_dispatch<GEMM_SAMPLE>(a, num_cu, s);
 }
 
 }  // namespace vdb

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void k_select_tau_small(const float *__restric
 void launch_select_tau(const float *keys, uint64_t ld, uint32_t n, uint32_t nq, uint32_t nq_real, uint32_t kth, float *tau,
                        hipStream_t s) {
     if (nq == 0) return;
-    if (kth >= 1 && kth <= 64 && n >= 8 * 512) {  // small rank in a long sample: the subset bound
+    if (kth >= 1 && kth <= 64 && n >= 4 * 512) {  // small rank in a long sample: the subset bound
         hipLaunchKernelGGL(k_select_tau_small, dim3(nq), dim3(256), 0, s, keys, ld, n, kth, nq_real, tau);
         VDB_HIP(hipGetLastError());
         return;

@@ -98,6 +98,11 @@ void launch_flat_gemm_filter(const float *XT, uint64_t n, uint32_t dim, const fl
                              const float *xsq, int cosine, const float *tau, uint64_t *cand, uint32_t *cnt,
                              uint32_t cap, int debug, int num_cu, hipStream_t s);
 uint32_t gemm_group();
+// threshold sample with the same kernel: every unit_step-th unit of rows, dense keys out[q*ld + j]
+uint64_t gemm_sample_rows(uint64_t n, uint32_t unit_step);
+void launch_flat_gemm_sample(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t ngroups,
+                             const float *xsq, int cosine, uint32_t unit_step, float *out, uint64_t ld, int num_cu,
+                             hipStream_t s);
 void gemm_set_tw(int v);
 void launch_mfma_pack_queries_nh(const float *Q, uint32_t nq, uint32_t nq_cover, uint32_t dim, uint32_t NH, float *qfrag,
                                  hipStream_t s);
