@@ -84,9 +84,9 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--cpu-queries", type=int, default=512,
                     help="queries timed on the CPU oracle and parity-checked (0 = skip); 512 = ~12 s on 16 cores")
-    ap.add_argument("--workload", choices=["flat", "pq_flat", "hnsw"], default="flat",
+    ap.add_argument("--workload", choices=["flat", "pq_flat", "hnsw", "ivf"], default="flat",
                     help="flat = the headline (BASELINE metric); pq_flat / hnsw = the other SURVEY 8d configs")
-    ap.add_argument("--ef", type=int, default=0, help="pq_flat: ADC shortlist (default 100); hnsw: search ef (default 128)")
+    ap.add_argument("--ef", type=int, default=0, help="pq_flat: ADC shortlist (default 100); hnsw: search ef (default 128); ivf: n_probes (default 4)")
     ap.add_argument("--dist", choices=["l2sqr", "cosine"], default="l2sqr",
                     help="l2sqr = the BASELINE metric; cosine = the reference's default table distance (pyo3/mod.rs:73)")
     ap.add_argument("--data", choices=["gistlike", "lowrank"], default="gistlike",
@@ -125,13 +125,13 @@ def main():
     wl = args.workload
     if args.rows <= 0:
         args.rows = 1_000_000  # hnsw: the host builder (hnsw_index.rs:391-457 batches) takes ~3-4 min for this graph
-    ef = args.ef or (100 if wl == "pq_flat" else 128)
+    ef = args.ef or {"pq_flat": 100, "hnsw": 128, "ivf": 4}.get(wl, 0)
     n, dim, nq, k = args.rows, args.dim, args.nq, args.k
     # identical corpus on every rank (same seed), each keeps its row block
     gen = gist_like_gpu if args.data == "gistlike" else gist_lowrank_gpu
     base = gen(torch, n, dim, 1806, device)
     queries = gen(torch, nq, dim, 1807, device)
-    r0, r1 = shard_bounds(n, world, rank) if wl != "hnsw" else (0, n)  # HNSW: full replica per GPU
+    r0, r1 = shard_bounds(n, world, rank) if wl in ("flat", "pq_flat") else (0, n)  # HNSW / IVF: full replica per GPU
     shard = base[r0:r1].contiguous()
     torch.cuda.synchronize()
 
@@ -152,6 +152,11 @@ def main():
         cent = tr.pq_export()["centroids"]
         del tr
         ix.pq_attach(4, m, cent, None)
+    elif wl == "ivf":
+        # IVFIndex::from_vec_set (ivf_index.rs:66-118): sqrt(N) clusters, k-means on 10000 sampled rows, 10 iterations
+        t_b = time.perf_counter()
+        ix.ivf_build(int(round(n ** 0.5)), train_n=10000, max_iter=10, tol=1e-6, seed=42)
+        build_s = time.perf_counter() - t_b
     elif wl == "hnsw":
         t_b = time.perf_counter()
         ix.hnsw_build(M=16, ef_construction=200, seed=42, batch=64, nthreads=min(len(os.sched_getaffinity(0)), 16))
@@ -184,8 +189,11 @@ def main():
             if host_xchg:
                 return allgather_merge_pq(s_adc.cpu(), s_ex.cpu(), k)
             return allgather_merge_pq(s_adc, s_ex, k, gpu_index=ix)
-        # hnsw: replicas, each rank answers its block of the queries, blocks are concatenated
-        if q1 > q0:
+        # hnsw / ivf: replicas, each rank answers its block of the queries, blocks are concatenated
+        if q1 > q0 and wl == "ivf":
+            ix.ivf_knn_device(queries[q0:q1].data_ptr(), q1 - q0, k, ef, o_idx.data_ptr(), o_dist.data_ptr(),
+                              o_cnt.data_ptr())
+        elif q1 > q0:
             ix.hnsw_knn_device(queries[q0:q1].data_ptr(), q1 - q0, k, ef, o_idx.data_ptr(), o_dist.data_ptr(),
                                o_cnt.data_ptr())
         li, ld, lc = o_idx[: q1 - q0], o_dist[: q1 - q0], o_cnt[: q1 - q0]
@@ -218,7 +226,7 @@ def main():
     if wl == "flat":
         kernel = "flat_mfma" if ix.prof_get("flat_mfma")["launches"] else "flat_exact"
     else:
-        kernel = "pq_adc" if wl == "pq_flat" else "hnsw"
+        kernel = {"pq_flat": "pq_adc", "hnsw": "hnsw", "ivf": "ivf_rerank"}[wl]
     p = ix.prof_get(kernel)
     roofline = None
     if p["launches"] and wl != "flat":
@@ -262,8 +270,10 @@ def main():
     qps = nq * args.steps / elapsed
     dname = "L2Sqr" if args.dist == "l2sqr" else "Cosine"
     names = {"flat": ("Flat brute force", "flat_knn_gist1m"), "pq_flat": (f"PQ-Flat 4-bit m={dim // 3}, ADC ef={ef}", "pq_flat_knn_gist1m"),
-             "hnsw": (f"HNSW M=16 efc=200, ef={ef}", f"hnsw_knn_gistlike_{n}")}[wl]
-    par = {"flat": f"row-shard x{world}", "pq_flat": f"row-shard x{world}", "hnsw": f"replica x{world}, queries split"}[wl]
+             "hnsw": (f"HNSW M=16 efc=200, ef={ef}", f"hnsw_knn_gistlike_{n}"),
+             "ivf": (f"IVF {int(round(n ** 0.5))} clusters, n_probes={ef}", f"ivf_knn_gistlike_{n}")}[wl]
+    par = {"flat": f"row-shard x{world}", "pq_flat": f"row-shard x{world}", "hnsw": f"replica x{world}, queries split",
+           "ivf": f"replica x{world}, queries split"}[wl]
     out = {
         "metric": f"queries/sec at recall@10, Gist1M d=960 ({names[0]}, {dname}, k=10)",
         "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -279,6 +289,8 @@ def main():
         out["fallback_queries"] = ix.flat_fallback_count()
     else:
         out["config"]["ef"] = ef
+    if wl == "ivf":
+        out["config"]["host_build_s"] = round(build_s, 1)
     if wl == "hnsw":
         nd, ne = ix.hnsw_last_stats()
         out["config"]["host_build_s"] = round(build_s, 1)
@@ -319,6 +331,14 @@ def main():
                     r = list(ex.map(lambda q: O.flat_knn_pq(host_base, opq, hq[q], k, ef, okind), range(ncpu)))
                 cpu_s = time.perf_counter() - t0
                 what = "FlatIndex::knn_pq"
+            elif wl == "ivf":
+                ex_ivf = ix.ivf_export()  # centroids and clusters are inputs of the oracle (assignment parity: tests/test_ivf_gpu.py)
+                oiv = O.IVF(host_base, ex_ivf["centroids"], okind, assign=ex_ivf["assign"])
+                t0 = time.perf_counter()
+                with ThreadPoolExecutor(threads) as ex:
+                    r = list(ex.map(lambda q: oiv.knn(hq[q], k, ef), range(ncpu)))
+                cpu_s = time.perf_counter() - t0
+                what = "IVFIndex::knn_with_ef on the same centroids and clusters"
             else:
                 oh = O.HNSW.from_graph(host_base, okind, 16, 200, ix.hnsw_export())
                 t0 = time.perf_counter()

@@ -180,6 +180,10 @@ int vdb_ivf_export(vdb_index *idx, float *centroids, uint64_t *assign);
 int vdb_ivf_knn(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t n_probes,
                 uint64_t *out_idx, float *out_dist, uint64_t *out_count);
 
+/* device-pointer variant; returns synchronised */
+int vdb_ivf_knn_device(vdb_index *idx, const void *d_queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t n_probes,
+                       void *d_out_idx, void *d_out_dist, void *d_out_count, void *stream);
+
 /* ---- row-sharded FlatIndex::knn_pq -------------------------------------------
  * pq_resort (candidate_pair.rs:102-108) replays ResultSet::add in the GLOBAL (ADC distance, id) order, so the
  * exchange carries, per shard and query, max(ef,k) pair keys twice: the ADC key row (ascending) and the exact-distance

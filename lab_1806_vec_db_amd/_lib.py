@@ -63,6 +63,7 @@ SIGNATURES = {
     "vdb_ivf_info": [vp, intp, u64p, u64p],
     "vdb_ivf_export": [vp, f32p, u64p],
     "vdb_ivf_knn": [vp, f32p, u64, u64, u64, u64, u64p, f32p, u64p],
+    "vdb_ivf_knn_device": [vp, vp, u64, u64, u64, u64, vp, vp, vp, vp],
     "vdb_hnsw_build": [vp, u64, u64, u64, u64, C.c_int],
     "vdb_hnsw_attach": [vp, u64, u64, u32p, u64p, u64p, u32p, u64p, C.c_int, u64, u64],
     "vdb_hnsw_clear": [vp],

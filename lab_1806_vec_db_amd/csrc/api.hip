@@ -541,6 +541,16 @@ int vdb_ivf_knn(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim,
     VDB_API_END
 }
 
+int vdb_ivf_knn_device(vdb_index *idx, const void *d_queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t n_probes,
+                       void *d_out_idx, void *d_out_dist, void *d_out_count, void *stream) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    VDB_REQUIRE(idx->ix.ivf.present, "knn needs an IVF index (vdb_ivf_build / vdb_ivf_attach)");
+    if (n_probes == 0) n_probes = idx->ix.ivf.default_n_probes;
+    device_search(idx->ix, d_queries, nq, dim, k, n_probes, d_out_idx, d_out_dist, d_out_count, stream, ivf_dev);
+    VDB_API_END
+}
+
 // ---- HNSW -----------------------------------------------------------------------------------------
 int vdb_hnsw_build(vdb_index *idx, uint64_t M, uint64_t ef_construction, uint64_t seed, uint64_t batch,
                    int nthreads) {

@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void k_ivf_candidates(const uint64_t *__restri
                                                         const uint64_t *__restrict__ probe_cnt, uint32_t n_probes,
                                                         const uint32_t *__restrict__ offsets,
                                                         const uint32_t *__restrict__ members, uint32_t ld,
-                                                        uint64_t *__restrict__ cand) {
+                                                        uint64_t *__restrict__ cand,
+                                                        unsigned long long *__restrict__ n_cand_total) {
     const uint32_t q = blockIdx.x;
     uint64_t *row = cand + uint64_t(q) * ld;
     uint32_t base = 0;
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(256) void k_ivf_candidates(const uint64_t *__restri
         base += e - b;
     }
     for (uint32_t j = base + threadIdx.x; j < ld; j += blockDim.x) row[j] = PAIR_NONE;
+    if (threadIdx.x == 0) atomicAdd(n_cand_total, (unsigned long long)base);  // rows scanned for this query (SURVEY 8d bytes)
 }
 
 void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t n_probes,
@@ -193,17 +195,28 @@ void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uin
     ws.keys_c.reserve(nq * capk * sizeof(uint64_t));
     ws.qsq.reserve(nq * sizeof(float));
     launch_row_sqnorm(d_q, nq, (uint32_t)ix.dim, ws.qsq.as<float>(), s);
+    ws.misc.reserve(64);
+    unsigned long long *d_ncand = ws.misc.as<unsigned long long>();
+    VDB_HIP(hipMemsetAsync(d_ncand, 0, sizeof(unsigned long long), s));
     hipLaunchKernelGGL(k_ivf_candidates, dim3((unsigned)nq), dim3(256), 0, s, d_pidx, pcnt.as<uint64_t>(), (uint32_t)np,
-                       iv.d_offsets.as<uint32_t>(), iv.d_members.as<uint32_t>(), ld, ws.keys_a.as<uint64_t>());
+                       iv.d_offsets.as<uint32_t>(), iv.d_members.as<uint32_t>(), ld, ws.keys_a.as<uint64_t>(), d_ncand);
+    ix.prof_begin(ws, "ivf_rerank", 0.0);
     // (3) exact distances in offer order, (4) ResultSet::add replay, sorted output (into_sorted_vec, :153)
     launch_rerank(ix.d_rows.as<float>(), (uint32_t)ix.dim, d_q, (uint32_t)nq, ix.dist == 0 ? MET_L2_DIRECT : MET_COSINE,
                   ix.d_sq.as<float>(), ws.qsq.as<float>(), ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), ld, ld, s);
+    ix.prof_end(ws);
     pq_resort_launch(ws.keys_b.as<uint64_t>(), ld, ld, (uint32_t)nq, ksel, ws.keys_c.as<uint64_t>(), s);
     if (k > ksel) {
         VDB_HIP(hipMemsetAsync(d_idx, 0, nq * k * sizeof(uint64_t), s));
         VDB_HIP(hipMemsetAsync(d_dist, 0, nq * k * sizeof(float), s));
     }
     launch_finalize(ws.keys_c.as<uint64_t>(), capk, (uint32_t)nq, ksel, (uint32_t)k, ix.id_offset, d_idx, d_dist, d_cnt, s);
+    if (!ws.pending.empty()) {  // measurement on: the scan's algorithmic bytes = scanned rows x (dim*4 + 4), known only now
+        unsigned long long total = 0;
+        VDB_HIP(hipMemcpyAsync(&total, d_ncand, sizeof(total), hipMemcpyDeviceToHost, s));
+        VDB_SYNC(s);
+        ws.pending.back().bytes += double(total) * (double(ix.dim) * sizeof(float) + sizeof(float));
+    }
 }
 
 }  // namespace vdb

@@ -351,6 +351,11 @@ class GpuIndex:
         """IVFIndex::knn_with_ef (ef = n_probes; 0 -> default 4)."""
         return self._search(self._lib.vdb_ivf_knn, queries, k, n_probes)
 
+    def ivf_knn_device(self, q_ptr: int, nq: int, k: int, n_probes: int, out_idx_ptr: int, out_dist_ptr: int,
+                       out_cnt_ptr: int, stream: int = 0):
+        L.check(self._lib.vdb_ivf_knn_device(self._h, L.vp(q_ptr), int(nq), self.dim, int(k), int(n_probes),
+                                             L.vp(out_idx_ptr), L.vp(out_dist_ptr), L.vp(out_cnt_ptr), L.vp(stream)))
+
     # -- measurement ---------------------------------------------------------------------------------------------
     def prof_enable(self, on: bool = True):
         L.check(self._lib.vdb_prof_enable(self._h, 1 if on else 0))

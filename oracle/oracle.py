@@ -299,14 +299,17 @@ def kmeans(rows, c0, c1, k, max_iter=20, tol=1e-6, kind=L2SQR, seed=42):
 class IVF:
     """oracle IVFIndex (ivf_index.rs:34-47) for given centroids: clusters by find_nearest, search by probes."""
 
-    def __init__(self, base, centroids, kind=L2SQR):
+    def __init__(self, base, centroids, kind=L2SQR, assign=None):
         self.base = _f32(base)
         self.cents = _f32(centroids)
         self.kind = kind
         n, dim = self.base.shape
         k = self.cents.shape[0]
-        self.assign = np.zeros(n, dtype=np.uint64)
-        lib().orc_assign_nearest(_p(self.base, _f32p), n, dim, kind, _p(self.cents, _f32p), k, _p(self.assign, _u64p))
+        if assign is not None:  # clusters supplied (a serialized IVFIndex carries them, ivf_index.rs:44)
+            self.assign = np.ascontiguousarray(assign, dtype=np.uint64)
+        else:
+            self.assign = np.zeros(n, dtype=np.uint64)
+            lib().orc_assign_nearest(_p(self.base, _f32p), n, dim, kind, _p(self.cents, _f32p), k, _p(self.assign, _u64p))
         order = np.argsort(self.assign, kind="stable")  # ascending id inside a cluster (ivf_index.rs:98-100)
         self.members = order.astype(np.uint64)
         counts = np.bincount(self.assign.astype(np.int64), minlength=k)
