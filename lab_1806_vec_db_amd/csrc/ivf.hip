@@ -30,26 +30,50 @@ void ivf_clear(Index &ix) {
     ix.ivf.d_members.release();
 }
 
-// nearest centroid of n device-resident rows (k_means.rs:40-57): exact top-1 search of the rows, as queries, against
-// a Flat index over the centroids -- strict-order distances, ties to the lower centroid index
-static void assign_nearest(Index &cent, const float *d_rows, uint64_t n, uint64_t dim, uint64_t *out) {
+// ids 0..k-1 as a candidate row per query (PAIR_NONE pads): "every centroid is a candidate"
+__global__ void k_iota_keys(uint64_t *__restrict__ rows, uint32_t k, uint32_t ld) {
+    uint64_t *row = rows + uint64_t(blockIdx.x) * ld;
+    for (uint32_t j = threadIdx.x; j < ld; j += blockDim.x) row[j] = j < k ? uint64_t(j) : PAIR_NONE;
+}
+
+// Exact (distance, centroid) pair keys of EVERY centroid for nq device-resident queries, unsorted, in out[q][0..ld):
+// one thread per (query, centroid) pair folds in reference order (k_rerank with the identity candidate list).  The
+// centroid set is small and L2-resident, the pairs are many: this keeps every CU busy where a Flat scan of a
+// 1000-row "corpus" launches 4 workgroups per 8 queries (measured: 15 ms of a 24 ms IVF step, 16 s of a 23 s build).
+static void all_centroid_keys(Index &cent, const float *d_q, const float *d_qsq, uint64_t nq, uint32_t ld, uint64_t *ids,
+                              uint64_t *out, hipStream_t s) {
+    const uint32_t k = (uint32_t)cent.n;
+    hipLaunchKernelGGL(k_iota_keys, dim3((unsigned)nq), dim3(256), 0, s, ids, k, ld);
+    launch_rerank(cent.d_rows.as<float>(), (uint32_t)cent.dim, d_q, (uint32_t)nq, cent.dist == 0 ? MET_L2_DIRECT : MET_COSINE,
+                  cent.d_sq.as<float>(), d_qsq, ids, out, k, ld, s);
+}
+
+// nearest centroid of n device-resident rows (k_means.rs:40-57: minimum under the CandidatePair order): all exact
+// distances, then a top-1 select per row
+static void assign_nearest(Index &cent, const float *d_rows, const float *d_rows_sq, uint64_t n, uint64_t dim, uint64_t *out) {
     WsLease ws(cent);
     hipStream_t s = ws->stream;
     constexpr uint64_t CHUNK = 8192;
-    ws->out_idx.reserve(CHUNK * sizeof(uint64_t));
-    ws->out_dist.reserve(CHUNK * sizeof(float));
-    ws->out_cnt.reserve(CHUNK * sizeof(uint64_t));
+    const uint32_t ld = (uint32_t)((cent.n + 63) & ~63ull);
+    ws->keys_a.reserve(CHUNK * ld * sizeof(uint64_t));
+    ws->keys_b.reserve(CHUNK * ld * sizeof(uint64_t));
+    ws->keys_c.reserve(CHUNK * 64 * sizeof(uint64_t));
+    ws->qsq.reserve(CHUNK * sizeof(float));
+    std::vector<uint64_t> top(CHUNK * 64);
     for (uint64_t r0 = 0; r0 < n; r0 += CHUNK) {
         const uint64_t nb = std::min<uint64_t>(CHUNK, n - r0);
-        cent.flat_knn_device(*ws, d_rows + r0 * dim, nb, 1, ws->out_idx.as<uint64_t>(), ws->out_dist.as<float>(),
-                             ws->out_cnt.as<uint64_t>());
-        VDB_HIP(hipMemcpyAsync(out + r0, ws->out_idx.p, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        const float *qsq = d_rows_sq ? d_rows_sq + r0 : ws->qsq.as<float>();
+        if (!d_rows_sq) launch_row_sqnorm(d_rows + r0 * dim, nb, (uint32_t)dim, ws->qsq.as<float>(), s);
+        all_centroid_keys(cent, d_rows + r0 * dim, qsq, nb, ld, ws->keys_a.as<uint64_t>(), ws->keys_b.as<uint64_t>(), s);
+        launch_topk_merge(ws->keys_b.as<uint64_t>(), 1, ld, (uint32_t)nb, 1, ws->keys_c.as<uint64_t>(), s);
+        VDB_HIP(hipMemcpyAsync(top.data(), ws->keys_c.p, nb * 64 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         VDB_SYNC(s);
+        for (uint64_t i = 0; i < nb; i++) out[r0 + i] = uint32_t(top[i * 64]);  // smallest pair key: (distance, index)
     }
 }
 static void ivf_assign_rows(Index &ix, std::vector<uint64_t> &assign) {
     assign.resize(ix.n);
-    assign_nearest(*ix.ivf.cent, ix.d_rows.as<float>(), ix.n, ix.dim, assign.data());
+    assign_nearest(*ix.ivf.cent, ix.d_rows.as<float>(), ix.d_sq.as<float>(), ix.n, ix.dim, assign.data());
 }
 
 static void ivf_install(Index &ix, uint64_t k, const float *centroids, const uint64_t *assign) {
@@ -122,7 +146,7 @@ void ivf_build(Index &ix, uint64_t k_clusters, uint64_t train_n, uint64_t max_it
         Index tmp(ix.device, ix.dim, ix.dist);
         tmp.flat_mode = 1;
         tmp.add_rows(c, k_clusters, false);
-        assign_nearest(tmp, d_train.as<float>(), nt, dim, a64.data());
+        assign_nearest(tmp, d_train.as<float>(), nullptr, nt, dim, a64.data());
         for (size_t i = 0; i < nt; i++) assign[i] = (uint32_t)a64[i];
     };
     host_kmeans(train, nt, dim, 0, dim, k_clusters, max_iter, tol, ix.dist, rng, cent.data(), on_gpu);
@@ -136,8 +160,8 @@ void ivf_export(Index &ix, float *centroids, uint64_t *assign) {
 }
 
 // candidate ids of query q in offer order: clusters in probe order, rows ascending inside a cluster; PAIR_NONE pads
-__global__ __launch_bounds__(256) void k_ivf_candidates(const uint64_t *__restrict__ probe_idx,
-                                                        const uint64_t *__restrict__ probe_cnt, uint32_t n_probes,
+__global__ __launch_bounds__(256) void k_ivf_candidates(const uint64_t *__restrict__ probe_keys, uint32_t ldp,
+                                                        uint32_t n_probes,
                                                         const uint32_t *__restrict__ offsets,
                                                         const uint32_t *__restrict__ members, uint32_t ld,
                                                         uint64_t *__restrict__ cand,
@@ -145,9 +169,10 @@ __global__ __launch_bounds__(256) void k_ivf_candidates(const uint64_t *__restri
     const uint32_t q = blockIdx.x;
     uint64_t *row = cand + uint64_t(q) * ld;
     uint32_t base = 0;
-    const uint32_t np = (uint32_t)probe_cnt[q];
-    for (uint32_t p = 0; p < np; p++) {  // block-uniform
-        const uint32_t c = (uint32_t)probe_idx[uint64_t(q) * n_probes + p];
+    for (uint32_t p = 0; p < n_probes; p++) {  // block-uniform
+        const uint64_t pk = probe_keys[uint64_t(q) * ldp + p];  // sorted (distance, centroid) keys, PAIR_NONE pads
+        if (pk == PAIR_NONE) break;
+        const uint32_t c = uint32_t(pk);
         const uint32_t b = offsets[c], e = offsets[c + 1];
         for (uint32_t j = threadIdx.x; j < e - b; j += blockDim.x) row[base + j] = members[b + j];
         base += e - b;
@@ -169,18 +194,17 @@ void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uin
     VDB_REQUIRE(k <= 1024, "ivf knn: k must be <= 1024 in this build");
     const uint64_t np = std::min<uint64_t>(n_probes, iv.k);
     VDB_REQUIRE(np <= 1024, "ivf knn: at most 1024 probes in this build");
-    // (1) probes: Flat knn over the centroids on the centroid index's own workspace and stream
-    DevBuf &pidx = ws.lut, &pcnt = ws.flags;  // scratch not used by the Flat exact path of another index
-    pidx.reserve(nq * np * (sizeof(uint64_t) + sizeof(float)));
-    pcnt.reserve(nq * sizeof(uint64_t));
-    uint64_t *d_pidx = pidx.as<uint64_t>();
-    float *d_pdist = reinterpret_cast<float *>(d_pidx + nq * np);
-    {
-        WsLease cws(*iv.cent);
-        VDB_SYNC(s);  // d_q may have been produced on this workspace's stream
-        iv.cent->flat_knn_device(*cws, d_q, nq, np, d_pidx, d_pdist, pcnt.as<uint64_t>());
-        VDB_SYNC(cws->stream);
-    }
+    // (1) probes = find_n_nearest (k_means.rs:174-190): a ResultSet over all centroids in index order keeps, on equal
+    // distances, the lower index -- the np smallest (distance, index) pairs.  All centroid distances, then a select.
+    ws.qsq.reserve(nq * sizeof(float));
+    launch_row_sqnorm(d_q, nq, (uint32_t)ix.dim, ws.qsq.as<float>(), s);
+    const uint32_t ldc = (uint32_t)((iv.k + 63) & ~63ull), capp = topk_capacity((uint32_t)np);
+    ws.keys_a.reserve(nq * ldc * sizeof(uint64_t));
+    ws.keys_b.reserve(nq * ldc * sizeof(uint64_t));
+    ws.lut.reserve(nq * capp * sizeof(uint64_t));
+    uint64_t *d_probes = ws.lut.as<uint64_t>();
+    all_centroid_keys(*iv.cent, d_q, ws.qsq.as<float>(), nq, ldc, ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), s);
+    launch_topk_merge(ws.keys_b.as<uint64_t>(), 1, ldc, (uint32_t)nq, (uint32_t)np, d_probes, s);
     // (2) candidate lists; the np largest clusters bound every query's candidate count
     uint64_t bound = 0;
     for (uint64_t j = 0; j < np; j++) bound += iv.sizes_desc[j];
@@ -193,12 +217,10 @@ void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uin
     ws.keys_a.reserve(nq * ld * sizeof(uint64_t));
     ws.keys_b.reserve(nq * ld * sizeof(uint64_t));
     ws.keys_c.reserve(nq * capk * sizeof(uint64_t));
-    ws.qsq.reserve(nq * sizeof(float));
-    launch_row_sqnorm(d_q, nq, (uint32_t)ix.dim, ws.qsq.as<float>(), s);
     ws.misc.reserve(64);
     unsigned long long *d_ncand = ws.misc.as<unsigned long long>();
     VDB_HIP(hipMemsetAsync(d_ncand, 0, sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(k_ivf_candidates, dim3((unsigned)nq), dim3(256), 0, s, d_pidx, pcnt.as<uint64_t>(), (uint32_t)np,
+    hipLaunchKernelGGL(k_ivf_candidates, dim3((unsigned)nq), dim3(256), 0, s, d_probes, capp, (uint32_t)np,
                        iv.d_offsets.as<uint32_t>(), iv.d_members.as<uint32_t>(), ld, ws.keys_a.as<uint64_t>(), d_ncand);
     ix.prof_begin(ws, "ivf_rerank", 0.0);
     // (3) exact distances in offer order, (4) ResultSet::add replay, sorted output (into_sorted_vec, :153)
