@@ -163,6 +163,30 @@ void Index::flat_exact_device(Workspace &ws, const float *d_q, const float *d_qs
     ws.dense.reserve(size_t(BQ) * ld * sizeof(float));
     ws.lists.reserve(size_t(BQ) * nl * cap * sizeof(uint64_t));
     ws.keys_c.reserve(size_t(BQ) * cap * sizeof(uint64_t));
+    // Small corpus, many queries (tables of a few thousand rows, centroid sets): one thread per (query, row) pair
+    // folds in reference order and a wave per query selects -- three launches for the whole batch.  The scan kernel
+    // below assigns a thread per ROW and walks 8 queries per launch: 4 workgroups for 1000 rows (measured 119 us per
+    // 8 queries, i.e. launch- and latency-bound).
+    if (n <= 8192 && nq >= 32) {
+        constexpr uint64_t QCH = 4096;  // queries per round: QCH x ld pair keys twice
+        const uint64_t qch = std::min<uint64_t>(nq, QCH);
+        ws.keys_a.reserve(qch * ld * sizeof(uint64_t));
+        ws.keys_b.reserve(qch * ld * sizeof(uint64_t));
+        ws.keys_c.reserve(qch * cap * sizeof(uint64_t));
+        for (uint64_t q0 = 0; q0 < nq; q0 += qch) {
+            const uint32_t nb = (uint32_t)std::min<uint64_t>(qch, nq - q0);
+            launch_iota_keys(ws.keys_a.as<uint64_t>(), nb, (uint32_t)n, (uint32_t)ld, s);
+            prof_begin(ws, "flat_exact", double(n) * dim * sizeof(float));
+            launch_rerank(d_rows.as<float>(), (uint32_t)dim, d_q + q0 * dim, nb, metric, d_sq.as<float>(),
+                          d_qsq ? d_qsq + q0 : nullptr, ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), (uint32_t)n,
+                          (uint32_t)ld, s);
+            prof_end(ws);
+            launch_topk_merge(ws.keys_b.as<uint64_t>(), 1, (uint32_t)ld, nb, ksel, ws.keys_c.as<uint64_t>(), s);
+            launch_finalize(ws.keys_c.as<uint64_t>(), cap, nb, ksel, (uint32_t)k, id_offset, d_idx + q0 * k, d_dist + q0 * k,
+                            d_cnt + q0, s);
+        }
+        return;
+    }
     const bool use_lds = n >= 4096;
     for (uint64_t q0 = 0; q0 < nq; q0 += BQ) {
         uint32_t nb = (uint32_t)std::min<uint64_t>(BQ, nq - q0);

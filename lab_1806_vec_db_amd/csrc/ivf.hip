@@ -30,12 +30,6 @@ void ivf_clear(Index &ix) {
     ix.ivf.d_members.release();
 }
 
-// ids 0..k-1 as a candidate row per query (PAIR_NONE pads): "every centroid is a candidate"
-__global__ void k_iota_keys(uint64_t *__restrict__ rows, uint32_t k, uint32_t ld) {
-    uint64_t *row = rows + uint64_t(blockIdx.x) * ld;
-    for (uint32_t j = threadIdx.x; j < ld; j += blockDim.x) row[j] = j < k ? uint64_t(j) : PAIR_NONE;
-}
-
 // Exact (distance, centroid) pair keys of EVERY centroid for nq device-resident queries, unsorted, in out[q][0..ld):
 // one thread per (query, centroid) pair folds in reference order (k_rerank with the identity candidate list).  The
 // centroid set is small and L2-resident, the pairs are many: this keeps every CU busy where a Flat scan of a
@@ -43,7 +37,7 @@ __global__ void k_iota_keys(uint64_t *__restrict__ rows, uint32_t k, uint32_t ld
 static void all_centroid_keys(Index &cent, const float *d_q, const float *d_qsq, uint64_t nq, uint32_t ld, uint64_t *ids,
                               uint64_t *out, hipStream_t s) {
     const uint32_t k = (uint32_t)cent.n;
-    hipLaunchKernelGGL(k_iota_keys, dim3((unsigned)nq), dim3(256), 0, s, ids, k, ld);
+    launch_iota_keys(ids, (uint32_t)nq, k, ld, s);
     launch_rerank(cent.d_rows.as<float>(), (uint32_t)cent.dim, d_q, (uint32_t)nq, cent.dist == 0 ? MET_L2_DIRECT : MET_COSINE,
                   cent.d_sq.as<float>(), d_qsq, ids, out, k, ld, s);
 }

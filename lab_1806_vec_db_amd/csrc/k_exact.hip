@@ -305,6 +305,16 @@ void launch_rerank(const float *X, uint32_t dim, const float *Q, uint32_t nq, in
         hipLaunchKernelGGL((k_rerank<FOLD_DOT>), grid, block, 0, s, X, dim, Q, metric, xsq, qsq, cand, out, ncand, ldc);
 }
 
+// ids 0..n-1 as a candidate row per query (PAIR_NONE pads): "every row is a candidate"
+__global__ void k_iota_keys(uint64_t *__restrict__ rows, uint32_t n, uint32_t ld) {
+    uint64_t *row = rows + uint64_t(blockIdx.x) * ld;
+    for (uint32_t j = threadIdx.x; j < ld; j += blockDim.x) row[j] = j < n ? uint64_t(j) : PAIR_NONE;
+}
+void launch_iota_keys(uint64_t *rows, uint32_t nq, uint32_t n, uint32_t ld, hipStream_t s) {
+    if (nq == 0) return;
+    hipLaunchKernelGGL(k_iota_keys, dim3(nq), dim3(256), 0, s, rows, n, ld);
+}
+
 // ---------------------------------------------------------------------------------------------
 // pair keys -> reference-shaped outputs
 // ---------------------------------------------------------------------------------------------

@@ -29,6 +29,7 @@ void launch_finalize(const uint64_t *keys, uint32_t ldk, uint32_t nq, uint32_t k
                      uint64_t id_offset, uint64_t *out_idx, float *out_dist, uint64_t *out_count, hipStream_t s);
 // certification of an MFMA shortlist (see k_exact.hip): flags[q] = 1 when the exact top-k might
 // not be contained in the shortlist
+void launch_iota_keys(uint64_t *rows, uint32_t nq, uint32_t n, uint32_t ld, hipStream_t s);
 void launch_flat_finish(const uint64_t *exact_sorted, uint32_t lde, const uint64_t *approx_sorted, uint32_t lda,
                         uint32_t nq, uint32_t ksel, uint32_t kstride, uint32_t kprime, uint64_t n_rows, const float *qsq,
                         float xsq_max, float xsq_min_pos, int cosine, uint32_t dim, const uint32_t *cnt, uint32_t cap,
