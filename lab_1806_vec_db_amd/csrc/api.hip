@@ -302,6 +302,8 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         mfma_set_share((int)value);
     else if (n == "flat_gemm")  // 0 auto (more than 64 queries), 1 off, 2 forced
         idx->ix.flat_gemm_mode = (int)value;
+    else if (n == "hnsw_dma")
+        hnsw_set_dma((int)value);
     else if (n == "pq_adc_fast")
         pq_set_adc_fast((int)value);
     else if (n == "flat_sample_thin")

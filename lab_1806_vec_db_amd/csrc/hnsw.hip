@@ -56,6 +56,7 @@ struct HnswDev {
     const uint8_t *codes;
     const float *cent_cache;
     uint32_t enc_dim, pq_m, pq_kc, n_bits;
+    int dma;  // exact level-0 distances through LDS-DMA staging (max_m0 <= 32, dim % 32 == 0)
 };
 
 constexpr uint32_t HNSW_POOL = 2048;  // candidate pool entries per query (LDS)
@@ -132,6 +133,90 @@ __device__ __forceinline__ float hnsw_adc_dist(const HnswDev &g, const float *lu
     return 1.0f - r;
 }
 
+// ---- exact distances of up to 32 neighbours at once, rows staged through LDS by DMA ----------------------------
+// The walk's time is the 30 dependent 128-B lines of every neighbour row: one lane folds one row (the fold is a strict
+// chain, distance/mod.rs:72-74) and with register destinations it keeps a single line in flight (more lines per lane
+// thrash the L1: measured).  `global_load_lds_dwordx4` has no register destination: lane l's 16-B piece lands at
+// base + 16*l, so one instruction moves chunk c of all (<= 32) fresh rows into LDS as [chunk][lane] -- which is also
+// the conflict-free layout for the lane-private fold.  HNSW_DMA_BUF line buffers of 8 chunks rotate, HNSW_DMA_BUF-1
+// lines per row are in flight while the oldest is folded.  The DMAs are issued through inline asm (hipcc would wait
+// vmcnt(0) before every LDS read after a tracked LDS-DMA); their completion is counted here: 8 instructions per line.
+constexpr int HNSW_DMA_BUF = 4;  // 3 lines per row in flight (measured 2/3/4 buffers: 3.33 / 3.29 / 3.22 ms per 1000 queries; 5 costs a wave of occupancy)
+constexpr uint32_t HNSW_DMA_BYTES = HNSW_DMA_BUF * 8 * 512 + 32 * 4;    // line buffers (32-lane stride) + |x|^2 of the rows
+
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ void glds4(const void *gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// lanes with fresh == true (all < 32) get the cached-form distance of row nb; dim % 32 == 0; at least one lane fresh
+__device__ __forceinline__ float hnsw_exact_dists_dma(const HnswDev &g, const float *qlds, float qsq, uint32_t nb, bool fresh,
+                                                      unsigned char *stage, uint32_t lane) {
+    typedef __attribute__((address_space(3))) unsigned char *lds_p;
+    const uint32_t sbase = (uint32_t)(uintptr_t)(lds_p)stage;  // LDS byte address of the staging area
+    const uint32_t xs_off = HNSW_DMA_BUF * 8 * 512;
+    const char *row = reinterpret_cast<const char *>(g.rows + uint64_t(fresh ? nb : 0) * g.dim);
+    const uint32_t nlines = g.dim / 32;
+    auto issue = [&](uint32_t L) {  // 8 DMA instructions: the 8 chunks of line L of every fresh row
+        const uint32_t b = L % HNSW_DMA_BUF;
+        if (fresh) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) glds16(row + uint64_t(L) * 128 + c * 16, sbase + (b * 8 + c) * 512);
+        }
+    };
+    if (fresh) glds4(g.xsq + nb, sbase + xs_off);  // the oldest DMA: done when the first line is
+#pragma unroll
+    for (int L = 0; L < HNSW_DMA_BUF - 1; L++)
+        if ((uint32_t)L < nlines) issue(L);
+    float acc = 0.0f;
+    const float4 *q4 = reinterpret_cast<const float4 *>(qlds);
+    for (uint32_t L = 0; L < nlines; L++) {
+        const uint32_t ahead = L + HNSW_DMA_BUF - 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads of the buffer about to be refilled are done
+        if (ahead < nlines) {
+            issue(ahead);
+            wait_vm<8 * (HNSW_DMA_BUF - 1)>();  // all but the newest HNSW_DMA_BUF-1 lines have landed: line L is in LDS
+        } else {
+            wait_vm<0>();  // tail of the row: drain
+        }
+        const uint32_t b = L % HNSW_DMA_BUF;
+        const unsigned char *src = stage + (b * 8) * 512 + lane * 16;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + c * 512);
+            const float4 qq = q4[L * 8 + c];
+            float p;
+            p = v.x * qq.x; acc = acc + p;
+            p = v.y * qq.y; acc = acc + p;
+            p = v.z * qq.z; acc = acc + p;
+            p = v.w * qq.w; acc = acc + p;
+        }
+    }
+    const float xs = *reinterpret_cast<const float *>(stage + xs_off + lane * 4);
+    if (g.cosine) {  // cosine_distance_cached with norms sqrt(dot) (distance/mod.rs:66-69, :31-36)
+        float den = fmaxf(sqrtf(xs) * sqrtf(qsq), 1e-10f);
+        float r = acc / den;
+        return 1.0f - r;
+    }
+    float s2 = xs + qsq;
+    float t2 = 2.0f * acc;
+    return s2 - t2;
+}
+
 template <int R, bool ADC>
 __global__ __launch_bounds__(64) void k_hnsw_search(HnswDev g, const float *__restrict__ Q,
                                                     const float *__restrict__ qsq_all,
@@ -143,6 +228,9 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswDev g, const float *__re
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t *pool = reinterpret_cast<uint64_t *>(smem_raw);
     float *fl = reinterpret_cast<float *>(smem_raw + HNSW_POOL * sizeof(uint64_t));
+    // DMA staging behind the query (exact walk only, see hnsw_exact_dists_dma); 512-B aligned for the line buffers
+    unsigned char *stage = smem_raw + ((HNSW_POOL * sizeof(uint64_t) + g.dim * sizeof(float) + 511) & ~size_t(511));
+    const bool dma = !ADC && g.dma != 0;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t q = blockIdx.x;
     const float qsq = qsq_all[q];
@@ -302,9 +390,13 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswDev g, const float *__re
                 uint32_t old = atomicOr(&vis[nb >> 5], bit);
                 fresh = (old & bit) == 0;
             }
-            float d = 0.0f;
-            if (fresh) d = dist_of(nb);
             uint64_t fm = __ballot(fresh);
+            float d = 0.0f;
+            if (dma) {
+                if (fm) d = hnsw_exact_dists_dma(g, fl, qsq, nb, fresh, stage, lane);  // wave-uniform branch
+            } else if (fresh) {
+                d = dist_of(nb);
+            }
             n_dist += __builtin_popcountll(fm);
             while (fm) {  // stored order
                 uint32_t t = (uint32_t)__builtin_ctzll(fm);
@@ -942,6 +1034,9 @@ static void hnsw_launch(const HnswDev &g, const float *d_q, const float *qsq, co
                        vwords, out, stats, err);
 }
 
+static int g_hnsw_dma = 1;
+void hnsw_set_dma(int v) { g_hnsw_dma = v; }
+
 void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef, bool use_pq,
                      uint64_t *d_idx, float *d_dist, uint64_t *d_cnt) {
     hipStream_t s = ws.stream;
@@ -978,7 +1073,10 @@ void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, ui
     } else {
         lds += ix.dim * sizeof(float);
     }
+    const bool dma = !use_pq && g_hnsw_dma && h.max_m0 <= 32 && ix.dim % 32 == 0;
+    if (dma) lds = ((lds + 511) & ~size_t(511)) + HNSW_DMA_BYTES;
     HnswDev g{};
+    g.dma = dma ? 1 : 0;
     g.rows = ix.d_rows.as<float>();
     g.xsq = ix.d_sq.as<float>();
     g.level0 = h.d_level0.as<uint32_t>();
