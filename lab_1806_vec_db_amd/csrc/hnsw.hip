@@ -355,14 +355,28 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswDev g, const float *__re
     }
     while (pool_n > 0 && !overflow) {
         __builtin_amdgcn_wave_barrier();
-        // pop_first: smallest pair in the pool
+        // pop_first: smallest pair in the pool.  The same pass drops the pairs that can no longer be expanded (>= worst:
+        // popping one of them would only end the walk, and only when nothing better is left), so the pool stays at the
+        // few hundred live candidates instead of growing towards its capacity and being re-scanned every expansion.
         uint64_t best = PAIR_NONE;
-        for (uint32_t i = lane; i < pool_n; i += 64) {
-            uint64_t v = pool[i];
-            best = v < best ? v : best;
+        {
+            uint32_t kept = 0;
+            for (uint32_t base = 0; base < pool_n; base += 64) {
+                uint32_t i = base + lane;
+                uint64_t v = i < pool_n ? pool[i] : PAIR_NONE;
+                bool live = v < tau;
+                uint64_t mask = __ballot(live);
+                uint32_t before = __builtin_popcountll(mask & ((1ull << lane) - 1));
+                __builtin_amdgcn_wave_barrier();
+                if (live) pool[kept + before] = v;  // kept + before <= i: never overwrites unread entries
+                __builtin_amdgcn_wave_barrier();
+                kept += __builtin_popcountll(mask);
+                best = live && v < best ? v : best;
+            }
+            pool_n = kept;
         }
         best = wave_min_u64(best);
-        if (!(best < tau)) break;  // check_candidate: size < ef (tau == NONE) or pair < worst
+        if (best == PAIR_NONE) break;  // check_candidate fails for everything left (size == ef and every pair >= worst)
         // remove it (pairs are unique)
         for (uint32_t base = 0; base < pool_n; base += 64) {
             uint32_t i = base + lane;
