@@ -124,6 +124,31 @@ def test_duplicates_and_ties(mods):
             assert np.array_equal(d[q, :c], od)
 
 
+@pytest.mark.parametrize("M,dim,dma", [(24, 64, 1), (16, 50, 1), (16, 64, 0), (8, 960, 1)])
+def test_walk_variants_agree_with_oracle(mods, M, dim, dma):
+    """The level-0 distance evaluation has two forms: rows staged through LDS by DMA (max_m0 <= 32 and dim % 32 == 0)
+    and one register-fed fold per lane (wide graphs, odd dims, or hnsw_dma = 0).  Both must reproduce the oracle's
+    results and work counters."""
+    vdb, O = mods
+    rng = np.random.default_rng(M * 1000 + dim)
+    base = rng.standard_normal((2500, dim)).astype(np.float32)
+    qs = rng.standard_normal((20, dim)).astype(np.float32)
+    for dist, kind in (("l2sqr", 0), ("cosine", 1)):
+        ix = vdb.GpuIndex(dim, dist)
+        ix.batch_add(base)
+        ix.hnsw_build(M=M, ef_construction=50, seed=11, batch=16, nthreads=4)
+        oh = O.HNSW.from_graph(base, kind, M, 50, ix.hnsw_export())
+        ix.set_param("hnsw_dma", dma)
+        try:
+            idx, d, cnt = ix.knn_with_ef(qs, 10, 64)
+        finally:
+            ix.set_param("hnsw_dma", 1)
+        for q in range(qs.shape[0]):
+            oi, od = oh.knn(qs[q], 10, 64)
+            c = int(cnt[q])
+            assert idx[q, :c].tolist() == oi.tolist() and np.array_equal(d[q, :c], od), (dist, q)
+
+
 def test_add_after_build_keeps_graph_valid(mods, gist_base):
     """DynamicIndex::add on the HNSW arm (dynamic_index.rs:47-52): HNSWIndex::add per new row."""
     vdb, O = mods
