@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--cpu-queries", type=int, default=512,
                     help="queries timed on the CPU oracle and parity-checked (0 = skip); 512 = ~12 s on 16 cores")
-    ap.add_argument("--workload", choices=["flat", "pq_flat", "hnsw", "ivf"], default="flat",
+    ap.add_argument("--workload", choices=["flat", "pq_flat", "hnsw", "hnsw_pq", "ivf"], default="flat",
                     help="flat = the headline (BASELINE metric); pq_flat / hnsw = the other SURVEY 8d configs")
     ap.add_argument("--ef", type=int, default=0, help="pq_flat: ADC shortlist (default 100); hnsw: search ef (default 128); ivf: n_probes (default 4)")
     ap.add_argument("--dist", choices=["l2sqr", "cosine"], default="l2sqr",
@@ -125,7 +125,7 @@ def main():
     wl = args.workload
     if args.rows <= 0:
         args.rows = 1_000_000  # hnsw: the host builder (hnsw_index.rs:391-457 batches) takes ~3-4 min for this graph
-    ef = args.ef or {"pq_flat": 100, "hnsw": 128, "ivf": 4}.get(wl, 0)
+    ef = args.ef or {"pq_flat": 100, "hnsw": 128, "hnsw_pq": 128, "ivf": 4}.get(wl, 0)
     n, dim, nq, k = args.rows, args.dim, args.nq, args.k
     # identical corpus on every rank (same seed), each keeps its row block
     gen = gist_like_gpu if args.data == "gistlike" else gist_lowrank_gpu
@@ -142,7 +142,7 @@ def main():
     host_base = None
     if rank == 0 and world == 1 and args.cpu_queries > 0:
         host_base = base.cpu().numpy()
-    if wl == "pq_flat":
+    if wl in ("pq_flat", "hnsw_pq"):
         # config/bench_pq_hnsw.toml:16-23: n_bits 4, m = dim/3, k_means_size 10000, max_iter 20, tol 1e-6.  Every rank
         # trains on the same first 10000 rows (same seed) -> identical centroids; codes are encoded per shard on the GPU.
         m = dim // 3
@@ -152,12 +152,12 @@ def main():
         cent = tr.pq_export()["centroids"]
         del tr
         ix.pq_attach(4, m, cent, None)
-    elif wl == "ivf":
+    if wl == "ivf":
         # IVFIndex::from_vec_set (ivf_index.rs:66-118): sqrt(N) clusters, k-means on 10000 sampled rows, 10 iterations
         t_b = time.perf_counter()
         ix.ivf_build(int(round(n ** 0.5)), train_n=10000, max_iter=10, tol=1e-6, seed=42)
         build_s = time.perf_counter() - t_b
-    elif wl == "hnsw":
+    if wl in ("hnsw", "hnsw_pq"):
         t_b = time.perf_counter()
         ix.hnsw_build(M=16, ef_construction=200, seed=42, batch=64, nthreads=min(len(os.sched_getaffinity(0)), 16))
         build_s = time.perf_counter() - t_b
@@ -195,7 +195,7 @@ def main():
                               o_cnt.data_ptr())
         elif q1 > q0:
             ix.hnsw_knn_device(queries[q0:q1].data_ptr(), q1 - q0, k, ef, o_idx.data_ptr(), o_dist.data_ptr(),
-                               o_cnt.data_ptr())
+                               o_cnt.data_ptr(), use_pq=(wl == "hnsw_pq"))
         li, ld, lc = o_idx[: q1 - q0], o_dist[: q1 - q0], o_cnt[: q1 - q0]
         if host_xchg:
             return allgather_concat(li.cpu(), ld.cpu(), lc.cpu(), nq)
@@ -226,7 +226,7 @@ def main():
     if wl == "flat":
         kernel = "flat_mfma" if ix.prof_get("flat_mfma")["launches"] else "flat_exact"
     else:
-        kernel = {"pq_flat": "pq_adc", "hnsw": "hnsw", "ivf": "ivf_rerank"}[wl]
+        kernel = {"pq_flat": "pq_adc", "hnsw": "hnsw", "hnsw_pq": "hnsw", "ivf": "ivf_rerank"}[wl]
     p = ix.prof_get(kernel)
     roofline = None
     if p["launches"] and wl != "flat":
@@ -271,9 +271,10 @@ def main():
     dname = "L2Sqr" if args.dist == "l2sqr" else "Cosine"
     names = {"flat": ("Flat brute force", "flat_knn_gist1m"), "pq_flat": (f"PQ-Flat 4-bit m={dim // 3}, ADC ef={ef}", "pq_flat_knn_gist1m"),
              "hnsw": (f"HNSW M=16 efc=200, ef={ef}", f"hnsw_knn_gistlike_{n}"),
+             "hnsw_pq": (f"HNSW M=16 efc=200 + PQ 4-bit m={dim // 3}, ef={ef}", f"hnsw_pq_knn_gistlike_{n}"),
              "ivf": (f"IVF {int(round(n ** 0.5))} clusters, n_probes={ef}", f"ivf_knn_gistlike_{n}")}[wl]
     par = {"flat": f"row-shard x{world}", "pq_flat": f"row-shard x{world}", "hnsw": f"replica x{world}, queries split",
-           "ivf": f"replica x{world}, queries split"}[wl]
+           "hnsw_pq": f"replica x{world}, queries split", "ivf": f"replica x{world}, queries split"}[wl]
     out = {
         "metric": f"queries/sec at recall@10, Gist1M d=960 ({names[0]}, {dname}, k=10)",
         "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -291,7 +292,7 @@ def main():
         out["config"]["ef"] = ef
     if wl == "ivf":
         out["config"]["host_build_s"] = round(build_s, 1)
-    if wl == "hnsw":
+    if wl in ("hnsw", "hnsw_pq"):
         nd, ne = ix.hnsw_last_stats()
         out["config"]["host_build_s"] = round(build_s, 1)
         out["hnsw_work_per_query"] = {"n_dist": round(nd / max(q1 - q0, 1), 1), "n_expanded": round(ne / max(q1 - q0, 1), 1)}
@@ -327,23 +328,33 @@ def main():
                 opq = O.PQ.from_centroids(dim, pq["m"], pq["n_bits"], okind, pq["centroids"])
                 opq.set_codes(pq["codes"])  # GPU-encoded codes (bit-equal to the oracle's encoder, tests/test_pq_gpu.py)
                 t0 = time.perf_counter()
-                with ThreadPoolExecutor(threads) as ex:  # ctypes releases the GIL: one query per thread
-                    r = list(ex.map(lambda q: O.flat_knn_pq(host_base, opq, hq[q], k, ef, okind), range(ncpu)))
+                with ThreadPoolExecutor(threads) as pool:  # ctypes releases the GIL: one query per thread
+                    r = list(pool.map(lambda q: O.flat_knn_pq(host_base, opq, hq[q], k, ef, okind), range(ncpu)))
                 cpu_s = time.perf_counter() - t0
                 what = "FlatIndex::knn_pq"
             elif wl == "ivf":
                 ex_ivf = ix.ivf_export()  # centroids and clusters are inputs of the oracle (assignment parity: tests/test_ivf_gpu.py)
                 oiv = O.IVF(host_base, ex_ivf["centroids"], okind, assign=ex_ivf["assign"])
                 t0 = time.perf_counter()
-                with ThreadPoolExecutor(threads) as ex:
-                    r = list(ex.map(lambda q: oiv.knn(hq[q], k, ef), range(ncpu)))
+                with ThreadPoolExecutor(threads) as pool:
+                    r = list(pool.map(lambda q: oiv.knn(hq[q], k, ef), range(ncpu)))
                 cpu_s = time.perf_counter() - t0
                 what = "IVFIndex::knn_with_ef on the same centroids and clusters"
+            elif wl == "hnsw_pq":
+                pq = ix.pq_export()
+                opq = O.PQ.from_centroids(dim, pq["m"], pq["n_bits"], okind, pq["centroids"])
+                opq.set_codes(pq["codes"])
+                oh = O.HNSW.from_graph(host_base, okind, 16, 200, ix.hnsw_export())
+                t0 = time.perf_counter()
+                with ThreadPoolExecutor(threads) as pool:
+                    r = list(pool.map(lambda q: oh.knn_pq(opq, hq[q], k, ef), range(ncpu)))
+                cpu_s = time.perf_counter() - t0
+                what = "HNSWIndex::knn_pq on the same graph and PQ table"
             else:
                 oh = O.HNSW.from_graph(host_base, okind, 16, 200, ix.hnsw_export())
                 t0 = time.perf_counter()
-                with ThreadPoolExecutor(threads) as ex:
-                    r = list(ex.map(lambda q: oh.knn(hq[q], k, ef), range(ncpu)))
+                with ThreadPoolExecutor(threads) as pool:
+                    r = list(pool.map(lambda q: oh.knn(hq[q], k, ef), range(ncpu)))
                 cpu_s = time.perf_counter() - t0
                 what = "HNSWIndex::knn_with_ef on the same graph"
             ci = np.stack([np.pad(x[0], (0, k - len(x[0]))) for x in r]).astype(np.uint64)
