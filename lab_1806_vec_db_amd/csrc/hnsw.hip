@@ -109,6 +109,36 @@ __device__ __forceinline__ float hnsw_adc_dist(const HnswDev &g, const float *lu
     const uint8_t *cr = g.codes + uint64_t(idx) * g.enc_dim;
     float sum = 0.0f, cdp = 0.0f;
     const uint32_t kc = g.pq_kc, m = g.pq_m;
+    if (g.n_bits == 4 && (g.enc_dim & 15) == 0 && m == 2 * g.enc_dim) {
+        // every nibble is a group (the Gist1M table: 160-B code rows): 16-B code loads, the 8 lookups of a code word
+        // issued together, then the strict-order adds (pq_table.rs:254-292).  The byte-at-a-time loop below costs 160
+        // dependent byte loads and 320 branches per neighbour (measured 43 us per expansion).
+        const uint4 *cw = reinterpret_cast<const uint4 *>(cr);
+        uint4 v = cw[0];
+        for (uint32_t w = 0; w < g.enc_dim / 16; w++) {
+            const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+            if (w + 1 < g.enc_dim / 16) v = cw[w + 1];
+#pragma unroll
+            for (int wi = 0; wi < 4; wi++) {
+                float t[8], c[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {  // nibble j of the word = group 32w + 8wi + j (low nibble of a byte first)
+                    const uint32_t at = (w * 32 + 8 * wi + j) * 16 + ((words[wi] >> (4 * j)) & 0xf);
+                    t[j] = lut[at];
+                    if (g.cosine) c[j] = g.cent_cache[at];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    sum = sum + t[j];
+                    if (g.cosine) cdp = cdp + c[j];
+                }
+            }
+        }
+        if (!g.cosine) return sum;
+        float den0 = fmaxf(sqrtf(cdp) * sqrtf(qsq), 1e-10f);
+        float r0 = sum / den0;
+        return 1.0f - r0;
+    }
     for (uint32_t b = 0; b < g.enc_dim; b++) {
         uint32_t u = cr[b];
         if (g.n_bits == 4) {
