@@ -93,6 +93,8 @@ def main():
                     help="gistlike = per-dimension Gaussians (SURVEY 8d generator); lowrank = same marginals with a 32-d "
                          "latent factor, for informative ANN recall")
     ap.add_argument("--mode", type=int, default=0, help="flat mode: 0 auto, 1 exact scan, 2 MFMA forced")
+    ap.add_argument("--half", type=int, default=0, help="flat: fp16 first pass of large query batches: 0 auto, 1 off, 2 forced")
+    ap.add_argument("--half-kmul", type=int, default=0, help="flat: shortlist of the fp16 pass = max(64, kmul*k) (0: library default)")
     ap.add_argument("--dump", type=str, default="", help="rank 0 saves the last step's results to this .npz (tests)")
     args = ap.parse_args()
 
@@ -139,6 +141,10 @@ def main():
     ix.add_device(shard.data_ptr(), r1 - r0)
     ix.set_id_offset(r0)
     ix.set_flat_mode(args.mode)
+    if args.half:
+        ix.set_param("flat_half", args.half)
+    if args.half_kmul:
+        ix.set_param("flat_half_kmul", args.half_kmul)
     host_base = None
     if rank == 0 and world == 1 and args.cpu_queries > 0:
         host_base = base.cpu().numpy()
@@ -224,7 +230,9 @@ def main():
         elapsed = float(t.item())
 
     if wl == "flat":
-        kernel = "flat_mfma" if ix.prof_get("flat_mfma")["launches"] else "flat_exact"
+        # dominant kernel: the fp16 first pass (k_flat_gemm<GEMM_F16>, calls with more than 64 queries) when it ran, else
+        # the split-bf16 pass, else the exact scan
+        kernel = next((kn for kn in ("flat_half", "flat_mfma") if ix.prof_get(kn)["launches"]), "flat_exact")
     else:
         kernel = {"pq_flat": "pq_adc", "hnsw": "hnsw", "hnsw_pq": "hnsw", "ivf": "ivf_rerank"}[wl]
     p = ix.prof_get(kernel)
@@ -240,16 +248,21 @@ def main():
                     "avg_launch_ms": round(avg_ms, 4), "launches": p["launches"], "bytes_per_launch": bytes_per_launch}
     elif p["launches"]:
         avg_ms = p["ms"] / p["launches"]
-        bytes_per_launch = p["bytes"] / p["launches"]  # shard_rows * dim * 4
+        # bytes the kernel has to stream: passes x shard_rows x dim x 4 for the split-bf16 / exact kernels;
+        # the fp16 first pass reads a 2-byte mirror, so ITS operand bytes are half of that -- the roofline fraction is
+        # quoted on the bytes really needed, the f32-equivalent rate is reported next to it
+        elem = 2 if kernel == "flat_half" else 4
+        bytes_per_launch = p["bytes"] / p["launches"]
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         # queries one corpus pass serves: 128 (k_flat_gemm) when a call carries more than 64 queries, else 2 x 32
         # (k_flat_mfma, XCD-shared passes) -- the rule of Index::flat_knn_device
         qpp = 128 if nq > 64 else 64
         traffic = None  # HBM bytes per launch from the committed PMC passes (same kernel, same shard size only)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_flat_gemm.json" if qpp == 128 else "pmc_flat_mfma.json")))
+            pmc_name = "pmc_flat_half.json" if kernel == "flat_half" else ("pmc_flat_gemm.json" if qpp == 128 else "pmc_flat_mfma.json")
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             passes = round(bytes_per_launch / pmc["algorithmic_bytes_per_pass"])  # HBM passes in one launch
-            if kernel == "flat_mfma" and abs(pmc["algorithmic_bytes_per_pass"] * passes - bytes_per_launch) < 1:
+            if kernel in ("flat_mfma", "flat_half") and abs(pmc["algorithmic_bytes_per_pass"] * passes - bytes_per_launch) < 1:
                 traffic = pmc["hbm_bytes_per_pass"] * passes
         except (OSError, KeyError, ValueError):
             pass
@@ -257,8 +270,11 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel,
                     "avg_launch_ms": round(avg_ms, 4), "launches": p["launches"],
                     "bytes_per_launch": bytes_per_launch,
-                    "units_per_launch": f"{round(bytes_per_launch / ((r1 - r0) * dim * 4))} corpus passes x {r1 - r0} rows "
-                                        f"x {dim} x 4 B; one pass serves {qpp} queries"}
+                    "units_per_launch": f"{round(bytes_per_launch / ((r1 - r0) * dim * elem))} corpus passes x {r1 - r0} rows "
+                                        f"x {dim} x {elem} B; one pass serves {qpp} queries"}
+        if kernel == "flat_half":
+            roofline["operand"] = "scaled fp16 mirror of the rows (2 B/element); exact f32 re-rank + certification downstream"
+            roofline["f32_equivalent_GBps"] = round(2 * achieved, 1)
 
     if rank != 0:
         if world > 1:
@@ -288,6 +304,7 @@ def main():
     if wl == "flat":
         out["config"]["queries_per_corpus_pass"] = 128 if nq > 64 else 64
         out["fallback_queries"] = ix.flat_fallback_count()
+        out["half_pass"] = {"queries": ix.get_stat("flat_half_queries"), "redone_split_bf16": ix.get_stat("flat_half_redo")}
     else:
         out["config"]["ef"] = ef
     if wl == "ivf":

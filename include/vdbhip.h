@@ -99,6 +99,12 @@ int vdb_flat_set_mode(vdb_index *idx, int mode);
 int vdb_set_param(vdb_index *idx, const char *name, int64_t value);
 /* number of queries whose MFMA shortlist failed certification and were redone by the exact scan */
 int vdb_flat_fallback_count(const vdb_index *idx, uint64_t *out);
+/* counters of the Flat pipeline (diagnostics; results never depend on them):
+ *   "flat_fallback"      = vdb_flat_fallback_count,
+ *   "flat_half_queries"  queries that went through the fp16 first pass (calls with more than 64 queries),
+ *   "flat_half_redo"     of those, the ones it could not certify (redone with the split-bf16 pass),
+ *   "flat_half_valid"    1 when the index holds the fp16 mirror. */
+int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out);
 
 /* ---- PQTable (distance/pq_table.rs) ----------------------------------------------------
  * centroids: group g, centroid c at k_c*gstart[g] + c*len(g) (pq_groups, pq_table.rs:38-53),

@@ -40,6 +40,7 @@ SIGNATURES = {
     "vdb_flat_knn_device": [vp, vp, u64, u64, u64, vp, vp, vp, vp],
     "vdb_flat_set_mode": [vp, C.c_int],
     "vdb_flat_fallback_count": [vp, u64p],
+    "vdb_get_stat": [vp, C.c_char_p, u64p],
     "vdb_set_param": [vp, C.c_char_p, C.c_int64],
     "vdb_pq_attach": [vp, u64, u64, f32p, u8p],
     "vdb_pq_build": [vp, u64, u64, u64, u64, C.c_float, u64],

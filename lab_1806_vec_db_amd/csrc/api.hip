@@ -312,6 +312,12 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         gemm_set_tw((int)value);
     else if (n == "flat_gemm_debug")
         idx->ix.flat_gemm_debug = (int)value;
+    else if (n == "flat_half")  // fp16 first pass of large query batches: 0 auto, 1 off, 2 on regardless of the redo rate
+        idx->ix.flat_half_mode = (int)value;
+    else if (n == "flat_half_kmul") {  // its shortlist: max(64, kmul * k) rows per query
+        VDB_REQUIRE(value >= 1 && value <= 64, "flat_half_kmul must be in [1, 64]");
+        idx->ix.flat_half_kmul = (uint32_t)value;
+    }
     else
         throw Error(VDB_ERR_INVALID, "unknown parameter " + n);
     VDB_API_END
@@ -320,6 +326,23 @@ int vdb_flat_fallback_count(const vdb_index *idx, uint64_t *out) {
     VDB_API_BEGIN
     VDB_REQUIRE(idx && out, "null argument");
     *out = idx->ix.fallback_count.load();
+    VDB_API_END
+}
+
+int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx && name && out, "null argument");
+    std::string n(name);
+    if (n == "flat_fallback")
+        *out = idx->ix.fallback_count.load();
+    else if (n == "flat_half_queries")
+        *out = idx->ix.half_queries.load();
+    else if (n == "flat_half_redo")
+        *out = idx->ix.half_redo.load();
+    else if (n == "flat_half_valid")
+        *out = idx->ix.half_valid ? 1 : 0;
+    else
+        throw Error(VDB_ERR_INVALID, "unknown statistic " + n);
     VDB_API_END
 }
 

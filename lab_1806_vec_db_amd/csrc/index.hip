@@ -75,6 +75,7 @@ void Index::add_rows(const float *rows, uint64_t count, bool on_device) {
         if (v > 0.0f && v < xsq_min_pos) xsq_min_pos = v;
     }
     h_sq.insert(h_sq.end(), sq.begin(), sq.end());
+    half_refresh(*ws, n, n + count);  // needs the new xsq_max
     {
         std::lock_guard<std::mutex> g(host_mu);
         if (on_device) {
@@ -101,6 +102,10 @@ void Index::swap_remove(uint64_t i) {
     if (mfma_supported((uint32_t)dim)) {  // rewrite the tiles of the moved row and of the removed last row
         launch_tile_rows(d_rows.as<float>(), last, (uint32_t)dim, i / 16, i / 16 + 1, d_tiled.as<float>(), s);
         launch_tile_rows(d_rows.as<float>(), last, (uint32_t)dim, last / 16, last / 16 + 1, d_tiled.as<float>(), s);
+        if (half_valid) {  // same scale; the moved row's rounding error is already part of half_dx_*
+            launch_tile_rows_h(d_rows.as<float>(), last, (uint32_t)dim, i / 16, i / 16 + 1, half_sx(), d_tiled_h.p, s);
+            launch_tile_rows_h(d_rows.as<float>(), last, (uint32_t)dim, last / 16, last / 16 + 1, half_sx(), d_tiled_h.p, s);
+        }
     }
     VDB_SYNC(s);
     {
@@ -114,6 +119,45 @@ void Index::swap_remove(uint64_t i) {
     h_sq.resize(last);
     n = last;
     // xsq_max stays an upper bound (certification only needs a bound)
+}
+
+// ---- scaled fp16 mirror (k_half.hip) ---------------------------------------------------------------
+// Called with d_rows, d_sq and xsq_max valid for n_new rows; rows [n_old, n_new) are new.  The scale follows the
+// largest row norm: when that grows past the current scale's range the whole mirror is rewritten (one extra bit of
+// headroom, so this happens at most once per doubling of the largest norm).
+void Index::half_refresh(Workspace &ws, uint64_t n_old, uint64_t n_new) {
+    if (!gemm_f16_supported((uint32_t)dim)) return;
+    if (!(xsq_max >= 0x1p-80f && xsq_max <= 0x1p80f)) {  // all-zero or extreme data: the split-bf16 / exact paths serve it
+        half_valid = false;
+        return;
+    }
+    hipStream_t s = ws.stream;
+    int e = 0;
+    (void)std::frexp(xsq_max, &e);                           // xsq_max = m * 2^e, m in [0.5, 1)  =>  |x| < 2^ceil(e/2)
+    const int need = e >= 0 ? (e + 1) / 2 : -((-e) / 2);
+    const bool rebuild = !half_valid || need > half_exp;
+    const uint64_t tiles_new = ((n_new + 15) / 16 + 11) / 12 * 12;  // whole units of k_flat_gemm (TW = 2 or 3)
+    const uint64_t tile_bytes = 16 * size_t(mfma_dim_pad((uint32_t)dim)) * sizeof(uint16_t);
+    uint64_t t0 = n_old / 16, r0 = n_old;
+    if (rebuild) {
+        half_exp = need + 1;
+        half_dx_abs = half_dx_rel = 0.0f;
+        t0 = 0;
+        r0 = 0;
+    }
+    d_tiled_h.grow(tiles_new * tile_bytes, t0 * tile_bytes, s);
+    d_half_err.reserve(2 * sizeof(uint32_t));
+    VDB_HIP(hipMemsetAsync(d_half_err.p, 0, 2 * sizeof(uint32_t), s));
+    launch_tile_rows_h(d_rows.as<float>(), n_new, (uint32_t)dim, t0, tiles_new, half_sx(), d_tiled_h.p, s);
+    launch_row_split_err(d_rows.as<float>(), d_sq.as<float>(), r0, n_new, (uint32_t)dim, half_sx(), d_half_err.as<uint32_t>(), s);
+    uint32_t *h = static_cast<uint32_t *>(ws.pinned(2 * sizeof(uint32_t)));
+    VDB_HIP(hipMemcpyAsync(h, d_half_err.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    VDB_SYNC(s);
+    float e2[2];
+    std::memcpy(e2, h, sizeof(e2));
+    half_dx_abs = std::max(half_dx_abs, std::sqrt(e2[0]) * 1.001f);  // the kernel's f32 sums: relative error << 1e-3
+    half_dx_rel = std::max(half_dx_rel, std::sqrt(e2[1]) * 1.001f);
+    half_valid = true;
 }
 
 // ---- timing hooks ------------------------------------------------------------------------------
@@ -235,7 +279,7 @@ void Index::flat_sorted_device(Workspace &ws, const float *d_q, uint64_t nq, uin
 
 // ---- Flat: full pipeline ---------------------------------------------------------------------------
 void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t *d_idx,
-                            float *d_dist, uint64_t *d_cnt) {
+                            float *d_dist, uint64_t *d_cnt, bool allow_half) {
     hipStream_t s = ws.stream;
     if (nq == 0) return;
     if (k == 0 || n == 0) {  // ResultSet::new(0) rejects everything; empty VecSet -> empty result
@@ -255,7 +299,7 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     ws.qsq.reserve(nq * sizeof(float));
     launch_row_sqnorm(d_q, nq, (uint32_t)dim, ws.qsq.as<float>(), s);
 
-    const uint32_t kprime = std::max<uint32_t>(32, 2 * ksel);
+    uint32_t kprime = std::max<uint32_t>(32, 2 * ksel);
     const int cosine = dist == 1 ? 1 : 0;
     bool mfma = mfma_supported((uint32_t)dim) && kprime <= 1024 && n > kprime &&
                 (flat_mode == 2 || (flat_mode == 0 && n >= 16384));
@@ -276,6 +320,14 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     // more than 64 queries: the filter pass runs as k_flat_gemm, 128 queries per corpus pass (k_gemm.hip); the
     // sample pass keeps the small-batch kernel, so the padded query count is a multiple of both batch sizes
     const bool gemm = flat_gemm_mode == 2 || (flat_gemm_mode == 0 && nq > 64);
+    // first pass with fp16 operands (k_half.hip): half the HBM bytes and a third of the matrix work per row, coarser
+    // keys -> a longer shortlist and a wider certification margin; what it cannot certify is redone below with the
+    // split-bf16 operands.  Switched off (auto mode) once more than 1/8 of the queries had to be redone.
+    const uint32_t kprime_h = std::max<uint32_t>(64, flat_half_kmul * ksel);
+    const uint64_t hq = half_queries.load(), hr = half_redo.load();
+    const bool half = allow_half && gemm && half_valid && flat_half_mode != 1 && kprime_h <= 1024 && n > kprime_h &&
+                      (flat_half_mode == 2 || hq < 1024 || hr * 8 <= hq);
+    if (half) kprime = kprime_h;
     const uint64_t gq = gemm_group();
     const uint64_t ngroups = gemm ? (nq + gq - 1) / gq : 0;
     const uint64_t nq_pad = gemm ? ngroups * gq : (nq + bq - 1) / bq * bq;
@@ -299,12 +351,24 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     float *d_tau = ws.misc.as<float>();
     uint32_t *d_hits = reinterpret_cast<uint32_t *>(d_tau + nq_pad);
     if (!gemm) launch_mfma_pack_queries(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, ws.qfrag.as<float>(), s);
+    const float *xt = half ? d_tiled_h.as<float>() : d_tiled.as<float>();
+    float *d_qscale = nullptr, *d_qmul = nullptr, *d_qerr = nullptr;
     if (gemm) {
         ws.qfrag_g.reserve(nq_pad * size_t(mfma_dim_pad((uint32_t)dim)) * sizeof(float));
-        launch_mfma_pack_queries_nh(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, 8, ws.qfrag_g.as<float>(), s);
+        if (half) {
+            ws.qaux.reserve(3 * nq_pad * sizeof(float));
+            d_qscale = ws.qaux.as<float>();
+            d_qmul = d_qscale + nq_pad;
+            d_qerr = d_qmul + nq_pad;
+            launch_query_prep_h(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, ws.qsq.as<float>(), half_sx(), d_qscale, d_qmul,
+                                d_qerr, s);
+            launch_pack_queries_h(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, 8, d_qscale, ws.qfrag_g.p, s);
+        } else {
+            launch_mfma_pack_queries_nh(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, 8, ws.qfrag_g.as<float>(), s);
+        }
     }
     if (gemm)  // the sample through the 128-query kernel too: same arithmetic as the filter, 4x fewer re-reads of the sample
-        launch_flat_gemm_sample(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag_g.as<float>(), (uint32_t)ngroups,
+        launch_flat_gemm_sample(xt, n, (uint32_t)dim, ws.qfrag_g.as<float>(), d_qmul, (uint32_t)ngroups,
                                 d_sq.as<float>(), cosine, s_step, ws.dense.as<float>(), ld_s, num_cu, s);
     else
         launch_flat_mfma_sample(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>(), (uint32_t)nbatch,
@@ -324,10 +388,11 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     uint32_t *d_sync = d_hits + nq_pad;
     VDB_HIP(hipMemsetAsync(d_hits, 0, (nq_pad + sync_words) * sizeof(uint32_t), s));
     // algorithmic bytes: one corpus pass (N*d*4) serves 32*share queries (bytes/query = N*d*4 / B)
+    // (the fp16 pass streams N*d*2 bytes per 128 queries: its own counter, so that GB/s are the bytes really read)
     const uint64_t hbm_passes = gemm ? ngroups : (nbatch + mfma_share() - 1) / mfma_share();
-    prof_begin(ws, "flat_mfma", double(hbm_passes) * double(n) * dim * sizeof(float));
+    prof_begin(ws, half ? "flat_half" : "flat_mfma", double(hbm_passes) * double(n) * dim * (half ? sizeof(uint16_t) : sizeof(float)));
     if (gemm)
-        launch_flat_gemm_filter(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag_g.as<float>(), (uint32_t)ngroups,
+        launch_flat_gemm_filter(xt, n, (uint32_t)dim, ws.qfrag_g.as<float>(), d_qmul, (uint32_t)ngroups,
                                 d_sq.as<float>(), cosine, d_tau, d_cand, d_hits, CAND_CAP, flat_gemm_debug, num_cu, s);
     else
         launch_flat_mfma_filter(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>(), (uint32_t)nbatch,
@@ -337,18 +402,29 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     launch_rerank(d_rows.as<float>(), (uint32_t)dim, d_q, (uint32_t)nq, cosine ? MET_COSINE : MET_L2_DIRECT, d_sq.as<float>(),
                   ws.qsq.as<float>(), ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), kprime, capp, s);  // pads its rows
     launch_topk_merge(ws.keys_b.as<uint64_t>(), 1, capp, (uint32_t)nq, ksel, ws.keys_c.as<uint64_t>(), s);
+    SplitErr se;
+    if (half) {
+        se.qerr = d_qerr;
+        se.dx_abs = half_dx_abs;
+        se.dx_rel = half_dx_rel;
+    }
     launch_flat_finish(ws.keys_c.as<uint64_t>(), capk, ws.keys_a.as<uint64_t>(), capp, (uint32_t)nq, ksel, (uint32_t)k, kprime,
-                       n, ws.qsq.as<float>(), xsq_max, xsq_min_pos, cosine, (uint32_t)dim, d_hits, CAND_CAP, id_offset,
+                       n, ws.qsq.as<float>(), xsq_max, xsq_min_pos, cosine, (uint32_t)dim, se, d_hits, CAND_CAP, id_offset,
                        ws.flags.as<uint8_t>(), d_idx, d_dist, d_cnt, s);
     const uint8_t *flags = static_cast<const uint8_t *>(ws.pinned(nq));
     VDB_HIP(hipMemcpyAsync(ws.pinned(nq), ws.flags.p, nq, hipMemcpyDeviceToHost, s));
     VDB_SYNC(s);
-    // uncertified queries: gather them, redo them 8 per corpus pass with the exact scan, scatter the results
+    // uncertified queries: gather them, redo them (fp16 pass: through this function again with the split-bf16
+    // operands; split-bf16 pass: 8 per corpus pass with the exact scan), scatter the results
     std::vector<uint64_t> redo;
     for (uint64_t q = 0; q < nq; q++)
         if (flags[q]) redo.push_back(q);
+    if (half) {
+        half_queries += nq;
+        half_redo += redo.size();
+    }
     if (redo.empty()) return;
-    fallback_count += redo.size();
+    if (!half) fallback_count += redo.size();
     const uint64_t nr = redo.size();
     DevBuf rq, rqs, ri, rd, rc;  // small, rare: allocated on demand
     rq.reserve(nr * dim * sizeof(float));
@@ -362,7 +438,10 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     }
     VDB_HIP(hipMemsetAsync(ri.p, 0, nr * k * sizeof(uint64_t), s));
     VDB_HIP(hipMemsetAsync(rd.p, 0, nr * k * sizeof(float), s));
-    flat_exact_device(ws, rq.as<float>(), rqs.as<float>(), nr, ksel, k, ri.as<uint64_t>(), rd.as<float>(), rc.as<uint64_t>());
+    if (half)
+        flat_knn_device(ws, rq.as<float>(), nr, k, ri.as<uint64_t>(), rd.as<float>(), rc.as<uint64_t>(), false);
+    else
+        flat_exact_device(ws, rq.as<float>(), rqs.as<float>(), nr, ksel, k, ri.as<uint64_t>(), rd.as<float>(), rc.as<uint64_t>());
     for (uint64_t j = 0; j < nr; j++) {
         VDB_HIP(hipMemcpyAsync(d_idx + redo[j] * k, ri.as<uint64_t>() + j * k, k * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
         VDB_HIP(hipMemcpyAsync(d_dist + redo[j] * k, rd.as<float>() + j * k, k * sizeof(float), hipMemcpyDeviceToDevice, s));

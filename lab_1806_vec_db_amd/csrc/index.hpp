@@ -1,6 +1,7 @@
 // index.hpp -- the HBM-resident index object behind the C ABI (include/vdbhip.h).
 #pragma once
 #include <atomic>
+#include <cmath>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -61,7 +62,7 @@ struct ProfEntry {
 // per-call scratch: one per concurrent reader (read-side calls are re-entrant, see vdbhip.h)
 struct Workspace {
     hipStream_t stream = nullptr;
-    DevBuf q, qsq, qfrag, qfrag_g, dense, lists, keys_a, keys_b, keys_c, flags, out_idx, out_dist, out_cnt, lut, misc;
+    DevBuf q, qsq, qfrag, qfrag_g, qaux, dense, lists, keys_a, keys_b, keys_c, flags, out_idx, out_dist, out_cnt, lut, misc;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     struct Pending {
         std::string name;
@@ -141,6 +142,17 @@ struct Index {
     uint64_t id_offset = 0;
     DevBuf d_rows, d_sq;
     DevBuf d_tiled;  // MFMA-fragment-ordered mirror of d_rows (k_mfma.hip), only when mfma_supported(dim)
+    // scaled fp16 mirror for k_flat_gemm<GEMM_F16> (k_half.hip): rows stored as fp16(x * 2^(13 - half_exp)), every row
+    // norm < 2^half_exp; half_dx_* = measured rounding error of the mirror (max |dx_r|, max |dx_r| / |x_r|)
+    DevBuf d_tiled_h, d_half_err;
+    bool half_valid = false;
+    int half_exp = 0;
+    float half_dx_abs = 0.0f, half_dx_rel = 0.0f;
+    int flat_half_mode = 0;        // 0 auto, 1 off, 2 on even after many uncertified queries
+    uint32_t flat_half_kmul = 4;   // shortlist of the fp16 pass: max(64, kmul * k) rows per query
+    std::atomic<uint64_t> half_queries{0}, half_redo{0};  // queries through the fp16 pass / redone with split-bf16
+    void half_refresh(Workspace &ws, uint64_t n_old, uint64_t n_new);  // after rows [n_old, n_new) changed
+    float half_sx() const { return std::ldexp(1.0f, 13 - half_exp); }
     std::vector<float> h_sq;  // host mirror of d_sq (4 B/row), kept in step by add_rows / swap_remove
     float xsq_max = 0.0f;
     float xsq_min_pos = 3.4e38f;  // smallest positive row |x|^2 seen (cosine certification: clamp check)
@@ -178,7 +190,7 @@ struct Index {
 
     // search entry points; d_* are device pointers, results [nq][k]
     void flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t *d_idx, float *d_dist,
-                         uint64_t *d_cnt);
+                         uint64_t *d_cnt, bool allow_half = true);
     void flat_sorted_device(Workspace &ws, const float *d_q, uint64_t nq, uint64_t ksel, uint64_t k, uint64_t *d_idx,
                             float *d_dist, uint64_t *d_cnt);
     void flat_exact_device(Workspace &ws, const float *d_q, const float *d_qsq, uint64_t nq, uint32_t ksel,

@@ -434,7 +434,7 @@ __global__ __launch_bounds__(64) void k_flat_finish(const uint64_t *__restrict__
                                                     const uint64_t *__restrict__ approx_sorted, uint32_t lda,
                                                     uint32_t ksel, uint32_t kstride, uint32_t kprime, uint64_t n_rows,
                                                     const float *__restrict__ qsq, float xsq_max, float xsq_min_pos,
-                                                    int cosine, uint32_t dim, const uint32_t *__restrict__ cnt,
+                                                    int cosine, uint32_t dim, SplitErr se, const uint32_t *__restrict__ cnt,
                                                     uint32_t cap, uint64_t id_offset, uint8_t *__restrict__ flags,
                                                     uint64_t *__restrict__ out_idx, float *__restrict__ out_dist,
                                                     uint64_t *__restrict__ out_count) {
@@ -454,12 +454,22 @@ __global__ __launch_bounds__(64) void k_flat_finish(const uint64_t *__restrict__
                 bool ok;
                 if (cosine) {
                     float qn = sqrtf(qs);
-                    float E = 2.5f * float(dim + 8) * 5.9604645e-8f + 6e-5f;
+                    float split = 6e-5f;  // split-bf16: 3 * 2^-18 relative to |x||q|, with slack
+                    if (se.qerr) {        // fp16 operands: measured |dx|/|x| and |dq| (k_half.hip); NaN / inf -> not certified
+                        const float qr = se.qerr[q] / qn;
+                        split = (se.dx_rel + qr + se.dx_rel * qr) * 1.001f;
+                    }
+                    float E = 2.5f * float(dim + 8) * 5.9604645e-8f + split;
                     bool clamp_free = sqrtf(xsq_min_pos) * qn > 1e-9f;
                     ok = clamp_free && dk < (1.0f + kappa / qn) - E;
                 } else {
                     float nrm = sqrtf(xsq_max) + sqrtf(qs);
-                    float E = 2.5f * float(dim + 8) * 5.9604645e-8f * nrm * nrm + 5e-5f * sqrtf(xsq_max) * sqrtf(qs);
+                    float split = 5e-5f * sqrtf(xsq_max) * sqrtf(qs);  // split-bf16: 2 * 3 * 2^-18 |x||q|, with slack
+                    if (se.qerr) {  // the key holds -2S: twice |dx||q| + |x||dq| + |dx||dq|
+                        const float qe = se.qerr[q];
+                        split = 2.0f * (se.dx_abs * sqrtf(qs) + sqrtf(xsq_max) * qe + se.dx_abs * qe) * 1.001f;
+                    }
+                    float E = 2.5f * float(dim + 8) * 5.9604645e-8f * nrm * nrm + split;
                     ok = dk < (kappa + qs) - E;
                 }
                 flag = ok ? 0 : 1;
@@ -482,12 +492,12 @@ __global__ __launch_bounds__(64) void k_flat_finish(const uint64_t *__restrict__
 }
 void launch_flat_finish(const uint64_t *exact_sorted, uint32_t lde, const uint64_t *approx_sorted, uint32_t lda,
                         uint32_t nq, uint32_t ksel, uint32_t kstride, uint32_t kprime, uint64_t n_rows, const float *qsq,
-                        float xsq_max, float xsq_min_pos, int cosine, uint32_t dim, const uint32_t *cnt, uint32_t cap,
+                        float xsq_max, float xsq_min_pos, int cosine, uint32_t dim, SplitErr se, const uint32_t *cnt, uint32_t cap,
                         uint64_t id_offset, uint8_t *flags, uint64_t *out_idx, float *out_dist, uint64_t *out_count,
                         hipStream_t s) {
     if (nq == 0) return;
     hipLaunchKernelGGL(k_flat_finish, dim3(nq), dim3(64), 0, s, exact_sorted, lde, approx_sorted, lda, ksel, kstride,
-                       kprime, n_rows, qsq, xsq_max, xsq_min_pos, cosine, dim, cnt, cap, id_offset, flags, out_idx,
+                       kprime, n_rows, qsq, xsq_max, xsq_min_pos, cosine, dim, se, cnt, cap, id_offset, flags, out_idx,
                        out_dist, out_count);
 }
 

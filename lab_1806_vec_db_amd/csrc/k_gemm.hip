@@ -28,6 +28,7 @@ namespace vdb {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr uint32_t GEMM_NH = 8;             // 16-query halves per group
 constexpr uint32_t GEMM_BQ = 16 * GEMM_NH;  // 128 queries per pass
@@ -37,8 +38,9 @@ void gemm_set_tw(int v) { g_gemm_tw = v == 2 ? 2 : 3; }
 uint32_t gemm_group() { return GEMM_BQ; }
 
 struct GemmArgs {
-    const uint4 *XT;     // fragment-ordered split-bf16 mirror (k_tile_rows)
-    const uint4 *qfrag;  // [ngroups][KB][8 halves][hi|lo][64] (k_mfma_pack_queries with NH = 8)
+    const uint4 *XT;     // fragment-ordered split-bf16 mirror (k_tile_rows); GEMM_F16: the scaled fp16 mirror (k_tile_rows_h)
+    const uint4 *qfrag;  // [ngroups][KB][8 halves][hi|lo][64] (k_mfma_pack_queries with NH = 8); GEMM_F16: [..][sub 0|1][64]
+    const float *qmul;   // GEMM_F16: [ngroups*128] 1 / (row scale * query scale), a power of two: S = acc * qmul exactly
     const float *xsq;
     uint64_t n;
     uint32_t KB, n_units, ngroups;
@@ -54,11 +56,18 @@ struct GemmArgs {
 };
 
 enum { GEMM_FILTER = 0, GEMM_SAMPLE = 1 };
+// Arithmetic of the contraction.  GEMM_BF16X3: x*q ~ xh*qh + xh*ql + xl*qh on 32-column k-blocks, 4 B per element
+// in the mirror.  GEMM_F16: x*q ~ fp16(sx*x) * fp16(sq*q) on 64-column k-blocks (two 16x16x32 f16 MFMAs), 2 B per
+// element: a third of the matrix work and half of the HBM bytes per row.  The data movement is the same in both: a
+// k-block of a tile is two 1-KB fragments ([hi|lo] or [columns 0-31 | 32-63]).  The coarser rounding of GEMM_F16 is
+// measured when the mirror / the query image is written (k_row_split_err, k_query_prep_h) and enters the
+// certification bound (k_flat_finish); queries it cannot certify are redone with GEMM_BF16X3 (index.hip).
+enum { GEMM_BF16X3 = 0, GEMM_F16 = 1 };
 
 // GEMM_SAMPLE: blockIdx.y = query group, one step per workgroup over the sampled units, keys written densely -- the
 // threshold sample of the same queries with the same arithmetic as the filter pass (the small-batch kernel's sample
 // mode re-reads the sampled rows once per 32 queries; this one once per 128: 80 -> ~25 us at a 125k-row shard).
-template <int TW, int KC, int MODE>
+template <int TW, int KC, int MODE, int PREC>
 __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
     constexpr int NT = 512, NW = 8, NH = GEMM_NH, R = KC;
     constexpr uint32_t CHUNK = KC * NH * 128;  // uint4 per Q chunk
@@ -69,6 +78,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
     uint32_t *hit_q = reinterpret_cast<uint32_t *>(hit_key + GEMM_WGBUF);
     uint32_t *hit_n = hit_q + GEMM_WGBUF;  // [0] entries, [1..128] per-query counts, [129..256] per-query bases
     float *tau_s = reinterpret_cast<float *>(hit_n + 1 + 2 * GEMM_BQ);  // [128] thresholds of the current group
+    float *qm_s = tau_s + GEMM_BQ;                                      // [128] GEMM_F16: scale undo per query
 
     // wave-uniform values are made visibly uniform (readfirstlane) so that addresses are SGPR base + 32-bit lane offset
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -142,6 +152,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
         if (MODE == GEMM_FILTER && threadIdx.x < 1 + 2 * GEMM_BQ) hit_n[threadIdx.x] = 0;  // ordered before the first append by the chunk barriers
         if (MODE == GEMM_FILTER && threadIdx.x < GEMM_BQ)  // thresholds live in LDS, not in 8 registers per lane
             tau_s[threadIdx.x] = (a.debug & 1) ? -INFINITY : a.tau[grp * GEMM_BQ + threadIdx.x];
+        if (PREC == GEMM_F16 && threadIdx.x < GEMM_BQ) qm_s[threadIdx.x] = a.qmul[grp * GEMM_BQ + threadIdx.x];
         const uint32_t steps = steps_of(slot_cur);
         for (uint32_t st = 0; st < steps; st++) {
             const uint32_t u_raw = unit_of(slot_cur, st);
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
                 uint4 *qdst = smem + (buf ^ 1) * CHUNK + threadIdx.x;
                 const uint4 *qcur = smem + buf * CHUNK + lane;
                 const bool last_c = c + 1 == nchunk;
-                bf16x8 qh_n = __builtin_bit_cast(bf16x8, qcur[0]);
+                bf16x8 qh_n = __builtin_bit_cast(bf16x8, qcur[0]);  // [hi|lo] (GEMM_F16: [columns 0-31 | 32-63]) of half 0
                 bf16x8 ql_n = __builtin_bit_cast(bf16x8, qcur[64]);
 #pragma unroll
                 for (int p = 0; p < KC; p++) {
@@ -190,15 +201,24 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
                             ql_n = __builtin_bit_cast(bf16x8, qcur[((pn * NH + hn) * 2 + 1) * 64]);
                         }
                         __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (PREC == GEMM_BF16X3) {
 #pragma unroll
-                        for (int t = 0; t < TW; t++)
-                            acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[t], qh, acc[t][h], 0, 0, 0);
+                            for (int t = 0; t < TW; t++)
+                                acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[t], qh, acc[t][h], 0, 0, 0);
 #pragma unroll
-                        for (int t = 0; t < TW; t++)
-                            acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[t], ql, acc[t][h], 0, 0, 0);
+                            for (int t = 0; t < TW; t++)
+                                acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[t], ql, acc[t][h], 0, 0, 0);
 #pragma unroll
-                        for (int t = 0; t < TW; t++)
-                            acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl[t], qh, acc[t][h], 0, 0, 0);
+                            for (int t = 0; t < TW; t++)
+                                acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl[t], qh, acc[t][h], 0, 0, 0);
+                        } else {  // the two fragments are columns 0-31 and 32-63 of the 64-column k-block
+#pragma unroll
+                            for (int t = 0; t < TW; t++)
+                                acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xh[t]), __builtin_bit_cast(f16x8, qh), acc[t][h], 0, 0, 0);
+#pragma unroll
+                            for (int t = 0; t < TW; t++)
+                                acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xl[t]), __builtin_bit_cast(f16x8, ql), acc[t][h], 0, 0, 0);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     qdst[(p * QP + 0) * NT] = qs0;
@@ -246,7 +266,9 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
 #pragma unroll
                 for (int h = 0; h < NH; h++) {
                     const float tau_h = MODE == GEMM_FILTER ? tau_s[h * 16 + r] : 0.0f;
-                    const f32x2 a01 = {acc[t][h][0], acc[t][h][1]}, a23 = {acc[t][h][2], acc[t][h][3]};
+                    const float qm = PREC == GEMM_F16 ? qm_s[h * 16 + r] : 1.0f;  // undoes the power-of-two scales: exact
+                    const f32x2 a01 = PREC == GEMM_F16 ? (f32x2){acc[t][h][0] * qm, acc[t][h][1] * qm} : (f32x2){acc[t][h][0], acc[t][h][1]};
+                    const f32x2 a23 = PREC == GEMM_F16 ? (f32x2){acc[t][h][2] * qm, acc[t][h][3] * qm} : (f32x2){acc[t][h][2], acc[t][h][3]};
                     f32x2 k01, k23;
                     if (a.cosine) {
                         k01 = -a01 * xv01;
@@ -319,7 +341,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
     }
 }
 
-template <int TW, int KC, int MODE>
+template <int TW, int KC, int MODE, int PREC>
 static void flat_gemm_launch(const GemmArgs &a0, int num_cu, hipStream_t s) {
     GemmArgs a = a0;
     const uint64_t n_tiles = (a.n + 15) / 16;
@@ -336,41 +358,63 @@ static void flat_gemm_launch(const GemmArgs &a0, int num_cu, hipStream_t s) {
         if (need < grid) grid = need;
     }
     if (grid == 0 || a.ngroups == 0) return;
-    const size_t lds = size_t(2) * KC * GEMM_NH * 128 * sizeof(uint4) + size_t(GEMM_WGBUF) * 12 + (1 + 3 * GEMM_BQ) * 4 + 16;
+    const size_t lds = size_t(2) * KC * GEMM_NH * 128 * sizeof(uint4) + size_t(GEMM_WGBUF) * 12 + (1 + 4 * GEMM_BQ) * 4 + 16;
     static bool attr_done = false;
     if (!attr_done) {
-        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_gemm<TW, KC, MODE>),
+        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_gemm<TW, KC, MODE, PREC>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_flat_gemm<TW, KC, MODE>), dim3(grid, MODE == GEMM_SAMPLE ? a.ngroups : 1), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((k_flat_gemm<TW, KC, MODE, PREC>), dim3(grid, MODE == GEMM_SAMPLE ? a.ngroups : 1), dim3(512), lds, s, a);
     VDB_HIP(hipGetLastError());
 }
 
 template <int MODE>
 static void flat_gemm_dispatch(const GemmArgs &a, int num_cu, hipStream_t s) {
+    if (a.qmul) {  // GEMM_F16: KB counts 64-column k-blocks; chunks of 3, 2 or 1 of them
+        VDB_REQUIRE(a.KB % 3 == 0 || a.KB % 2 == 0, "flat_gemm: fp16 mirror needs a k-block count divisible by 2 or 3");
+        if (a.KB % 3 == 0) {
+            if (g_gemm_tw == 2)
+                flat_gemm_launch<2, 3, MODE, GEMM_F16>(a, num_cu, s);
+            else
+                flat_gemm_launch<3, 3, MODE, GEMM_F16>(a, num_cu, s);
+        } else {
+            if (g_gemm_tw == 2)
+                flat_gemm_launch<2, 2, MODE, GEMM_F16>(a, num_cu, s);
+            else
+                flat_gemm_launch<3, 2, MODE, GEMM_F16>(a, num_cu, s);
+        }
+        return;
+    }
     if (a.KB % 3 == 0) {
         if (g_gemm_tw == 2)
-            flat_gemm_launch<2, 3, MODE>(a, num_cu, s);
+            flat_gemm_launch<2, 3, MODE, GEMM_BF16X3>(a, num_cu, s);
         else
-            flat_gemm_launch<3, 3, MODE>(a, num_cu, s);
+            flat_gemm_launch<3, 3, MODE, GEMM_BF16X3>(a, num_cu, s);
     } else {  // KB is even (columns padded to a multiple of 64)
         if (g_gemm_tw == 2)
-            flat_gemm_launch<2, 2, MODE>(a, num_cu, s);
+            flat_gemm_launch<2, 2, MODE, GEMM_BF16X3>(a, num_cu, s);
         else
-            flat_gemm_launch<3, 2, MODE>(a, num_cu, s);
+            flat_gemm_launch<3, 2, MODE, GEMM_BF16X3>(a, num_cu, s);
     }
 }
+// GEMM_F16 serves dims whose 64-column k-block count splits into chunks of 3 or 2 (every dim except those with an odd
+// count that is not a multiple of 3: 64*5, 64*7, ... use the split-bf16 kernel only)
+bool gemm_f16_supported(uint32_t dim) {
+    const uint32_t kb = mfma_dim_pad(dim) / 64;
+    return kb >= 2 && (kb % 3 == 0 || kb % 2 == 0) && mfma_dim_pad(dim) <= 2048;
+}
 
-static GemmArgs gemm_args(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t ngroups, const float *xsq,
-                          int cosine) {
+static GemmArgs gemm_args(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, const float *qmul, uint32_t ngroups,
+                          const float *xsq, int cosine) {
     VDB_REQUIRE(n < (1ull << 32), "flat_gemm: too many rows for one shard");
     GemmArgs a{};
     a.XT = reinterpret_cast<const uint4 *>(XT);
     a.qfrag = reinterpret_cast<const uint4 *>(qfrag);
     a.xsq = xsq;
     a.n = n;
-    a.KB = mfma_dim_pad(dim) / 32;
+    a.qmul = qmul;
+    a.KB = mfma_dim_pad(dim) / (qmul ? 64 : 32);
     a.ngroups = ngroups;
     a.cosine = cosine;
     a.unit_step = 1;
@@ -378,11 +422,11 @@ static GemmArgs gemm_args(const float *XT, uint64_t n, uint32_t dim, const float
 }
 
 // rows past n up to a whole unit are read from the mirror (zero tiles) and from xsq (padding): see Index::add_rows
-void launch_flat_gemm_filter(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t ngroups,
+void launch_flat_gemm_filter(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, const float *qmul, uint32_t ngroups,
                              const float *xsq, int cosine, const float *tau, uint64_t *cand, uint32_t *cnt,
                              uint32_t cap, int debug, int num_cu, hipStream_t s) {
     if (n == 0 || ngroups == 0) return;
-    GemmArgs a = gemm_args(XT, n, dim, qfrag, ngroups, xsq, cosine);
+    GemmArgs a = gemm_args(XT, n, dim, qfrag, qmul, ngroups, xsq, cosine);
     a.tau = tau;
     a.cand = cand;
     a.cnt = cnt;
@@ -398,13 +442,13 @@ uint64_t gemm_sample_rows(uint64_t n, uint32_t unit_step) {
     return (units + unit_step - 1) / unit_step * (16 * tw);
 }
 // dense keys of the sample for every query of every group: out[q*ld + j], j < gemm_sample_rows(n, unit_step), +inf past n
-void launch_flat_gemm_sample(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t ngroups,
+void launch_flat_gemm_sample(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, const float *qmul, uint32_t ngroups,
                              const float *xsq, int cosine, uint32_t unit_step, float *out, uint64_t ld, int num_cu,
                              hipStream_t s) {
     if (n == 0 || ngroups == 0) return;
     VDB_REQUIRE(unit_step >= 1 && (ld & 3) == 0 && ld >= gemm_sample_rows(n, unit_step), "flat_gemm: ld must cover the sample");
     VDB_REQUIRE(ngroups <= 65535, "flat_gemm: too many query groups");
-    GemmArgs a = gemm_args(XT, n, dim, qfrag, ngroups, xsq, cosine);
+    GemmArgs a = gemm_args(XT, n, dim, qfrag, qmul, ngroups, xsq, cosine);
     a.unit_step = unit_step;
     a.out = out;
     a.ld = ld;

@@ -1,0 +1,173 @@
+// k_half.hip -- operands of k_flat_gemm<.., GEMM_F16> (k_gemm.hip): the scaled fp16 mirror of the rows, the scaled
+// fp16 query images, and the MEASURED rounding error of both.
+//
+// Rows are stored as fp16(x * sx), queries as fp16(q * sq[q]); sx and sq[q] are powers of two chosen from the largest
+// row norm / the query norm so that no element can overflow (|x_i| <= |x| < 2^c  =>  |x_i * 2^(13-c)| < 2^13), so the
+// products are exact in f32 and S = (sum of products) / (sx * sq) differs from x.q only by
+//     | x~.q~ - x.q |  <=  |dx| |q| + |x| |dq| + |dx| |dq|,      dx = x - x~/sx,  dq = q - q~/sq      (Cauchy-Schwarz)
+// plus the f32 accumulation error that the split-bf16 kernels have as well.  |dx| is not bounded by the format's
+// worst case (2^-11 |x|, and an absolute term for fp16 subnormals) but measured: k_row_split_err keeps the maximum
+// of |dx_r|^2 and of |dx_r|^2 / |x_r|^2 over all rows ever tiled, k_query_prep_h returns |dq|^2 per query.  Measured
+// values are ~2.4x smaller than the worst case and cover subnormals and flushed elements by construction.  These
+// numbers go into the certification bound of k_flat_finish (k_exact.hip); the shortlist is re-ranked with the
+// reference's strict-order f32 arithmetic as always, so the coarser keys cost certifications, never results.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace vdb {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint4 pack8h(const float4 &a, const float4 &b, float scale) {
+    f16x8 h = {(_Float16)(a.x * scale), (_Float16)(a.y * scale), (_Float16)(a.z * scale), (_Float16)(a.w * scale),
+               (_Float16)(b.x * scale), (_Float16)(b.y * scale), (_Float16)(b.z * scale), (_Float16)(b.w * scale)};
+    return __builtin_bit_cast(uint4, h);  // v_cvt_f16_f32: round to nearest even
+}
+
+__device__ __forceinline__ void load8_pad(const float *row, uint32_t dim, uint32_t col, float4 &a, float4 &b) {
+    if ((dim & 3) == 0 && col + 8 <= dim) {
+        a = *reinterpret_cast<const float4 *>(row + col);
+        b = *reinterpret_cast<const float4 *>(row + col + 4);
+        return;
+    }
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = col + i < dim ? row[col + i] : 0.0f;
+    a = make_float4(v[0], v[1], v[2], v[3]);
+    b = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// rows [16*tile0, 16*tile1) -> T[(tile*KB32 + kb32)*64 + lane] = 8 fp16: row 16*tile + (lane & 15), columns
+// 32*kb32 + 8*(lane >> 4) + j -- the A operand of v_mfma_f32_16x16x32_f16; a 64-column k-block of k_flat_gemm is two
+// consecutive 1-KB fragments, exactly like the [hi|lo] pair of the split-bf16 mirror.  Rows >= n: zero.
+__global__ __launch_bounds__(256) void k_tile_rows_h(const float *__restrict__ X, uint64_t n, uint32_t dim,
+                                                     uint64_t tile0, uint64_t tile1, float sx, uint4 *__restrict__ T) {
+    const uint32_t KB = ((dim + 63) & ~63u) / 32;
+    uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;  // (tile, kb32, lane)
+    uint64_t total = (tile1 - tile0) * KB * 64;
+    if (i >= total) return;
+    uint32_t l = uint32_t(i & 63);
+    uint64_t tk = i >> 6;
+    uint32_t kb = uint32_t(tk % KB);
+    uint64_t tile = tile0 + tk / KB;
+    uint64_t row = tile * 16 + (l & 15);
+    uint32_t col = kb * 32 + 8 * (l >> 4);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (row < n) load8_pad(X + row * dim, dim, col, a, b);
+    T[(tile * KB + kb) * 64 + l] = pack8h(a, b, sx);
+}
+void launch_tile_rows_h(const float *X, uint64_t n, uint32_t dim, uint64_t tile0, uint64_t tile1, float sx, void *T,
+                        hipStream_t s) {
+    if (tile1 <= tile0) return;
+    uint64_t total = (tile1 - tile0) * (mfma_dim_pad(dim) / 32) * 64;
+    hipLaunchKernelGGL(k_tile_rows_h, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, X, n, dim, tile0, tile1, sx,
+                       reinterpret_cast<uint4 *>(T));
+}
+
+// |v - fp16(v * scale) / scale|^2 summed over a vector by one wave (all differences are exact in f32: v~ is v rounded
+// to 11 bits, or a subnormal / zero whose distance to v is representable)
+__device__ __forceinline__ float wave_round_err2(const float *v, uint32_t dim, float scale, float inv_scale, uint32_t lane) {
+    float acc = 0.0f;
+    for (uint32_t j = lane; j < dim; j += 64) {
+        float x = v[j];
+        float d = x - float((_Float16)(x * scale)) * inv_scale;
+        acc += d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    return acc;
+}
+
+// out2[0] = max over rows of |dx_r|^2, out2[1] = max of |dx_r|^2 / |x_r|^2 (float bits, atomicMax as unsigned: both are
+// non-negative).  Rows with a non-finite norm are skipped: their keys are NaN / inf in every kernel and never pass a
+// threshold.  One wave per row.
+__global__ __launch_bounds__(256) void k_row_split_err(const float *__restrict__ X, const float *__restrict__ xsq,
+                                                       uint64_t row0, uint64_t row1, uint32_t dim, float sx, float inv_sx,
+                                                       uint32_t *__restrict__ out2) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t row = row0 + uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= row1) return;
+    const float e2 = wave_round_err2(X + row * dim, dim, sx, inv_sx, lane);
+    const float xs = xsq[row];
+    if (lane == 0 && e2 > 0.0f && e2 < INFINITY && xs > 0.0f && xs < INFINITY) {
+        atomicMax(&out2[0], __float_as_uint(e2));
+        const float rel = e2 / xs;
+        if (rel < INFINITY) atomicMax(&out2[1], __float_as_uint(rel));
+    }
+}
+void launch_row_split_err(const float *X, const float *xsq, uint64_t row0, uint64_t row1, uint32_t dim, float sx,
+                          uint32_t *out2, hipStream_t s) {
+    if (row1 <= row0) return;
+    hipLaunchKernelGGL(k_row_split_err, dim3((unsigned)((row1 - row0 + 3) / 4)), dim3(256), 0, s, X, xsq, row0, row1, dim,
+                       sx, 1.0f / sx, out2);
+}
+
+// per query: scale sq = 2^(13 - c) with |q| < 2^c, multiplier qmul = 1 / (sx * sq) that undoes both scales, and the
+// measured rounding error qerr = |q - q~/sq| (an upper bound: the f32 sum is inflated by 2^-10).  Queries whose norm
+// is not a normal number of moderate size get qerr = +inf: they cannot be certified by the fp16 pass and are redone.
+// One wave per query; queries in [nq, nq_pad) are padding (zero images, tau = -inf).
+__global__ __launch_bounds__(256) void k_query_prep_h(const float *__restrict__ Q, uint32_t nq, uint32_t nq_pad, uint32_t dim,
+                                                      const float *__restrict__ qsq, float inv_sx, float *__restrict__ qscale,
+                                                      float *__restrict__ qmul, float *__restrict__ qerr) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq_pad) return;
+    float sc = 1.0f, err = 0.0f;
+    if (q < nq) {
+        const float qs = qsq[q];
+        if (qs == 0.0f) {
+            // zero query: the image is exactly zero
+        } else if (qs >= 0x1p-80f && qs <= 0x1p80f) {
+            int e;
+            (void)frexpf(qs, &e);            // qs = m * 2^e, m in [0.5, 1)  =>  |q| < 2^ceil(e/2)
+            const int c = (e + 1) >> 1;       // arithmetic shift: ceil(e / 2)
+            sc = ldexpf(1.0f, 13 - c);
+            const float e2 = wave_round_err2(Q + size_t(q) * dim, dim, sc, ldexpf(1.0f, c - 13), lane);
+            err = sqrtf(e2) * 1.001f;
+        } else {
+            err = INFINITY;
+        }
+    }
+    if (lane == 0) {
+        qscale[q] = sc;
+        qmul[q] = inv_sx / sc;  // powers of two: exact
+        qerr[q] = err;
+    }
+}
+void launch_query_prep_h(const float *Q, uint32_t nq, uint32_t nq_pad, uint32_t dim, const float *qsq, float sx, float *qscale,
+                         float *qmul, float *qerr, hipStream_t s) {
+    if (nq_pad == 0) return;
+    hipLaunchKernelGGL(k_query_prep_h, dim3((nq_pad + 3) / 4), dim3(256), 0, s, Q, nq, nq_pad, dim, qsq, 1.0f / sx, qscale,
+                       qmul, qerr);
+}
+
+// Q [nq][dim] -> per group of 16*NH queries a B-operand image [kb64][half][sub 0|1][lane]: 8 fp16 of query
+// 16*half + (lane & 15), columns 64*kb64 + 32*sub + 8*(lane >> 4) + j, scaled by qscale[query]  (queries >= nq: zero)
+__global__ void k_pack_queries_h(const float *__restrict__ Q, uint32_t nq, uint32_t dim, uint32_t NH,
+                                 const float *__restrict__ qscale, uint4 *__restrict__ qfrag) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // (kb32, half, lane)
+    uint32_t KB = ((dim + 63) & ~63u) / 32;
+    if (i >= KB * NH * 64) return;
+    qfrag += uint64_t(blockIdx.y) * KB * NH * 64;
+    uint32_t l = i & 63, h = (i >> 6) % NH, kb = (i >> 6) / NH;
+    uint32_t q = blockIdx.y * 16 * NH + h * 16 + (l & 15);
+    uint32_t c = kb * 32 + 8 * (l >> 4);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    float sc = 1.0f;
+    if (q < nq) {
+        load8_pad(Q + size_t(q) * dim, dim, c, a, b);
+        sc = qscale[q];
+    }
+    qfrag[(((kb >> 1) * NH + h) * 2 + (kb & 1)) * 64 + l] = pack8h(a, b, sc);
+}
+void launch_pack_queries_h(const float *Q, uint32_t nq, uint32_t nq_cover, uint32_t dim, uint32_t NH, const float *qscale,
+                           void *qfrag, hipStream_t s) {
+    const uint32_t bq = 16 * NH;
+    uint32_t total = (mfma_dim_pad(dim) / 32) * NH * 64;
+    uint32_t nbatch = (std::max(nq, nq_cover) + bq - 1) / bq;
+    if (nbatch == 0) return;
+    hipLaunchKernelGGL(k_pack_queries_h, dim3((total + 255) / 256, nbatch), dim3(256), 0, s, Q, nq, dim, NH, qscale,
+                       reinterpret_cast<uint4 *>(qfrag));
+}
+
+}  // namespace vdb

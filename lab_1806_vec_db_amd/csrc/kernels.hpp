@@ -30,9 +30,15 @@ void launch_finalize(const uint64_t *keys, uint32_t ldk, uint32_t nq, uint32_t k
 // certification of an MFMA shortlist (see k_exact.hip): flags[q] = 1 when the exact top-k might
 // not be contained in the shortlist
 void launch_iota_keys(uint64_t *rows, uint32_t nq, uint32_t n, uint32_t ld, hipStream_t s);
+// rounding of the shortlist keys' operands: qerr == nullptr -> split-bf16 (format constants); otherwise the measured
+// errors of the fp16 operands (k_half.hip): dx_abs = max |dx_r|, dx_rel = max |dx_r| / |x_r|, qerr[q] = |dq|
+struct SplitErr {
+    const float *qerr = nullptr;
+    float dx_abs = 0.0f, dx_rel = 0.0f;
+};
 void launch_flat_finish(const uint64_t *exact_sorted, uint32_t lde, const uint64_t *approx_sorted, uint32_t lda,
                         uint32_t nq, uint32_t ksel, uint32_t kstride, uint32_t kprime, uint64_t n_rows, const float *qsq,
-                        float xsq_max, float xsq_min_pos, int cosine, uint32_t dim, const uint32_t *cnt, uint32_t cap,
+                        float xsq_max, float xsq_min_pos, int cosine, uint32_t dim, SplitErr se, const uint32_t *cnt, uint32_t cap,
                         uint64_t id_offset, uint8_t *flags, uint64_t *out_idx, float *out_dist, uint64_t *out_count,
                         hipStream_t s);
 void launch_certify(const uint64_t *exact_sorted, uint32_t lde, const uint64_t *approx_sorted, uint32_t lda,
@@ -95,16 +101,28 @@ void launch_flat_mfma_filter(const float *XT, uint64_t n, uint32_t dim, const fl
 size_t mfma_sync_words(uint32_t nbatch, int num_cu);
 // k_gemm.hip: the same filter for groups of gemm_group() = 128 queries per corpus pass; qfrag = images packed with
 // launch_mfma_pack_queries_nh(.., 8, ..), tau / cand / cnt indexed by the global query number as above
-void launch_flat_gemm_filter(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t ngroups,
+// qmul == nullptr: split-bf16 operands (launch_tile_rows / launch_mfma_pack_queries_nh); otherwise the scaled fp16
+// operands of k_half.hip and qmul[q] = 1 / (row scale * query scale)
+void launch_flat_gemm_filter(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, const float *qmul, uint32_t ngroups,
                              const float *xsq, int cosine, const float *tau, uint64_t *cand, uint32_t *cnt,
                              uint32_t cap, int debug, int num_cu, hipStream_t s);
 uint32_t gemm_group();
 // threshold sample with the same kernel: every unit_step-th unit of rows, dense keys out[q*ld + j]
 uint64_t gemm_sample_rows(uint64_t n, uint32_t unit_step);
-void launch_flat_gemm_sample(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, uint32_t ngroups,
+void launch_flat_gemm_sample(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, const float *qmul, uint32_t ngroups,
                              const float *xsq, int cosine, uint32_t unit_step, float *out, uint64_t ld, int num_cu,
                              hipStream_t s);
 void gemm_set_tw(int v);
+bool gemm_f16_supported(uint32_t dim);
+// k_half.hip: scaled fp16 mirror / query images for the GEMM_F16 variant and their measured rounding errors
+void launch_tile_rows_h(const float *X, uint64_t n, uint32_t dim, uint64_t tile0, uint64_t tile1, float sx, void *T,
+                        hipStream_t s);
+void launch_row_split_err(const float *X, const float *xsq, uint64_t row0, uint64_t row1, uint32_t dim, float sx,
+                          uint32_t *out2 /* [2] float bits: max |dx|^2, max |dx|^2/|x|^2 (atomicMax) */, hipStream_t s);
+void launch_query_prep_h(const float *Q, uint32_t nq, uint32_t nq_pad, uint32_t dim, const float *qsq, float sx, float *qscale,
+                         float *qmul, float *qerr, hipStream_t s);
+void launch_pack_queries_h(const float *Q, uint32_t nq, uint32_t nq_cover, uint32_t dim, uint32_t NH, const float *qscale,
+                           void *qfrag, hipStream_t s);
 void launch_mfma_pack_queries_nh(const float *Q, uint32_t nq, uint32_t nq_cover, uint32_t dim, uint32_t NH, float *qfrag,
                                  hipStream_t s);
 void mfma_set_sample_thin(int v);

@@ -246,6 +246,11 @@ class GpuIndex:
         L.check(self._lib.vdb_flat_fallback_count(self._h, C.byref(v)))
         return int(v.value)
 
+    def get_stat(self, name: str) -> int:
+        v = C.c_uint64()
+        L.check(self._lib.vdb_get_stat(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
+
     # -- PQ ------------------------------------------------------------------------------------------------
     def pq_attach(self, n_bits: int, m: int, centroids, codes=None):
         c = _f32(centroids).ravel()

@@ -181,6 +181,7 @@ def test_gemm_filter_parity(mods, dim, n, nq, dist, kind):
     ix = vdb.GpuIndex(dim, dist)
     ix.batch_add(base)
     ix.set_flat_mode(2)
+    ix.set_param("flat_half", 1)  # this test compares the split-bf16 kernels (the fp16 first pass: test_flat_half_gpu.py)
     fb = []
     for tw in (3, 2):
         ix.set_param("flat_gemm_tw", tw)
