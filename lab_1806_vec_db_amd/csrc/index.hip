@@ -314,8 +314,6 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     //          upper bound of the k'-th smallest key over all rows (the sample is a subset of the rows)
     // phase 2: one corpus pass per 32 queries that appends only the keys <= tau[q] (expected ~k'*step hits)
     // phase 3: shortlist = k' smallest appended pairs per query
-    const uint32_t capp = topk_capacity(kprime);
-    const uint32_t capk = topk_capacity(ksel);
     const uint64_t bq = mfma_batch((uint32_t)dim);  // queries per workgroup batch (32, or 16 for 1024 < dim <= 2048)
     // more than 64 queries: the filter pass runs as k_flat_gemm, 128 queries per corpus pass (k_gemm.hip); the
     // sample pass keeps the small-batch kernel, so the padded query count is a multiple of both batch sizes
@@ -328,6 +326,8 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     const bool half = allow_half && gemm && half_valid && flat_half_mode != 1 && kprime_h <= 1024 && n > kprime_h &&
                       (flat_half_mode == 2 || hq < 1024 || hr * 8 <= hq);
     if (half) kprime = kprime_h;
+    const uint32_t capp = topk_capacity(kprime);
+    const uint32_t capk = topk_capacity(ksel);
     const uint64_t gq = gemm_group();
     const uint64_t ngroups = gemm ? (nq + gq - 1) / gq : 0;
     const uint64_t nq_pad = gemm ? ngroups * gq : (nq + bq - 1) / bq * bq;

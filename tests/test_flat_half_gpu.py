@@ -55,6 +55,12 @@ def test_half_pass_parity(mods, dist, kind, dim, n, nq):
     np.testing.assert_array_equal(d, d2)
     print(f"dim {dim} {dist}: fp16 pass redid {redo} of {nq} queries")
     assert redo <= nq // 4  # random / gist-like data certify almost always
+    ix.set_param("flat_half", 0)
+    for k in (1, 50, 200):  # shortlists of 64, 200 and 800 rows
+        h0 = ix.get_stat("flat_half_queries")
+        idx, d, cnt = ix.flat_knn(qs[:66], k)
+        assert ix.get_stat("flat_half_queries") == h0 + 66
+        _check_all(idx, d, cnt, *O.flat_knn_batch(base, qs[:66], k, kind, nthreads=8))
 
 
 def test_half_pass_redo_tier(mods):
