@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvdbhip.so")
+LIB_PATH = os.environ.get("VDBHIP_LIB") or os.path.join(_HERE, "libvdbhip.so")  # override: measurement builds
 
 L2SQR, COSINE = 0, 1
 

@@ -33,6 +33,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr uint32_t GEMM_NH = 8;             // 16-query halves per group
 constexpr uint32_t GEMM_BQ = 16 * GEMM_NH;  // 128 queries per pass
 constexpr uint32_t GEMM_WGBUF = 3072;       // LDS hit buffer entries per workgroup and group
+constexpr uint32_t GEMM_STAGE = 64;         // per wave and unit: lanes whose (tile, half) key quartet passed the threshold
 static int g_gemm_tw = 3;
 void gemm_set_tw(int v) { g_gemm_tw = v == 2 ? 2 : 3; }
 uint32_t gemm_group() { return GEMM_BQ; }
@@ -56,6 +57,11 @@ struct GemmArgs {
 };
 
 enum { GEMM_FILTER = 0, GEMM_SAMPLE = 1 };
+// measurement builds only (make EXTRA=-DGEMM_ABLATE=n): 1 = the epilogue looks at one (tile, half) pair only,
+// 2 = only the first half's MFMAs are issued; loads, LDS traffic and barriers stay.  Results are wrong by design.
+#ifndef GEMM_ABLATE
+#define GEMM_ABLATE 0
+#endif
 // Arithmetic of the contraction.  GEMM_BF16X3: x*q ~ xh*qh + xh*ql + xl*qh on 32-column k-blocks, 4 B per element
 // in the mirror.  GEMM_F16: x*q ~ fp16(sx*x) * fp16(sq*q) on 64-column k-blocks (two 16x16x32 f16 MFMAs), 2 B per
 // element: a third of the matrix work and half of the HBM bytes per row.  The data movement is the same in both: a
@@ -77,8 +83,10 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
     uint64_t *hit_key = reinterpret_cast<uint64_t *>(smem + 2 * CHUNK);
     uint32_t *hit_q = reinterpret_cast<uint32_t *>(hit_key + GEMM_WGBUF);
     uint32_t *hit_n = hit_q + GEMM_WGBUF;  // [0] entries, [1..128] per-query counts, [129..256] per-query bases
-    float *tau_s = reinterpret_cast<float *>(hit_n + 1 + 2 * GEMM_BQ);  // [128] thresholds of the current group
+    float *tau_s = reinterpret_cast<float *>(hit_n + 4 + 2 * GEMM_BQ);  // [128] thresholds of the current group (16-B aligned from here on)
     float *qm_s = tau_s + GEMM_BQ;                                      // [128] GEMM_F16: scale undo per query
+    float *xs_s = qm_s + GEMM_BQ;                                       // [8 waves][64] row norms of the wave's current unit
+    float *stage_s = xs_s + 8 * 64;  // [8 waves][GEMM_STAGE] float4 keys, then [8][GEMM_STAGE] first rows, then [8][GEMM_STAGE] queries
 
     // wave-uniform values are made visibly uniform (readfirstlane) so that addresses are SGPR base + 32-bit lane offset
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -87,11 +95,12 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
     const uint32_t KB = a.KB, nchunk = KB / KC;
     const uint64_t n = a.n;
 
-    // ---- X stream: k-block k of a unit is consumed from ring slot k % R while the loads for k-block k + PD land in
-    // the slot consumed one step earlier.  Past the unit's last k-blocks the loads run into the wave's NEXT unit
-    // (next step, or step 0 again for the next query group), so the ring never drains; the position where that
-    // happens is static (last chunk, p >= KC - PD), which keeps the chunk body free of branches.
-    constexpr int PD = R - 1;
+    // ---- X stream: k-block k of a unit is consumed from ring slot k % R; as soon as its MFMAs are issued the slot is
+    // refilled with k-block k + R (R = KC: the same position of the next chunk).  In the unit's last chunk the refills
+    // run into the wave's NEXT unit (next step, or step 0 again for the next query group), so the ring never drains
+    // and R k-blocks (18 KB per wave at TW = 3) stay in flight across the chunk barrier and the unit's epilogue; the
+    // position where that happens is static (last chunk), which keeps the chunk body free of branches.
+    static_assert(R == KC, "a refill targets the same slot of the next chunk");
     // Units are dealt round-robin: step s < S0 gives wave gw unit s*nwaves + gw.  The n_units % nwaves units that are
     // left do not fill another step of the whole chip; they go to a window of workgroups that ROTATES with the query
     // group, so that over the launch every workgroup gets about the same number of steps (1M rows, TW = 3: 10.17
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
         }
     };
 #pragma unroll
-    for (int p = 0; p < PD; p++) fetch_at(ring[p], cp_cur, p);
+    for (int p = 0; p < R; p++) fetch_at(ring[p], cp_cur, p);
 
     // ---- Q chunk staging: QP uint4 per thread and k-block, global -> registers at the top of the k-block (BEFORE
     // its X loads, so that waiting for them later is a counted vmcnt that leaves the X loads in flight), registers ->
@@ -162,6 +171,10 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
             for (int t = 0; t < TW; t++)
 #pragma unroll
                 for (int h = 0; h < NH; h++) acc[t][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // row norms of this unit: one dword per lane, staged global -> VGPR -> LDS with the Q chunk (every chunk
+            // re-stages the same 16*TW values: no branch in the chunk body).  As scalar loads in the epilogue they cost
+            // several dependent round trips per unit with all 8 waves waiting (measured: 0.58 of 3.1 ms).
+            const float *xs_src = a.xsq + uint64_t(__builtin_amdgcn_readfirstlane(u)) * a.unit_step * (16 * TW) + (lane < 16 * TW ? lane : 0);
             for (uint32_t c = 0; c < nchunk; c++) {
                 // next chunk in consumption order: same group until its last step is done
                 const uint4 *nxt = (c + 1 < nchunk ? qgrp + uint64_t(c + 1) * CHUNK
@@ -172,16 +185,13 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
                 const bool last_c = c + 1 == nchunk;
                 bf16x8 qh_n = __builtin_bit_cast(bf16x8, qcur[0]);  // [hi|lo] (GEMM_F16: [columns 0-31 | 32-63]) of half 0
                 bf16x8 ql_n = __builtin_bit_cast(bf16x8, qcur[64]);
+                float xs_stage = 0.0f;
 #pragma unroll
                 for (int p = 0; p < KC; p++) {
                     static_assert(QP == 2, "two staged uint4 per thread and k-block");  // scalars: an array here stays in scratch
                     const uint4 qs0 = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(nxt + (p * QP + 0) * NT) + tid16);
                     const uint4 qs1 = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(nxt + (p * QP + 1) * NT) + tid16);
-                    {
-                        const uint32_t kf = c * KC + p + PD;  // k-block the cursor is at
-                        const bool wrap = p >= KC - PD && last_c;
-                        fetch_at(ring[(p + R - 1) % R], wrap ? cp_nxt : cp_cur, wrap ? kf - KB : kf);
-                    }
+                    if (p == 0) xs_stage = *xs_src;
                     // the machine scheduler otherwise sinks these loads next to their uses (measured: vmcnt(0) before every
                     // staging ds_write, i.e. the whole X ring drained once per k-block) and pulls the B-fragment reads
                     // back to just before their MFMAs; pin the issue order instead
@@ -201,7 +211,9 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
                             ql_n = __builtin_bit_cast(bf16x8, qcur[((pn * NH + hn) * 2 + 1) * 64]);
                         }
                         __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (PREC == GEMM_BF16X3) {
+                        if ((GEMM_ABLATE & 2) && h > 0) {
+                            acc[0][h][0] += __builtin_bit_cast(f32x4, qh)[0] + __builtin_bit_cast(f32x4, ql)[0];  // keep the reads
+                        } else if constexpr (PREC == GEMM_BF16X3) {
 #pragma unroll
                             for (int t = 0; t < TW; t++)
                                 acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[t], qh, acc[t][h], 0, 0, 0);
@@ -221,8 +233,12 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    // slot p is free: refill it (before the staging writes, the chunk barrier and a possible epilogue)
+                    fetch_at(ring[p], last_c ? cp_nxt : cp_cur, last_c ? uint32_t(p) : (c + 1) * KC + p);
+                    __builtin_amdgcn_sched_barrier(0);
                     qdst[(p * QP + 0) * NT] = qs0;
                     qdst[(p * QP + 1) * NT] = qs1;
+                    if (p == 0) xs_s[wave * 64 + lane] = xs_stage;
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 __syncthreads();
@@ -241,71 +257,127 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
                 cp_nxt = unit_ptr(un);
             }
             // ---- epilogue: lane holds rows 4*g4..4*g4+3 of each tile for query r of each half ----
-            typedef const __attribute__((address_space(4))) float *cfloat_p;
-            cfloat_p xs_unit = (cfloat_p)(a.xsq + uint64_t(__builtin_amdgcn_readfirstlane(u)) * a.unit_step * (16 * TW));
+            // All 8 waves reach their epilogues together, so these cycles are not hidden behind a partner wave's MFMAs
+            // and everything on the common path is kept short: key = c + (acc * qm) * m with c = |x|^2, m = -2 (L2Sqr)
+            // or c = 0, m = -1/|x| (Cosine; the products with powers of two are exact, so one rounding per key in either
+            // form, the same in the sample and the filter instantiation); one v_min3 + v_min per (tile, half); the
+            // thresholds / scale factors of the next half are read from LDS while this one is tested.  A lane whose
+            // smallest key passes only STAGES its four keys (one ds_write_b128 + one b64); the per-key tests, the slot
+            // reservation in the workgroup's hit buffer and the pair keys are done once per tile, for all staged records
+            // in parallel, by one shared piece of code (24 inlined copies of that path cost an instruction-cache miss
+            // per use: 0.35 of 3.0 ms).
             const uint64_t row0 = uint64_t(u_raw) * a.unit_step * (16 * TW);  // the unclamped unit: idle waves are past n
+            uint32_t stage_n = 0;                                             // wave-uniform
+            float4 *stage_k = reinterpret_cast<float4 *>(stage_s) + wave * GEMM_STAGE;
+            uint32_t *stage_r = reinterpret_cast<uint32_t *>(reinterpret_cast<float4 *>(stage_s) + 8 * GEMM_STAGE) + wave * GEMM_STAGE;  // first row
+            uint32_t *stage_q = stage_r + 8 * GEMM_STAGE;                                                                             // query in group
+            float tau_n = MODE == GEMM_FILTER ? tau_s[r] : 0.0f, qm_n = PREC == GEMM_F16 ? qm_s[r] : 1.0f;
 #pragma unroll
             for (int t = 0; t < TW; t++) {
-                float xsv[16];
+                const float4 x4 = *reinterpret_cast<const float4 *>(&xs_s[wave * 64 + t * 16 + 4 * g4]);
+                float cv[4] = {x4.x, x4.y, x4.z, x4.w}, mv[4];
 #pragma unroll
-                for (int i = 0; i < 16; i++) xsv[i] = xs_unit[t * 16 + i];
-                float xv[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float x0 = xsv[0 + e], x1 = xsv[4 + e], x2 = xsv[8 + e], x3 = xsv[12 + e];
-                    const float x = g4 == 0 ? x0 : (g4 == 1 ? x1 : (g4 == 2 ? x2 : x3));
-                    // cosine keys -S/|x|; zero-norm rows: S = 0 and the reference distance is exactly 1 -> key 0
-                    xv[e] = a.cosine ? (x > 0.0f ? __frsqrt_rn(x) : 0.0f) : x;
+                for (int e = 0; e < 4; e++) {  // zero-norm rows under Cosine: S = 0 and the reference distance is exactly 1 -> key 0
+                    const float inv = cv[e] > 0.0f ? __frsqrt_rn(cv[e]) : 0.0f;
+                    mv[e] = a.cosine ? -inv : -2.0f;
+                    cv[e] = a.cosine ? 0.0f : cv[e];
                 }
-                const uint64_t rb = row0 + t * 16 + 4 * g4;
-                // The common case (no key of the 4 rows passes) must be cheap and small: the 24 (tile, half) pairs are
-                // tested through one min each (packed mul/add, same unfused rounding as the sample pass so that tau
-                // stays an upper bound); the append code is a rolled loop.  All 8 waves reach their epilogues
-                // together, so these cycles are not hidden behind a partner wave's MFMAs.
-                const f32x2 xv01 = {xv[0], xv[1]}, xv23 = {xv[2], xv[3]};
+                const f32x2 c01 = {cv[0], cv[1]}, c23 = {cv[2], cv[3]}, m01 = {mv[0], mv[1]}, m23 = {mv[2], mv[3]};
+                const uint32_t rb32 = uint32_t(row0) + t * 16 + 4 * g4;  // rows < 2^32 (gemm_args)
+                // the stage holds GEMM_STAGE lane records; when the next pair's passing lanes do not fit, the loop over the
+                // halves stops there, the stage is drained and the loop resumes at that pair (hub rows -- small norms under
+                // L2Sqr -- pass for most queries of a group at once)
+                uint32_t h_from = 0;  // wave-uniform
+                for (;;) {
+                uint32_t h_stop = NH;
+                if (h_from) {
+                    if (MODE == GEMM_FILTER) tau_n = tau_s[h_from * 16 + r];
+                    if (PREC == GEMM_F16) qm_n = qm_s[h_from * 16 + r];
+                }
 #pragma unroll
                 for (int h = 0; h < NH; h++) {
-                    const float tau_h = MODE == GEMM_FILTER ? tau_s[h * 16 + r] : 0.0f;
-                    const float qm = PREC == GEMM_F16 ? qm_s[h * 16 + r] : 1.0f;  // undoes the power-of-two scales: exact
-                    const f32x2 a01 = PREC == GEMM_F16 ? (f32x2){acc[t][h][0] * qm, acc[t][h][1] * qm} : (f32x2){acc[t][h][0], acc[t][h][1]};
-                    const f32x2 a23 = PREC == GEMM_F16 ? (f32x2){acc[t][h][2] * qm, acc[t][h][3] * qm} : (f32x2){acc[t][h][2], acc[t][h][3]};
-                    f32x2 k01, k23;
-                    if (a.cosine) {
-                        k01 = -a01 * xv01;
-                        k23 = -a23 * xv23;
-                    } else {
-                        const f32x2 two = {2.0f, 2.0f};
-                        k01 = xv01 - two * a01;
-                        k23 = xv23 - two * a23;
+                    if (MODE == GEMM_FILTER && uint32_t(h) < h_from) continue;
+                    if ((GEMM_ABLATE & 1) && (t > 0 || h > 0)) {
+                        if (acc[t][h][0] + acc[t][h][1] + acc[t][h][2] + acc[t][h][3] == 1.2345f) atomicAdd(hit_n, 1u);
+                        continue;
                     }
+                    const float tau_h = tau_n, qm = qm_n;
+                    {
+                        const int hn = (h + 1) % NH;  // the next pair's query (h = 0 again for the next tile)
+                        if (MODE == GEMM_FILTER) tau_n = tau_s[hn * 16 + r];
+                        if (PREC == GEMM_F16) qm_n = qm_s[hn * 16 + r];
+                    }
+                    f32x2 a01 = {acc[t][h][0], acc[t][h][1]}, a23 = {acc[t][h][2], acc[t][h][3]};
+                    if (PREC == GEMM_F16) {  // undo the power-of-two scales of the fp16 images: exact
+                        a01 *= qm;
+                        a23 *= qm;
+                    }
+                    const f32x2 k01 = c01 + a01 * m01, k23 = c23 + a23 * m23;
                     if (MODE == GEMM_SAMPLE) {
                         if (u_raw < a.n_units) {  // wave-uniform: waves past the last sampled unit write nothing
                             float4 kv;
-                            kv.x = rb + 0 < n ? k01.x : INFINITY;
-                            kv.y = rb + 1 < n ? k01.y : INFINITY;
-                            kv.z = rb + 2 < n ? k23.x : INFINITY;
-                            kv.w = rb + 3 < n ? k23.y : INFINITY;
+                            kv.x = rb32 + 0 < n ? k01.x : INFINITY;
+                            kv.y = rb32 + 1 < n ? k01.y : INFINITY;
+                            kv.z = rb32 + 2 < n ? k23.x : INFINITY;
+                            kv.w = rb32 + 3 < n ? k23.y : INFINITY;
                             const uint64_t col = uint64_t(u_raw) * (16 * TW) + t * 16 + 4 * g4;  // dense position in the sample
                             *reinterpret_cast<float4 *>(a.out + (uint64_t(grp) * GEMM_BQ + h * 16 + r) * a.ld + col) = kv;
                         }
                         continue;
                     }
-                    const float kmin = fminf(fminf(k01.x, k01.y), fminf(k23.x, k23.y));  // NaN keys never pass
-                    if (kmin <= tau_h) {  // rare: ~k' * sample step hits per query in total
-#pragma nounroll
-                        for (int e = 0; e < 4; e++) {
-                            const float key = e == 0 ? k01.x : (e == 1 ? k01.y : (e == 2 ? k23.x : k23.y));
-                            if (key <= tau_h && rb + e < n) {
-                                uint32_t pos = atomicAdd(hit_n, 1u);
-                                if (pos < GEMM_WGBUF) {
-                                    hit_key[pos] = pair_key(key, uint32_t(rb + e));
-                                    hit_q[pos] = h * 16 + r;
-                                } else {  // buffer full: mark the query as overflowed (-> exact fallback)
-                                    atomicAdd(&a.cnt[grp * GEMM_BQ + h * 16 + r], a.cap + 1);
-                                }
-                            }
+                    float kmin3, kmin;  // NaN keys never pass: v_min returns the other operand, the per-key tests are ordered
+                    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(kmin3) : "v"(k01.x), "v"(k01.y), "v"(k23.x));
+                    asm("v_min_f32 %0, %1, %2" : "=v"(kmin) : "v"(kmin3), "v"(k23.y));
+                    const bool pass = kmin <= tau_h;
+                    const uint64_t pm = __ballot(pass);
+                    if (pm) {  // rare: ~1000 rows per query in total (mfma_sample_plan)
+                        const uint32_t np = __builtin_popcountll(pm);
+                        if (stage_n + np > GEMM_STAGE) {  // wave-uniform
+                            h_stop = h;
+                            break;
+                        }
+                        if (pass) {
+                            const uint32_t slot = stage_n + __builtin_amdgcn_mbcnt_hi(uint32_t(pm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(pm), 0u));
+                            stage_k[slot] = make_float4(k01.x, k01.y, k23.x, k23.y);
+                            stage_r[slot] = rb32;
+                            stage_q[slot] = h * 16 + r;
+                        }
+                        stage_n += np;
+                    }
+                }
+                if (MODE == GEMM_FILTER && stage_n) {  // wave-uniform; drained per tile (and whenever the stage fills up)
+                    const uint32_t cnt = stage_n < GEMM_STAGE ? stage_n : GEMM_STAGE;
+                    for (uint32_t i = lane; i < cnt; i += 64) {
+                        const float4 kv = stage_k[i];
+                        const uint2 mt = make_uint2(stage_r[i], stage_q[i]);
+                        const float tq = tau_s[mt.y];
+                        const bool p0 = kv.x <= tq && mt.x + 0 < n, p1 = kv.y <= tq && mt.x + 1 < n;
+                        const bool p2 = kv.z <= tq && mt.x + 2 < n, p3 = kv.w <= tq && mt.x + 3 < n;
+                        const uint32_t mine = uint32_t(p0) + uint32_t(p1) + uint32_t(p2) + uint32_t(p3);
+                        if (mine) {
+                            uint32_t pos = atomicAdd(hit_n, mine);
+                            // every reserved slot below GEMM_WGBUF is written (the hand-off reads min(total, GEMM_WGBUF) slots)
+    #define VDB_PARK(P, KEY, E)                                   \
+        if (P) {                                                  \
+            if (pos < GEMM_WGBUF) {                               \
+                hit_key[pos] = pair_key(KEY, mt.x + E);           \
+                hit_q[pos] = mt.y;                                \
+            }                                                     \
+            pos++;                                                \
+        }
+                            VDB_PARK(p0, kv.x, 0)
+                            VDB_PARK(p1, kv.y, 1)
+                            VDB_PARK(p2, kv.z, 2)
+                            VDB_PARK(p3, kv.w, 3)
+    #undef VDB_PARK
+                            if (pos > GEMM_WGBUF)  // buffer full: mark the query as overflowed (-> redone by the caller)
+                                atomicAdd(&a.cnt[grp * GEMM_BQ + mt.y], a.cap + 1);
                         }
                     }
+                    stage_n = 0;
+                }
+                if (MODE != GEMM_FILTER || h_stop == NH) break;
+                h_from = h_stop;
                 }
             }
         }
@@ -358,7 +430,7 @@ static void flat_gemm_launch(const GemmArgs &a0, int num_cu, hipStream_t s) {
         if (need < grid) grid = need;
     }
     if (grid == 0 || a.ngroups == 0) return;
-    const size_t lds = size_t(2) * KC * GEMM_NH * 128 * sizeof(uint4) + size_t(GEMM_WGBUF) * 12 + (1 + 4 * GEMM_BQ) * 4 + 16;
+    const size_t lds = size_t(2) * KC * GEMM_NH * 128 * sizeof(uint4) + size_t(GEMM_WGBUF) * 12 + (4 + 4 * GEMM_BQ + 8 * 64) * 4 + size_t(8) * GEMM_STAGE * 24 + 16;
     static bool attr_done = false;
     if (!attr_done) {
         VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_gemm<TW, KC, MODE, PREC>),

@@ -518,29 +518,35 @@ static void flat_mfma_dispatch(const MfmaArgs &a, int num_cu, hipStream_t s) {
 
 uint32_t mfma_num_items(uint64_t n) { return (uint32_t)((n + 16 * MFMA_RT - 1) / (16 * MFMA_RT)); }
 // Threshold sample: every `step`-th item (32 rows) is scored and tau = the `rank`-th smallest sampled key.  Expected
-// rows with key <= tau over the whole shard: step * rank, aimed at ~2048 per query (candidate lists hold 8192).
+// rows with key <= tau over the whole shard: step * rank, aimed at ~1024 per query (candidate lists hold 8192; every
+// hit costs the filter kernel's epilogue a divergent LDS append: 2048 hits per query were 0.37 of 3.0 ms).
 //  - rank = k': tau is an upper bound of the k'-th smallest key of ALL rows (the sample is a subset), so the filter
 //    pass is guaranteed to return at least k' rows;
-//  - large shards (step >= 32) use rank = max(8, k'/4) on a 4x thinner sample: a quarter of the sample-pass and
-//    selection work for the same expected hit count.  The k'-hit guarantee becomes a probability (P[hits < k'] is
-//    below 1e-100 at 256 * 8 expected hits), so it is CHECKED: a query with fewer than k' hits is redone by the exact
-//    scan like any other uncertified query.
+//  - when the shard is large enough, rank r = max(8, k'/8) on a thinner sample (>= 64 items): less sample-pass and
+//    selection work for the same expected hit count (target = max(1024, 4 k')).  The k'-hit guarantee becomes a probability: hits / step is
+//    Gamma(r)-distributed, P[hits < k'] = P[Gamma(r) < k'/step] (r = 8, k'/step = 0.5: 6e-8), so it is CHECKED: a
+//    query with fewer than k' hits is redone like any other uncertified query.
 static int g_sample_thin = 1;
 void mfma_set_sample_thin(int v) { g_sample_thin = v; }
 void mfma_sample_plan(uint64_t n, uint32_t kprime, uint32_t *step_out, uint32_t *rank_out) {
-    const uint32_t items = mfma_num_items(n), target = 2048;
+    const uint32_t items = mfma_num_items(n), target = std::max<uint32_t>(1024, 4 * kprime);
     uint32_t rank = kprime < 1 ? 1 : kprime;
     uint32_t step = items / 256;  // >= 256 sampled items (8192 rows) when the shard has them
     step = step < 1 ? 1 : step;
-    uint32_t cap = target / rank < 1 ? 1 : target / rank;
+    const uint32_t cap = target / rank < 1 ? 1 : target / rank;
     if (step > cap) step = cap;
-    if (g_sample_thin && step >= 32 && items / (4 * step) >= 64) {  // thin the sample 4x, lower the rank 4x
-        uint32_t r4 = kprime / 4 < 8 ? 8 : kprime / 4;
-        if (r4 < rank) {
-            rank = r4;
-            step *= 4;
-            cap = target / rank < 1 ? 1 : target / rank;
-            if (step > cap) step = cap;
+    if (g_sample_thin) {  // thinner sample (>= 64 items), lower rank: same expected hits, less sample work
+        for (uint32_t div = 8; div >= 2; div /= 2) {
+            const uint32_t r = kprime / div < 8 ? 8 : kprime / div;
+            uint32_t st = items / 64;
+            if (st > target / r) st = target / r;
+            // P[hits < k'] = P[Gamma(r) < k'/st] must be negligible: k'/st <= r/8 (r < 16: 1e-5), r/4 (r < 32: 1e-6), r/3
+            const double thr = r < 16 ? r / 8.0 : (r < 32 ? r / 4.0 : r / 3.0);
+            if (r < rank && st >= 2 * step && double(kprime) <= thr * st * 1.1) {
+                rank = r;
+                step = st;
+                break;
+            }
         }
     }
     *step_out = step;
