@@ -312,7 +312,9 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
                         a01 *= qm;
                         a23 *= qm;
                     }
-                    const f32x2 k01 = c01 + a01 * m01, k23 = c23 + a23 * m23;
+                    // one v_pk_fma per key pair; same value as the unfused form: with m = -2 the product is exact, with
+                    // c = 0 the sum is
+                    const f32x2 k01 = __builtin_elementwise_fma(a01, m01, c01), k23 = __builtin_elementwise_fma(a23, m23, c23);
                     if (MODE == GEMM_SAMPLE) {
                         if (u_raw < a.n_units) {  // wave-uniform: waves past the last sampled unit write nothing
                             float4 kv;
