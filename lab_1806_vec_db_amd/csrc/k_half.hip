@@ -68,10 +68,21 @@ void launch_tile_rows_h(const float *X, uint64_t n, uint32_t dim, uint64_t tile0
 // to 11 bits, or a subnormal / zero whose distance to v is representable)
 __device__ __forceinline__ float wave_round_err2(const float *v, uint32_t dim, float scale, float inv_scale, uint32_t lane) {
     float acc = 0.0f;
-    for (uint32_t j = lane; j < dim; j += 64) {
-        float x = v[j];
-        float d = x - float((_Float16)(x * scale)) * inv_scale;
-        acc += d * d;
+    if ((dim & 3) == 0) {  // 16-B loads, four in flight (the order of the sum is free)
+        const float4 *v4 = reinterpret_cast<const float4 *>(v);
+#pragma unroll 4
+        for (uint32_t j = lane; j < dim / 4; j += 64) {
+            const float4 x = v4[j];
+            const float d0 = x.x - float((_Float16)(x.x * scale)) * inv_scale, d1 = x.y - float((_Float16)(x.y * scale)) * inv_scale;
+            const float d2 = x.z - float((_Float16)(x.z * scale)) * inv_scale, d3 = x.w - float((_Float16)(x.w * scale)) * inv_scale;
+            acc += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+    } else {
+        for (uint32_t j = lane; j < dim; j += 64) {
+            float x = v[j];
+            float d = x - float((_Float16)(x * scale)) * inv_scale;
+            acc += d * d;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
@@ -90,9 +101,12 @@ __global__ __launch_bounds__(256) void k_row_split_err(const float *__restrict__
     const float e2 = wave_round_err2(X + row * dim, dim, sx, inv_sx, lane);
     const float xs = xsq[row];
     if (lane == 0 && e2 > 0.0f && e2 < INFINITY && xs > 0.0f && xs < INFINITY) {
-        atomicMax(&out2[0], __float_as_uint(e2));
+        // a million same-address atomics serialise in L2 (22 ms for 1M rows): only rows above the running maximum (a
+        // plain, possibly stale read: the atomic below is what counts) issue one
+        const volatile uint32_t *seen = out2;
+        if (__float_as_uint(e2) > seen[0]) atomicMax(&out2[0], __float_as_uint(e2));
         const float rel = e2 / xs;
-        if (rel < INFINITY) atomicMax(&out2[1], __float_as_uint(rel));
+        if (rel < INFINITY && __float_as_uint(rel) > seen[1]) atomicMax(&out2[1], __float_as_uint(rel));
     }
 }
 void launch_row_split_err(const float *X, const float *xsq, uint64_t row0, uint64_t row1, uint32_t dim, float sx,
