@@ -297,7 +297,6 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
         VDB_HIP(hipMemsetAsync(d_dist, 0, nq * k * sizeof(float), s));
     }
     ws.qsq.reserve(nq * sizeof(float));
-    launch_row_sqnorm(d_q, nq, (uint32_t)dim, ws.qsq.as<float>(), s);
 
     uint32_t kprime = std::max<uint32_t>(32, 2 * ksel);
     const int cosine = dist == 1 ? 1 : 0;
@@ -305,6 +304,7 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
                 (flat_mode == 2 || (flat_mode == 0 && n >= 16384));
     if (flat_mode == 1) mfma = false;
     if (!mfma) {
+        launch_row_sqnorm(d_q, nq, (uint32_t)dim, ws.qsq.as<float>(), s);
         flat_exact_device(ws, d_q, ws.qsq.as<float>(), nq, ksel, k, d_idx, d_dist, d_cnt);
         return;
     }
@@ -326,6 +326,7 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     const bool half = allow_half && gemm && half_valid && flat_half_mode != 1 && kprime_h <= 1024 && n > kprime_h &&
                       (flat_half_mode == 2 || hq < 1024 || hr * 8 <= hq);
     if (half) kprime = kprime_h;
+    if (!half) launch_row_sqnorm(d_q, nq, (uint32_t)dim, ws.qsq.as<float>(), s);  // (the fp16 pass: k_query_prep_h)
     const uint32_t capp = topk_capacity(kprime);
     const uint32_t capk = topk_capacity(ksel);
     const uint64_t gq = gemm_group();
@@ -360,8 +361,8 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
             d_qscale = ws.qaux.as<float>();
             d_qmul = d_qscale + nq_pad;
             d_qerr = d_qmul + nq_pad;
-            launch_query_prep_h(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, ws.qsq.as<float>(), half_sx(), d_qscale, d_qmul,
-                                d_qerr, s);
+            launch_query_prep_h(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, half_sx(), ws.qsq.as<float>(), d_qscale, d_qmul,
+                                d_qerr, d_hits, s);
             launch_pack_queries_h(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, 8, d_qscale, ws.qfrag_g.p, s);
         } else {
             launch_mfma_pack_queries_nh(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, 8, ws.qfrag_g.as<float>(), s);
@@ -386,7 +387,7 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
         VDB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_tau + nq), (int)0xFF800000u, nq_pad - nq, s));
     uint64_t *d_cand = ws.lists.as<uint64_t>();  // the sample lists are dead now
     uint32_t *d_sync = d_hits + nq_pad;
-    VDB_HIP(hipMemsetAsync(d_hits, 0, (nq_pad + sync_words) * sizeof(uint32_t), s));
+    if (!half) VDB_HIP(hipMemsetAsync(d_hits, 0, (nq_pad + sync_words) * sizeof(uint32_t), s));  // (k_query_prep_h zeroes the counters)
     // algorithmic bytes: one corpus pass (N*d*4) serves 32*share queries (bytes/query = N*d*4 / B)
     // (the fp16 pass streams N*d*2 bytes per 128 queries: its own counter, so that GB/s are the bytes really read)
     const uint64_t hbm_passes = gemm ? ngroups : (nbatch + mfma_share() - 1) / mfma_share();
@@ -410,9 +411,9 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     }
     launch_flat_finish(ws.keys_c.as<uint64_t>(), capk, ws.keys_a.as<uint64_t>(), capp, (uint32_t)nq, ksel, (uint32_t)k, kprime,
                        n, ws.qsq.as<float>(), xsq_max, xsq_min_pos, cosine, (uint32_t)dim, se, d_hits, CAND_CAP, id_offset,
-                       ws.flags.as<uint8_t>(), d_idx, d_dist, d_cnt, s);
+                       static_cast<uint8_t *>(ws.pinned(nq)), d_idx, d_dist, d_cnt, s);
+    // the flags go straight to pinned host memory (device-visible): no copy kernel between the last kernel and the sync
     const uint8_t *flags = static_cast<const uint8_t *>(ws.pinned(nq));
-    VDB_HIP(hipMemcpyAsync(ws.pinned(nq), ws.flags.p, nq, hipMemcpyDeviceToHost, s));
     VDB_SYNC(s);
     // uncertified queries: gather them, redo them (fp16 pass: through this function again with the split-bf16
     // operands; split-bf16 pass: 8 per corpus pass with the exact scan), scatter the results

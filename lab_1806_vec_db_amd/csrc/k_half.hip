@@ -116,19 +116,39 @@ void launch_row_split_err(const float *X, const float *xsq, uint64_t row0, uint6
                        sx, 1.0f / sx, out2);
 }
 
-// per query: scale sq = 2^(13 - c) with |q| < 2^c, multiplier qmul = 1 / (sx * sq) that undoes both scales, and the
-// measured rounding error qerr = |q - q~/sq| (an upper bound: the f32 sum is inflated by 2^-10).  Queries whose norm
-// is not a normal number of moderate size get qerr = +inf: they cannot be certified by the fp16 pass and are redone.
-// One wave per query; queries in [nq, nq_pad) are padding (zero images, tau = -inf).
+// per query: |q|^2 in the reference's order (strict f32 fold, distance/mod.rs:72-74 -- what k_row_sqnorm computes for the
+// other paths: one launch less), scale sq = 2^(13 - c) with |q| < 2^c, multiplier qmul = 1 / (sx * sq) that undoes both
+// scales, and the measured rounding error qerr = |q - q~/sq| (an upper bound: the f32 sum is inflated by 2^-10).  Queries
+// whose norm is not a normal number of moderate size get qerr = +inf: they cannot be certified by the fp16 pass and are
+// redone.  One wave per query: the query is parked in LDS with coalesced loads, lane 0 folds it in order.  Queries in
+// [nq, nq_pad) are padding (zero images, tau = -inf).  hits[q] = 0 readies the filter pass's hit counters.
 __global__ __launch_bounds__(256) void k_query_prep_h(const float *__restrict__ Q, uint32_t nq, uint32_t nq_pad, uint32_t dim,
-                                                      const float *__restrict__ qsq, float inv_sx, float *__restrict__ qscale,
-                                                      float *__restrict__ qmul, float *__restrict__ qerr) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                      float inv_sx, float *__restrict__ qsq, float *__restrict__ qscale,
+                                                      float *__restrict__ qmul, float *__restrict__ qerr,
+                                                      uint32_t *__restrict__ hits) {
+    extern __shared__ float qp_smem[];  // [4 waves][dim]
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t q = blockIdx.x * 4 + wave;
     if (q >= nq_pad) return;
     float sc = 1.0f, err = 0.0f;
     if (q < nq) {
-        const float qs = qsq[q];
+        const float *qv = Q + size_t(q) * dim;
+        float *sq = qp_smem + size_t(wave) * dim;
+        for (uint32_t j = lane; j < dim; j += 64) sq[j] = qv[j];
+        float qs = 0.0f;
+        if (lane == 0) {  // same-wave LDS traffic is ordered: no barrier
+            uint32_t j = 0;
+            for (; j + 4 <= dim; j += 4) {
+                const float a = sq[j], b = sq[j + 1], c = sq[j + 2], d = sq[j + 3];
+                qs = qs + a * a;
+                qs = qs + b * b;
+                qs = qs + c * c;
+                qs = qs + d * d;
+            }
+            for (; j < dim; j++) qs = qs + sq[j] * sq[j];
+            qsq[q] = qs;
+        }
+        qs = __shfl(qs, 0);
         if (qs == 0.0f) {
             // zero query: the image is exactly zero
         } else if (qs >= 0x1p-80f && qs <= 0x1p80f) {
@@ -136,7 +156,7 @@ __global__ __launch_bounds__(256) void k_query_prep_h(const float *__restrict__ 
             (void)frexpf(qs, &e);            // qs = m * 2^e, m in [0.5, 1)  =>  |q| < 2^ceil(e/2)
             const int c = (e + 1) >> 1;       // arithmetic shift: ceil(e / 2)
             sc = ldexpf(1.0f, 13 - c);
-            const float e2 = wave_round_err2(Q + size_t(q) * dim, dim, sc, ldexpf(1.0f, c - 13), lane);
+            const float e2 = wave_round_err2(qv, dim, sc, ldexpf(1.0f, c - 13), lane);
             err = sqrtf(e2) * 1.001f;
         } else {
             err = INFINITY;
@@ -146,13 +166,14 @@ __global__ __launch_bounds__(256) void k_query_prep_h(const float *__restrict__ 
         qscale[q] = sc;
         qmul[q] = inv_sx / sc;  // powers of two: exact
         qerr[q] = err;
+        hits[q] = 0;
     }
 }
-void launch_query_prep_h(const float *Q, uint32_t nq, uint32_t nq_pad, uint32_t dim, const float *qsq, float sx, float *qscale,
-                         float *qmul, float *qerr, hipStream_t s) {
+void launch_query_prep_h(const float *Q, uint32_t nq, uint32_t nq_pad, uint32_t dim, float sx, float *qsq, float *qscale,
+                         float *qmul, float *qerr, uint32_t *hits, hipStream_t s) {
     if (nq_pad == 0) return;
-    hipLaunchKernelGGL(k_query_prep_h, dim3((nq_pad + 3) / 4), dim3(256), 0, s, Q, nq, nq_pad, dim, qsq, 1.0f / sx, qscale,
-                       qmul, qerr);
+    hipLaunchKernelGGL(k_query_prep_h, dim3((nq_pad + 3) / 4), dim3(256), size_t(4) * dim * sizeof(float), s, Q, nq, nq_pad, dim,
+                       1.0f / sx, qsq, qscale, qmul, qerr, hits);
 }
 
 // Q [nq][dim] -> per group of 16*NH queries a B-operand image [kb64][half][sub 0|1][lane]: 8 fp16 of query
