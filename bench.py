@@ -256,7 +256,7 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         # queries one corpus pass serves: 128 (k_flat_gemm) when a call carries more than 64 queries, else 2 x 32
         # (k_flat_mfma, XCD-shared passes) -- the rule of Index::flat_knn_device
-        qpp = 128 if nq > 64 else 64
+        qpp = 128 if (nq > 64 or kernel == "flat_half") else 64
         traffic = None  # HBM bytes per launch from the committed PMC passes (same kernel, same shard size only)
         try:
             pmc_name = "pmc_flat_half.json" if kernel == "flat_half" else ("pmc_flat_gemm.json" if qpp == 128 else "pmc_flat_mfma.json")
@@ -302,7 +302,7 @@ def main():
         "roofline": roofline, "recall_at_10": None,
     }
     if wl == "flat":
-        out["config"]["queries_per_corpus_pass"] = 128 if nq > 64 else 64
+        out["config"]["queries_per_corpus_pass"] = 128 if (nq > 64 or (roofline or {}).get("kernel") == "flat_half") else 64
         out["fallback_queries"] = ix.flat_fallback_count()
         out["half_pass"] = {"queries": ix.get_stat("flat_half_queries"), "redone_split_bf16": ix.get_stat("flat_half_redo")}
     else:

@@ -317,14 +317,17 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     const uint64_t bq = mfma_batch((uint32_t)dim);  // queries per workgroup batch (32, or 16 for 1024 < dim <= 2048)
     // more than 64 queries: the filter pass runs as k_flat_gemm, 128 queries per corpus pass (k_gemm.hip); the
     // sample pass keeps the small-batch kernel, so the padded query count is a multiple of both batch sizes
-    const bool gemm = flat_gemm_mode == 2 || (flat_gemm_mode == 0 && nq > 64);
     // first pass with fp16 operands (k_half.hip): half the HBM bytes and a third of the matrix work per row, coarser
     // keys -> a longer shortlist and a wider certification margin; what it cannot certify is redone below with the
-    // split-bf16 operands.  Switched off (auto mode) once more than 1/8 of the queries had to be redone.
+    // split-bf16 operands.  Switched off (auto mode) once more than 1/8 of the queries had to be redone.  When it is
+    // available it also serves small calls (one 128-query group, mostly padding: the pass is HBM-bound and reads half
+    // the bytes of the small-batch kernel's -- 0.36 instead of 0.63 ms per pass at 1M x 960).
     const uint32_t kprime_h = std::max<uint32_t>(64, flat_half_kmul * ksel);
     const uint64_t hq = half_queries.load(), hr = half_redo.load();
-    const bool half = allow_half && gemm && half_valid && flat_half_mode != 1 && kprime_h <= 1024 && n > kprime_h &&
-                      (flat_half_mode == 2 || hq < 1024 || hr * 8 <= hq);
+    const bool half_ok = allow_half && half_valid && flat_half_mode != 1 && kprime_h <= 1024 && n > kprime_h &&
+                         (flat_half_mode == 2 || hq < 1024 || hr * 8 <= hq);
+    const bool gemm = flat_gemm_mode == 2 || (flat_gemm_mode == 0 && (nq > 64 || half_ok));
+    const bool half = half_ok && gemm;
     if (half) kprime = kprime_h;
     if (!half) launch_row_sqnorm(d_q, nq, (uint32_t)dim, ws.qsq.as<float>(), s);  // (the fp16 pass: k_query_prep_h)
     const uint32_t capp = topk_capacity(kprime);
