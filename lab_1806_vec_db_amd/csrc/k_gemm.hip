@@ -20,6 +20,8 @@
 //
 // HBM traffic: one corpus pass (N x d x 4 B) per 128 queries.  The keys are approximate ranking keys exactly as in
 // k_flat_mfma; exactness comes from k_rerank + k_certify downstream (index.hip).
+#include <type_traits>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -284,6 +286,10 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
                 }
                 const f32x2 c01 = {cv[0], cv[1]}, c23 = {cv[2], cv[3]}, m01 = {mv[0], mv[1]}, m23 = {mv[2], mv[3]};
                 const uint32_t rb32 = uint32_t(row0) + t * 16 + 4 * g4;  // rows < 2^32 (gemm_args)
+                // two instantiations of the pair loop (the metric is launch-uniform): L2Sqr needs one packed fma per key pair
+                // (m = -2 qm per query), Cosine two packed multiplies
+                auto tile_pairs = [&](auto cos_tag) {
+                constexpr bool COS = decltype(cos_tag)::value;
                 // the stage holds GEMM_STAGE lane records; when the next pair's passing lanes do not fit, the loop over the
                 // halves stops there, the stage is drained and the loop resumes at that pair (hub rows -- small norms under
                 // L2Sqr -- pass for most queries of a group at once)
@@ -308,13 +314,20 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
                         if (PREC == GEMM_F16) qm_n = qm_s[hn * 16 + r];
                     }
                     f32x2 a01 = {acc[t][h][0], acc[t][h][1]}, a23 = {acc[t][h][2], acc[t][h][3]};
-                    if (PREC == GEMM_F16) {  // undo the power-of-two scales of the fp16 images: exact
-                        a01 *= qm;
-                        a23 *= qm;
+                    f32x2 k01, k23;
+                    if constexpr (COS) {  // -(S qm) / |x|: the power-of-two scale is exact, one rounding
+                        if (PREC == GEMM_F16) {
+                            a01 *= qm;
+                            a23 *= qm;
+                        }
+                        k01 = a01 * m01;
+                        k23 = a23 * m23;
+                    } else {  // |x|^2 - 2 qm S as one fma: the product with the power of two is exact, one rounding
+                        const float mq = PREC == GEMM_F16 ? -2.0f * qm : -2.0f;
+                        const f32x2 mq2 = {mq, mq};
+                        k01 = __builtin_elementwise_fma(a01, mq2, c01);
+                        k23 = __builtin_elementwise_fma(a23, mq2, c23);
                     }
-                    // one v_pk_fma per key pair; same value as the unfused form: with m = -2 the product is exact, with
-                    // c = 0 the sum is
-                    const f32x2 k01 = __builtin_elementwise_fma(a01, m01, c01), k23 = __builtin_elementwise_fma(a23, m23, c23);
                     if (MODE == GEMM_SAMPLE) {
                         if (u_raw < a.n_units) {  // wave-uniform: waves past the last sampled unit write nothing
                             float4 kv;
@@ -381,6 +394,11 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
                 if (MODE != GEMM_FILTER || h_stop == NH) break;
                 h_from = h_stop;
                 }
+                };
+                if (a.cosine)
+                    tile_pairs(std::true_type{});
+                else
+                    tile_pairs(std::false_type{});
             }
         }
         // ---- group end: hand the parked hits to the per-query candidate lists (one global atomic per query) ----
