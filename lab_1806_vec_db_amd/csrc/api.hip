@@ -312,6 +312,8 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         gemm_set_tw((int)value);
     else if (n == "flat_gemm_debug")
         idx->ix.flat_gemm_debug = (int)value;
+    else if (n == "flat_tail")  // exact stage of the Flat pipeline: 0 fused launch when the shortlist fits 64 rows, 1 separate kernels
+        idx->ix.flat_tail_mode = (int)value;
     else if (n == "flat_half")  // fp16 first pass of large query batches: 0 auto, 1 off, 2 on regardless of the redo rate
         idx->ix.flat_half_mode = (int)value;
     else if (n == "flat_half_kmul") {  // its shortlist: max(64, kmul * k) rows per query

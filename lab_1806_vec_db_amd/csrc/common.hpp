@@ -65,4 +65,64 @@ __host__ __device__ inline uint64_t pair_key(float d, uint32_t idx) {
 }
 constexpr uint64_t PAIR_NONE = ~0ull;  // sorts after every real pair
 
+
+#if defined(__HIPCC__)
+// ---- 64-key bitonic networks across the lanes of a wave (shuffles, no LDS) ----------------------------------------
+__device__ __forceinline__ uint64_t cmpx64(uint64_t v, uint32_t lane, uint32_t j, bool up) {
+    const uint64_t o = __shfl_xor(v, j);
+    const bool take_min = ((lane & j) == 0) == up;
+    return ((v < o) == take_min) ? v : o;
+}
+// ascending sort of one key per lane (21 compare-exchange stages)
+__device__ __forceinline__ uint64_t sort64(uint64_t r, uint32_t lane) {
+#pragma unroll
+    for (uint32_t k = 2; k <= 64; k <<= 1)
+#pragma unroll
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) r = cmpx64(r, lane, j, (lane & k) == 0);
+    return r;
+}
+// a, b ascending across the lanes -> the 64 smallest of both, ascending
+__device__ __forceinline__ uint64_t merge64(uint64_t a, uint64_t b, uint32_t lane) {
+    const uint64_t rev = __shfl(b, 63 - lane);
+    uint64_t m = a < rev ? a : rev;
+#pragma unroll
+    for (uint32_t j = 32; j > 0; j >>= 1) m = cmpx64(m, lane, j, true);
+    return m;
+}
+// The 64 smallest of `total` keys at src, ascending across the lanes of wave 0 (other waves: unspecified).  Block of
+// 256 threads; a wave takes every fourth batch of 4 x 64 keys, sorts the four runs (interleaved, so that the shuffle
+// latencies overlap), merges them pairwise and into its running best-64; the four lists meet in LDS.  A batch without
+// a key below the wave's current 64th smallest is skipped.  Contains one __syncthreads().
+__device__ __forceinline__ uint64_t block_top64(const uint64_t *__restrict__ src, uint32_t total, uint64_t (*sbest)[64]) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t batches = (total + 255) / 256;
+    uint64_t best = PAIR_NONE;
+    for (uint32_t bt = wave; bt < batches; bt += 4) {
+        uint64_t r[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = (bt * 4 + u) * 64 + lane;
+            r[u] = i < total ? src[i] : PAIR_NONE;
+        }
+        const uint64_t tau = __shfl(best, 63);
+        uint64_t lo = r[0] < r[1] ? r[0] : r[1], lo2 = r[2] < r[3] ? r[2] : r[3];
+        lo = lo < lo2 ? lo : lo2;
+        if (__ballot(lo < tau) == 0) continue;  // wave-uniform
+#pragma unroll
+        for (uint32_t k = 2; k <= 64; k <<= 1)
+#pragma unroll
+            for (uint32_t j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+                for (int u = 0; u < 4; u++) r[u] = cmpx64(r[u], lane, j, (lane & k) == 0);
+        const uint64_t a = merge64(r[0], r[1], lane), b = merge64(r[2], r[3], lane);
+        best = merge64(best, merge64(a, b, lane), lane);
+    }
+    sbest[wave][lane] = best;
+    __syncthreads();
+    if (wave != 0) return PAIR_NONE;
+    const uint64_t a = merge64(sbest[0][lane], sbest[1][lane], lane), b = merge64(sbest[2][lane], sbest[3][lane], lane);
+    return merge64(a, b, lane);
+}
+#endif
+
 }  // namespace vdb

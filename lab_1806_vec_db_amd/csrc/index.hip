@@ -402,19 +402,46 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
         launch_flat_mfma_filter(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>(), (uint32_t)nbatch,
                                 d_sq.as<float>(), cosine, d_tau, d_cand, d_hits, CAND_CAP, d_sync, num_cu, s);
     prof_end(ws);
-    launch_topk_merge_counted(d_cand, CAND_CAP, d_hits, (uint32_t)nq, kprime, ws.keys_a.as<uint64_t>(), s);
-    launch_rerank(d_rows.as<float>(), (uint32_t)dim, d_q, (uint32_t)nq, cosine ? MET_COSINE : MET_L2_DIRECT, d_sq.as<float>(),
-                  ws.qsq.as<float>(), ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), kprime, capp, s);  // pads its rows
-    launch_topk_merge(ws.keys_b.as<uint64_t>(), 1, capp, (uint32_t)nq, ksel, ws.keys_c.as<uint64_t>(), s);
     SplitErr se;
     if (half) {
         se.qerr = d_qerr;
         se.dx_abs = half_dx_abs;
         se.dx_rel = half_dx_rel;
     }
-    launch_flat_finish(ws.keys_c.as<uint64_t>(), capk, ws.keys_a.as<uint64_t>(), capp, (uint32_t)nq, ksel, (uint32_t)k, kprime,
-                       n, ws.qsq.as<float>(), xsq_max, xsq_min_pos, cosine, (uint32_t)dim, se, d_hits, CAND_CAP, id_offset,
-                       static_cast<uint8_t *>(ws.pinned(nq)), d_idx, d_dist, d_cnt, s);
+    if (flat_tail_mode != 1 && flat_tail64_supported((uint32_t)dim, kprime, ksel)) {
+        FlatTailArgs t{};
+        t.cand = d_cand;
+        t.cap = CAND_CAP;
+        t.cnt = d_hits;
+        t.kprime = kprime;
+        t.ksel = ksel;
+        t.kstride = (uint32_t)k;
+        t.X = d_rows.as<float>();
+        t.dim = (uint32_t)dim;
+        t.Q = d_q;
+        t.metric = cosine ? MET_COSINE : MET_L2_DIRECT;
+        t.xsq = d_sq.as<float>();
+        t.qsq = ws.qsq.as<float>();
+        t.n_rows = n;
+        t.xsq_max = xsq_max;
+        t.xsq_min_pos = xsq_min_pos;
+        t.cosine = cosine;
+        t.se = se;
+        t.id_offset = id_offset;
+        t.flags = static_cast<uint8_t *>(ws.pinned(nq));
+        t.out_idx = d_idx;
+        t.out_dist = d_dist;
+        t.out_count = d_cnt;
+        launch_flat_tail64(t, (uint32_t)nq, s);
+    } else {
+        launch_topk_merge_counted(d_cand, CAND_CAP, d_hits, (uint32_t)nq, kprime, ws.keys_a.as<uint64_t>(), s);
+        launch_rerank(d_rows.as<float>(), (uint32_t)dim, d_q, (uint32_t)nq, cosine ? MET_COSINE : MET_L2_DIRECT, d_sq.as<float>(),
+                      ws.qsq.as<float>(), ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), kprime, capp, s);  // pads its rows
+        launch_topk_merge(ws.keys_b.as<uint64_t>(), 1, capp, (uint32_t)nq, ksel, ws.keys_c.as<uint64_t>(), s);
+        launch_flat_finish(ws.keys_c.as<uint64_t>(), capk, ws.keys_a.as<uint64_t>(), capp, (uint32_t)nq, ksel, (uint32_t)k, kprime,
+                           n, ws.qsq.as<float>(), xsq_max, xsq_min_pos, cosine, (uint32_t)dim, se, d_hits, CAND_CAP, id_offset,
+                           static_cast<uint8_t *>(ws.pinned(nq)), d_idx, d_dist, d_cnt, s);
+    }
     // the flags go straight to pinned host memory (device-visible): no copy kernel between the last kernel and the sync
     const uint8_t *flags = static_cast<const uint8_t *>(ws.pinned(nq));
     VDB_SYNC(s);

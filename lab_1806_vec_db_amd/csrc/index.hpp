@@ -163,6 +163,7 @@ struct Index {
     int flat_mode = 0;
     int flat_gemm_mode = 0;   // 0 auto (more than 64 queries per call), 1 off, 2 forced (k_gemm.hip)
     int flat_gemm_debug = 0;
+    int flat_tail_mode = 0;  // 0 auto (fused exact stage when k' <= 64), 1 separate kernels
     std::atomic<uint64_t> fallback_count{0};
     PQState pq;
     HNSWState hnsw;

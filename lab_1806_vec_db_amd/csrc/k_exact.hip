@@ -514,23 +514,13 @@ void launch_flag_overflow(const uint32_t *cnt, uint32_t cap, uint32_t min_hits, 
     hipLaunchKernelGGL(k_flag_overflow, dim3((nq + 63) / 64), dim3(64), 0, s, cnt, cap, min_hits, nq, flags);
 }
 
-// certification + overflow check + output formatting of the Flat MFMA pipeline in one launch (one block per query):
-// k_certify's test, k_flag_overflow's test and k_finalize's writes (three 5-us launches per step otherwise)
-__global__ __launch_bounds__(64) void k_flat_finish(const uint64_t *__restrict__ exact_sorted, uint32_t lde,
-                                                    const uint64_t *__restrict__ approx_sorted, uint32_t lda,
-                                                    uint32_t ksel, uint32_t kstride, uint32_t kprime, uint64_t n_rows,
-                                                    const float *__restrict__ qsq, float xsq_max, float xsq_min_pos,
-                                                    int cosine, uint32_t dim, SplitErr se, const uint32_t *__restrict__ cnt,
-                                                    uint32_t cap, uint64_t id_offset, uint8_t *__restrict__ flags,
-                                                    uint64_t *__restrict__ out_idx, float *__restrict__ out_dist,
-                                                    uint64_t *__restrict__ out_count) {
-    const uint32_t q = blockIdx.x;
-    if (threadIdx.x == 0) {
-        uint8_t flag = 0;
-        if (n_rows > kprime) {
-            uint32_t kk = ksel < kprime ? ksel : kprime;
-            uint64_t ek = exact_sorted[uint64_t(q) * lde + (kk - 1)];
-            uint64_t ak = approx_sorted[uint64_t(q) * lda + (kprime - 1)];
+// the certification rule (see the comment above k_certify): ek = the kk-th smallest exact pair of the shortlist, ak = the
+// k'-th smallest approximate pair; returns 1 when the exact top-k might not be contained in the shortlist
+__device__ __forceinline__ uint8_t flat_certify_flag(uint64_t ek, uint64_t ak, uint32_t q, uint32_t kprime, uint64_t n_rows,
+                                                     const float *__restrict__ qsq, float xsq_max, float xsq_min_pos, int cosine,
+                                                     uint32_t dim, const SplitErr &se, uint32_t cnt_q, uint32_t cap) {
+    uint8_t flag = 0;
+    if (n_rows > kprime) {
             if (ek == PAIR_NONE || ak == PAIR_NONE) {
                 flag = 1;  // fewer than k' hits (thinned sample) or an emptied overflow list
             } else {
@@ -561,8 +551,26 @@ __global__ __launch_bounds__(64) void k_flat_finish(const uint64_t *__restrict__
                 flag = ok ? 0 : 1;
             }
         }
-        if (cnt[q] > cap || cnt[q] < (n_rows > kprime ? kprime : 0)) flag = 1;
-        flags[q] = flag;
+    if (cnt_q > cap || cnt_q < (n_rows > kprime ? kprime : 0)) flag = 1;
+    return flag;
+}
+
+// certification + overflow check + output formatting of the Flat MFMA pipeline in one launch (one block per query):
+// k_certify's test, k_flag_overflow's test and k_finalize's writes (three 5-us launches per step otherwise)
+__global__ __launch_bounds__(64) void k_flat_finish(const uint64_t *__restrict__ exact_sorted, uint32_t lde,
+                                                    const uint64_t *__restrict__ approx_sorted, uint32_t lda,
+                                                    uint32_t ksel, uint32_t kstride, uint32_t kprime, uint64_t n_rows,
+                                                    const float *__restrict__ qsq, float xsq_max, float xsq_min_pos,
+                                                    int cosine, uint32_t dim, SplitErr se, const uint32_t *__restrict__ cnt,
+                                                    uint32_t cap, uint64_t id_offset, uint8_t *__restrict__ flags,
+                                                    uint64_t *__restrict__ out_idx, float *__restrict__ out_dist,
+                                                    uint64_t *__restrict__ out_count) {
+    const uint32_t q = blockIdx.x;
+    if (threadIdx.x == 0) {
+        uint32_t kk = ksel < kprime ? ksel : kprime;
+        uint64_t ek = exact_sorted[uint64_t(q) * lde + (kk - 1)];
+        uint64_t ak = approx_sorted[uint64_t(q) * lda + (kprime - 1)];
+        flags[q] = flat_certify_flag(ek, ak, q, kprime, n_rows, qsq, xsq_max, xsq_min_pos, cosine, dim, se, cnt[q], cap);
     }
     uint32_t c = 0;
     for (uint32_t j = threadIdx.x; j < ksel; j += blockDim.x) {
@@ -585,6 +593,105 @@ void launch_flat_finish(const uint64_t *exact_sorted, uint32_t lde, const uint64
     hipLaunchKernelGGL(k_flat_finish, dim3(nq), dim3(64), 0, s, exact_sorted, lde, approx_sorted, lda, ksel, kstride,
                        kprime, n_rows, qsq, xsq_max, xsq_min_pos, cosine, dim, se, cnt, cap, id_offset, flags, out_idx,
                        out_dist, out_count);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The whole exact stage of the Flat pipeline in ONE launch (shortlists of at most 64 rows, dim % 4 == 0): per query a
+// workgroup (i) selects the k' smallest approximate pairs of the query's hit list (block_top64, 4 waves), then wave 0
+// (ii) re-ranks them in reference order (the coalesced scheme of k_rerank_t), (iii) sorts the exact pairs across its
+// lanes and writes the first ksel, (iv) certifies (flat_certify_flag).  Replaces k_top64_counted + k_rerank_t +
+// k_topk_merge + k_flat_finish: 4 launches and 3 round trips through HBM scratch per step (~110 -> ~60 us per 1000
+// queries; at a 125k-row shard the step is 0.5 ms, so this is what is left to trim there).
+// ---------------------------------------------------------------------------------------------
+template <int FOLD>
+__global__ __launch_bounds__(256) void k_flat_tail64(FlatTailArgs a) {
+    extern __shared__ float4 ft_smem[];  // [dim/4] query, then [64 rows][9] float4 (8 used)
+    __shared__ uint64_t sbest[4][64];
+    const uint32_t q = blockIdx.x, lane = threadIdx.x & 63;
+    const uint32_t d4 = a.dim / 4;
+    float4 *qs4 = ft_smem, *tile = ft_smem + d4;
+    for (uint32_t i = threadIdx.x; i < d4; i += 256) qs4[i] = reinterpret_cast<const float4 *>(a.Q + uint64_t(q) * a.dim)[i];
+    const uint32_t cnt_q = a.cnt[q];
+    const uint32_t total = cnt_q <= a.cap ? cnt_q : 0;  // cnt > cap: slots are not all written, the query is redone
+    const uint64_t best = block_top64(a.cand + uint64_t(q) * a.cap, total, sbest);  // (its barrier also covers qs4)
+    if (threadIdx.x >= 64) return;
+    const uint64_t ak = __shfl(best, a.kprime - 1);
+    const uint64_t c = lane < a.kprime ? best : PAIR_NONE;
+    const bool live = c != PAIR_NONE;
+    const uint32_t idx = live ? uint32_t(c) : 0u;
+    const float4 *rp[8];
+    bool rl[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t ri = __shfl(idx, 8 * i + (lane >> 3));
+        rl[i] = __shfl(live ? 1 : 0, 8 * i + (lane >> 3)) != 0;
+        rp[i] = reinterpret_cast<const float4 *>(a.X + uint64_t(ri) * a.dim) + (lane & 7);
+    }
+    const uint32_t nch = (d4 + 7) / 8;
+    float4 stg[8];
+    auto fetch = [&](uint32_t ch) {
+        const bool inside = ch * 8 + (lane & 7) < d4;
+#pragma unroll
+        for (int i = 0; i < 8; i++) stg[i] = (inside && rl[i]) ? rp[i][ch * 8] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    fetch(0);
+    float acc = 0.0f;
+    for (uint32_t ch = 0; ch < nch; ch++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) tile[(8 * i + (lane >> 3)) * 9 + (lane & 7)] = stg[i];
+        if (ch + 1 < nch) fetch(ch + 1);
+        const uint32_t np = d4 - ch * 8 < 8 ? d4 - ch * 8 : 8;  // uniform
+        if (np == 8) {
+#pragma unroll
+            for (int p = 0; p < 8; p++) {
+                const float4 x = tile[lane * 9 + p], w = qs4[ch * 8 + p];
+                acc = fold1<FOLD>(acc, x.x, w.x);
+                acc = fold1<FOLD>(acc, x.y, w.y);
+                acc = fold1<FOLD>(acc, x.z, w.z);
+                acc = fold1<FOLD>(acc, x.w, w.w);
+            }
+        } else {
+            for (uint32_t p = 0; p < np; p++) {
+                const float4 x = tile[lane * 9 + p], w = qs4[ch * 8 + p];
+                acc = fold1<FOLD>(acc, x.x, w.x);
+                acc = fold1<FOLD>(acc, x.y, w.y);
+                acc = fold1<FOLD>(acc, x.z, w.z);
+                acc = fold1<FOLD>(acc, x.w, w.w);
+            }
+        }
+    }
+    uint64_t r = PAIR_NONE;
+    if (live) {
+        const float xs = (a.metric == MET_L2_DIRECT) ? 0.0f : a.xsq[idx];
+        const float qs = (a.metric == MET_L2_DIRECT) ? 0.0f : a.qsq[q];
+        r = pair_key(epilogue(a.metric, acc, xs, qs), idx);
+    }
+    const uint64_t sorted = sort64(r, lane);  // (distance, index) order, PAIR_NONE last
+    const uint32_t kk = a.ksel < a.kprime ? a.ksel : a.kprime;
+    const uint64_t ek = __shfl(sorted, kk - 1);
+    const bool ok = lane < a.ksel && sorted != PAIR_NONE;
+    if (lane < a.ksel) {
+        a.out_idx[uint64_t(q) * a.kstride + lane] = ok ? uint64_t(uint32_t(sorted)) + a.id_offset : 0;
+        a.out_dist[uint64_t(q) * a.kstride + lane] = ok ? f32_from_orderable(uint32_t(sorted >> 32)) : 0.0f;
+    }
+    const uint32_t count = __builtin_popcountll(__ballot(ok));
+    if (lane == 0) {
+        if (a.out_count) a.out_count[q] = count;
+        a.flags[q] = flat_certify_flag(ek, ak, q, a.kprime, a.n_rows, a.qsq, a.xsq_max, a.xsq_min_pos, a.cosine, a.dim, a.se, cnt_q, a.cap);
+    }
+}
+bool flat_tail64_supported(uint32_t dim, uint32_t kprime, uint32_t ksel) {
+    return (dim & 3) == 0 && dim >= 64 && dim <= 8192 && kprime >= 1 && kprime <= 64 && ksel >= 1 && ksel <= 64;
+}
+void launch_flat_tail64(const FlatTailArgs &a, uint32_t nq, hipStream_t s) {
+    if (nq == 0) return;
+    VDB_REQUIRE(flat_tail64_supported(a.dim, a.kprime, a.ksel), "flat_tail64: unsupported shape");
+    const size_t lds = (size_t(a.dim / 4) + 64 * 9) * sizeof(float4);
+    if (a.metric == MET_L2_DIRECT)
+        hipLaunchKernelGGL((k_flat_tail64<FOLD_L2>), dim3(nq), dim3(256), lds, s, a);
+    else
+        hipLaunchKernelGGL((k_flat_tail64<FOLD_DOT>), dim3(nq), dim3(256), lds, s, a);
+    VDB_HIP(hipGetLastError());
 }
 
 void launch_certify(const uint64_t *exact_sorted, uint32_t lde, const uint64_t *approx_sorted, uint32_t lda,

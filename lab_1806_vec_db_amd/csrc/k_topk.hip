@@ -425,54 +425,13 @@ void launch_topk_dense(const float *keys, uint64_t ld, uint64_t n, uint32_t nq, 
 // against the reversed partner = the 64 smallest of the 128 as a bitonic sequence, 6 more stages) and into its
 // running best-64; the four best lists meet in LDS and wave 0 merges them.  A batch without a key below the wave's
 // current 64th smallest is skipped.
-__device__ __forceinline__ uint64_t cmpx64(uint64_t v, uint32_t lane, uint32_t j, bool up) {
-    const uint64_t o = __shfl_xor(v, j);
-    const bool take_min = ((lane & j) == 0) == up;
-    return ((v < o) == take_min) ? v : o;
-}
-// a, b ascending across the lanes -> the 64 smallest of both, ascending
-__device__ __forceinline__ uint64_t merge64(uint64_t a, uint64_t b, uint32_t lane) {
-    const uint64_t rev = __shfl(b, 63 - lane);
-    uint64_t m = a < rev ? a : rev;
-#pragma unroll
-    for (uint32_t j = 32; j > 0; j >>= 1) m = cmpx64(m, lane, j, true);
-    return m;
-}
 __global__ __launch_bounds__(256) void k_top64_counted(const uint64_t *__restrict__ lists, uint32_t cap,
                                                        const uint32_t *__restrict__ cnt, uint64_t *__restrict__ out) {
     __shared__ uint64_t sbest[4][64];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t q = blockIdx.x;
-    const uint64_t *src = lists + uint64_t(q) * cap;
     const uint32_t total = cnt[q] <= cap ? cnt[q] : 0;  // cnt > cap: see k_topk_merge_counted
-    const uint32_t batches = (total + 255) / 256;
-    uint64_t best = PAIR_NONE;  // ascending across the lanes
-    for (uint32_t bt = wave; bt < batches; bt += 4) {
-        uint64_t r[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t i = (bt * 4 + u) * 64 + lane;
-            r[u] = i < total ? src[i] : PAIR_NONE;
-        }
-        const uint64_t tau = __shfl(best, 63);
-        uint64_t lo = r[0] < r[1] ? r[0] : r[1], lo2 = r[2] < r[3] ? r[2] : r[3];
-        lo = lo < lo2 ? lo : lo2;
-        if (__ballot(lo < tau) == 0) continue;  // wave-uniform
-#pragma unroll
-        for (uint32_t k = 2; k <= 64; k <<= 1)
-#pragma unroll
-            for (uint32_t j = k >> 1; j > 0; j >>= 1)
-#pragma unroll
-                for (int u = 0; u < 4; u++) r[u] = cmpx64(r[u], lane, j, (lane & k) == 0);
-        const uint64_t a = merge64(r[0], r[1], lane), b = merge64(r[2], r[3], lane);
-        best = merge64(best, merge64(a, b, lane), lane);
-    }
-    sbest[wave][lane] = best;
-    __syncthreads();
-    if (wave == 0) {
-        const uint64_t a = merge64(sbest[0][lane], sbest[1][lane], lane), b = merge64(sbest[2][lane], sbest[3][lane], lane);
-        out[uint64_t(q) * 64 + lane] = merge64(a, b, lane);
-    }
+    const uint64_t best = block_top64(lists + uint64_t(q) * cap, total, sbest);
+    if (threadIdx.x < 64) out[uint64_t(q) * 64 + threadIdx.x] = best;
 }
 
 void launch_topk_merge_counted(const uint64_t *lists, uint32_t cap_in, const uint32_t *cnt, uint32_t nq, uint32_t k,

@@ -41,6 +41,30 @@ void launch_flat_finish(const uint64_t *exact_sorted, uint32_t lde, const uint64
                         float xsq_max, float xsq_min_pos, int cosine, uint32_t dim, SplitErr se, const uint32_t *cnt, uint32_t cap,
                         uint64_t id_offset, uint8_t *flags, uint64_t *out_idx, float *out_dist, uint64_t *out_count,
                         hipStream_t s);
+// the exact stage of the Flat pipeline fused into one launch (k' <= 64, k <= 64, dim % 4 == 0): counted select of the hit
+// list + re-rank + sort + certification + outputs (k_exact.hip)
+struct FlatTailArgs {
+    const uint64_t *cand;  // [nq][cap] hit lists of the filter pass
+    uint32_t cap;
+    const uint32_t *cnt;   // [nq]
+    uint32_t kprime, ksel, kstride;
+    const float *X;        // row-major rows
+    uint32_t dim;
+    const float *Q;
+    int metric;            // MET_L2_DIRECT or MET_COSINE
+    const float *xsq, *qsq;
+    uint64_t n_rows;
+    float xsq_max, xsq_min_pos;
+    int cosine;
+    SplitErr se;
+    uint64_t id_offset;
+    uint8_t *flags;
+    uint64_t *out_idx;
+    float *out_dist;
+    uint64_t *out_count;
+};
+bool flat_tail64_supported(uint32_t dim, uint32_t kprime, uint32_t ksel);
+void launch_flat_tail64(const FlatTailArgs &a, uint32_t nq, hipStream_t s);
 void launch_certify(const uint64_t *exact_sorted, uint32_t lde, const uint64_t *approx_sorted, uint32_t lda,
                     uint32_t nq, uint32_t k, uint32_t kprime, uint64_t n_rows, const float *qsq, float xsq_max,
                     float xsq_min_pos, int cosine, uint32_t dim, uint8_t *flags, hipStream_t s);
