@@ -310,14 +310,13 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     }
 
     // --- MFMA shortlist -> exact re-rank -> certification --------------------------------------
-    // phase 1: keys of a strided row sample for every query -> tau[q] = k'-th smallest sampled key, an
-    //          upper bound of the k'-th smallest key over all rows (the sample is a subset of the rows)
-    // phase 2: one corpus pass per 32 queries that appends only the keys <= tau[q] (expected ~k'*step hits)
-    // phase 3: shortlist = k' smallest appended pairs per query
+    // phase 1: keys of a strided row sample for every query -> tau[q] = r-th smallest sampled key, an upper bound of
+    //          the r-th smallest key over all rows (the sample is a subset of the rows; mfma_sample_plan picks r)
+    // phase 2: one corpus pass per 128 queries (k_flat_gemm; calls of at most 64 queries without an fp16 mirror: per
+    //          2 x 32 queries, k_flat_mfma) that parks only the keys <= tau[q] (expected ~r * step ~ 1000 hits)
+    // phase 3: shortlist = k' smallest parked pairs per query -> exact re-rank -> top-k -> certification
     const uint64_t bq = mfma_batch((uint32_t)dim);  // queries per workgroup batch (32, or 16 for 1024 < dim <= 2048)
-    // more than 64 queries: the filter pass runs as k_flat_gemm, 128 queries per corpus pass (k_gemm.hip); the
-    // sample pass keeps the small-batch kernel, so the padded query count is a multiple of both batch sizes
-    // first pass with fp16 operands (k_half.hip): half the HBM bytes and a third of the matrix work per row, coarser
+    // First pass with fp16 operands (k_half.hip): half the HBM bytes and a third of the matrix work per row, coarser
     // keys -> a longer shortlist and a wider certification margin; what it cannot certify is redone below with the
     // split-bf16 operands.  Switched off (auto mode) once more than 1/8 of the queries had to be redone.  When it is
     // available it also serves small calls (one 128-query group, mostly padding: the pass is HBM-bound and reads half
@@ -351,7 +350,6 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     ws.keys_c.reserve(nq_pad * capk * sizeof(uint64_t));  // exact top-k, sorted
     const size_t sync_words = mfma_sync_words((uint32_t)nbatch, num_cu);
     ws.misc.reserve(nq_pad * (sizeof(float) + sizeof(uint32_t)) + sync_words * sizeof(uint32_t));  // tau | hit counters | rendezvous
-    ws.flags.reserve(nq_pad);
     float *d_tau = ws.misc.as<float>();
     uint32_t *d_hits = reinterpret_cast<uint32_t *>(d_tau + nq_pad);
     if (!gemm) launch_mfma_pack_queries(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, ws.qfrag.as<float>(), s);
