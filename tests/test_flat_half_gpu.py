@@ -160,3 +160,37 @@ def test_half_pass_odd_queries(mods):
         idx, d, cnt = ix.flat_knn(qs, 10)
         assert ix.get_stat("flat_half_queries") == 90
         _check_all(idx, d, cnt, *O.flat_knn_batch(base, qs, 10, kind, nthreads=8))
+
+
+def test_fused_exact_stage_equals_separate_kernels(mods):
+    """k_flat_tail64 (counted select + re-rank + sort + certification in one launch, shortlists of up to 64 rows) against the
+    four separate kernels, through both first passes and for Cosine's norm epilogue; ragged k, small calls."""
+    vdb, O = mods
+    base, qs = gist_like(30000, seed=51), gist_like(150, seed=52)
+    base[29999] = base[5]
+    for dist, kind in (("l2sqr", 0), ("cosine", 1)):
+        ix = vdb.GpuIndex(960, dist)
+        ix.batch_add(base)
+        ix.set_flat_mode(2)
+        for half in (0, 1):
+            ix.set_param("flat_half", half)
+            for nq, k in ((150, 10), (150, 16), (7, 3), (70, 1)):
+                ix.set_param("flat_tail", 0)
+                i0, d0, c0 = ix.flat_knn(qs[:nq], k)
+                ix.set_param("flat_tail", 1)
+                i1, d1, c1 = ix.flat_knn(qs[:nq], k)
+                np.testing.assert_array_equal(i0, i1)
+                np.testing.assert_array_equal(d0, d1)
+                np.testing.assert_array_equal(c0, c1)
+                if (nq, k) == (150, 10):
+                    _check_all(i0, d0, c0, *O.flat_knn_batch(base, qs[:nq], k, kind, nthreads=8))
+        assert ix.flat_fallback_count() == 0
+
+
+def test_stat_names(mods):
+    vdb, _ = mods
+    ix = vdb.GpuIndex(128, "l2sqr")
+    for name in ("flat_fallback", "flat_half_queries", "flat_half_redo", "flat_half_valid"):
+        assert ix.get_stat(name) == 0
+    with pytest.raises(vdb.VdbError):
+        ix.get_stat("no_such_counter")
