@@ -38,6 +38,8 @@ constexpr uint32_t GEMM_WGBUF = 3072;       // LDS hit buffer entries per workgr
 constexpr uint32_t GEMM_STAGE = 64;         // per wave and unit: lanes whose (tile, half) key quartet passed the threshold
 static int g_gemm_tw = 3;
 void gemm_set_tw(int v) { g_gemm_tw = v == 2 ? 2 : 3; }
+static int g_gemm_stagger = 1;
+void gemm_set_stagger(int v) { g_gemm_stagger = v; }
 uint32_t gemm_group() { return GEMM_BQ; }
 
 struct GemmArgs {
@@ -56,6 +58,7 @@ struct GemmArgs {
     uint32_t cap;
     int cosine;
     uint32_t debug;
+    uint32_t stagger;  // GEMM_FILTER: one unit step in 10-ns ticks (0: start all workgroups together), see the kernel
 };
 
 enum { GEMM_FILTER = 0, GEMM_SAMPLE = 1 };
@@ -126,6 +129,14 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
         if (u >= a.n_units) u = a.n_units - 1;  // idle waves re-read the last unit (L2 hits, results masked)
         return reinterpret_cast<const char *>(a.XT) + uint64_t(u) * a.unit_step * TW * KB * 2048;
     };
+    // Every workgroup does the same work at the same rate, so without help all 256 CUs reach their unit epilogues -- where a
+    // workgroup issues no loads for ~2.5 us -- at the same moments and HBM idles chip-wide once per unit step.  A one-off
+    // start delay of 0..15/16 of a unit step, different for neighbouring workgroups, spreads those gaps over the period.
+    if (MODE == GEMM_FILTER && a.stagger) {
+        const uint64_t t0 = wall_clock64();
+        const uint64_t wait = (uint64_t((blockIdx.x * 7u) & 15u) * a.stagger) >> 4;
+        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
     uint32_t slot_cur = blockIdx.x, slot_nxt = adv(slot_cur);  // of the current and of the next query group
     const char *cp_cur = unit_ptr(unit_of(slot_cur, 0)),
                *cp_nxt = unit_ptr(1 < steps_of(slot_cur) ? unit_of(slot_cur, 1) : unit_of(slot_nxt, 0));
@@ -265,11 +276,17 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
             // form, the same in the sample and the filter instantiation); one v_min3 + v_min per (tile, half); the
             // thresholds / scale factors of the next half are read from LDS while this one is tested.  A lane whose
             // smallest key passes only STAGES its four keys (one ds_write_b128 + one b64); the per-key tests, the slot
-            // reservation in the workgroup's hit buffer and the pair keys are done once per tile, for all staged records
+            // reservation in the workgroup's hit buffer and the pair keys are done once per unit, for all staged records
             // in parallel, by one shared piece of code (24 inlined copies of that path cost an instruction-cache miss
             // per use: 0.35 of 3.0 ms).
             const uint64_t row0 = uint64_t(u_raw) * a.unit_step * (16 * TW);  // the unclamped unit: idle waves are past n
             uint32_t stage_n = 0;                                             // wave-uniform
+            // Lane constants of the epilogue are recomputed here from an opaque lane id: carried across the main loop they
+            // are spilled, and a scratch reload at this point waits (vmcnt is in order) for the whole X ring to land --
+            // a full drain of the prefetch once per unit (measured: the epilogue cost its full duration, 0.3 of 2.8 ms).
+            uint32_t lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(lane_e));
+            const uint32_t r = lane_e & 15, g4 = lane_e >> 4, lane = lane_e;  // shadow the kernel-wide copies
             float4 *stage_k = reinterpret_cast<float4 *>(stage_s) + wave * GEMM_STAGE;
             uint32_t *stage_r = reinterpret_cast<uint32_t *>(reinterpret_cast<float4 *>(stage_s) + 8 * GEMM_STAGE) + wave * GEMM_STAGE;  // first row
             uint32_t *stage_q = stage_r + 8 * GEMM_STAGE;                                                                             // query in group
@@ -293,16 +310,16 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
                 // the stage holds GEMM_STAGE lane records; when the next pair's passing lanes do not fit, the loop over the
                 // halves stops there, the stage is drained and the loop resumes at that pair (hub rows -- small norms under
                 // L2Sqr -- pass for most queries of a group at once)
-                uint32_t h_from = 0;  // wave-uniform
+                int h_from = -1;  // wave-uniform; >= 0: resume at this pair after a drain
                 for (;;) {
-                uint32_t h_stop = NH;
-                if (h_from) {
+                int h_stop = NH;
+                if (h_from >= 0) {  // the stopped pair's prefetch has already moved tau_n / qm_n on (also when it was pair 0)
                     if (MODE == GEMM_FILTER) tau_n = tau_s[h_from * 16 + r];
                     if (PREC == GEMM_F16) qm_n = qm_s[h_from * 16 + r];
                 }
 #pragma unroll
                 for (int h = 0; h < NH; h++) {
-                    if (MODE == GEMM_FILTER && uint32_t(h) < h_from) continue;
+                    if (MODE == GEMM_FILTER && h < h_from) continue;
                     if ((GEMM_ABLATE & 1) && (t > 0 || h > 0)) {
                         if (acc[t][h][0] + acc[t][h][1] + acc[t][h][2] + acc[t][h][3] == 1.2345f) atomicAdd(hit_n, 1u);
                         continue;
@@ -347,7 +364,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
                     const uint64_t pm = __ballot(pass);
                     if (pm) {  // rare: ~1000 rows per query in total (mfma_sample_plan)
                         const uint32_t np = __builtin_popcountll(pm);
-                        if (stage_n + np > GEMM_STAGE) {  // wave-uniform
+                        if (__builtin_amdgcn_readfirstlane(stage_n + np > GEMM_STAGE)) {  // wave-uniform
                             h_stop = h;
                             break;
                         }
@@ -360,7 +377,8 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
                         stage_n += np;
                     }
                 }
-                if (MODE == GEMM_FILTER && stage_n) {  // wave-uniform; drained per tile (and whenever the stage fills up)
+                // drained once per unit (after the last tile) and whenever the stage fills up
+                if (MODE == GEMM_FILTER && stage_n && (h_stop != NH || t == TW - 1)) {  // wave-uniform
                     const uint32_t cnt = stage_n < GEMM_STAGE ? stage_n : GEMM_STAGE;
                     for (uint32_t i = lane; i < cnt; i += 64) {
                         const float4 kv = stage_k[i];
@@ -524,6 +542,10 @@ void launch_flat_gemm_filter(const float *XT, uint64_t n, uint32_t dim, const fl
     a.cnt = cnt;
     a.cap = cap;
     a.debug = (uint32_t)debug;
+    if (g_gemm_stagger) {  // one unit step of a workgroup at ~6 TB/s spread over the CUs, in 10-ns ticks (wall_clock64 runs at 100 MHz)
+        const double unit_bytes = 8.0 * g_gemm_tw * 16 * mfma_dim_pad(dim) * (qmul ? 2 : 4);
+        a.stagger = (uint32_t)(unit_bytes / (6.0e12 / num_cu) * 1e8 * g_gemm_stagger);
+    }
     flat_gemm_dispatch<GEMM_FILTER>(a, num_cu, s);
 }
 
