@@ -38,7 +38,7 @@ constexpr uint32_t GEMM_WGBUF = 3072;       // LDS hit buffer entries per workgr
 constexpr uint32_t GEMM_STAGE = 64;         // per wave and unit: lanes whose (tile, half) key quartet passed the threshold
 static int g_gemm_tw = 3;
 void gemm_set_tw(int v) { g_gemm_tw = v == 2 ? 2 : 3; }
-static int g_gemm_stagger = 1;
+static int g_gemm_stagger = 0;  // measured: no effect (the epilogue cost is per CU, not a chip-wide HBM gap), kept as a switch
 void gemm_set_stagger(int v) { g_gemm_stagger = v; }
 uint32_t gemm_group() { return GEMM_BQ; }
 
@@ -187,7 +187,11 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
             // row norms of this unit: one dword per lane, staged global -> VGPR -> LDS with the Q chunk (every chunk
             // re-stages the same 16*TW values: no branch in the chunk body).  As scalar loads in the epilogue they cost
             // several dependent round trips per unit with all 8 waves waiting (measured: 0.58 of 3.1 ms).
-            const float *xs_src = a.xsq + uint64_t(__builtin_amdgcn_readfirstlane(u)) * a.unit_step * (16 * TW) + (lane < 16 * TW ? lane : 0);
+            // (scalar base + 32-bit lane offset, like the X loads: a 64-bit per-lane pointer held across the unit gets spilled,
+            // and its reload waits behind the whole X ring)
+            const char *xs_base = reinterpret_cast<const char *>(a.xsq + uint64_t(__builtin_amdgcn_readfirstlane(u)) * a.unit_step * (16 * TW));
+            uint32_t xs_off = (lane < 16 * TW ? lane : 0) * 4;
+            asm volatile("" : "+v"(xs_off));  // per unit on purpose: hoisted out of the unit loop it becomes base + offset as a 64-bit VGPR pair
             for (uint32_t c = 0; c < nchunk; c++) {
                 // next chunk in consumption order: same group until its last step is done
                 const uint4 *nxt = (c + 1 < nchunk ? qgrp + uint64_t(c + 1) * CHUNK
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
                     static_assert(QP == 2, "two staged uint4 per thread and k-block");  // scalars: an array here stays in scratch
                     const uint4 qs0 = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(nxt + (p * QP + 0) * NT) + tid16);
                     const uint4 qs1 = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(nxt + (p * QP + 1) * NT) + tid16);
-                    if (p == 0) xs_stage = *xs_src;
+                    if (p == 0) xs_stage = *reinterpret_cast<const float *>(xs_base + xs_off);
                     // the machine scheduler otherwise sinks these loads next to their uses (measured: vmcnt(0) before every
                     // staging ds_write, i.e. the whole X ring drained once per k-block) and pulls the B-fragment reads
                     // back to just before their MFMAs; pin the issue order instead
