@@ -136,14 +136,25 @@ __global__ __launch_bounds__(256) void k_query_prep_h(const float *__restrict__ 
         float *sq = qp_smem + size_t(wave) * dim;
         for (uint32_t j = lane; j < dim; j += 64) sq[j] = qv[j];
         float qs = 0.0f;
-        if (lane == 0) {  // same-wave LDS traffic is ordered: no barrier
-            uint32_t j = 0;
-            for (; j + 4 <= dim; j += 4) {
-                const float a = sq[j], b = sq[j + 1], c = sq[j + 2], d = sq[j + 3];
-                qs = qs + a * a;
-                qs = qs + b * b;
-                qs = qs + c * c;
-                qs = qs + d * d;
+        if (lane == 0) {  // same-wave LDS traffic is ordered: no barrier.  The adds are a strict chain, the reads are not:
+            uint32_t j = 0;  // eight 16-B reads in flight (dim * 4 B per wave keeps the rows 16-B aligned when dim % 4 == 0)
+            if ((dim & 3) == 0) {
+                const float4 *s4 = reinterpret_cast<const float4 *>(sq);
+                const uint32_t nv = dim / 4;
+                uint32_t i = 0;
+                for (; i + 8 <= nv; i += 8) {
+                    float4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) v[u] = s4[i + u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        qs = qs + v[u].x * v[u].x;
+                        qs = qs + v[u].y * v[u].y;
+                        qs = qs + v[u].z * v[u].z;
+                        qs = qs + v[u].w * v[u].w;
+                    }
+                }
+                j = i * 4;
             }
             for (; j < dim; j++) qs = qs + sq[j] * sq[j];
             qsq[q] = qs;
