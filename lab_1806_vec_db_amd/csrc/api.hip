@@ -727,6 +727,14 @@ static void merge_topk_dev(Index &ix, const void *d_dists, const void *d_ids, co
     ix.use_device();
     WsLease ws(ix);
     VDB_SYNC(static_cast<hipStream_t>(stream));
+    if (k <= 64) {  // one launch, no scratch lists
+        launch_merge_shards64(static_cast<const float *>(d_dists), static_cast<const uint64_t *>(d_ids),
+                              static_cast<const uint64_t *>(d_counts), stride_d, stride_i, stride_c, (uint32_t)n_shards,
+                              (uint32_t)nq, (uint32_t)k, static_cast<uint64_t *>(d_out_idx), static_cast<float *>(d_out_dist),
+                              static_cast<uint64_t *>(d_out_count), ws->stream);
+        VDB_SYNC(ws->stream);
+        return;
+    }
     uint32_t cap = topk_capacity((uint32_t)k);
     ws->lists.reserve(nq * n_shards * cap * sizeof(uint64_t));
     ws->keys_c.reserve(nq * cap * sizeof(uint64_t));

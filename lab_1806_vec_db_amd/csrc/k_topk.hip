@@ -398,6 +398,50 @@ void launch_pack_pairs(const float *dists, const uint64_t *ids, const uint64_t *
                        stride_c, S, nq, k, cap_in, lists);
 }
 
+// The whole shard merge for k <= 64 in one launch: a wave per query reads the S per-shard results (distance, global id,
+// count) in rounds of 64 pairs, sorts each round across its lanes and merges it into the running best-64
+// (CandidatePair order: distance, then id), then writes the first k.  Replaces k_pack_pairs + k_topk_merge + k_finalize
+// and their scratch lists.
+__global__ __launch_bounds__(64) void k_merge_shards64(const char *__restrict__ dists, const char *__restrict__ ids,
+                                                       const char *__restrict__ counts, uint64_t stride_d, uint64_t stride_i,
+                                                       uint64_t stride_c, uint32_t S, uint32_t nq, uint32_t k,
+                                                       uint64_t *__restrict__ out_idx, float *__restrict__ out_dist,
+                                                       uint64_t *__restrict__ out_count) {
+    const uint32_t q = blockIdx.x, lane = threadIdx.x & 63;
+    const uint32_t total = S * k;
+    uint64_t best = PAIR_NONE;
+    for (uint32_t base = 0; base < total; base += 64) {
+        const uint32_t i = base + lane;
+        uint64_t c = PAIR_NONE;
+        if (i < total) {
+            const uint32_t s = i / k, j = i - s * k;
+            const uint64_t cnt = reinterpret_cast<const uint64_t *>(counts + s * stride_c)[q];
+            if (j < cnt) {
+                const uint64_t at = uint64_t(q) * k + j;
+                c = pair_key(reinterpret_cast<const float *>(dists + s * stride_d)[at],
+                             uint32_t(reinterpret_cast<const uint64_t *>(ids + s * stride_i)[at]));
+            }
+        }
+        best = merge64(best, sort64(c, lane), lane);
+    }
+    const bool ok = lane < k && best != PAIR_NONE;
+    if (lane < k) {
+        out_idx[uint64_t(q) * k + lane] = ok ? uint64_t(uint32_t(best)) : 0;
+        out_dist[uint64_t(q) * k + lane] = ok ? f32_from_orderable(uint32_t(best >> 32)) : 0.0f;
+    }
+    const uint32_t n_ok = __builtin_popcountll(__ballot(ok));
+    if (lane == 0) out_count[q] = n_ok;
+}
+void launch_merge_shards64(const float *dists, const uint64_t *ids, const uint64_t *counts, uint64_t stride_d,
+                           uint64_t stride_i, uint64_t stride_c, uint32_t S, uint32_t nq, uint32_t k, uint64_t *out_idx,
+                           float *out_dist, uint64_t *out_count, hipStream_t s) {
+    if (nq == 0 || S == 0) return;
+    VDB_REQUIRE(k >= 1 && k <= 64, "merge_shards64: k must be in 1..64");
+    hipLaunchKernelGGL(k_merge_shards64, dim3(nq), dim3(64), 0, s, reinterpret_cast<const char *>(dists),
+                       reinterpret_cast<const char *>(ids), reinterpret_cast<const char *>(counts), stride_d, stride_i,
+                       stride_c, S, nq, k, out_idx, out_dist, out_count);
+}
+
 #define VDB_DISPATCH_R(cap, CALL)                                   \
     switch ((cap) / 64) {                                           \
         case 1: CALL(1); break;                                     \

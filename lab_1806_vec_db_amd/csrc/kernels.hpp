@@ -95,6 +95,10 @@ void launch_topk_merge(const uint64_t *lists, uint32_t nlists, uint32_t cap_in, 
 // level 2 over ONE list per query of which only the first min(cnt[q], cap_in) entries are scanned
 void launch_topk_merge_counted(const uint64_t *lists, uint32_t cap_in, const uint32_t *cnt, uint32_t nq, uint32_t k,
                                uint64_t *out, hipStream_t s);
+// shard merge for k <= 64 in one launch (wave per query); strides in BYTES between consecutive shards' arrays
+void launch_merge_shards64(const float *dists, const uint64_t *ids, const uint64_t *counts, uint64_t stride_d,
+                           uint64_t stride_i, uint64_t stride_c, uint32_t S, uint32_t nq, uint32_t k, uint64_t *out_idx,
+                           float *out_dist, uint64_t *out_count, hipStream_t s);
 void launch_pack_pairs(const float *dists, const uint64_t *ids, const uint64_t *counts, uint64_t stride_d,
                        uint64_t stride_i, uint64_t stride_c /* bytes between shards */, uint32_t S, uint32_t nq, uint32_t k,
                        uint32_t cap_in, uint64_t *lists, hipStream_t s);

@@ -166,8 +166,9 @@ class ShardExchange:
         import torch.distributed as dist
 
         dist.all_gather_into_tensor(self.recv, self.send, group=group)
-        torch.cuda.current_stream().synchronize()
+        # the collective is ordered on torch's current stream; the merge waits for that stream itself (one host
+        # synchronisation per exchange, inside the library call)
         gpu_index.merge_topk_gathered(self.recv.data_ptr(), self.block, self.off_ids, self.off_dists, self.off_counts,
                                       self.world, self.nq, self.k, self.m_idx.data_ptr(), self.m_dist.data_ptr(),
-                                      self.m_cnt.data_ptr())
+                                      self.m_cnt.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
         return self.m_idx, self.m_dist, self.m_cnt
