@@ -788,9 +788,25 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
     };
 
     const uint64_t nblk = (n + nt - 1) / nt;
-    const uint32_t step = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, nblk / 16));
+    // Threshold sample: every step-th row block, tau = the s_rank-th smallest sampled ADC value.  s_rank = efk guarantees
+    // >= efk hits (the sample is a subset) at efk * step expected ones; when the shard is large enough a thinner rank
+    // r = max(8, efk / 8) with step ~ max(1024, 4 efk) / r gives ~1000 hits instead of ~6400 (every hit costs the scan's
+    // epilogue an LDS append and the counted merge an insertion) and the hit count is CHECKED: hits / step is
+    // Gamma(r)-distributed, the rule below keeps P[hits < efk] under ~1e-5 (same rule as mfma_sample_plan).
+    uint32_t step = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, nblk / 16));
+    uint32_t s_rank = efk;
+    {
+        const uint32_t r = efk / 8 < 8 ? 8 : efk / 8;
+        const uint64_t target = std::max<uint64_t>(1024, 4ull * efk);
+        const uint64_t st = std::min<uint64_t>(nblk / 16, target / r);
+        const double thr = r < 16 ? r / 8.0 : (r < 32 ? r / 4.0 : r / 3.0);
+        if (r < efk && st >= step && double(efk) <= thr * double(st) * 1.1) {
+            s_rank = r;
+            step = (uint32_t)st;
+        }
+    }
     const uint64_t n_s = (nblk + step - 1) / step * nt;  // sampled rows (incl. padding past n)
-    const bool fused = n_s >= 2 * uint64_t(efk) && n >= 65536;
+    const bool fused = n_s >= 2 * uint64_t(efk) && n >= 65536 && n_s >= 64ull * s_rank;
     if (!fused) {
         const uint64_t GQ = std::max<uint64_t>(BQ, std::min<uint64_t>(64, (size_t(512) << 20) / ((n + nt + 64) * sizeof(float))) / BQ * BQ);
         for (uint64_t g0 = 0; g0 < nq; g0 += GQ) dense_group(g0, std::min<uint64_t>(GQ, nq - g0));
@@ -798,7 +814,7 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
         // fused path: tau[q] from a strided row-block sample, then one filtered scan per BQ queries
         const uint64_t ld_s = (n_s + 63) & ~63ull;
         const uint32_t nl_s = topk_num_lists(n_s);
-        const uint32_t cap = (uint32_t)std::min<uint64_t>(65536, std::max<uint64_t>(4096, 4ull * efk * step));
+        const uint32_t cap = (uint32_t)std::min<uint64_t>(65536, std::max<uint64_t>(4096, 4ull * s_rank * step));
         const uint64_t GQ = 64;
         ws.dense.reserve(GQ * ld_s * sizeof(float));
         ws.lists.reserve(std::max<size_t>(GQ * nl_s * cape, GQ * size_t(cap)) * sizeof(uint64_t));
@@ -819,11 +835,11 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
                 adc_launch<0>(ix, ws, BQ, a);
             }
             if (n_s <= select_tau_max_n()) {  // tau = efk-th smallest sampled ADC value: a selection, not a sort
-                launch_select_tau(ws.dense.as<float>(), ld_s, (uint32_t)n_s, (uint32_t)gn, (uint32_t)gn, efk, d_tau + g0, s);
+                launch_select_tau(ws.dense.as<float>(), ld_s, (uint32_t)n_s, (uint32_t)gn, (uint32_t)gn, s_rank, d_tau + g0, s);
             } else {
-                launch_topk_dense(ws.dense.as<float>(), ld_s, n_s, (uint32_t)gn, efk, ws.lists.as<uint64_t>(), s);
-                launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, cape, (uint32_t)gn, efk, ws.keys_a.as<uint64_t>() + g0 * cape, s);
-                launch_extract_tau(ws.keys_a.as<uint64_t>() + g0 * cape, cape, (uint32_t)gn, efk, d_tau + g0, s);
+                launch_topk_dense(ws.dense.as<float>(), ld_s, n_s, (uint32_t)gn, s_rank, ws.lists.as<uint64_t>(), s);
+                launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, cape, (uint32_t)gn, s_rank, ws.keys_a.as<uint64_t>() + g0 * cape, s);
+                launch_extract_tau(ws.keys_a.as<uint64_t>() + g0 * cape, cape, (uint32_t)gn, s_rank, d_tau + g0, s);
             }
             uint64_t *d_cand = ws.lists.as<uint64_t>();  // the sample lists are dead now
             {
@@ -846,7 +862,7 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
         VDB_HIP(hipMemcpyAsync(hits.data(), d_hits, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         VDB_SYNC(s);
         for (uint64_t q = 0; q < nq; q++)
-            if (hits[q] > cap) dense_group(q, 1);
+            if (hits[q] > cap || hits[q] < std::min<uint64_t>(efk, n)) dense_group(q, 1);  // overflow, or (thinned sample) too few hits
     }
 }
 
