@@ -95,7 +95,6 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
 
     // wave-uniform values are made visibly uniform (readfirstlane) so that addresses are SGPR base + 32-bit lane offset
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t r = lane & 15, g4 = lane >> 4;
     const uint32_t nwaves = gridDim.x * NW, gw = blockIdx.x * NW + wave;
     const uint32_t KB = a.KB, nchunk = KB / KC;
     const uint64_t n = a.n;
@@ -290,7 +289,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
             // a full drain of the prefetch once per unit (measured: the epilogue cost its full duration, 0.3 of 2.8 ms).
             uint32_t lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
             asm volatile("" : "+v"(lane_e));
-            const uint32_t r = lane_e & 15, g4 = lane_e >> 4, lane = lane_e;  // shadow the kernel-wide copies
+            const uint32_t r = lane_e & 15, g4 = lane_e >> 4, lane = lane_e;  // (shadows the kernel-wide lane)
             float4 *stage_k = reinterpret_cast<float4 *>(stage_s) + wave * GEMM_STAGE;
             uint32_t *stage_r = reinterpret_cast<uint32_t *>(reinterpret_cast<float4 *>(stage_s) + 8 * GEMM_STAGE) + wave * GEMM_STAGE;  // first row
             uint32_t *stage_q = stage_r + 8 * GEMM_STAGE;                                                                             // query in group
