@@ -95,13 +95,20 @@ int vdb_flat_knn_device(vdb_index *idx, const void *d_queries, uint64_t nq, uint
  *   mode 1 = exact scan only (strict-order f32 fold for every row),
  *   mode 2 = MFMA path forced (still certified, still falls back per query). */
 int vdb_flat_set_mode(vdb_index *idx, int mode);
-/* developer tuning knobs (kernel variants); results never depend on them */
+/* developer tuning knobs (kernel variants); results never depend on them.  Names:
+ *   "flat_half"        fp16 first pass of the Flat pipeline: 0 auto (off once > 1/8 of its queries needed the redo), 1 off, 2 on
+ *   "flat_half_kmul"   its shortlist = max(64, kmul * k) rows per query (default 4)
+ *   "flat_gemm"        128-queries-per-pass kernel: 0 auto, 1 off (small-batch kernel), 2 forced
+ *   "flat_gemm_tw"     row tiles per wave (3 default, 2);  "flat_gemm_stagger" workgroup start delays (0 default)
+ *   "flat_tail"        exact stage: 0 fused launch when the shortlist fits 64 rows, 1 separate kernels
+ *   "flat_share", "mfma_variant", "flat_sample_thin", "flat_gemm_debug"   small-batch kernel / sample plan / measurement hooks
+ *   "pq_adc_fast", "hnsw_dma"   inner-loop variants of the ADC scan and of the HNSW walk */
 int vdb_set_param(vdb_index *idx, const char *name, int64_t value);
 /* number of queries whose MFMA shortlist failed certification and were redone by the exact scan */
 int vdb_flat_fallback_count(const vdb_index *idx, uint64_t *out);
 /* counters of the Flat pipeline (diagnostics; results never depend on them):
  *   "flat_fallback"      = vdb_flat_fallback_count,
- *   "flat_half_queries"  queries that went through the fp16 first pass (calls with more than 64 queries),
+ *   "flat_half_queries"  queries that went through the fp16 first pass,
  *   "flat_half_redo"     of those, the ones it could not certify (redone with the split-bf16 pass),
  *   "flat_half_valid"    1 when the index holds the fp16 mirror. */
 int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out);
