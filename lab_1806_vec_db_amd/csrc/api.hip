@@ -310,6 +310,8 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         mfma_set_sample_thin((int)value);
     else if (n == "flat_gemm_tw")
         gemm_set_tw((int)value);
+    else if (n == "flat_gemm_nt")
+        gemm_set_nt((int)value);
     else if (n == "flat_gemm_stagger")
         gemm_set_stagger((int)value);
     else if (n == "flat_gemm_debug")

@@ -38,6 +38,8 @@ constexpr uint32_t GEMM_WGBUF = 3072;       // LDS hit buffer entries per workgr
 constexpr uint32_t GEMM_STAGE = 64;         // per wave and unit: lanes whose (tile, half) key quartet passed the threshold
 static int g_gemm_tw = 3;
 void gemm_set_tw(int v) { g_gemm_tw = v == 2 ? 2 : 3; }
+static int g_gemm_nt = 0;  // 0 auto (by mirror size), 1 never, 2 always
+void gemm_set_nt(int v) { g_gemm_nt = v; }
 static int g_gemm_stagger = 0;  // measured: no effect (the epilogue cost is per CU, not a chip-wide HBM gap), kept as a switch
 void gemm_set_stagger(int v) { g_gemm_stagger = v; }
 uint32_t gemm_group() { return GEMM_BQ; }
@@ -59,6 +61,7 @@ struct GemmArgs {
     int cosine;
     uint32_t debug;
     uint32_t stagger;  // GEMM_FILTER: one unit step in 10-ns ticks (0: start all workgroups together), see the kernel
+    uint32_t nt;       // GEMM_FILTER: non-temporal X loads (host-side choice, see GEMM_NT_BIT)
 };
 
 enum { GEMM_FILTER = 0, GEMM_SAMPLE = 1 };
@@ -67,6 +70,13 @@ enum { GEMM_FILTER = 0, GEMM_SAMPLE = 1 };
 #ifndef GEMM_ABLATE
 #define GEMM_ABLATE 0
 #endif
+// Cache policy of the X stream (template bit GEMM_NT_BIT of the precision parameter, filter pass only).  A mirror far
+// larger than the 256 MB Infinity Cache is read exactly once per pass and nothing of it survives to the next pass:
+// non-temporal loads leave L2 / the Infinity Cache to the Q chunks and stream faster (1M x 960: 2.69 -> 2.58 ms fp16,
+// 5.43 -> 5.24 ms split-bf16, old and new library on one box).  A shard that FITS the Infinity Cache (125k x 960 fp16 =
+// 240 MB) is served from it in passes 2..8 -- there non-temporal loads cost 0.32 -> 0.38 ms.  launch_flat_gemm_filter
+// picks by the mirror's size.
+constexpr int GEMM_NT_BIT = 2;
 // Arithmetic of the contraction.  GEMM_BF16X3: x*q ~ xh*qh + xh*ql + xl*qh on 32-column k-blocks, 4 B per element
 // in the mirror.  GEMM_F16: x*q ~ fp16(sx*x) * fp16(sq*q) on 64-column k-blocks (two 16x16x32 f16 MFMAs), 2 B per
 // element: a third of the matrix work and half of the HBM bytes per row.  The data movement is the same in both: a
@@ -78,8 +88,10 @@ enum { GEMM_BF16X3 = 0, GEMM_F16 = 1 };
 // GEMM_SAMPLE: blockIdx.y = query group, one step per workgroup over the sampled units, keys written densely -- the
 // threshold sample of the same queries with the same arithmetic as the filter pass (the small-batch kernel's sample
 // mode re-reads the sampled rows once per 32 queries; this one once per 128: 80 -> ~25 us at a 125k-row shard).
-template <int TW, int KC, int MODE, int PREC>
+template <int TW, int KC, int MODE, int PV>
 __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
+    constexpr int PREC = PV & 1;
+    constexpr bool XNT = (PV & GEMM_NT_BIT) != 0;
     constexpr int NT = 512, NW = 8, NH = GEMM_NH, R = KC;
     constexpr uint32_t CHUNK = KC * NH * 128;  // uint4 per Q chunk
     constexpr int QST = CHUNK / NT;            // staged uint4 per thread
@@ -147,8 +159,14 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
         const char *sb = base + kb * 2048;  // scalar
 #pragma unroll
         for (int t = 0; t < TW; t++) {
-            dst[t][0] = *reinterpret_cast<const uint4 *>(sb + voff[t]);
-            dst[t][1] = *reinterpret_cast<const uint4 *>(sb + voff[t] + 1024);
+            if constexpr (XNT) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                dst[t][0] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(sb + voff[t])));
+                dst[t][1] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(sb + voff[t] + 1024)));
+            } else {
+                dst[t][0] = *reinterpret_cast<const uint4 *>(sb + voff[t]);
+                dst[t][1] = *reinterpret_cast<const uint4 *>(sb + voff[t] + 1024);
+            }
         }
     };
 #pragma unroll
@@ -455,7 +473,19 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
 }
 
 template <int TW, int KC, int MODE, int PREC>
-static void flat_gemm_launch(const GemmArgs &a0, int num_cu, hipStream_t s) {
+static void flat_gemm_launch1(const GemmArgs &a0, int num_cu, hipStream_t s);
+template <int TW, int KC, int MODE, int PREC>
+static void flat_gemm_launch(const GemmArgs &a, int num_cu, hipStream_t s) {
+    if constexpr (MODE == GEMM_FILTER) {
+        if (a.nt) {
+            flat_gemm_launch1<TW, KC, MODE, PREC | GEMM_NT_BIT>(a, num_cu, s);
+            return;
+        }
+    }
+    flat_gemm_launch1<TW, KC, MODE, PREC>(a, num_cu, s);
+}
+template <int TW, int KC, int MODE, int PREC>
+static void flat_gemm_launch1(const GemmArgs &a0, int num_cu, hipStream_t s) {
     GemmArgs a = a0;
     const uint64_t n_tiles = (a.n + 15) / 16;
     const uint32_t units_all = (uint32_t)((n_tiles + TW - 1) / TW);
@@ -545,6 +575,10 @@ void launch_flat_gemm_filter(const float *XT, uint64_t n, uint32_t dim, const fl
     a.cnt = cnt;
     a.cap = cap;
     a.debug = (uint32_t)debug;
+    {   // mirror bytes of this shard against the Infinity Cache (256 MB): stream past it, or let it serve passes 2..
+        const double mirror_bytes = double((n + 15) / 16 * 16) * mfma_dim_pad(dim) * (qmul ? 2 : 4);
+        a.nt = g_gemm_nt == 2 || (g_gemm_nt == 0 && mirror_bytes > 384.0 * 1024 * 1024) ? 1u : 0u;
+    }
     if (g_gemm_stagger) {  // one unit step of a workgroup at ~6 TB/s spread over the CUs, in 10-ns ticks (wall_clock64 runs at 100 MHz)
         const double unit_bytes = 8.0 * g_gemm_tw * 16 * mfma_dim_pad(dim) * (qmul ? 2 : 4);
         a.stagger = (uint32_t)(unit_bytes / (6.0e12 / num_cu) * 1e8 * g_gemm_stagger);
