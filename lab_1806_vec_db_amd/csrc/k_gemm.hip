@@ -66,7 +66,7 @@ struct GemmArgs {
 
 enum { GEMM_FILTER = 0, GEMM_SAMPLE = 1 };
 // measurement builds only (make EXTRA=-DGEMM_ABLATE=n): 1 = the epilogue looks at one (tile, half) pair only,
-// 2 = only the first half's MFMAs are issued; loads, LDS traffic and barriers stay.  Results are wrong by design.
+// 2 = only the first half's MFMAs are issued, 4 = no chunk barrier; loads and LDS traffic stay.  Results are wrong by design.
 #ifndef GEMM_ABLATE
 #define GEMM_ABLATE 0
 #endif
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
                     if (p == 0) xs_s[wave * 64 + lane] = xs_stage;
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                __syncthreads();
+                if (!(GEMM_ABLATE & 4)) __syncthreads();  // (4: measurement only -- the Q chunks race)
                 buf ^= 1;
             }
             cp_cur = cp_nxt;
