@@ -100,6 +100,7 @@ int vdb_flat_set_mode(vdb_index *idx, int mode);
  *   "flat_half_kmul"   its shortlist = max(64, kmul * k) rows per query (default 4)
  *   "flat_gemm"        128-queries-per-pass kernel: 0 auto, 1 off (small-batch kernel), 2 forced
  *   "flat_gemm_tw"     row tiles per wave (3 default, 2);  "flat_gemm_stagger" workgroup start delays (0 default)
+ *   "flat_gemm_block_rows"  filter pass in row blocks, one launch per block over all query groups (measurement switch): 0 off, n rows
  *   "flat_gemm_nt"     cache policy of the row stream: 0 auto (non-temporal when the mirror exceeds the Infinity Cache), 1 default, 2 non-temporal
  *   "flat_tail"        exact stage: 0 fused launch when the shortlist fits 64 rows, 1 separate kernels
  *   "flat_share", "mfma_variant", "flat_sample_thin", "flat_gemm_debug"   small-batch kernel / sample plan / measurement hooks

@@ -194,3 +194,24 @@ def test_stat_names(mods):
         assert ix.get_stat(name) == 0
     with pytest.raises(vdb.VdbError):
         ix.get_stat("no_such_counter")
+
+
+def test_row_blocked_filter_pass(mods):
+    """flat_gemm_block_rows scans the mirror in row blocks, one launch per block over all query groups (global row ids =
+    block base + local id; a measurement switch, off by default).  Small corpus: ragged last block, both precisions."""
+    vdb, O = mods
+    base, qs = gist_like(50000, seed=61), gist_like(300, seed=62)
+    oi, od, oc = O.flat_knn_batch(base, qs, 10, 0, nthreads=8)
+    ix = vdb.GpuIndex(960, "l2sqr")
+    ix.batch_add(base)
+    ix.set_flat_mode(2)
+    try:
+        for half in (0, 1):
+            ix.set_param("flat_half", half)
+            for block in (0, 384, 9600, 1 << 20):
+                ix.set_param("flat_gemm_block_rows", block)
+                idx, d, cnt = ix.flat_knn(qs, 10)
+                _check_all(idx, d, cnt, oi, od, oc)
+    finally:
+        ix.set_param("flat_gemm_block_rows", 0)
+    assert ix.flat_fallback_count() == 0
