@@ -294,6 +294,67 @@ __global__ __launch_bounds__(64) void k_rerank(const float *__restrict__ X, uint
     out[uint64_t(q) * ldc + j] = pair_key(epilogue(metric, acc, xs, qs), idx);
 }
 
+// Strict-order fold of a wave's (up to) 64 candidate rows against one query, rows fetched cooperatively: the wave reads a
+// 32-column chunk of all its rows together (8 lanes per row: every 128-B line is fetched whole by one instruction), parks
+// it in LDS (row stride 36 floats: conflict-free b128 accesses) and every lane folds ITS row's 32 values in reference
+// order against the query chunk (LDS broadcast).  DEPTH chunks of global loads are in flight during the folds (three instead
+// of two bought nothing, nor did capping the registers for a fourth workgroup per CU: 64 x 1000 rows of 3 840 B in ~45 us
+// is ~5.4 TB/s of random row gathers, the rate the hardware guide quotes for them).  qs4 = the query in LDS, tile = [64][9] float4.
+template <int FOLD, int DEPTH>
+__device__ __forceinline__ float wave_rerank_fold(const float *__restrict__ X, uint32_t dim, uint32_t idx, bool live,
+                                                  const float4 *qs4, float4 *tile, uint32_t lane) {
+    const uint32_t d4 = dim / 4;
+    const float4 *rp[8];  // the 8 rows this lane helps to fetch: rows 8*i + lane/8, piece lane%8 of each chunk
+    bool rl[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t ri = __shfl(idx, 8 * i + (lane >> 3));
+        rl[i] = __shfl(live ? 1 : 0, 8 * i + (lane >> 3)) != 0;
+        rp[i] = reinterpret_cast<const float4 *>(X + uint64_t(ri) * dim) + (lane & 7);
+    }
+    const uint32_t nch = (d4 + 7) / 8;
+    float4 stg[DEPTH][8];
+    auto fetch = [&](float4(&dst)[8], uint32_t ch) {
+        const bool inside = ch * 8 + (lane & 7) < d4;
+#pragma unroll
+        for (int i = 0; i < 8; i++) dst[i] = (inside && rl[i]) ? rp[i][ch * 8] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+#pragma unroll
+    for (int st = 0; st < DEPTH; st++)
+        if (uint32_t(st) < nch) fetch(stg[st], st);
+    float acc = 0.0f;
+    for (uint32_t ch0 = 0; ch0 < nch; ch0 += DEPTH) {
+#pragma unroll
+        for (int st = 0; st < DEPTH; st++) {
+            const uint32_t ch = ch0 + st;
+            if (ch >= nch) break;  // uniform
+#pragma unroll
+            for (int i = 0; i < 8; i++) tile[(8 * i + (lane >> 3)) * 9 + (lane & 7)] = stg[st][i];
+            if (ch + DEPTH < nch) fetch(stg[st], ch + DEPTH);
+            const uint32_t np = d4 - ch * 8 < 8 ? d4 - ch * 8 : 8;  // uniform
+            if (np == 8) {
+#pragma unroll
+                for (int p = 0; p < 8; p++) {
+                    const float4 x = tile[lane * 9 + p], w = qs4[ch * 8 + p];
+                    acc = fold1<FOLD>(acc, x.x, w.x);
+                    acc = fold1<FOLD>(acc, x.y, w.y);
+                    acc = fold1<FOLD>(acc, x.z, w.z);
+                    acc = fold1<FOLD>(acc, x.w, w.w);
+                }
+            } else {
+                for (uint32_t p = 0; p < np; p++) {
+                    const float4 x = tile[lane * 9 + p], w = qs4[ch * 8 + p];
+                    acc = fold1<FOLD>(acc, x.x, w.x);
+                    acc = fold1<FOLD>(acc, x.y, w.y);
+                    acc = fold1<FOLD>(acc, x.z, w.z);
+                    acc = fold1<FOLD>(acc, x.w, w.w);
+                }
+            }
+        }
+    }
+    return acc;
+}
+
 // The same re-rank with coalesced row fetches (dim % 4 == 0): k_rerank lets every lane walk its own row 16 B at a time,
 // i.e. one load instruction touches 64 different 128-B lines and each line has to survive in the L1 across 8
 // instructions -- 35 us for 32 candidates x 1000 queries at dim 960, but 184 us for 64 (the lines of the waves
@@ -318,48 +379,7 @@ __global__ __launch_bounds__(64) void k_rerank_t(const float *__restrict__ X, ui
     const uint32_t d4 = dim / 4;
     float4 *qs4 = rr_smem, *tile = rr_smem + d4;
     for (uint32_t i = lane; i < d4; i += 64) qs4[i] = reinterpret_cast<const float4 *>(Q + uint64_t(q) * dim)[i];
-    // the 8 rows this lane helps to fetch: rows 8*i + lane/8, piece lane%8 of each 32-column chunk
-    const float4 *rp[8];
-    bool rl[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint32_t ri = __shfl(idx, 8 * i + (lane >> 3));
-        rl[i] = __shfl(live ? 1 : 0, 8 * i + (lane >> 3)) != 0;
-        rp[i] = reinterpret_cast<const float4 *>(X + uint64_t(ri) * dim) + (lane & 7);
-    }
-    const uint32_t nch = (d4 + 7) / 8;
-    float4 stg[8];
-    auto fetch = [&](uint32_t ch) {
-        const bool inside = ch * 8 + (lane & 7) < d4;
-#pragma unroll
-        for (int i = 0; i < 8; i++) stg[i] = (inside && rl[i]) ? rp[i][ch * 8] : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    fetch(0);
-    float acc = 0.0f;
-    for (uint32_t ch = 0; ch < nch; ch++) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) tile[(8 * i + (lane >> 3)) * 9 + (lane & 7)] = stg[i];
-        if (ch + 1 < nch) fetch(ch + 1);
-        const uint32_t np = d4 - ch * 8 < 8 ? d4 - ch * 8 : 8;  // uniform
-        if (np == 8) {
-#pragma unroll
-            for (int p = 0; p < 8; p++) {
-                const float4 x = tile[lane * 9 + p], w = qs4[ch * 8 + p];
-                acc = fold1<FOLD>(acc, x.x, w.x);
-                acc = fold1<FOLD>(acc, x.y, w.y);
-                acc = fold1<FOLD>(acc, x.z, w.z);
-                acc = fold1<FOLD>(acc, x.w, w.w);
-            }
-        } else {
-            for (uint32_t p = 0; p < np; p++) {
-                const float4 x = tile[lane * 9 + p], w = qs4[ch * 8 + p];
-                acc = fold1<FOLD>(acc, x.x, w.x);
-                acc = fold1<FOLD>(acc, x.y, w.y);
-                acc = fold1<FOLD>(acc, x.z, w.z);
-                acc = fold1<FOLD>(acc, x.w, w.w);
-            }
-        }
-    }
+    const float acc = wave_rerank_fold<FOLD, 2>(X, dim, idx, live, qs4, tile, lane);
     if (j < ldc) {
         uint64_t r = PAIR_NONE;
         if (live) {
@@ -619,47 +639,7 @@ __global__ __launch_bounds__(256) void k_flat_tail64(FlatTailArgs a) {
     const uint64_t c = lane < a.kprime ? best : PAIR_NONE;
     const bool live = c != PAIR_NONE;
     const uint32_t idx = live ? uint32_t(c) : 0u;
-    const float4 *rp[8];
-    bool rl[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint32_t ri = __shfl(idx, 8 * i + (lane >> 3));
-        rl[i] = __shfl(live ? 1 : 0, 8 * i + (lane >> 3)) != 0;
-        rp[i] = reinterpret_cast<const float4 *>(a.X + uint64_t(ri) * a.dim) + (lane & 7);
-    }
-    const uint32_t nch = (d4 + 7) / 8;
-    float4 stg[8];
-    auto fetch = [&](uint32_t ch) {
-        const bool inside = ch * 8 + (lane & 7) < d4;
-#pragma unroll
-        for (int i = 0; i < 8; i++) stg[i] = (inside && rl[i]) ? rp[i][ch * 8] : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    fetch(0);
-    float acc = 0.0f;
-    for (uint32_t ch = 0; ch < nch; ch++) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) tile[(8 * i + (lane >> 3)) * 9 + (lane & 7)] = stg[i];
-        if (ch + 1 < nch) fetch(ch + 1);
-        const uint32_t np = d4 - ch * 8 < 8 ? d4 - ch * 8 : 8;  // uniform
-        if (np == 8) {
-#pragma unroll
-            for (int p = 0; p < 8; p++) {
-                const float4 x = tile[lane * 9 + p], w = qs4[ch * 8 + p];
-                acc = fold1<FOLD>(acc, x.x, w.x);
-                acc = fold1<FOLD>(acc, x.y, w.y);
-                acc = fold1<FOLD>(acc, x.z, w.z);
-                acc = fold1<FOLD>(acc, x.w, w.w);
-            }
-        } else {
-            for (uint32_t p = 0; p < np; p++) {
-                const float4 x = tile[lane * 9 + p], w = qs4[ch * 8 + p];
-                acc = fold1<FOLD>(acc, x.x, w.x);
-                acc = fold1<FOLD>(acc, x.y, w.y);
-                acc = fold1<FOLD>(acc, x.z, w.z);
-                acc = fold1<FOLD>(acc, x.w, w.w);
-            }
-        }
-    }
+    const float acc = wave_rerank_fold<FOLD, 2>(a.X, a.dim, idx, live, qs4, tile, lane);
     uint64_t r = PAIR_NONE;
     if (live) {
         const float xs = (a.metric == MET_L2_DIRECT) ? 0.0f : a.xsq[idx];
