@@ -1,0 +1,53 @@
+"""Randomised parity run of the Flat pipeline against the oracle (longer than tests/test_fuzz_gpu.py; not part of the suite).
+usage: python tools/fuzz_flat.py [seconds] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import lab_1806_vec_db_amd as vdb
+from oracle import oracle as O
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1806)
+t_end = time.time() + budget
+it = bad = 0
+while time.time() < t_end:
+    it += 1
+    dim = int(rng.choice([64, 96, 100, 128, 192, 256, 320, 384, 512, 768, 960, 1000, 1024, 1536]))
+    n = int(rng.integers(17000, 60000))
+    nq = int(rng.choice([1, 3, 17, 64, 65, 100, 128, 129, 200, 257]))
+    k = int(rng.choice([1, 2, 5, 10, 16, 17, 33, 64, 70]))
+    dist = str(rng.choice(["l2sqr", "cosine"]))
+    kind = 0 if dist == "l2sqr" else 1
+    style = int(rng.integers(0, 4))
+    if style == 0:
+        base = rng.standard_normal((n, dim)).astype(np.float32)
+        qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    elif style == 1:  # positive, quantised like gist
+        base = np.round(np.abs(rng.normal(0.07, 0.045, (n, dim))), 4).astype(np.float32)
+        qs = np.round(np.abs(rng.normal(0.07, 0.045, (nq, dim))), 4).astype(np.float32)
+    elif style == 2:  # clusters of near-duplicates (tiny margins -> redo tiers)
+        c = rng.standard_normal((n // 50 + 1, dim)).astype(np.float32)
+        base = (np.repeat(c, 50, axis=0)[:n] + 1e-4 * rng.standard_normal((n, dim))).astype(np.float32)
+        qs = (c[rng.integers(0, len(c), nq)] + 1e-4 * rng.standard_normal((nq, dim))).astype(np.float32)
+    else:  # wildly different row norms (hub rows under L2Sqr)
+        base = (rng.standard_normal((n, dim)) * np.exp(rng.normal(0, 1.0, (n, 1)))).astype(np.float32)
+        qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    ix = vdb.GpuIndex(dim, dist)
+    if rng.random() < 0.5:
+        ix.batch_add(base)
+    else:
+        cut = int(rng.integers(1, n - 1))
+        ix.batch_add(base[:cut]); ix.batch_add(base[cut:])
+    ix.set_flat_mode(int(rng.choice([0, 2])))
+    ix.set_param("flat_half", int(rng.choice([0, 0, 1, 2])))
+    ix.set_param("flat_tail", int(rng.choice([0, 0, 1])))
+    idx, d, cnt = ix.flat_knn(qs, k)
+    oi, od, oc = O.flat_knn_batch(base, qs, k, kind, nthreads=16)
+    ok = cnt.tolist() == oc.tolist() and all(idx[q, :int(cnt[q])].tolist() == oi[q][:int(cnt[q])].tolist() and
+                                             np.array_equal(d[q, :int(cnt[q])], od[q][:int(cnt[q])]) for q in range(nq))
+    print(f"#{it} dim {dim} n {n} nq {nq} k {k} {dist} style {style}: {'ok' if ok else 'MISMATCH'} "
+          f"half {ix.get_stat('flat_half_queries')} redo {ix.get_stat('flat_half_redo')} fallback {ix.flat_fallback_count()}", flush=True)
+    bad += 0 if ok else 1
+    del ix
+print(f"done: {it} configurations, {bad} mismatches")
+sys.exit(1 if bad else 0)
