@@ -466,6 +466,8 @@ void launch_finalize(const uint64_t *keys, uint32_t ldk, uint32_t nq, uint32_t k
 // e(r) >= kappa + qsq - E.  If the k-th smallest exact distance D_k among the shortlisted rows
 // satisfies D_k < kappa + qsq - E, no outside row can enter the exact top-k: certified.
 // When the shortlist holds every row (n <= k') it is trivially certified.
+// flat_certify_flag (the rule in use) replaces sqrt(xsq_max) by min(sqrt(xsq_max), |q| + sqrt(D_k)): a row whose norm
+// exceeds |q| + sqrt(D_k) is farther than D_k by the triangle inequality, whatever its key says.
 // ---------------------------------------------------------------------------------------------
 //
 // Cosine (keys -S/|x|, approximate distance a = 1 + key/|q|): S is off by at most
@@ -559,11 +561,17 @@ __device__ __forceinline__ uint8_t flat_certify_flag(uint64_t ek, uint64_t ak, u
                     bool clamp_free = sqrtf(xsq_min_pos) * qn > 1e-9f;
                     ok = clamp_free && dk < (1.0f + kappa / qn) - E;
                 } else {
-                    float nrm = sqrtf(xsq_max) + sqrtf(qs);
-                    float split = 5e-5f * sqrtf(xsq_max) * sqrtf(qs);  // split-bf16: 2 * 3 * 2^-18 |x||q|, with slack
-                    if (se.qerr) {  // the key holds -2S: twice |dx||q| + |x||dq| + |dx||dq|
+                    // Only rows with |x| <= |q| + sqrt(D_k) can have a distance below D_k (triangle inequality; 0.1 % slack
+                    // for the roundings of the norms and of the fold), so the error terms are those of rows up to that norm,
+                    // not of the largest row of the index: outlier norms do not loosen the bound of ordinary queries.
+                    const float qn = sqrtf(qs);
+                    const float rx = fminf(sqrtf(xsq_max), (qn + sqrtf(fmaxf(dk, 0.0f))) * 1.001f);
+                    float nrm = rx + qn;
+                    float split = 5e-5f * rx * qn;  // split-bf16: 2 * 3 * 2^-18 |x||q|, with slack
+                    if (se.qerr) {  // the key holds -2S: twice |dx||q| + |x||dq| + |dx||dq|; |dx_r| <= dx_rel |x_r|
                         const float qe = se.qerr[q];
-                        split = 2.0f * (se.dx_abs * sqrtf(qs) + sqrtf(xsq_max) * qe + se.dx_abs * qe) * 1.001f;
+                        const float dxa = fminf(se.dx_abs, se.dx_rel * rx);
+                        split = 2.0f * (dxa * qn + rx * qe + dxa * qe) * 1.001f;
                     }
                     float E = 2.5f * float(dim + 8) * 5.9604645e-8f * nrm * nrm + split;
                     ok = dk < (kappa + qs) - E;

@@ -1,5 +1,5 @@
 """Randomised parity run of the Flat pipeline against the oracle (longer than tests/test_fuzz_gpu.py; not part of the suite).
-usage: python tools/fuzz_flat.py [seconds] [seed]"""
+usage: python tools/fuzz_flat.py [seconds] [seed] [data style 0-3]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -18,7 +18,7 @@ while time.time() < t_end:
     k = int(rng.choice([1, 2, 5, 10, 16, 17, 33, 64, 70]))
     dist = str(rng.choice(["l2sqr", "cosine"]))
     kind = 0 if dist == "l2sqr" else 1
-    style = int(rng.integers(0, 4))
+    style = int(sys.argv[3]) if len(sys.argv) > 3 else int(rng.integers(0, 4))
     if style == 0:
         base = rng.standard_normal((n, dim)).astype(np.float32)
         qs = rng.standard_normal((nq, dim)).astype(np.float32)
