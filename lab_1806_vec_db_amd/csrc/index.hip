@@ -279,7 +279,7 @@ void Index::flat_sorted_device(Workspace &ws, const float *d_q, uint64_t nq, uin
 
 // ---- Flat: full pipeline ---------------------------------------------------------------------------
 void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t *d_idx,
-                            float *d_dist, uint64_t *d_cnt, bool allow_half) {
+                            float *d_dist, uint64_t *d_cnt, bool allow_half, uint32_t kprime_min) {
     hipStream_t s = ws.stream;
     if (nq == 0) return;
     if (k == 0 || n == 0) {  // ResultSet::new(0) rejects everything; empty VecSet -> empty result
@@ -299,6 +299,9 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     ws.qsq.reserve(nq * sizeof(float));
 
     uint32_t kprime = std::max<uint32_t>(32, 2 * ksel);
+    // a redo of queries the fp16 pass could not certify keeps that pass's (longer) shortlist: tiny margins -- clusters of
+    // near-duplicates -- need rows, not precision, and the split-bf16 tier should never certify less than the tier before it
+    if (kprime_min > kprime && kprime_min <= 1024 && n > kprime_min) kprime = kprime_min;
     const int cosine = dist == 1 ? 1 : 0;
     bool mfma = mfma_supported((uint32_t)dim) && kprime <= 1024 && n > kprime &&
                 (flat_mode == 2 || (flat_mode == 0 && n >= 16384));
@@ -468,7 +471,7 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     VDB_HIP(hipMemsetAsync(ri.p, 0, nr * k * sizeof(uint64_t), s));
     VDB_HIP(hipMemsetAsync(rd.p, 0, nr * k * sizeof(float), s));
     if (half)
-        flat_knn_device(ws, rq.as<float>(), nr, k, ri.as<uint64_t>(), rd.as<float>(), rc.as<uint64_t>(), false);
+        flat_knn_device(ws, rq.as<float>(), nr, k, ri.as<uint64_t>(), rd.as<float>(), rc.as<uint64_t>(), false, kprime);
     else
         flat_exact_device(ws, rq.as<float>(), rqs.as<float>(), nr, ksel, k, ri.as<uint64_t>(), rd.as<float>(), rc.as<uint64_t>());
     for (uint64_t j = 0; j < nr; j++) {

@@ -191,7 +191,7 @@ struct Index {
 
     // search entry points; d_* are device pointers, results [nq][k]
     void flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t *d_idx, float *d_dist,
-                         uint64_t *d_cnt, bool allow_half = true);
+                         uint64_t *d_cnt, bool allow_half = true, uint32_t kprime_min = 0);
     void flat_sorted_device(Workspace &ws, const float *d_q, uint64_t nq, uint64_t ksel, uint64_t k, uint64_t *d_idx,
                             float *d_dist, uint64_t *d_cnt);
     void flat_exact_device(Workspace &ws, const float *d_q, const float *d_qsq, uint64_t nq, uint32_t ksel,
