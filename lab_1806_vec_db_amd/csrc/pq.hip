@@ -331,11 +331,14 @@ __global__ __launch_bounds__(64) void k_pq_resort(const uint64_t *__restrict__ e
     for (uint32_t j0 = 0; j0 < ncand; j0 += 64) {
       const uint64_t mine = j0 + lane < ncand ? exact_keys[uint64_t(q) * ldc + j0 + lane] : PAIR_NONE;
       if (__ballot(mine != PAIR_NONE) == 0) continue;
-      const uint32_t jn = ncand - j0 < 64 ? ncand - j0 : 64;
-      for (uint32_t jj = 0; jj < jn; jj++) {
+      // only lanes whose distance beats the current worst can be admitted (tau only tightens): visit those, in offer order
+      // (a serial pass over all 64 lanes cost 1.07 ms per 1000 queries x ~4000 IVF candidates)
+      uint64_t todo = __ballot(mine != PAIR_NONE && uint32_t(mine >> 32) < uint32_t(tau >> 32));
+      while (todo) {
+        const uint32_t jj = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1;
         uint64_t e = __shfl(mine, jj);  // wave-uniform
-        if (e == PAIR_NONE) continue;
-        if (uint32_t(e >> 32) >= uint32_t(tau >> 32)) continue;  // full and not strictly closer
+        if (uint32_t(e >> 32) >= uint32_t(tau >> 32)) continue;  // full and not strictly closer (tau moved since the ballot)
         bool placed = false;
 #pragma unroll
         for (int r = 0; r < R; r++) {
