@@ -95,7 +95,9 @@ int vdb_flat_knn_device(vdb_index *idx, const void *d_queries, uint64_t nq, uint
  *   mode 1 = exact scan only (strict-order f32 fold for every row),
  *   mode 2 = MFMA path forced (still certified, still falls back per query). */
 int vdb_flat_set_mode(vdb_index *idx, int mode);
-/* developer tuning knobs (kernel variants); results never depend on them.  Names:
+/* developer tuning knobs (kernel variants); results never depend on them.  "flat_half", "flat_half_kmul", "flat_gemm",
+ * "flat_gemm_debug" and "flat_tail" are per index; ALL OTHER names set process-wide switches (the handle only routes the
+ * call) and are not synchronised: set them before concurrent searches start, never while one is running.  Names:
  *   "flat_half"        fp16 first pass of the Flat pipeline: 0 auto (off once > 1/8 of its queries needed the redo), 1 off, 2 on
  *   "flat_half_kmul"   its shortlist = max(64, kmul * k) rows per query (default 4)
  *   "flat_gemm"        128-queries-per-pass kernel: 0 auto, 1 off (small-batch kernel), 2 forced

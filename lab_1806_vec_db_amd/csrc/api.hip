@@ -103,6 +103,9 @@ int vdb_index_row(const vdb_index *idx, uint64_t i, float *out) {
 static void add_common(Index &ix, const float *rows, uint64_t n, uint64_t *first_id, bool on_device) {
     VDB_REQUIRE(rows || n == 0, "null rows");
     if (ix.ivf.present && n) ivf_clear(ix);  // IVFIndex has no add (built from_vec_set only): the clusters go stale
+    // MetadataVecTable::add / batch_add clear the PQ table before they touch the index (metadata_vec_table.rs:65,77):
+    // the codes cover the old rows only, a later knn_pq must fail with "needs a PQ table", not scan past d_codes
+    if (ix.pq.present && n) pq_clear(ix);
     if (first_id) *first_id = ix.n;
     if (ix.hnsw.present) {
         // DynamicIndex::add on the HNSW arm (dynamic_index.rs:47-52): HNSWIndex::add per row

@@ -99,6 +99,7 @@ struct Workspace {
 struct PQState {
     bool present = false;
     uint64_t n_bits = 0, m = 0, kc = 0, enc_dim = 0;
+    uint64_t n_coded = 0;            // rows d_codes covers; every PQ search requires n_coded == Index::n
     std::vector<uint64_t> gstart;    // m+1
     std::vector<float> h_centroids;  // kc*dim
     std::vector<float> h_cent_cache; // m*kc

@@ -481,6 +481,7 @@ static float host_dist(int dist, const float *a, const float *b, size_t n) {
 
 void pq_clear(Index &ix) {
     ix.pq.present = false;
+    ix.pq.n_coded = 0;
     ix.pq.d_codes.release();
 }
 
@@ -533,6 +534,7 @@ void pq_attach(Index &ix, uint64_t n_bits, uint64_t m, const float *centroids, c
     } else {
         pq_encode_all(ix);
     }
+    ix.pq.n_coded = ix.n;
     ix.pq.present = true;
 }
 
@@ -673,6 +675,7 @@ void pq_build(Index &ix, uint64_t n_bits, uint64_t m, uint64_t train_n, uint64_t
     for (auto &t : th) t.join();
     pq_install(ix, n_bits, m, cent.data());
     pq_encode_all(ix);
+    ix.pq.n_coded = ix.n;
     ix.pq.present = true;
 }
 
@@ -744,6 +747,7 @@ void pq_resort_launch(const uint64_t *exact_keys, uint32_t ncand, uint32_t ldc, 
 static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint32_t efk) {
     hipStream_t s = ws.stream;
     PQState &pq = ix.pq;
+    VDB_REQUIRE(pq.present && pq.n_coded == ix.n, "PQ table does not cover the rows of the index (rebuild it after add)");
     const uint64_t n = ix.n;
     ws.qsq.reserve(nq * sizeof(float));
     launch_row_sqnorm(d_q, nq, (uint32_t)ix.dim, ws.qsq.as<float>(), s);

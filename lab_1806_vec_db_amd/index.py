@@ -253,8 +253,20 @@ class GpuIndex:
 
     # -- PQ ------------------------------------------------------------------------------------------------
     def pq_attach(self, n_bits: int, m: int, centroids, codes=None):
+        """PQTable fields (pq_table.rs:116-137) as arrays: centroids = (1 << n_bits) * dim floats in group order,
+        codes = len x ceil(m * n_bits / 8) bytes or None (encoded on the GPU).  Sizes are checked here: the C side
+        copies exactly that many elements."""
         c = _f32(centroids).ravel()
         cd = None if codes is None else np.ascontiguousarray(codes, dtype=np.uint8)
+        if n_bits not in (4, 8):
+            raise L.VdbError("n_bits must be 4 or 8 in PQTable.")
+        if not 0 < int(m) <= self.dim:
+            raise L.VdbError("m must be in 1..=dim")
+        if c.size != (1 << n_bits) * self.dim:
+            raise L.VdbError(f"pq_attach: centroids hold {c.size} floats, expected (1 << n_bits) * dim = {(1 << n_bits) * self.dim}")
+        enc = (int(m) + 1) // 2 if n_bits == 4 else int(m)
+        if cd is not None and cd.size != len(self) * enc:
+            raise L.VdbError(f"pq_attach: codes hold {cd.size} bytes, expected len * encoded_dim = {len(self) * enc}")
         L.check(self._lib.vdb_pq_attach(self._h, n_bits, m, _ptr(c, L.f32p), _ptr(cd, L.u8p)))
 
     def pq_build(self, n_bits: int = 4, m: int | None = None, train_n: int = 0, max_iter: int = 20,
@@ -289,6 +301,12 @@ class GpuIndex:
         vl = np.ascontiguousarray(g["vec_level"], dtype=np.uint64)
         up = np.ascontiguousarray(g["upper"], dtype=np.uint32)
         ul = np.ascontiguousarray(g["upper_len"], dtype=np.uint64)
+        # the C side reads n * max_m0 / n / n / sum(vec_level) * m / sum(vec_level) elements: check before it does
+        n, mm = len(self), min(int(M), 10000)
+        tot = int(vl.sum()) if vl.size == n else -1
+        if l0.size != n * 2 * mm or len0.size != n or vl.size != n or up.size != tot * mm or ul.size != tot:
+            raise L.VdbError(f"hnsw_attach: array sizes do not match len={n}, M={M}: level0 {l0.size}, len0 {len0.size}, "
+                             f"vec_level {vl.size}, upper {up.size}, upper_len {ul.size}")
         L.check(self._lib.vdb_hnsw_attach(self._h, M, ef_construction, _ptr(l0, L.u32p), _ptr(len0, L.u64p),
                                           _ptr(vl, L.u64p), _ptr(up, L.u32p), _ptr(ul, L.u64p),
                                           int(g["has_enter"]), int(g["enter_point"]), int(g["enter_level"])))
@@ -332,6 +350,10 @@ class GpuIndex:
     def ivf_attach(self, centroids, assign=None):
         c = _f32(centroids)
         a = None if assign is None else np.ascontiguousarray(assign, dtype=np.uint64)
+        if c.ndim != 2 or c.shape[1] != self.dim:
+            raise L.VdbError(f"ivf_attach: centroids must be k x dim = ? x {self.dim}, got {c.shape}")
+        if a is not None and a.size != len(self):
+            raise L.VdbError(f"ivf_attach: assign holds {a.size} entries, expected len = {len(self)}")
         L.check(self._lib.vdb_ivf_attach(self._h, c.shape[0], _ptr(c.ravel(), L.f32p), _ptr(a, L.u64p)))
 
     def ivf_clear(self):

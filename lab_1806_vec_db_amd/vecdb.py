@@ -17,6 +17,7 @@ Semantics reproduced from src/database/metadata_vec_table.rs:
 from __future__ import annotations
 
 import threading
+from contextlib import contextmanager
 
 import numpy as np
 
@@ -26,11 +27,54 @@ from .index import GpuIndex, parse_dist
 _DIST_STR = {0: "l2sqr", 1: "cosine"}
 
 
+class _RwLock:
+    """Reader/writer exclusion of one table: the reference wraps every table in an RwLock -- read guard in search /
+    extract_data / len (database/mod.rs:248-256), write guard in add / delete / build_* / clear_* (thread_save.rs:108-113).
+    The library's read-side calls are re-entrant on one handle, its write-side calls reallocate HBM buffers under running
+    kernels, so a search must never overlap a write on the same table.  Writers are preferred (a waiting writer holds
+    back new readers), like std's RwLock on Linux."""
+
+    def __init__(self):
+        self._cv = threading.Condition(threading.Lock())
+        self._readers = 0
+        self._writer = False
+        self._writers_waiting = 0
+
+    @contextmanager
+    def read(self):
+        with self._cv:
+            while self._writer or self._writers_waiting:
+                self._cv.wait()
+            self._readers += 1
+        try:
+            yield
+        finally:
+            with self._cv:
+                self._readers -= 1
+                if self._readers == 0:
+                    self._cv.notify_all()
+
+    @contextmanager
+    def write(self):
+        with self._cv:
+            self._writers_waiting += 1
+            while self._writer or self._readers:
+                self._cv.wait()
+            self._writers_waiting -= 1
+            self._writer = True
+        try:
+            yield
+        finally:
+            with self._cv:
+                self._writer = False
+                self._cv.notify_all()
+
+
 class _Table:
     def __init__(self, dim: int, dist: str, device: int):
         self.index = GpuIndex(dim, dist, device)
         self.metadata: list[dict[str, str]] = []
-        self.lock = threading.RLock()  # writers exclusive (thread_save.rs:108-113); reads are re-entrant in the library
+        self.lock = _RwLock()
         self.seed = 0x1806
 
     def next_seed(self) -> int:
@@ -61,7 +105,9 @@ class VecDB:
             raise RuntimeError(f"Table {key} not found") from None
 
     def get_len(self, key: str) -> int:
-        return len(self._t(key).index)
+        t = self._t(key)
+        with t.lock.read():
+            return len(t.index)
 
     def get_dim(self, key: str) -> int:
         return self._t(key).index.dim
@@ -74,7 +120,8 @@ class VecDB:
             t = self._tables.pop(key, None)
         if t is None:
             return False
-        t.index.close()
+        with t.lock.write():  # wait for searches still running on the table
+            t.index.close()
         return True
 
     def get_all_keys(self) -> list[str]:
@@ -106,14 +153,14 @@ class VecDB:
             raise RuntimeError(f"Dimension mismatch: table dim {t.index.dim}, got {rows.shape}")
         if len(metadata_list) != rows.shape[0]:
             raise RuntimeError("vec_list and metadata_list differ in length")
-        with t.lock:
+        with t.lock.write():
             t.index.pq_clear()  # metadata_vec_table.rs:65,77
             t.metadata.extend(dict(m) for m in metadata_list)
             t.index.batch_add(rows)
 
     def delete(self, key: str, pattern: dict[str, str]) -> int:
         t = self._t(key)
-        with t.lock:
+        with t.lock.write():
             t.index.hnsw_clear()  # :170
             t.index.pq_clear()    # :171
             matches = [i for i, m in enumerate(t.metadata) if all(m.get(k) == v for k, v in pattern.items())]
@@ -126,7 +173,7 @@ class VecDB:
 
     def build_hnsw_index(self, key: str, ef_construction: int | None = None) -> None:
         t = self._t(key)
-        with t.lock:
+        with t.lock.write():
             if t.index.has_hnsw():
                 return
             t.index.hnsw_build(M=16, ef_construction=200 if ef_construction is None else ef_construction,
@@ -134,16 +181,18 @@ class VecDB:
 
     def clear_hnsw_index(self, key: str) -> None:
         t = self._t(key)
-        with t.lock:
+        with t.lock.write():
             t.index.hnsw_clear()
 
     def has_hnsw_index(self, key: str) -> bool:
-        return self._t(key).index.has_hnsw()
+        t = self._t(key)
+        with t.lock.read():
+            return t.index.has_hnsw()
 
     def build_pq_table(self, key: str, train_proportion: float | None = None, n_bits: int | None = None,
                        m: int | None = None) -> None:
         t = self._t(key)
-        with t.lock:
+        with t.lock.write():
             if t.index.has_pq():
                 return
             n = len(t.index)
@@ -165,29 +214,33 @@ class VecDB:
 
     def clear_pq_table(self, key: str) -> None:
         t = self._t(key)
-        with t.lock:
+        with t.lock.write():
             t.index.pq_clear()
 
     def has_pq_table(self, key: str) -> bool:
-        return self._t(key).index.has_pq()
+        t = self._t(key)
+        with t.lock.read():
+            return t.index.has_pq()
 
     # ---- reads ------------------------------------------------------------------------------------------------
     def search(self, key: str, query, k: int, ef: int | None = None, upper_bound: float | None = None):
         t = self._t(key)
         ix = t.index
         q = np.asarray(query, dtype=np.float32).ravel()
-        if ef is not None and ix.has_pq():
-            idx, dist = ix.knn_pq(q, k, ef)
-        elif ef is not None:
-            idx, dist = ix.knn_with_ef(q, k, ef)
-        else:
-            idx, dist = ix.knn(q, k)
-        ub = np.float32(np.inf) if upper_bound is None else np.float32(upper_bound)
-        return [(dict(t.metadata[int(i)]), float(d)) for i, d in zip(idx, dist) if d <= ub]
+        with t.lock.read():  # database/mod.rs:255: read guard for the whole search, metadata lookup included
+            if ef is not None and ix.has_pq():
+                idx, dist = ix.knn_pq(q, k, ef)
+            elif ef is not None:
+                idx, dist = ix.knn_with_ef(q, k, ef)
+            else:
+                idx, dist = ix.knn(q, k)
+            ub = np.float32(np.inf) if upper_bound is None else np.float32(upper_bound)
+            return [(dict(t.metadata[int(i)]), float(d)) for i, d in zip(idx, dist) if d <= ub]
 
     def extract_data(self, key: str):
         t = self._t(key)
-        return [(t.index[i].tolist(), dict(t.metadata[i])) for i in range(len(t.index))]
+        with t.lock.read():
+            return [(t.index[i].tolist(), dict(t.metadata[i])) for i in range(len(t.index))]
 
 
 __all__ = ["VecDB", "VdbError"]

@@ -45,3 +45,52 @@ def test_concurrent_readers_same_results():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_vecdb_search_interleaved_with_writes():
+    """VecDB holds a reader/writer lock per table like the reference's RwLock (read guard in search, database/mod.rs:255;
+    write guard in add / delete, thread_save.rs:108-113): searches running while another thread adds and deletes rows must
+    neither fault (the writes reallocate HBM buffers) nor see metadata and rows out of step."""
+    import lab_1806_vec_db_amd as vdb
+
+    rng = np.random.default_rng(3)
+    db = vdb.VecDB("")
+    db.create_table_if_not_exists("t", 32, "l2sqr")
+    fixed = rng.standard_normal((64, 32)).astype(np.float32)
+    db.batch_add("t", fixed, [{"kind": "fixed", "id": str(i)} for i in range(64)])
+    stop = threading.Event()
+    errors = []
+
+    def reader(seed):
+        r = np.random.default_rng(seed)
+        try:
+            while not stop.is_set():
+                j = int(r.integers(0, 64))
+                hits = db.search("t", fixed[j], 1)
+                # the fixed rows are never deleted: their nearest neighbour is themselves at distance 0
+                assert len(hits) == 1 and hits[0][1] == 0.0 and hits[0][0] == {"kind": "fixed", "id": str(j)}, hits
+                assert db.get_len("t") >= 64
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def writer():
+        try:
+            for it in range(30):
+                extra = (rng.standard_normal((500, 32)) * 3 + 50).astype(np.float32)  # grows d_rows past its capacity
+                db.batch_add("t", extra, [{"kind": "tmp"}] * 500)
+                if it % 3 == 2:
+                    assert db.delete("t", {"kind": "tmp"}) == 1500
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    rs = [threading.Thread(target=reader, args=(100 + i,)) for i in range(3)]
+    w = threading.Thread(target=writer)
+    for t in rs:
+        t.start()
+    w.start()
+    w.join()
+    stop.set()
+    for t in rs:
+        t.join()
+    assert not errors, errors
+    assert db.get_len("t") == 64

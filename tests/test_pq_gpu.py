@@ -188,3 +188,58 @@ def test_gistlike_knn_pq_large(mods):
     for q in range(qs.shape[0]):
         oi, od = O.flat_knn_pq(base, opq, qs[q], 10, 128)
         assert idx[q].tolist() == oi.tolist() and np.array_equal(d[q], od)
+
+
+def test_add_after_pq_build_clears_table(mods):
+    """MetadataVecTable::add / batch_add clear the PQ table first (metadata_vec_table.rs:65,77): at the index level an
+    add after pq_build must drop the codes, so that knn_pq reports "needs a PQ table" instead of scanning code rows that
+    do not exist (device out-of-bounds read before this rule was enforced in the library)."""
+    vdb, O = mods
+    base = gist_like(3000, dim=64, seed=11)
+    ix = vdb.GpuIndex(64, "l2sqr")
+    ix.batch_add(base[:2000])
+    ix.pq_build(n_bits=4, m=16, train_n=500, max_iter=3, seed=1)
+    assert ix.has_pq()
+    ix.batch_add(base[2000:])
+    assert len(ix) == 3000 and not ix.has_pq()
+    with pytest.raises(vdb.VdbError):
+        ix.knn_pq(base[0], 5, 32)
+    with pytest.raises(vdb.VdbError):
+        ix.knn_pq_shard(base[:2], 5, 32)
+    # rebuilt table covers all rows again and matches the oracle
+    ix.pq_build(n_bits=4, m=16, train_n=500, max_iter=3, seed=1)
+    pq, opq = _oracle_pq(O, ix, base, 0)
+    assert pq["codes"].shape[0] == 3000 and np.array_equal(pq["codes"], opq.codes)
+    gi, gd = ix.knn_pq(base[7], 5, 32)
+    oi, od = O.flat_knn_pq(base, opq, base[7], 5, 32, 0)
+    assert gi.tolist() == oi.tolist() and np.array_equal(gd, od)
+
+
+def test_attach_rejects_wrong_sizes(mods):
+    """the wrappers check array sizes before the C side copies n * enc_dim / (1 << n_bits) * dim elements"""
+    vdb, O = mods
+    base = gist_like(200, dim=32, seed=12)
+    ix = vdb.GpuIndex(32, "l2sqr")
+    ix.batch_add(base)
+    cent = np.zeros(16 * 32, dtype=np.float32)
+    with pytest.raises(vdb.VdbError):
+        ix.pq_attach(4, 8, cent[:-1])
+    with pytest.raises(vdb.VdbError):
+        ix.pq_attach(4, 8, cent, np.zeros((199, 4), dtype=np.uint8))
+    with pytest.raises(vdb.VdbError):
+        ix.pq_attach(5, 8, cent)
+    with pytest.raises(vdb.VdbError):
+        ix.ivf_attach(np.zeros((4, 31), dtype=np.float32))
+    with pytest.raises(vdb.VdbError):
+        ix.ivf_attach(np.zeros((4, 32), dtype=np.float32), np.zeros(199, dtype=np.uint64))
+    ix.hnsw_build(M=4, ef_construction=16, seed=1)
+    g = ix.hnsw_export()
+    bad = dict(g)
+    bad["level0"] = g["level0"][:-1]
+    with pytest.raises(vdb.VdbError):
+        ix.hnsw_attach(4, 16, bad)
+    bad = dict(g)
+    bad["upper_len"] = np.concatenate([g["upper_len"], [0]]).astype(np.uint64)
+    with pytest.raises(vdb.VdbError):
+        ix.hnsw_attach(4, 16, bad)
+    ix.hnsw_attach(4, 16, g)  # the untouched export still attaches
