@@ -4,7 +4,7 @@
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
 torch.distributed.run, one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json configs[1] / configs[4]): corpus N=1,000,000 x 960 f32, L2Sqr, k=10, one step = one
+Headline workload (BASELINE.json configs[1] / configs[4]): corpus N=1,000,000 x 960 f32, L2Sqr, k=10, one step = one
 batch of nq=1000 queries (the size of data/gist_test.bin) through FlatIndex::knn semantics.  Gist1M is not
 available offline, so rows are synthetic gist-shaped (per-dimension mean/std of data/gist_1000.bin,
 |N(mu,sigma)| clipped to [0,0.8], 4 decimals), generated on the GPU from a fixed seed; queries likewise.
@@ -13,9 +13,21 @@ all-gather of [nq,k], exact merge by (distance, index) on every rank.
 
 Timed region: queries and corpus already resident in HBM; K steps between barrier+synchronize pairs; the
 maximum over ranks is reported.  `roofline` is computed from HIP-event timings of the dominant kernel
-(flat_mfma) taken inside the library on its own stream during the timed steps.  `cpu_baseline` is the CPU
+taken inside the library on its own stream during the timed steps.  `cpu_baseline` is the CPU
 oracle (a C restatement of the reference's Rust path, kind "port") timed on rank 0 at N=1 on a bounded
 query sample of the same corpus, and doubles as a parity check of the GPU results.
+
+At N=1 (default flags) the same run also reports, under "legs", every other item SURVEY.md 8(d) asks for:
+  flat_f32_operands  the same 1000-query step with the fp16 first pass switched off: the split-bf16 kernel streams the
+                     4-B/element rows mirror, so ITS roofline is on N*d*4 bytes per corpus pass -- the figure the
+                     ">= 70 % of HBM roofline" target is defined on
+  flat_B32, flat_B1  calls of 32 queries (SURVEY 8d's headline batch) and of 1 query
+  config1_gist_1000  BASELINE config 1: the reference's own data/gist_1000.bin x data/gist_test.bin, Flat, L2Sqr, k=10,
+                     GPU beside the CPU oracle serial and on all cores (protocol of examples/bench.rs:403-433)
+  pq_flat            PQ-Flat ADC (4-bit, m=320, ef=100) on a 1M low-rank gist-like corpus
+  hnsw               HNSW (M=16, efc=200, ef=128) on the first --hnsw-rows rows of that corpus (host build time bounds it)
+each with its own roofline / cpu_baseline / parity, plus `attainable_peak_GBps` from a streaming-read probe in this run.
+`--legs none` prints the headline only (what N>1 runs always do).
 """
 from __future__ import annotations
 
@@ -73,6 +85,59 @@ def gist_lowrank_gpu(torch, n, dim, seed, device, latent=32, chunk=131072):
     return out
 
 
+def hbm_roofline(kernel, p, extra=None):
+    """roofline object of one library kernel from its HIP-event record (vdb_prof_get): bytes and ms are sums over the
+    launches of the timed region; `traffic` (PMC HBM bytes) cannot be collected inside a bench run and stays null --
+    the rocprofv3 --pmc summaries of the same command are under profiles/."""
+    if not p["launches"]:
+        return None
+    avg_ms = p["ms"] / p["launches"]
+    bpl = p["bytes"] / p["launches"]
+    achieved = bpl / (avg_ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
+         "avg_launch_ms": round(avg_ms, 4), "launches": p["launches"], "bytes_per_launch": bpl}
+    if extra:
+        r.update(extra)
+    return r
+
+
+def flat_kernel_of(ix):
+    """dominant kernel of the Flat steps just timed: the fp16 first pass (k_flat_gemm<GEMM_F16>) when it ran, else the
+    split-bf16 pass (k_flat_gemm<GEMM_BF16X3> / k_flat_mfma), else the exact scan"""
+    return next((kn for kn in ("flat_half", "flat_mfma") if ix.prof_get(kn)["launches"]), "flat_exact")
+
+
+def flat_roofline(ix, rows, dim, nq):
+    """Flat roofline per SURVEY 8(d): algorithmic bytes of one corpus pass = rows*dim*4 (the f32 VecSet the reference
+    scans).  The split-bf16 and exact kernels read exactly that; the fp16 first pass reads a 2-B/element mirror, so for
+    it `achieved`/`frac` are quoted on the operand bytes the kernel really streams (named in `frac_of`), and the 8(d)
+    figure -- the f32-equivalent rate, which exceeds the HBM peak because half the bytes are never read -- is given next
+    to it as `achieved_8d` / `frac_8d`."""
+    kernel = flat_kernel_of(ix)
+    p = ix.prof_get(kernel)
+    if not p["launches"]:
+        return None
+    elem = 2 if kernel == "flat_half" else 4
+    bpl = p["bytes"] / p["launches"]
+    passes = round(bpl / (rows * dim * elem))
+    qpp = 128 if (nq > 64 or kernel == "flat_half") else 64  # the rule of Index::flat_knn_device
+    if kernel == "flat_exact":
+        qpp = 8
+    avg_s = p["ms"] / p["launches"] * 1e-3
+    alg = passes * rows * dim * 4
+    extra = {"units_per_launch": f"{passes} corpus passes x {rows} rows x {dim} x {elem} B; one pass serves up to {qpp} queries",
+             "algorithmic_bytes": alg,
+             "algorithmic_bytes_def": "SURVEY 8(d): corpus passes x N x d x 4 B (f32 rows)",
+             "achieved_8d": round(alg / avg_s / 1e9, 1), "frac_8d": round(alg / avg_s / 1e9 / HBM_PEAK_GBS, 4)}
+    if kernel == "flat_half":
+        extra["frac_of"] = "operand bytes: the scaled fp16 mirror of the rows (2 B/element) the first pass streams; exact f32 re-rank + certification downstream"
+        extra["operand_bytes"] = bpl
+    else:
+        extra["frac_of"] = "SURVEY 8(d) algorithmic bytes (the kernel streams 4 B/element)"
+    return hbm_roofline(kernel, p, extra)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +161,12 @@ def main():
     ap.add_argument("--half", type=int, default=0, help="flat: fp16 first pass of large query batches: 0 auto, 1 off, 2 forced")
     ap.add_argument("--half-kmul", type=int, default=0, help="flat: shortlist of the fp16 pass = max(64, kmul*k) (0: library default)")
     ap.add_argument("--dump", type=str, default="", help="rank 0 saves the last step's results to this .npz (tests)")
+    ap.add_argument("--legs", choices=["auto", "all", "none"], default="auto",
+                    help="the SURVEY 8(d) report items beside the headline (N=1, flat): auto = all when the headline runs at its "
+                         "default size, none = headline only")
+    ap.add_argument("--hnsw-rows", type=int, default=500_000,
+                    help="rows of the hnsw leg: the host build (hnsw_index.rs:391-457 batches) takes ~100 s for 500k and ~210 s for "
+                         "1M rows on 16 cores; the default keeps the whole run inside the driver's limit")
     args = ap.parse_args()
 
     import torch
@@ -125,10 +196,20 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     wl = args.workload
+    default_size = args.rows <= 0 and args.dim == 960 and args.nq == 1000
     if args.rows <= 0:
         args.rows = 1_000_000  # hnsw: the host builder (hnsw_index.rs:391-457 batches) takes ~3-4 min for this graph
+    legs_on = world == 1 and wl == "flat" and (args.legs == "all" or (args.legs == "auto" and default_size))
     ef = args.ef or {"pq_flat": 100, "hnsw": 128, "hnsw_pq": 128, "ivf": 4}.get(wl, 0)
     n, dim, nq, k = args.rows, args.dim, args.nq, args.k
+    threads = min(len(os.sched_getaffinity(0)), 16)  # the GPU box's CPU share for one GPU
+
+    attainable = None
+    if rank == 0 and world == 1:
+        from lab_1806_vec_db_amd.index import stream_probe
+
+        attainable = round(stream_probe(local_rank, 3_840_000_000, 5), 1)  # before the corpus exists: 3.84 GB of its own
+
     # identical corpus on every rank (same seed), each keeps its row block
     gen = gist_like_gpu if args.data == "gistlike" else gist_lowrank_gpu
     base = gen(torch, n, dim, 1806, device)
@@ -148,6 +229,7 @@ def main():
     host_base = None
     if rank == 0 and world == 1 and args.cpu_queries > 0:
         host_base = base.cpu().numpy()
+    build_s = 0.0
     if wl in ("pq_flat", "hnsw_pq"):
         # config/bench_pq_hnsw.toml:16-23: n_bits 4, m = dim/3, k_means_size 10000, max_iter 20, tol 1e-6.  Every rank
         # trains on the same first 10000 rows (same seed) -> identical centroids; codes are encoded per shard on the GPU.
@@ -165,7 +247,7 @@ def main():
         build_s = time.perf_counter() - t_b
     if wl in ("hnsw", "hnsw_pq"):
         t_b = time.perf_counter()
-        ix.hnsw_build(M=16, ef_construction=200, seed=42, batch=64, nthreads=min(len(os.sched_getaffinity(0)), 16))
+        ix.hnsw_build(M=16, ef_construction=200, seed=42, batch=64, nthreads=threads)
         build_s = time.perf_counter() - t_b
     del base, shard
     torch.cuda.empty_cache()
@@ -213,68 +295,38 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        res = step()
-    ix.prof_enable(True)
-    ix.prof_reset()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    ix.prof_enable(False)
+    def timed(index, fn, steps, warmup):
+        """W untimed + EXACTLY `steps` timed calls of fn between fences; the library's HIP-event records cover the timed calls"""
+        r = None
+        for _ in range(warmup):
+            r = fn()
+        index.prof_enable(True)
+        index.prof_reset()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = fn()
+        fence()
+        el = time.perf_counter() - t0
+        index.prof_enable(False)
+        return el, r
+
+    elapsed, res = timed(ix, step, args.steps, args.warmup)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if wl == "flat":
-        # dominant kernel: the fp16 first pass (k_flat_gemm<GEMM_F16>, calls with more than 64 queries) when it ran, else
-        # the split-bf16 pass, else the exact scan
-        kernel = next((kn for kn in ("flat_half", "flat_mfma") if ix.prof_get(kn)["launches"]), "flat_exact")
+        roofline = flat_roofline(ix, r1 - r0, dim, nq)
     else:
+        # pq_adc: code bytes of one scan = rows x ceil(m*n_bits/8), one scan serves the queries whose LUTs sit side by side
+        # in LDS; hnsw: n_dist x (dim*4 + 4) + n_expanded x max_m0*4 counted by the kernel (SURVEY 8d)
         kernel = {"pq_flat": "pq_adc", "hnsw": "hnsw", "hnsw_pq": "hnsw", "ivf": "ivf_rerank"}[wl]
-    p = ix.prof_get(kernel)
-    roofline = None
-    if p["launches"] and wl != "flat":
-        # pq_adc: code bytes of one scan = rows x ceil(m*n_bits/8), one scan serves 4 queries (LUTs side by side in
-        # LDS); hnsw: n_dist x (dim*4 + 4) + n_expanded x max_m0*4 counted by the kernel
-        avg_ms = p["ms"] / p["launches"]
-        bytes_per_launch = p["bytes"] / p["launches"]
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel,
-                    "avg_launch_ms": round(avg_ms, 4), "launches": p["launches"], "bytes_per_launch": bytes_per_launch}
-    elif p["launches"]:
-        avg_ms = p["ms"] / p["launches"]
-        # bytes the kernel has to stream: passes x shard_rows x dim x 4 for the split-bf16 / exact kernels;
-        # the fp16 first pass reads a 2-byte mirror, so ITS operand bytes are half of that -- the roofline fraction is
-        # quoted on the bytes really needed, the f32-equivalent rate is reported next to it
-        elem = 2 if kernel == "flat_half" else 4
-        bytes_per_launch = p["bytes"] / p["launches"]
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        # queries one corpus pass serves: 128 (k_flat_gemm) when a call carries more than 64 queries, else 2 x 32
-        # (k_flat_mfma, XCD-shared passes) -- the rule of Index::flat_knn_device
-        qpp = 128 if (nq > 64 or kernel == "flat_half") else 64
-        traffic = None  # HBM bytes per launch from the committed PMC passes (same kernel, same shard size only)
-        try:
-            pmc_name = "pmc_flat_half.json" if kernel == "flat_half" else ("pmc_flat_gemm.json" if qpp == 128 else "pmc_flat_mfma.json")
-            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
-            passes = round(bytes_per_launch / pmc["algorithmic_bytes_per_pass"])  # HBM passes in one launch
-            if kernel in ("flat_mfma", "flat_half") and abs(pmc["algorithmic_bytes_per_pass"] * passes - bytes_per_launch) < 1:
-                traffic = pmc["hbm_bytes_per_pass"] * passes
-        except (OSError, KeyError, ValueError):
-            pass
-        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel,
-                    "avg_launch_ms": round(avg_ms, 4), "launches": p["launches"],
-                    "bytes_per_launch": bytes_per_launch,
-                    "units_per_launch": f"{round(bytes_per_launch / ((r1 - r0) * dim * elem))} corpus passes x {r1 - r0} rows "
-                                        f"x {dim} x {elem} B; one pass serves {qpp} queries"}
-        if kernel == "flat_half":
-            roofline["operand"] = "scaled fp16 mirror of the rows (2 B/element); exact f32 re-rank + certification downstream"
-            roofline["f32_equivalent_GBps"] = round(2 * achieved, 1)
+        roofline = hbm_roofline(kernel, ix.prof_get(kernel))
+    if roofline and attainable:
+        roofline["attainable_peak_GBps"] = attainable
+        roofline["frac_of_attainable"] = round(roofline["achieved"] / attainable, 4)
 
     if rank != 0:
         if world > 1:
@@ -305,6 +357,7 @@ def main():
         out["config"]["queries_per_corpus_pass"] = 128 if (nq > 64 or (roofline or {}).get("kernel") == "flat_half") else 64
         out["fallback_queries"] = ix.flat_fallback_count()
         out["half_pass"] = {"queries": ix.get_stat("flat_half_queries"), "redone_split_bf16": ix.get_stat("flat_half_redo")}
+        out["hbm_bytes_per_row"] = ix.get_stat("hbm_bytes_per_row")
     else:
         out["config"]["ef"] = ef
     if wl == "ivf":
@@ -315,78 +368,242 @@ def main():
         out["hnsw_work_per_query"] = {"n_dist": round(nd / max(q1 - q0, 1), 1), "n_expanded": round(ne / max(q1 - q0, 1), 1)}
 
     # ---- CPU baseline + parity (rank 0, N=1 only) ------------------------------------------------------
+    O = None
     if host_base is not None:
-        from concurrent.futures import ThreadPoolExecutor
-
         from oracle import oracle as O
 
         O.build()
         okind = O.L2SQR if args.dist == "l2sqr" else O.COSINE
-        ncpu = min(args.cpu_queries, nq)
-        threads = min(len(os.sched_getaffinity(0)), 16)  # the GPU box's CPU share for one GPU
-        hq = queries[:ncpu].cpu().numpy()
-        gi = res[0][:ncpu].cpu().numpy().astype(np.uint64)
-        gd = res[1][:ncpu].cpu().numpy()
-        if wl == "flat":
-            t0 = time.perf_counter()
-            ci, cd, cc = O.flat_knn_batch(host_base, hq, k, okind, nthreads=threads)
-            cpu_s = time.perf_counter() - t0
-            truth = ci
-            what = "FlatIndex::knn"
-        else:
+        gt = None
+        if wl != "flat":
             # recall is against Flat ground truth (gen_gnd.rs:54-72), taken from the GPU Flat path of the same index
             t_idx = torch.zeros((nq, k), dtype=torch.int64, device=device)
             t_dist = torch.zeros((nq, k), dtype=torch.float32, device=device)
             t_cnt = torch.zeros((nq,), dtype=torch.int64, device=device)
             ix.flat_knn_device(queries.data_ptr(), nq, k, t_idx.data_ptr(), t_dist.data_ptr(), t_cnt.data_ptr())
-            truth = t_idx[:ncpu].cpu().numpy().astype(np.uint64)
-            if wl == "pq_flat":
-                pq = ix.pq_export()
-                opq = O.PQ.from_centroids(dim, pq["m"], pq["n_bits"], okind, pq["centroids"])
-                opq.set_codes(pq["codes"])  # GPU-encoded codes (bit-equal to the oracle's encoder, tests/test_pq_gpu.py)
-                t0 = time.perf_counter()
-                with ThreadPoolExecutor(threads) as pool:  # ctypes releases the GIL: one query per thread
-                    r = list(pool.map(lambda q: O.flat_knn_pq(host_base, opq, hq[q], k, ef, okind), range(ncpu)))
-                cpu_s = time.perf_counter() - t0
-                what = "FlatIndex::knn_pq"
-            elif wl == "ivf":
-                ex_ivf = ix.ivf_export()  # centroids and clusters are inputs of the oracle (assignment parity: tests/test_ivf_gpu.py)
-                oiv = O.IVF(host_base, ex_ivf["centroids"], okind, assign=ex_ivf["assign"])
-                t0 = time.perf_counter()
-                with ThreadPoolExecutor(threads) as pool:
-                    r = list(pool.map(lambda q: oiv.knn(hq[q], k, ef), range(ncpu)))
-                cpu_s = time.perf_counter() - t0
-                what = "IVFIndex::knn_with_ef on the same centroids and clusters"
-            elif wl == "hnsw_pq":
-                pq = ix.pq_export()
-                opq = O.PQ.from_centroids(dim, pq["m"], pq["n_bits"], okind, pq["centroids"])
-                opq.set_codes(pq["codes"])
-                oh = O.HNSW.from_graph(host_base, okind, 16, 200, ix.hnsw_export())
-                t0 = time.perf_counter()
-                with ThreadPoolExecutor(threads) as pool:
-                    r = list(pool.map(lambda q: oh.knn_pq(opq, hq[q], k, ef), range(ncpu)))
-                cpu_s = time.perf_counter() - t0
-                what = "HNSWIndex::knn_pq on the same graph and PQ table"
-            else:
-                oh = O.HNSW.from_graph(host_base, okind, 16, 200, ix.hnsw_export())
-                t0 = time.perf_counter()
-                with ThreadPoolExecutor(threads) as pool:
-                    r = list(pool.map(lambda q: oh.knn(hq[q], k, ef), range(ncpu)))
-                cpu_s = time.perf_counter() - t0
-                what = "HNSWIndex::knn_with_ef on the same graph"
-            ci = np.stack([np.pad(x[0], (0, k - len(x[0]))) for x in r]).astype(np.uint64)
-            cd = np.stack([np.pad(x[1], (0, k - len(x[1]))) for x in r]).astype(np.float32)
-        idx_equal = bool(np.array_equal(gi, ci))
-        dist_equal = bool(np.array_equal(gd, cd))
-        out["recall_at_10"] = float(np.mean([O.recall(truth[q], gi[q]) for q in range(ncpu)]))
-        out["parity"] = {"queries_checked": ncpu, "indices_identical": idx_equal, "distances_bit_exact": dist_equal}
-        out["cpu_baseline"] = {"value": round(ncpu / cpu_s, 2), "unit": "queries/s", "cores": threads,
-                               "kind": "port",
-                               "sample": f"{what}: {ncpu} of the {nq} queries against the full {n}x{dim} corpus, "
-                                         f"one query per thread (mirrors rayon par_iter, examples/bench.rs:414-416)"}
+            gt = t_idx.cpu().numpy().astype(np.uint64)
+        out.update(cpu_and_parity(O, wl, ix, host_base, queries, res, gt, min(args.cpu_queries, nq), k, ef, okind, threads, n, dim, nq))
+
+    if legs_on:
+        legs = {}
+        outs = (o_idx, o_dist, o_cnt)
+        legs["flat_f32_operands"] = leg_flat_f32(ix, timed, queries, nq, k, outs, args, n, dim, res, attainable)
+        for b in (32, 1):
+            legs[f"flat_B{b}"] = leg_flat_small(ix, timed, queries, b, k, outs, args, n, dim, res, attainable)
+        ix.close()
+        del ix
+        torch.cuda.empty_cache()
+        legs["config1_gist_1000"] = leg_config1(vdb, O, torch, device, local_rank, threads, k)
+        del host_base
+        legs.update(legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable))
+        out["legs"] = legs
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def cpu_and_parity(O, wl, ix, host_base, queries, res, gt, ncpu, k, ef, okind, threads, n, dim, nq):
+    """the CPU oracle on `ncpu` of the queries, one query per thread (mirrors rayon par_iter, examples/bench.rs:414-416),
+    timed; its answers are the parity reference of the GPU results `res`; recall@10 against `gt` (Flat ground truth; None:
+    the oracle's Flat answers themselves)"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    hq = queries[:ncpu].cpu().numpy()
+    gi = res[0][:ncpu].cpu().numpy().astype(np.uint64)
+    gd = res[1][:ncpu].cpu().numpy()
+    if wl == "flat":
+        t0 = time.perf_counter()
+        ci, cd, cc = O.flat_knn_batch(host_base, hq, k, okind, nthreads=threads)
+        cpu_s = time.perf_counter() - t0
+        truth = ci
+        what = "FlatIndex::knn"
+    else:
+        truth = gt[:ncpu]
+        if wl == "pq_flat":
+            pq = ix.pq_export()
+            opq = O.PQ.from_centroids(dim, pq["m"], pq["n_bits"], okind, pq["centroids"])
+            opq.set_codes(pq["codes"])  # GPU-encoded codes (bit-equal to the oracle's encoder, tests/test_pq_gpu.py)
+            fn = lambda q: O.flat_knn_pq(host_base, opq, hq[q], k, ef, okind)  # noqa: E731
+            what = "FlatIndex::knn_pq"
+        elif wl == "ivf":
+            ex_ivf = ix.ivf_export()  # centroids and clusters are inputs of the oracle (assignment parity: tests/test_ivf_gpu.py)
+            oiv = O.IVF(host_base, ex_ivf["centroids"], okind, assign=ex_ivf["assign"])
+            fn = lambda q: oiv.knn(hq[q], k, ef)  # noqa: E731
+            what = "IVFIndex::knn_with_ef on the same centroids and clusters"
+        elif wl == "hnsw_pq":
+            pq = ix.pq_export()
+            opq = O.PQ.from_centroids(dim, pq["m"], pq["n_bits"], okind, pq["centroids"])
+            opq.set_codes(pq["codes"])
+            oh = O.HNSW.from_graph(host_base, okind, 16, 200, ix.hnsw_export())
+            fn = lambda q: oh.knn_pq(opq, hq[q], k, ef)  # noqa: E731
+            what = "HNSWIndex::knn_pq on the same graph and PQ table"
+        else:
+            oh = O.HNSW.from_graph(host_base, okind, 16, 200, ix.hnsw_export())
+            fn = lambda q: oh.knn(hq[q], k, ef)  # noqa: E731
+            what = "HNSWIndex::knn_with_ef on the same graph"
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as pool:  # ctypes releases the GIL: one query per thread
+            r = list(pool.map(fn, range(ncpu)))
+        cpu_s = time.perf_counter() - t0
+        ci = np.stack([np.pad(x[0], (0, k - len(x[0]))) for x in r]).astype(np.uint64)
+        cd = np.stack([np.pad(x[1], (0, k - len(x[1]))) for x in r]).astype(np.float32)
+    return {
+        "recall_at_10": float(np.mean([O.recall(truth[q], gi[q]) for q in range(ncpu)])),
+        "parity": {"queries_checked": ncpu, "indices_identical": bool(np.array_equal(gi, ci)),
+                   "distances_bit_exact": bool(np.array_equal(gd, cd))},
+        "cpu_baseline": {"value": round(ncpu / cpu_s, 2), "unit": "queries/s", "cores": threads, "kind": "port",
+                         "sample": f"{what}: {ncpu} of the {nq} queries against the full {n}x{dim} corpus, "
+                                   f"one query per thread (mirrors rayon par_iter, examples/bench.rs:414-416)"}}
+
+
+def with_attainable(roofline, attainable):
+    if roofline and attainable:
+        roofline["attainable_peak_GBps"] = attainable
+        roofline["frac_of_attainable"] = round(roofline["achieved"] / attainable, 4)
+    return roofline
+
+
+def leg_flat_f32(ix, timed, queries, nq, k, outs, args, n, dim, ref, attainable):
+    """the headline step with the fp16 first pass off: every corpus pass streams the 4-B/element split-bf16 mirror, i.e.
+    SURVEY 8(d)'s N*d*4 algorithmic bytes; results must equal the headline's bit for bit"""
+    ref_idx, ref_dist = ref[0].clone(), ref[1].clone()
+    ix.set_param("flat_half", 1)
+    fn = lambda: ix.flat_knn_device(queries.data_ptr(), nq, k, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr())  # noqa: E731
+    el, _ = timed(ix, fn, args.steps, max(1, min(args.warmup, 2)))
+    r = with_attainable(flat_roofline(ix, n, dim, nq), attainable)
+    same = bool((outs[0] == ref_idx).all().item()) and bool((outs[1] == ref_dist).all().item())
+    ix.set_param("flat_half", args.half)
+    return {"value": round(nq * args.steps / el, 1), "unit": "queries/s", "steps": args.steps,
+            "ms_per_step": round(el / args.steps * 1e3, 3), "queries_per_step": nq, "queries_per_corpus_pass": 128,
+            "roofline": r, "results_equal_headline": same, "fallback_queries_total": ix.flat_fallback_count()}
+
+
+def leg_flat_small(ix, timed, queries, b, k, outs, args, n, dim, ref, attainable):
+    """calls of b queries (B=32 is the batch the HBM-bound roofline QPS = B*BW/(N*d*4) is quoted on; B=1 the
+    reference's own per-call semantics); the first b rows of the headline's results are the check"""
+    ref_idx, ref_dist = ref[0][:b].clone(), ref[1][:b].clone()
+    steps = max(args.steps, 20)
+    fn = lambda: ix.flat_knn_device(queries.data_ptr(), b, k, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr())  # noqa: E731
+    el, _ = timed(ix, fn, steps, 2)
+    r = with_attainable(flat_roofline(ix, n, dim, b), attainable)
+    same = bool((outs[0][:b] == ref_idx).all().item()) and bool((outs[1][:b] == ref_dist).all().item())
+    return {"value": round(b * steps / el, 1), "unit": "queries/s", "steps": steps, "ms_per_step": round(el / steps * 1e3, 4),
+            "queries_per_step": b, "roofline": r, "results_equal_headline": same,
+            "roofline_qps_8d": round(b * HBM_PEAK_GBS * 1e9 / (n * dim * 4), 1)}
+
+
+def leg_config1(vdb, O, torch, device, local_rank, threads, k):
+    """BASELINE config 1 (config/gist_1000.toml): the reference's own 1000 x 960 base and 1000 queries, Flat, L2Sqr, k=10.
+    Protocol of examples/bench.rs:403-433: wall time of the whole query loop / nq -- the CPU oracle serial and with one
+    query per thread on all cores; the GPU (i) the same loop, one vdb_flat_knn call per query with host pointers, and (ii)
+    the 1000 queries in ONE call.  Every GPU answer is compared with the oracle's."""
+    g = os.path.join(ROOT, "tests", "golden")
+    base = np.fromfile(os.path.join(g, "gist_1000.bin"), dtype=np.float32).reshape(1000, 960)
+    test = np.fromfile(os.path.join(g, "gist_test.bin"), dtype=np.float32).reshape(1000, 960)
+    nq = test.shape[0]
+    ix = vdb.GpuIndex(960, "l2sqr", device=local_rank)
+    ix.batch_add(base)
+    ix.flat_knn(test[:8], k)  # warm-up (workspace allocation)
+    t0 = time.perf_counter()
+    per = [ix.flat_knn(test[q], k) for q in range(nq)]
+    t_loop = time.perf_counter() - t0
+    ix.flat_knn(test, k)
+    t0 = time.perf_counter()
+    gi, gd, gc = ix.flat_knn(test, k)
+    t_batch = time.perf_counter() - t0
+    leg = {"data": "tests/golden/gist_1000.bin x gist_test.bin (the reference's data/ files, sha256 in SURVEY 8c)", "rows": 1000,
+           "dim": 960, "queries": nq, "k": k, "dist": "L2Sqr",
+           "gpu_per_query_calls": {"ms_per_query": round(t_loop / nq * 1e3, 4), "value": round(nq / t_loop, 1), "unit": "queries/s",
+                                   "note": "host pointers, one call per query (PCIe-inclusive), as bench.rs loops"},
+           "gpu_one_call": {"ms_per_query": round(t_batch / nq * 1e3, 5), "value": round(nq / t_batch, 1), "unit": "queries/s",
+                            "note": "host pointers, 1000 queries in one call (PCIe-inclusive)"}}
+    if O is not None:
+        t0 = time.perf_counter()
+        ci, cd, cc = O.flat_knn_batch(base, test, k, O.L2SQR, nthreads=1)
+        t_ser = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.flat_knn_batch(base, test, k, O.L2SQR, nthreads=threads)
+        t_par = time.perf_counter() - t0
+        loop_i = np.stack([p[0] for p in per]).astype(np.uint64)
+        loop_d = np.stack([p[1] for p in per])
+        leg["cpu_baseline"] = {"value": round(nq / t_par, 1), "unit": "queries/s", "cores": threads, "kind": "port",
+                               "sample": "FlatIndex::knn, all 1000 queries, one query per thread",
+                               "serial": {"value": round(nq / t_ser, 1), "ms_per_query": round(t_ser / nq * 1e3, 4), "cores": 1}}
+        leg["parity"] = {"queries_checked": nq,
+                         "indices_identical": bool(np.array_equal(gi.astype(np.uint64), ci) and np.array_equal(loop_i, ci)),
+                         "distances_bit_exact": bool(np.array_equal(gd, cd) and np.array_equal(loop_d, cd))}
+        leg["recall_at_10"] = float(np.mean([O.recall(ci[q], gi[q].astype(np.uint64)) for q in range(nq)]))
+    ix.close()
+    return leg
+
+
+def legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable):
+    """BASELINE configs 3 and 4 on ONE low-rank gist-like corpus (recall on per-dimension-Gaussian rows is uninformative:
+    0.2 for HNSW, 0.5 for PQ): PQ-Flat ADC on 1M rows, HNSW on the first --hnsw-rows of them."""
+    n, dim, nq, k = 1_000_000, 960, 1000, 10
+    legs = {}
+    base = gist_lowrank_gpu(torch, n, dim, 1806, device)
+    queries = gist_lowrank_gpu(torch, nq, dim, 1807, device)
+    o_idx = torch.zeros((nq, k), dtype=torch.int64, device=device)
+    o_dist = torch.zeros((nq, k), dtype=torch.float32, device=device)
+    o_cnt = torch.zeros((nq,), dtype=torch.int64, device=device)
+    t_idx = torch.zeros((nq, k), dtype=torch.int64, device=device)
+    ncpu = min(args.cpu_queries, nq)
+    okind = O.L2SQR if O is not None else 0
+
+    def run(ix, wl, rows, ef, fn, extra_cfg):
+        el, _ = timed(ix, fn, args.steps, max(1, min(args.warmup, 2)))
+        kernel = {"pq_flat": "pq_adc", "hnsw": "hnsw"}[wl]
+        leg = {"value": round(nq * args.steps / el, 1), "unit": "queries/s", "steps": args.steps,
+               "ms_per_step": round(el / args.steps * 1e3, 3), "data": "synthetic (low-rank gist-like)",
+               "config": dict({"rows": rows, "dim": dim, "queries_per_step": nq, "k": k, "dist": "L2Sqr", "ef": ef}, **extra_cfg),
+               "roofline": with_attainable(hbm_roofline(kernel, ix.prof_get(kernel)), attainable)}
+        if wl == "hnsw":
+            nd, ne = ix.hnsw_last_stats()
+            leg["hnsw_work_per_query"] = {"n_dist": round(nd / nq, 1), "n_expanded": round(ne / nq, 1)}
+            leg["roofline"]["units_per_launch"] = "n_dist x (dim*4 + 4) + n_expanded x max_m0*4 bytes, counted by the kernel (SURVEY 8d)"
+        else:
+            leg["roofline"]["units_per_launch"] = "rows x ceil(m*n_bits/8) code bytes per scan; one scan serves the queries whose LUTs share LDS"
+        if O is not None and ncpu > 0:
+            ix.flat_knn_device(queries.data_ptr(), nq, k, t_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr())  # Flat ground truth
+            gt = t_idx.cpu().numpy().astype(np.uint64)
+            fn()
+            hb = base[:rows].cpu().numpy()
+            leg.update(cpu_and_parity(O, wl, ix, hb, queries, (o_idx, o_dist, o_cnt), gt, ncpu, k, ef, okind, threads, rows, dim, nq))
+            del hb
+        return leg
+
+    # -- PQ-Flat: config/bench_pq_hnsw.toml:16-23 (n_bits 4, m = dim/3, k_means_size 10000, max_iter 20, tol 1e-6), ef = 100
+    ix = vdb.GpuIndex(dim, "l2sqr", device=local_rank)
+    ix.add_device(base.data_ptr(), n)
+    tr = vdb.GpuIndex(dim, "l2sqr", device=local_rank)
+    tr.add_device(base.data_ptr(), 10000)
+    t_b = time.perf_counter()
+    tr.pq_build(n_bits=4, m=dim // 3, train_n=0, max_iter=20, tol=1e-6, seed=42)
+    cent = tr.pq_export()["centroids"]
+    tr.close()
+    ix.pq_attach(4, dim // 3, cent, None)
+    pq_build_s = time.perf_counter() - t_b
+    legs["pq_flat"] = run(ix, "pq_flat", n, 100,
+                          lambda: ix.knn_pq_device(queries.data_ptr(), nq, k, 100, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr()),
+                          {"workload": "pq_flat_knn_gist1m", "n_bits": 4, "m": dim // 3, "train_and_encode_s": round(pq_build_s, 1)})
+    ix.close()
+    del ix
+    torch.cuda.empty_cache()
+
+    # -- HNSW: config/bench_hnsw.toml:12-14 (M 16, ef_construction 200), search ef = 128
+    hr = max(1000, min(args.hnsw_rows, n))
+    ix = vdb.GpuIndex(dim, "l2sqr", device=local_rank)
+    ix.add_device(base.data_ptr(), hr)
+    t_b = time.perf_counter()
+    ix.hnsw_build(M=16, ef_construction=200, seed=42, batch=64, nthreads=threads)
+    hb_s = time.perf_counter() - t_b
+    legs["hnsw"] = run(ix, "hnsw", hr, 128,
+                       lambda: ix.hnsw_knn_device(queries.data_ptr(), nq, k, 128, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr()),
+                       {"workload": f"hnsw_knn_gistlike_{hr}", "M": 16, "ef_construction": 200, "host_build_s": round(hb_s, 1),
+                        "rows_note": "the host builder bounds the size a default run can afford (--hnsw-rows); 1M-row lines: profiles/"})
+    ix.close()
+    return legs
 
 
 if __name__ == "__main__":

@@ -114,7 +114,10 @@ int vdb_flat_fallback_count(const vdb_index *idx, uint64_t *out);
  *   "flat_fallback"      = vdb_flat_fallback_count,
  *   "flat_half_queries"  queries that went through the fp16 first pass,
  *   "flat_half_redo"     of those, the ones it could not certify (redone with the split-bf16 pass),
- *   "flat_half_valid"    1 when the index holds the fp16 mirror. */
+ *   "flat_half_valid"    1 when the index holds the fp16 mirror,
+ *   "flat_bf16_mirror"   1 once the split-bf16 mirror (4 B/element) has been built -- lazily, by the first search that
+ *                        needs it (redo tier, flat_half = 1, calls without an fp16 mirror),
+ *   "hbm_bytes_per_row"  resident HBM bytes per row over all per-row buffers (rows, norms, mirrors, PQ codes, level-0 links). */
 int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out);
 
 /* ---- PQTable (distance/pq_table.rs) ----------------------------------------------------
@@ -130,6 +133,13 @@ int vdb_pq_clear(vdb_index *idx);                 /* MetadataVecTable::clear_pq_
 int vdb_pq_has(const vdb_index *idx, int *out);
 int vdb_pq_info(const vdb_index *idx, uint64_t *n_bits, uint64_t *m, uint64_t *enc_dim);
 int vdb_pq_export(const vdb_index *idx, float *centroids, uint8_t *codes);
+/* PQTable::create_lookup (pq_table.rs:195-224) for nq queries, as the search kernels build it: out_lut [nq][m * k_c]
+ * row-major [group][centroid] (l2 of the query slice to the centroid for L2Sqr, their dot product for Cosine),
+ * out_qcache [nq] = PQLookupTable::dist_cache (0 for L2Sqr, |q| for Cosine).  Either output may be NULL. */
+int vdb_pq_create_lookup(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, float *out_lut, float *out_qcache);
+/* the ADC adapter DistanceAdapter<[u8], PQLookupTable> (pq_table.rs:239-301) of every code row: out [nq][len], the values
+ * the knn_pq scan ranks (strict group-order f32 sums; Cosine: 1 - sum / max(sqrt(sum cent_cache) * |q|, 1e-10)) */
+int vdb_pq_adc_all(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, float *out);
 /* FlatIndex::knn_pq (flat_index.rs:84-104) */
 int vdb_flat_knn_pq(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef,
                     uint64_t *out_idx, float *out_dist, uint64_t *out_count);
@@ -223,6 +233,9 @@ int vdb_pq_merge_resort_device(vdb_index *idx, const void *d_adc_keys, const voi
  * When enabled, the dominant kernels are bracketed by HIP events on their own stream and the
  * elapsed time is accumulated per kernel name ("flat_mfma", "flat_exact", "pq_adc", "hnsw"). */
 int vdb_prof_enable(vdb_index *idx, int on);
+/* attainable HBM read bandwidth of this box: a pure streaming read of `bytes` (> the 256-MB Infinity Cache)
+ * repeated `iters` times, best of two access patterns, in GB/s (1e9 B/s).  Allocates and frees its own buffer. */
+int vdb_stream_probe(int device_id, uint64_t bytes, int iters, double *out_gbps);
 int vdb_prof_reset(vdb_index *idx);
 int vdb_prof_get(vdb_index *idx, const char *kernel, double *total_ms, uint64_t *launches, double *bytes);
 

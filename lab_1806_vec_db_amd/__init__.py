@@ -5,5 +5,6 @@ the host-side mirror of the reference's index / VecDB surface.  There is no CPU 
 """
 from ._lib import COSINE, L2SQR, VdbError  # noqa: F401
 from .index import GpuIndex, calc_dist, calc_dist_u8, merge_topk  # noqa: F401
+from .vecdb import VecDB  # noqa: F401
 
-__all__ = ["GpuIndex", "calc_dist", "calc_dist_u8", "merge_topk", "VdbError", "L2SQR", "COSINE"]
+__all__ = ["GpuIndex", "VecDB", "calc_dist", "calc_dist_u8", "merge_topk", "VdbError", "L2SQR", "COSINE"]

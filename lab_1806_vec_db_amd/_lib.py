@@ -48,6 +48,8 @@ SIGNATURES = {
     "vdb_pq_has": [vp, intp],
     "vdb_pq_info": [vp, u64p, u64p, u64p],
     "vdb_pq_export": [vp, f32p, u8p],
+    "vdb_pq_create_lookup": [vp, f32p, u64, u64, f32p, f32p],
+    "vdb_pq_adc_all": [vp, f32p, u64, u64, f32p],
     "vdb_flat_knn_pq": [vp, f32p, u64, u64, u64, u64, u64p, f32p, u64p],
     "vdb_flat_knn_pq_device": [vp, vp, u64, u64, u64, u64, vp, vp, vp, vp],
     "vdb_hnsw_knn_device": [vp, vp, u64, u64, u64, u64, C.c_int, vp, vp, vp, vp],
@@ -77,6 +79,7 @@ SIGNATURES = {
     "vdb_merge_topk": [f32p, u64p, u64p, u64, u64, u64, u64p, f32p, u64p],
     "vdb_merge_topk_device": [vp, vp, vp, vp, u64, u64, u64, vp, vp, vp, vp],
     "vdb_merge_topk_gathered": [vp, vp, u64, u64, u64, u64, u64, u64, u64, vp, vp, vp, vp],
+    "vdb_stream_probe": [C.c_int, u64, C.c_int, f64p],
     "vdb_prof_enable": [vp, C.c_int],
     "vdb_prof_reset": [vp],
     "vdb_prof_get": [vp, C.c_char_p, f64p, u64p, f64p],

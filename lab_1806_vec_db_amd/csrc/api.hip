@@ -354,6 +354,10 @@ int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out) {
         *out = idx->ix.half_redo.load();
     else if (n == "flat_half_valid")
         *out = idx->ix.half_valid ? 1 : 0;
+    else if (n == "flat_bf16_mirror")
+        *out = idx->ix.tiled_built ? 1 : 0;
+    else if (n == "hbm_bytes_per_row")
+        *out = idx->ix.hbm_bytes_per_row();
     else
         throw Error(VDB_ERR_INVALID, "unknown statistic " + n);
     VDB_API_END
@@ -427,6 +431,41 @@ int vdb_flat_knn_pq_device(vdb_index *idx, const void *d_queries, uint64_t nq, u
     VDB_REQUIRE(idx, "null index");
     VDB_REQUIRE(idx->ix.pq.present, "knn_pq needs a PQ table (vdb_pq_build / vdb_pq_attach)");
     device_search(idx->ix, d_queries, nq, dim, k, ef, d_out_idx, d_out_dist, d_out_count, stream, flat_pq_dev);
+    VDB_API_END
+}
+
+// PQTable::create_lookup (pq_table.rs:195-224) / the ADC adapter over every row (pq_table.rs:239-301)
+static const float *stage_queries(Index &ix, Workspace &ws, const float *queries, uint64_t nq) {
+    ws.q.reserve(std::max<uint64_t>(nq, 1) * ix.dim * sizeof(float));
+    VDB_HIP(hipMemcpyAsync(ws.q.p, queries, nq * ix.dim * sizeof(float), hipMemcpyHostToDevice, ws.stream));
+    return ws.q.as<float>();
+}
+int vdb_pq_create_lookup(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, float *out_lut, float *out_qcache) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    Index &ix = idx->ix;
+    VDB_REQUIRE(dim == ix.dim, "query dimension mismatch");  // assert_eq!(query.len(), self.dim) pq_table.rs:196
+    VDB_REQUIRE(nq == 0 || queries, "null argument");
+    VDB_REQUIRE(ix.pq.present, "create_lookup needs a PQ table (vdb_pq_build / vdb_pq_attach)");
+    VDB_REQUIRE(nq <= 65535, "at most 65535 queries per call");
+    if (nq == 0) return VDB_OK;
+    ix.use_device();
+    WsLease ws(ix);
+    pq_export_lookup(ix, *ws, stage_queries(ix, *ws, queries, nq), nq, out_lut, out_qcache);
+    VDB_API_END
+}
+int vdb_pq_adc_all(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, float *out) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    Index &ix = idx->ix;
+    VDB_REQUIRE(dim == ix.dim, "query dimension mismatch");
+    VDB_REQUIRE(nq == 0 || (queries && out), "null argument");
+    VDB_REQUIRE(ix.pq.present, "ADC needs a PQ table (vdb_pq_build / vdb_pq_attach)");
+    VDB_REQUIRE(nq <= 65535, "at most 65535 queries per call");
+    if (nq == 0) return VDB_OK;
+    ix.use_device();
+    WsLease ws(ix);
+    pq_export_adc_all(ix, *ws, stage_queries(ix, *ws, queries, nq), nq, out);
     VDB_API_END
 }
 
@@ -782,6 +821,13 @@ int vdb_merge_topk_gathered(vdb_index *idx, const void *d_gathered, uint64_t blo
 }
 
 // ---- measurement hooks --------------------------------------------------------------------------------
+int vdb_stream_probe(int device_id, uint64_t bytes, int iters, double *out_gbps) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(out_gbps, "null out");
+    require_gpu();
+    *out_gbps = stream_probe(device_id, bytes, iters);
+    VDB_API_END
+}
 int vdb_prof_enable(vdb_index *idx, int on) {
     VDB_API_BEGIN
     VDB_REQUIRE(idx, "null index");

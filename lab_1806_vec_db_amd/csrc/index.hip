@@ -59,7 +59,7 @@ void Index::add_rows(const float *rows, uint64_t count, bool on_device) {
     float *dst = d_rows.as<float>() + n * dim;
     VDB_HIP(hipMemcpyAsync(dst, rows, count * row_bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     launch_row_sqnorm(dst, count, (uint32_t)dim, d_sq.as<float>() + n, s);
-    if (mfma_supported((uint32_t)dim)) {
+    if (mfma_supported((uint32_t)dim) && tiled_built) {
         // refresh the fragment-ordered mirror for every 16-row tile that received rows
         uint64_t tiles_new = ((n + count + 15) / 16 + 11) / 12 * 12;  // whole 64-row items (k_flat_mfma) and whole 2/3-tile units (k_flat_gemm)
         uint64_t tiles_old = n / 16;                                // the partially filled tile is rewritten
@@ -100,8 +100,10 @@ void Index::swap_remove(uint64_t i) {
         VDB_HIP(hipMemcpyAsync(d_sq.as<float>() + i, d_sq.as<float>() + last, sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     if (mfma_supported((uint32_t)dim)) {  // rewrite the tiles of the moved row and of the removed last row
-        launch_tile_rows(d_rows.as<float>(), last, (uint32_t)dim, i / 16, i / 16 + 1, d_tiled.as<float>(), s);
-        launch_tile_rows(d_rows.as<float>(), last, (uint32_t)dim, last / 16, last / 16 + 1, d_tiled.as<float>(), s);
+        if (tiled_built) {
+            launch_tile_rows(d_rows.as<float>(), last, (uint32_t)dim, i / 16, i / 16 + 1, d_tiled.as<float>(), s);
+            launch_tile_rows(d_rows.as<float>(), last, (uint32_t)dim, last / 16, last / 16 + 1, d_tiled.as<float>(), s);
+        }
         if (half_valid) {  // same scale; the moved row's rounding error is already part of half_dx_*
             launch_tile_rows_h(d_rows.as<float>(), last, (uint32_t)dim, i / 16, i / 16 + 1, half_sx(), d_tiled_h.p, s);
             launch_tile_rows_h(d_rows.as<float>(), last, (uint32_t)dim, last / 16, last / 16 + 1, half_sx(), d_tiled_h.p, s);
@@ -119,6 +121,29 @@ void Index::swap_remove(uint64_t i) {
     h_sq.resize(last);
     n = last;
     // xsq_max stays an upper bound (certification only needs a bound)
+}
+
+// ---- split-bf16 mirror, on first need ----------------------------------------------------------------
+void Index::ensure_tiled(Workspace &ws) {
+    std::lock_guard<std::mutex> g(tiled_mu);
+    if (tiled_built || n == 0) return;
+    const uint64_t tiles = ((n + 15) / 16 + 11) / 12 * 12;  // whole 64-row items (k_flat_mfma) and whole 2/3-tile units (k_flat_gemm)
+    const uint64_t tile_bytes = 16 * size_t(mfma_dim_pad((uint32_t)dim)) * sizeof(float);
+    d_tiled.reserve(tiles * tile_bytes);
+    launch_tile_rows(d_rows.as<float>(), n, (uint32_t)dim, 0, tiles, d_tiled.as<float>(), ws.stream);
+    VDB_SYNC(ws.stream);
+    tiled_built = true;
+}
+
+uint64_t Index::hbm_bytes_per_row() const {
+    uint64_t b = dim * sizeof(float) + sizeof(float);  // VecSet row + dist_cache entry
+    if (mfma_supported((uint32_t)dim)) {
+        if (tiled_built) b += uint64_t(mfma_dim_pad((uint32_t)dim)) * sizeof(float);
+        if (half_valid) b += uint64_t(mfma_dim_pad((uint32_t)dim)) * sizeof(uint16_t);
+    }
+    if (pq.present) b += pq.enc_dim;
+    if (hnsw.present) b += hnsw.max_m0 * sizeof(uint32_t) + sizeof(uint32_t);
+    return b;
 }
 
 // ---- scaled fp16 mirror (k_half.hip) ---------------------------------------------------------------
@@ -331,6 +356,7 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     const bool gemm = flat_gemm_mode == 2 || (flat_gemm_mode == 0 && (nq > 64 || half_ok));
     const bool half = half_ok && gemm;
     if (half) kprime = kprime_h;
+    if (!half) ensure_tiled(ws);
     if (!half) launch_row_sqnorm(d_q, nq, (uint32_t)dim, ws.qsq.as<float>(), s);  // (the fp16 pass: k_query_prep_h)
     const uint32_t capp = topk_capacity(kprime);
     const uint32_t capk = topk_capacity(ksel);

@@ -142,7 +142,14 @@ struct Index {
     uint64_t n = 0;
     uint64_t id_offset = 0;
     DevBuf d_rows, d_sq;
-    DevBuf d_tiled;  // MFMA-fragment-ordered mirror of d_rows (k_mfma.hip), only when mfma_supported(dim)
+    // MFMA-fragment-ordered split-bf16 mirror of d_rows (k_mfma.hip; 4 B/element), only when mfma_supported(dim).  Built
+    // LAZILY by the first search that needs it (the redo tier of the fp16 pass, calls without an fp16 mirror,
+    // flat_half = 1): an index whose queries all certify on the fp16 pass never pays its N*d*4 bytes of HBM.
+    DevBuf d_tiled;
+    bool tiled_built = false;       // d_tiled covers rows [0, n); kept in step by add_rows / swap_remove once built
+    std::mutex tiled_mu;            // read-side calls are re-entrant: one of them builds, the others wait
+    void ensure_tiled(Workspace &ws);
+    uint64_t hbm_bytes_per_row() const;  // resident bytes per row over all per-row buffers (rows, norms, mirrors, codes, links)
     // scaled fp16 mirror for k_flat_gemm<GEMM_F16> (k_half.hip): rows stored as fp16(x * 2^(13 - half_exp)), every row
     // norm < 2^half_exp; half_dx_* = measured rounding error of the mirror (max |dx_r|, max |dx_r| / |x_r|)
     DevBuf d_tiled_h, d_half_err;

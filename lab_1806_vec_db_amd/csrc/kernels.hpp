@@ -103,6 +103,10 @@ void launch_pack_pairs(const float *dists, const uint64_t *ids, const uint64_t *
                        uint64_t stride_i, uint64_t stride_c /* bytes between shards */, uint32_t S, uint32_t nq, uint32_t k,
                        uint32_t cap_in, uint64_t *lists, hipStream_t s);
 
+// ---- k_probe.hip ---------------------------------------------------------------------------
+// attainable HBM read bandwidth in GB/s: pure streaming read of `bytes`, `iters` timed passes, best of two patterns
+double stream_probe(int device, uint64_t bytes, int iters);
+
 // ---- k_sort.hip (k > 1024) -----------------------------------------------------------------
 size_t sort_pairs_temp_bytes(uint64_t n);
 void launch_sort_pairs(const float *dist, uint64_t n, uint64_t *tmp_keys, uint64_t *out, void *temp, size_t temp_bytes,

@@ -873,6 +873,65 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
     }
 }
 
+// PQTable::create_lookup (pq_table.rs:195-224) and the ADC adapter (pq_table.rs:239-301) over every code row, exported
+// as they are computed by the search kernels (k_pq_lut, k_pq_adc dense mode): lut [nq][m*kc], qcache [nq] (0 for L2Sqr,
+// |q| for Cosine: PQLookupTable::dist_cache), adc [nq][n].  Host outputs; used by the direct parity tests of a11 / a12.
+void pq_export_lookup(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, float *h_lut, float *h_qcache) {
+    hipStream_t s = ws.stream;
+    PQState &pq = ix.pq;
+    VDB_REQUIRE(pq.present, "no PQ table");
+    if (nq == 0) return;
+    const uint64_t lsz = pq.m * pq.kc;
+    ws.qsq.reserve(nq * sizeof(float));
+    launch_row_sqnorm(d_q, nq, (uint32_t)ix.dim, ws.qsq.as<float>(), s);
+    pq_make_luts(ix, ws, d_q, nq);
+    if (h_lut) VDB_HIP(hipMemcpyAsync(h_lut, ws.lut.p, nq * lsz * sizeof(float), hipMemcpyDeviceToHost, s));
+    std::vector<float> qs(nq);
+    VDB_HIP(hipMemcpyAsync(qs.data(), ws.qsq.p, nq * sizeof(float), hipMemcpyDeviceToHost, s));
+    VDB_SYNC(s);
+    if (h_qcache)
+        for (uint64_t q = 0; q < nq; q++) h_qcache[q] = ix.dist == 1 ? std::sqrt(qs[q]) : 0.0f;
+}
+
+void pq_export_adc_all(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, float *h_out) {
+    hipStream_t s = ws.stream;
+    PQState &pq = ix.pq;
+    VDB_REQUIRE(pq.present && pq.n_coded == ix.n, "PQ table does not cover the rows of the index (rebuild it after add)");
+    const uint64_t n = ix.n;
+    if (nq == 0 || n == 0) return;
+    ws.qsq.reserve(nq * sizeof(float));
+    launch_row_sqnorm(d_q, nq, (uint32_t)ix.dim, ws.qsq.as<float>(), s);
+    pq_make_luts(ix, ws, d_q, nq);
+    const uint32_t lsz = (uint32_t)(pq.m * pq.kc);
+    const size_t lbytes = size_t(lsz) * sizeof(float), cbytes = ix.dist == 1 ? lbytes : 0;
+    const uint32_t BQ = lbytes * 4 + cbytes <= 120 * 1024 ? 4 : (lbytes * 2 + cbytes <= 120 * 1024 ? 2 : 1);
+    const uint32_t nt = lbytes * BQ + cbytes <= 120 * 1024 ? 1024 : 256;
+    const uint64_t ld = (n + nt + 63) & ~63ull;
+    const uint64_t GQ = std::max<uint64_t>(BQ, std::min<uint64_t>(64, (size_t(512) << 20) / (ld * sizeof(float))) / BQ * BQ);
+    ws.dense.reserve(GQ * ld * sizeof(float));
+    for (uint64_t g0 = 0; g0 < nq; g0 += GQ) {
+        const uint64_t gn = std::min<uint64_t>(GQ, nq - g0);
+        AdcArgs a{};
+        a.codes = pq.d_codes.as<uint8_t>();
+        a.n = n;
+        a.enc_dim = (uint32_t)pq.enc_dim;
+        a.m = (uint32_t)pq.m;
+        a.cent_cache = pq.d_cent_cache.as<float>();
+        a.cosine = ix.dist == 1 ? 1 : 0;
+        a.blk_step = 1;
+        a.fast = g_adc_fast;
+        a.nq_total = (uint32_t)gn;
+        a.lut = ws.lut.as<float>() + g0 * lsz;
+        a.qsq = ws.qsq.as<float>() + g0;
+        a.out = ws.dense.as<float>();
+        a.ld = ld;
+        adc_launch<0>(ix, ws, BQ, a);
+        VDB_HIP(hipMemcpy2DAsync(h_out + g0 * n, n * sizeof(float), ws.dense.p, ld * sizeof(float), n * sizeof(float), gn,
+                                 hipMemcpyDeviceToHost, s));
+        VDB_SYNC(s);
+    }
+}
+
 // exact distances of the ADC shortlist, in ADC order (the operand order of pq_resort, candidate_pair.rs:102-108):
 // ws.keys_a -> ws.keys_b
 static void pq_exact_of_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint32_t efk) {

@@ -14,6 +14,10 @@ void pq_set_adc_fast(int v);
 void flat_knn_pq_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef,
                         uint64_t *d_idx, float *d_dist, uint64_t *d_cnt);
 
+// create_lookup / ADC over all rows, as the search kernels compute them (host outputs; parity tests of a11 / a12)
+void pq_export_lookup(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, float *h_lut, float *h_qcache);
+void pq_export_adc_all(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, float *h_out);
+
 // row-sharded knn_pq: per-shard export of the ADC shortlist, and the merge + pq_resort replay
 void flat_knn_pq_shard_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef,
                               uint64_t *d_adc_keys, uint64_t *d_exact_keys);

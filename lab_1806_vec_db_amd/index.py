@@ -290,6 +290,25 @@ class GpuIndex:
         L.check(self._lib.vdb_pq_export(self._h, _ptr(cent, L.f32p), _ptr(codes, L.u8p)))
         return {"n_bits": int(nb.value), "m": int(m.value), "centroids": cent, "codes": codes}
 
+    def pq_create_lookup(self, queries):
+        """PQTable::create_lookup (pq_table.rs:195-224): (lut [nq, m * k_c], dist_cache [nq]) as the search kernels build them."""
+        q = _f32(queries)
+        q = q.reshape(1, -1) if q.ndim == 1 else q
+        nb, m, ed = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        L.check(self._lib.vdb_pq_info(self._h, C.byref(nb), C.byref(m), C.byref(ed)))
+        lut = np.zeros((q.shape[0], m.value << nb.value), dtype=np.float32)
+        qc = np.zeros(q.shape[0], dtype=np.float32)
+        L.check(self._lib.vdb_pq_create_lookup(self._h, _ptr(q, L.f32p), q.shape[0], q.shape[1], _ptr(lut, L.f32p), _ptr(qc, L.f32p)))
+        return lut, qc
+
+    def pq_adc_all(self, queries):
+        """ADC distance of every code row to every query (pq_table.rs:239-301): [nq, len] float32."""
+        q = _f32(queries)
+        q = q.reshape(1, -1) if q.ndim == 1 else q
+        out = np.zeros((q.shape[0], len(self)), dtype=np.float32)
+        L.check(self._lib.vdb_pq_adc_all(self._h, _ptr(q, L.f32p), q.shape[0], q.shape[1], _ptr(out, L.f32p)))
+        return out
+
     # -- HNSW ------------------------------------------------------------------------------------------------
     def hnsw_build(self, M: int = 16, ef_construction: int = 200, seed: int = 42, batch: int = 1,
                    nthreads: int = 1):
@@ -394,6 +413,13 @@ class GpuIndex:
         ms, n, by = C.c_double(), C.c_uint64(), C.c_double()
         L.check(self._lib.vdb_prof_get(self._h, kernel.encode(), C.byref(ms), C.byref(n), C.byref(by)))
         return {"ms": float(ms.value), "launches": int(n.value), "bytes": float(by.value)}
+
+
+def stream_probe(device: int = 0, nbytes: int = 3_840_000_000, iters: int = 5) -> float:
+    """Attainable HBM read bandwidth of this box in GB/s: pure streaming read, best of two patterns."""
+    v = C.c_double()
+    L.check(L.load().vdb_stream_probe(int(device), int(nbytes), int(iters), C.byref(v)))
+    return float(v.value)
 
 
 def merge_topk(dists: np.ndarray, ids: np.ndarray, counts: np.ndarray, k: int):

@@ -1,0 +1,93 @@
+"""GPU parity, directly on the intermediate values of the PQ path:
+
+  a11  PQTable::create_lookup (pq_table.rs:195-224): the lookup table k_pq_lut builds, bit for bit against the
+       oracle's orc_pq_lookup, and PQLookupTable::dist_cache (0 / |q|);
+  a12  the ADC adapter (pq_table.rs:239-301): the value of EVERY code row as the scan kernels compute it (dense
+       mode) against orc_pq_adc_all, and the fused threshold-filter path through what it exports -- the shard key
+       rows of vdb_flat_knn_pq_shard: the max(ef,k) smallest (ADC value, global id) pair keys with the exact
+       distance of the same row beside each.
+
+A compensating error pair (a wrong table entry and a wrong sum that cancel in the final top-k) would pass the
+end-to-end knn_pq tests; it cannot pass these.
+"""
+import numpy as np
+import pytest
+
+from conftest import gist_like
+
+pytestmark = pytest.mark.gpu
+
+NONE = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import lab_1806_vec_db_amd as vdb
+    from oracle import oracle as O
+    return vdb, O
+
+
+def _build(vdb, O, base, dist, kind, n_bits, m, seed=5):
+    ix = vdb.GpuIndex(base.shape[1], dist)
+    ix.batch_add(base)
+    ix.pq_build(n_bits=n_bits, m=m, train_n=min(len(base), 400), max_iter=4, seed=seed)
+    pq = ix.pq_export()
+    opq = O.PQ.from_centroids(ix.dim, pq["m"], pq["n_bits"], kind, pq["centroids"])
+    opq.set_codes(pq["codes"])
+    return ix, opq
+
+
+CASES = [  # dim, m, n_bits: the Gist1M table shape, 4-dim groups, odd m (last byte half used), uneven groups, 8-bit in / out of LDS
+    (960, 320, 4), (960, 240, 4), (96, 31, 4), (100, 7, 4), (64, 64, 4), (96, 24, 8), (960, 320, 8), (13, 5, 8),
+]
+
+
+@pytest.mark.parametrize("dist,kind", [("l2sqr", 0), ("cosine", 1)])
+@pytest.mark.parametrize("dim,m,n_bits", CASES)
+def test_lookup_table_and_adc_values_bit_exact(mods, dist, kind, dim, m, n_bits):
+    vdb, O = mods
+    n = 3000 if dim >= 960 else 5000
+    base = gist_like(n, dim=dim, seed=21)
+    if kind == 1:
+        base[17] = 0.0  # a zero row: cosine ADC denominators hit the 1e-10 clamp only through the query side, but its code row must still score like the oracle's
+    qs = gist_like(9, dim=dim, seed=22)
+    qs[3] = -qs[3]
+    qs[4] = 0.0        # zero query: L2 table = |c|^2, cosine ADC = 1 - 0 / max(.., 1e-10)
+    ix, opq = _build(vdb, O, base, dist, kind, n_bits, m)
+    lut, qc = ix.pq_create_lookup(qs)
+    assert lut.shape == (9, m << n_bits)
+    adc = ix.pq_adc_all(qs)
+    assert adc.shape == (9, n)
+    for q in range(9):
+        olut, oqc = opq.lookup(qs[q])
+        assert np.array_equal(lut[q].view(np.uint32), olut.view(np.uint32)), (q, "lookup table differs from orc_pq_lookup")
+        assert np.float32(qc[q]).view(np.uint32) == np.float32(oqc).view(np.uint32), (q, qc[q], oqc)
+        oadc = opq.adc_all(qs[q], n)
+        same = (adc[q].view(np.uint32) == oadc.view(np.uint32)) | (np.isnan(adc[q]) & np.isnan(oadc))
+        assert same.all(), (q, np.flatnonzero(~same)[:5], adc[q][~same][:5], oadc[~same][:5])
+
+
+@pytest.mark.parametrize("dist,kind", [("l2sqr", 0), ("cosine", 1)])
+@pytest.mark.parametrize("n,dim,m,n_bits,ef", [(70000, 96, 32, 4, 100), (66000, 960, 320, 4, 64), (5000, 64, 16, 8, 200), (80000, 64, 64, 4, 1000)])
+def test_shard_key_rows_equal_oracle_adc(mods, dist, kind, n, dim, m, n_bits, ef):
+    """vdb_flat_knn_pq_shard = what a shard hands to the all-gather; n >= 65536 goes through the sampled-threshold filter
+    scan (k_pq_adc MODE 1), the small case through the dense scan.  Duplicated rows give equal codes -> ADC ties that the
+    (value, id) order must break by id."""
+    vdb, O = mods
+    base = gist_like(n, dim=dim, seed=31)
+    base[n // 2:n // 2 + 40] = base[:40]
+    qs = gist_like(6, dim=dim, seed=32)
+    qs[5] = base[7]
+    ix, opq = _build(vdb, O, base, dist, kind, n_bits, m)
+    off = 1000
+    ix.set_id_offset(off)
+    k = 10
+    a, e = ix.knn_pq_shard(qs, k, ef)
+    efk = max(ef, k)
+    for q in range(len(qs)):
+        oadc = opq.adc_all(qs[q], n)
+        ok = np.sort(O.pair_keys(oadc, np.arange(off, off + n, dtype=np.uint64)))[:efk]
+        assert np.array_equal(a[q], ok), (q, np.flatnonzero(a[q] != ok)[:5])
+        sel = (ok & np.uint64(0xFFFFFFFF)).astype(np.int64) - off
+        ex = np.array([O.dist(kind, base[i], qs[q]) for i in sel], dtype=np.float32)
+        assert np.array_equal(e[q], O.pair_keys(ex, (sel + off).astype(np.uint64))), q
