@@ -106,7 +106,9 @@ int vdb_flat_set_mode(vdb_index *idx, int mode);
  *   "flat_gemm_nt"     cache policy of the row stream: 0 auto (non-temporal when the mirror exceeds the Infinity Cache), 1 default, 2 non-temporal
  *   "flat_tail"        exact stage: 0 fused launch when the shortlist fits 64 rows, 1 separate kernels
  *   "flat_share", "mfma_variant", "flat_sample_thin", "flat_gemm_debug"   small-batch kernel / sample plan / measurement hooks
- *   "pq_adc_fast", "hnsw_dma"   inner-loop variants of the ADC scan and of the HNSW walk */
+ *   "pq_adc_fast", "hnsw_dma"   inner-loop variants of the ADC scan and of the HNSW walk
+ *   "pq_adc16"         quantised first pass of the threshold-filter ADC scan (16-bit tables, 8 queries per pass; exact f32
+ *                      sums for its candidates): 0 auto (4-bit codes, L2Sqr, 16-B code words), 1 off */
 int vdb_set_param(vdb_index *idx, const char *name, int64_t value);
 /* number of queries whose MFMA shortlist failed certification and were redone by the exact scan */
 int vdb_flat_fallback_count(const vdb_index *idx, uint64_t *out);

@@ -309,6 +309,8 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         hnsw_set_dma((int)value);
     else if (n == "pq_adc_fast")
         pq_set_adc_fast((int)value);
+    else if (n == "pq_adc16")
+        pq_set_adc16((int)value);
     else if (n == "flat_sample_thin")
         mfma_set_sample_thin((int)value);
     else if (n == "flat_gemm_tw")

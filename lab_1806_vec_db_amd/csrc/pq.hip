@@ -82,6 +82,8 @@ struct AdcArgs {
 };
 static int g_adc_fast = 1;
 void pq_set_adc_fast(int v) { g_adc_fast = v; }
+static int g_adc16 = 0;  // quantised first pass of the threshold-filter scan: 0 auto (4-bit, L2Sqr, 16-B code words), 1 off
+void pq_set_adc16(int v) { g_adc16 = v; }
 constexpr uint32_t ADC_WGBUF = 2048;  // LDS hit buffer entries per workgroup (MODE 1)
 
 // One code row of the Gist1M-shaped table (4-bit codes, every nibble a group, 16-B code words) against 4 lookup tables
@@ -309,6 +311,233 @@ __global__ __launch_bounds__(1024) void k_pq_adc(AdcArgs a) {
             if (slot < a.cap) a.cand[uint64_t(q) * a.cap + slot] = hit_key[i];
         }
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Quantised first pass of the ADC scan (4-bit codes, L2Sqr).
+// The f32 scan above is bound by the LDS gather rate: one ds_read_b128 per (row, group) serves 4 queries (8 us per
+// query and 1M rows at the LDS array's 256 B/clk/CU; measured 15.5).  The scan only has to find the rows whose ADC
+// value is <= tau[q], so it can run on a coarser table as long as it never drops such a row:
+//   lut16[q][g][c] = floor((lut[q][g][c] - mn[q][g]) / D[q]),   mn = min_c lut[q][g][.],   D[q] = sum_g range_g / 65000
+// 16-bit entries, 8 queries side by side in one 16-B LDS entry -> one ds_read_b128 per (row, group) serves 8 queries,
+// and because no 16-bit field can overflow (sum_g max_c lut16 <= 65000) the 8 sums are accumulated with plain 32-bit
+// adds, two lookups per v_add3_u32.  For every row  M + D * S16 <= sum_g lut[g][code_g]  (real arithmetic; M = sum mn),
+// and the reference's f32 left fold S of m non-negative terms satisfies S >= real * (1 - gamma_{m-1}), so
+//   S <= tau   ==>   S16 <= T16 := floor((tau * (1 + 2 m 2^-24) - M (1 - 1e-12)) / D) + 2
+// (the +2 and the 1e-12 cover the double-precision evaluation).  Rows with S16 <= T16 go to the candidate list of the
+// query as bare row ids; k_pq_adc_exact then computes THEIR f32 ADC sums in group order with the f32 table in LDS and
+// keeps those <= tau -- the same set, the same values, the same (adc, idx) order as the f32 scan produces.
+// Queries whose table holds a non-finite or negative entry are flagged and take the f32 scan.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t ADC16_Q = 8;          // queries per workgroup pass
+constexpr uint32_t ADC16_WGBUF = 2048;   // LDS hit buffer entries per workgroup
+
+// one workgroup per query: table -> 16-bit image [q / 8][g][c][q % 8], offset M and step D
+__global__ __launch_bounds__(256) void k_pq_quant16(const float *__restrict__ lut, uint32_t m, uint32_t nq,
+                                                    uint16_t *__restrict__ img, double *__restrict__ qM,
+                                                    double *__restrict__ qD, uint32_t *__restrict__ qflag) {
+    const uint32_t q = blockIdx.x, t = threadIdx.x;
+    __shared__ double sR[256], sM[256];
+    __shared__ uint32_t sbad;
+    if (t == 0) sbad = 0;
+    __syncthreads();
+    const float *lq = lut + uint64_t(q) * m * 16;
+    double R = 0.0, M = 0.0;
+    bool bad = false;
+    for (uint32_t g = t; g < m; g += 256) {
+        float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            const float v = lq[g * 16 + c];
+            if (!(v >= 0.0f) || v > 3.0e38f) bad = true;  // NaN, negative, inf
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+        }
+        R += double(mx) - double(mn);
+        M += double(mn);
+    }
+    if (bad) atomicOr(&sbad, 1u);
+    sR[t] = R;
+    sM[t] = M;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (t < s) {
+            sR[t] += sR[t + s];
+            sM[t] += sM[t + s];
+        }
+        __syncthreads();
+    }
+    R = sR[0];
+    M = sM[0];
+    const bool flag = sbad != 0 || !(R < 1.0e300) || !(M < 1.0e300);
+    const double D = (!flag && R > 0.0) ? R / 65000.0 : 1.0;
+    uint16_t *dst = img + uint64_t(q / ADC16_Q) * m * 16 * ADC16_Q + (q % ADC16_Q);
+    for (uint32_t g = t; g < m; g += 256) {
+        float mn = INFINITY;
+#pragma unroll
+        for (int c = 0; c < 16; c++) mn = fminf(mn, lq[g * 16 + c]);
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            double x = flag ? 0.0 : floor((double(lq[g * 16 + c]) - double(mn)) / D);
+            x = x < 0.0 ? 0.0 : (x > 65000.0 ? 65000.0 : x);  // (unreachable clamps: x <= range_g / D <= 65000)
+            dst[(g * 16 + c) * ADC16_Q] = (uint16_t)x;
+        }
+    }
+    if (t == 0) {
+        qM[q] = M;
+        qD[q] = D;
+        qflag[q] = flag ? 1u : 0u;
+    }
+}
+
+struct Adc16Args {
+    const uint8_t *codes;
+    uint64_t n;
+    uint32_t enc_dim, m;
+    const uint4 *img;        // [ceil(nq/8)][m*16] 16-B entries
+    const double *qM, *qD;   // [nq]
+    const uint32_t *qflag;   // [nq]
+    const float *tau;        // [nq]
+    uint32_t nq;
+    uint64_t rows_per_wg;    // multiple of 64
+    uint64_t *cand;          // [nq][cap] row ids (upper word 0)
+    uint32_t *cnt;           // [nq]
+    uint32_t cap;
+};
+
+__global__ __launch_bounds__(1024) void k_pq_adc16(Adc16Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t m = a.m;
+    const uint32_t q0 = blockIdx.y * ADC16_Q;
+    uint4 *tab = reinterpret_cast<uint4 *>(smem16);                   // [m*16] entries of 8 x u16
+    int32_t *thr = reinterpret_cast<int32_t *>(tab + m * 16);         // [8] T16 per query slot (-1: slot unused / flagged)
+    uint32_t *hit_row = reinterpret_cast<uint32_t *>(thr + 8);        // [ADC16_WGBUF]
+    uint32_t *hit_q = hit_row + ADC16_WGBUF;                          // [ADC16_WGBUF] slot | rank << 8
+    uint32_t *hit_n = hit_q + ADC16_WGBUF;                            // [0] entries, [1..8] per-slot counts, [9..16] bases
+    {
+        const uint4 *src = a.img + uint64_t(blockIdx.y) * m * 16;
+        for (uint32_t i = tid; i < m * 16; i += 1024) tab[i] = src[i];
+        if (tid < 1 + 2 * ADC16_Q) hit_n[tid] = 0;
+        if (tid < ADC16_Q) {
+            int32_t T = -1;
+            const uint32_t q = q0 + tid;
+            if (q < a.nq && a.qflag[q] == 0) {
+                const double tau = double(a.tau[q]);
+                const double M = a.qM[q], D = a.qD[q];
+                const double x = floor((tau * (1.0 + 2.0 * double(m) * 0x1p-24) - M * (1.0 - 1e-12)) / D) + 2.0;
+                // tau = +inf / NaN (fewer sampled rows than the rank, NaN rows): everything passes -> the candidate list
+                // overflows and the query takes the f32 scan
+                T = !(x < 70000.0) ? 70000 : (x < 0.0 ? -1 : (int32_t)x);
+            }
+            thr[tid] = T;
+        }
+    }
+    __syncthreads();
+    int32_t T[ADC16_Q];
+#pragma unroll
+    for (int b = 0; b < (int)ADC16_Q; b++) T[b] = thr[b];
+    const uint64_t r_begin = uint64_t(blockIdx.x) * a.rows_per_wg;
+    const uint64_t r_end = r_begin + a.rows_per_wg < a.n ? r_begin + a.rows_per_wg : a.n;
+    const uint32_t nwords = a.enc_dim / 16;
+    const char *lbase = reinterpret_cast<const char *>(tab);
+    for (uint64_t rb = r_begin; rb < r_end; rb += 1024) {
+        const uint64_t row = rb + tid;
+        const bool valid = row < r_end;
+        const uint4 *cw = reinterpret_cast<const uint4 *>(a.codes + (valid ? row : r_end - 1) * a.enc_dim);
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        uint4 v = cw[0];
+        for (uint32_t w = 0; w < nwords; w++) {
+            const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+            if (w + 1 < nwords) v = cw[w + 1];  // next code word while this one is looked up
+            const char *wb = lbase + w * (32 * 256);
+#pragma unroll
+            for (int wi = 0; wi < 4; wi++) {
+                // byte b of the word: low nibble = group 32w + 8wi + 2b, high nibble = the next one; as byte offsets
+                // (code * 16) inside the group's 256-B block: packed in the bytes of e4 / o4
+                const uint32_t e4 = (words[wi] & 0x0f0f0f0fu) << 4, o4 = words[wi] & 0xf0f0f0f0u;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const uint4 E = *reinterpret_cast<const uint4 *>(wb + (wi * 8 + 2 * b) * 256 + ((e4 >> (8 * b)) & 0xffu));
+                    const uint4 O = *reinterpret_cast<const uint4 *>(wb + (wi * 8 + 2 * b + 1) * 256 + ((o4 >> (8 * b)) & 0xffu));
+                    a0 = a0 + E.x + O.x;
+                    a1 = a1 + E.y + O.y;
+                    a2 = a2 + E.z + O.z;
+                    a3 = a3 + E.w + O.w;
+                }
+            }
+        }
+        const int32_t s[ADC16_Q] = {int32_t(a0 & 0xffffu), int32_t(a0 >> 16), int32_t(a1 & 0xffffu), int32_t(a1 >> 16),
+                                    int32_t(a2 & 0xffffu), int32_t(a2 >> 16), int32_t(a3 & 0xffffu), int32_t(a3 >> 16)};
+#pragma unroll
+        for (int b = 0; b < (int)ADC16_Q; b++) {
+            if (valid && s[b] <= T[b]) {
+                const uint32_t pos = atomicAdd(hit_n, 1u);
+                if (pos < ADC16_WGBUF) {
+                    hit_row[pos] = uint32_t(row);
+                    hit_q[pos] = b;
+                } else {
+                    atomicAdd(&a.cnt[q0 + b], a.cap + 1);  // mark the query as overflowed (-> f32 scan)
+                }
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t total = hit_n[0];
+    if (total > ADC16_WGBUF) total = ADC16_WGBUF;
+    for (uint32_t i = tid; i < total; i += 1024) {
+        const uint32_t r_ = atomicAdd(&hit_n[1 + hit_q[i]], 1u);
+        hit_q[i] |= r_ << 8;
+    }
+    __syncthreads();
+    if (tid < ADC16_Q && hit_n[1 + tid] > 0) hit_n[1 + ADC16_Q + tid] = atomicAdd(&a.cnt[q0 + tid], hit_n[1 + tid]);
+    __syncthreads();
+    for (uint32_t i = tid; i < total; i += 1024) {
+        const uint32_t b = hit_q[i] & 0xffu, r_ = hit_q[i] >> 8;
+        const uint32_t slot = hit_n[1 + ADC16_Q + b] + r_;
+        if (slot < a.cap) a.cand[uint64_t(q0 + b) * a.cap + slot] = hit_row[i];
+    }
+}
+
+// exact f32 ADC sums (strict group order, pq_table.rs:254-292) of the candidates of every query: row ids in, pair keys
+// out (PAIR_NONE for sums above tau); valid[q] counts the pairs kept.  One workgroup per query, its f32 table in LDS.
+__global__ __launch_bounds__(256) void k_pq_adc_exact(const uint8_t *__restrict__ codes, uint32_t enc_dim, uint32_t m,
+                                                      const float *__restrict__ lut, const float *__restrict__ tau,
+                                                      uint64_t *__restrict__ cand, const uint32_t *__restrict__ cnt,
+                                                      uint32_t cap, uint32_t *__restrict__ valid) {
+    extern __shared__ __attribute__((aligned(16))) float slut[];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t total = cnt[q];
+    if (total > cap) return;  // overflowed list: the query is redone by the f32 scan
+    const float *lq = lut + uint64_t(q) * m * 16;
+    for (uint32_t i = tid; i < m * 16; i += 256) slut[i] = lq[i];
+    __syncthreads();
+    const float t = tau[q];
+    uint64_t *cq = cand + uint64_t(q) * cap;
+    uint32_t kept = 0;
+    for (uint32_t i = tid; i < total; i += 256) {
+        const uint32_t row = uint32_t(cq[i]);
+        const uint4 *cw = reinterpret_cast<const uint4 *>(codes + uint64_t(row) * enc_dim);
+        float sum = 0.0f;
+        uint4 v = cw[0];
+        for (uint32_t w = 0; w < enc_dim / 16; w++) {
+            const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+            if (w + 1 < enc_dim / 16) v = cw[w + 1];
+#pragma unroll
+            for (int wi = 0; wi < 4; wi++) {
+                float e[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) e[j] = slut[(w * 32 + 8 * wi + j) * 16 + ((words[wi] >> (4 * j)) & 0xf)];
+#pragma unroll
+                for (int j = 0; j < 8; j++) sum = sum + e[j];
+            }
+        }
+        const bool keep = sum <= t;
+        cq[i] = keep ? pair_key(sum, row) : PAIR_NONE;
+        kept += keep ? 1u : 0u;
+    }
+    if (kept) atomicAdd(&valid[q], kept);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -817,60 +1046,115 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
     if (!fused) {
         const uint64_t GQ = std::max<uint64_t>(BQ, std::min<uint64_t>(64, (size_t(512) << 20) / ((n + nt + 64) * sizeof(float))) / BQ * BQ);
         for (uint64_t g0 = 0; g0 < nq; g0 += GQ) dense_group(g0, std::min<uint64_t>(GQ, nq - g0));
-    } else {
-        // fused path: tau[q] from a strided row-block sample, then one filtered scan per BQ queries
-        const uint64_t ld_s = (n_s + 63) & ~63ull;
-        const uint32_t nl_s = topk_num_lists(n_s);
-        const uint32_t cap = (uint32_t)std::min<uint64_t>(65536, std::max<uint64_t>(4096, 4ull * s_rank * step));
-        const uint64_t GQ = 64;
-        ws.dense.reserve(GQ * ld_s * sizeof(float));
-        ws.lists.reserve(std::max<size_t>(GQ * nl_s * cape, GQ * size_t(cap)) * sizeof(uint64_t));
-        ws.misc.reserve(nq * (sizeof(float) + sizeof(uint32_t)));
-        float *d_tau = ws.misc.as<float>();
-        uint32_t *d_hits = reinterpret_cast<uint32_t *>(d_tau + nq);
-        VDB_HIP(hipMemsetAsync(d_hits, 0, nq * sizeof(uint32_t), s));
-        for (uint64_t g0 = 0; g0 < nq; g0 += GQ) {
-            const uint64_t gn = std::min<uint64_t>(GQ, nq - g0);
-            {
-                AdcArgs a = base;
-                a.nq_total = (uint32_t)gn;
-                a.lut = ws.lut.as<float>() + g0 * lsz;
-                a.qsq = ws.qsq.as<float>() + g0;
-                a.blk_step = step;
-                a.out = ws.dense.as<float>();
-                a.ld = ld_s;
-                adc_launch<0>(ix, ws, BQ, a);
-            }
-            if (n_s <= select_tau_max_n()) {  // tau = efk-th smallest sampled ADC value: a selection, not a sort
-                launch_select_tau(ws.dense.as<float>(), ld_s, (uint32_t)n_s, (uint32_t)gn, (uint32_t)gn, s_rank, d_tau + g0, s);
-            } else {
-                launch_topk_dense(ws.dense.as<float>(), ld_s, n_s, (uint32_t)gn, s_rank, ws.lists.as<uint64_t>(), s);
-                launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, cape, (uint32_t)gn, s_rank, ws.keys_a.as<uint64_t>() + g0 * cape, s);
-                launch_extract_tau(ws.keys_a.as<uint64_t>() + g0 * cape, cape, (uint32_t)gn, s_rank, d_tau + g0, s);
-            }
-            uint64_t *d_cand = ws.lists.as<uint64_t>();  // the sample lists are dead now
-            {
-                AdcArgs a = base;
-                a.nq_total = (uint32_t)gn;
-                a.lut = ws.lut.as<float>() + g0 * lsz;
-                a.qsq = ws.qsq.as<float>() + g0;
-                a.tau = d_tau + g0;
-                a.cand = d_cand;
-                a.cnt = d_hits + g0;
-                a.cap = cap;
-                ix.prof_begin(ws, "pq_adc", double((gn + BQ - 1) / BQ) * double(n) * pq.enc_dim);
-                adc_launch<1>(ix, ws, BQ, a);
-                ix.prof_end(ws);
-            }
-            launch_topk_merge_counted(d_cand, cap, d_hits + g0, (uint32_t)gn, efk, ws.keys_a.as<uint64_t>() + g0 * cape, s);
-        }
-        // queries whose candidate list overflowed (or whose workgroup buffer filled) are redone densely
-        std::vector<uint32_t> hits(nq);
-        VDB_HIP(hipMemcpyAsync(hits.data(), d_hits, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        VDB_SYNC(s);
-        for (uint64_t q = 0; q < nq; q++)
-            if (hits[q] > cap || hits[q] < std::min<uint64_t>(efk, n)) dense_group(q, 1);  // overflow, or (thinned sample) too few hits
+        return;
     }
+    // fused path: tau[q] from a strided row-block sample (exact f32 ADC values), then one filtered scan of all rows.
+    // q16: the scan runs on the 16-bit quantised tables, 8 queries per pass (k_pq_adc16), and the exact f32 sums are
+    // computed for its candidates only (k_pq_adc_exact); otherwise the f32 scan itself filters (k_pq_adc MODE 1).
+    const size_t lds16 = size_t(pq.m) * 256 + 32 + ADC16_WGBUF * 8 + (1 + 2 * ADC16_Q) * 4;
+    const bool q16 = g_adc16 != 1 && pq.n_bits == 4 && ix.dist == 0 && (pq.enc_dim % 16) == 0 && pq.m == 2 * pq.enc_dim &&
+                     lds16 <= 150 * 1024 && BQ == 4 && nt == 1024;
+    const uint64_t ld_s = (n_s + 63) & ~63ull;
+    const uint32_t nl_s = topk_num_lists(n_s);
+    const uint32_t cap = (uint32_t)std::min<uint64_t>(65536, std::max<uint64_t>(4096, 4ull * s_rank * step));
+    // queries per round: bounded by the sample matrix (GQ x ld_s floats) and the candidate lists (GQ x cap keys)
+    const uint64_t GQ = q16 ? std::max<uint64_t>(64, std::min<uint64_t>(2048, (size_t(256) << 20) / (ld_s * sizeof(float))) / 64 * 64) : 64;
+    const uint64_t gq_max = std::min<uint64_t>(GQ, nq);
+    ws.dense.reserve(gq_max * ld_s * sizeof(float));
+    ws.lists.reserve(std::max<size_t>(gq_max * nl_s * cape, gq_max * size_t(cap)) * sizeof(uint64_t));
+    ws.misc.reserve(nq * (sizeof(float) + 2 * sizeof(uint32_t)));
+    float *d_tau = ws.misc.as<float>();
+    uint32_t *d_hits = reinterpret_cast<uint32_t *>(d_tau + nq);
+    uint32_t *d_valid = d_hits + nq;
+    VDB_HIP(hipMemsetAsync(d_hits, 0, 2 * nq * sizeof(uint32_t), s));
+    double *d_qM = nullptr, *d_qD = nullptr;
+    uint32_t *d_qflag = nullptr;
+    if (q16) {
+        static bool attr = false;
+        if (!attr) {
+            VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pq_adc16), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        160 * 1024));
+            attr = true;
+        }
+        const uint64_t ngrp = (nq + ADC16_Q - 1) / ADC16_Q;
+        ws.qfrag_g.reserve(ngrp * pq.m * 256);
+        ws.qaux.reserve(nq * (2 * sizeof(double) + sizeof(uint32_t)));
+        d_qM = ws.qaux.as<double>();
+        d_qD = d_qM + nq;
+        d_qflag = reinterpret_cast<uint32_t *>(d_qD + nq);
+        // slots of the last image group beyond nq keep whatever the buffer held: their thresholds are -1 (never hit)
+        hipLaunchKernelGGL(k_pq_quant16, dim3((unsigned)nq), dim3(256), 0, s, ws.lut.as<float>(), (uint32_t)pq.m, (uint32_t)nq,
+                           ws.qfrag_g.as<uint16_t>(), d_qM, d_qD, d_qflag);
+    }
+    for (uint64_t g0 = 0; g0 < nq; g0 += GQ) {
+        const uint64_t gn = std::min<uint64_t>(GQ, nq - g0);
+        {
+            AdcArgs a = base;
+            a.nq_total = (uint32_t)gn;
+            a.lut = ws.lut.as<float>() + g0 * lsz;
+            a.qsq = ws.qsq.as<float>() + g0;
+            a.blk_step = step;
+            a.out = ws.dense.as<float>();
+            a.ld = ld_s;
+            adc_launch<0>(ix, ws, BQ, a);
+        }
+        if (n_s <= select_tau_max_n()) {  // tau = efk-th smallest sampled ADC value: a selection, not a sort
+            launch_select_tau(ws.dense.as<float>(), ld_s, (uint32_t)n_s, (uint32_t)gn, (uint32_t)gn, s_rank, d_tau + g0, s);
+        } else {
+            launch_topk_dense(ws.dense.as<float>(), ld_s, n_s, (uint32_t)gn, s_rank, ws.lists.as<uint64_t>(), s);
+            launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, cape, (uint32_t)gn, s_rank, ws.keys_a.as<uint64_t>() + g0 * cape, s);
+            launch_extract_tau(ws.keys_a.as<uint64_t>() + g0 * cape, cape, (uint32_t)gn, s_rank, d_tau + g0, s);
+        }
+        uint64_t *d_cand = ws.lists.as<uint64_t>();  // the sample lists are dead now
+        if (q16) {
+            Adc16Args a{};
+            a.codes = pq.d_codes.as<uint8_t>();
+            a.n = n;
+            a.enc_dim = (uint32_t)pq.enc_dim;
+            a.m = (uint32_t)pq.m;
+            a.img = reinterpret_cast<const uint4 *>(ws.qfrag_g.as<uint8_t>() + (g0 / ADC16_Q) * pq.m * 256);  // GQ % 8 == 0
+            a.qM = d_qM + g0;
+            a.qD = d_qD + g0;
+            a.qflag = d_qflag + g0;
+            a.tau = d_tau + g0;
+            a.nq = (uint32_t)gn;
+            a.rows_per_wg = ((n + ix.num_cu - 1) / ix.num_cu + 63) / 64 * 64;
+            a.cand = d_cand;
+            a.cnt = d_hits + g0;
+            a.cap = cap;
+            const uint32_t nwg = (uint32_t)((n + a.rows_per_wg - 1) / a.rows_per_wg);
+            const uint32_t ngrp = (uint32_t)((gn + ADC16_Q - 1) / ADC16_Q);
+            ix.prof_begin(ws, "pq_adc", double(ngrp) * double(n) * pq.enc_dim);
+            hipLaunchKernelGGL(k_pq_adc16, dim3(nwg, ngrp), dim3(1024), lds16, s, a);
+            ix.prof_end(ws);
+            hipLaunchKernelGGL(k_pq_adc_exact, dim3((unsigned)gn), dim3(256), lsz * sizeof(float), s, pq.d_codes.as<uint8_t>(),
+                               (uint32_t)pq.enc_dim, (uint32_t)pq.m, ws.lut.as<float>() + g0 * lsz, d_tau + g0, d_cand,
+                               d_hits + g0, cap, d_valid + g0);
+        } else {
+            AdcArgs a = base;
+            a.nq_total = (uint32_t)gn;
+            a.lut = ws.lut.as<float>() + g0 * lsz;
+            a.qsq = ws.qsq.as<float>() + g0;
+            a.tau = d_tau + g0;
+            a.cand = d_cand;
+            a.cnt = d_hits + g0;
+            a.cap = cap;
+            ix.prof_begin(ws, "pq_adc", double((gn + BQ - 1) / BQ) * double(n) * pq.enc_dim);
+            adc_launch<1>(ix, ws, BQ, a);
+            ix.prof_end(ws);
+        }
+        launch_topk_merge_counted(d_cand, cap, d_hits + g0, (uint32_t)gn, efk, ws.keys_a.as<uint64_t>() + g0 * cape, s);
+    }
+    // queries whose candidate list overflowed (or whose workgroup buffer filled, or whose table cannot be quantised) are
+    // redone densely; so are those with fewer than efk rows at or below tau (thinned sample)
+    uint32_t *hv = static_cast<uint32_t *>(ws.pinned(2 * nq * sizeof(uint32_t)));
+    VDB_HIP(hipMemcpyAsync(hv, d_hits, 2 * nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    VDB_SYNC(s);
+    const uint64_t need = std::min<uint64_t>(efk, n);
+    std::vector<uint64_t> redo;
+    for (uint64_t q = 0; q < nq; q++)
+        if (hv[q] > cap || (q16 ? hv[nq + q] : hv[q]) < need) redo.push_back(q);
+    for (uint64_t q : redo) dense_group(q, 1);
 }
 
 // PQTable::create_lookup (pq_table.rs:195-224) and the ADC adapter (pq_table.rs:239-301) over every code row, exported
