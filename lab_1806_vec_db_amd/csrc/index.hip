@@ -141,7 +141,7 @@ uint64_t Index::hbm_bytes_per_row() const {
         if (tiled_built) b += uint64_t(mfma_dim_pad((uint32_t)dim)) * sizeof(float);
         if (half_valid) b += uint64_t(mfma_dim_pad((uint32_t)dim)) * sizeof(uint16_t);
     }
-    if (pq.present) b += pq.enc_dim;
+    if (pq.present) b += pq.enc_dim * (pq.codes_t_valid ? 2 : 1);
     if (hnsw.present) b += hnsw.max_m0 * sizeof(uint32_t) + sizeof(uint32_t);
     return b;
 }

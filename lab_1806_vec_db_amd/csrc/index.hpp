@@ -104,6 +104,8 @@ struct PQState {
     std::vector<float> h_centroids;  // kc*dim
     std::vector<float> h_cent_cache; // m*kc
     DevBuf d_centroids, d_cent_cache, d_codes, d_gstart;
+    DevBuf d_codes_t;                // word-major mirror of d_codes for the quantised ADC scan (pq.hip: k_pq_tile_codes)
+    bool codes_t_valid = false;
 };
 
 struct HNSWState {

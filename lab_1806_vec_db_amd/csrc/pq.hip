@@ -330,6 +330,20 @@ __global__ __launch_bounds__(1024) void k_pq_adc(AdcArgs a) {
 // keeps those <= tau -- the same set, the same values, the same (adc, idx) order as the f32 scan produces.
 // Queries whose table holds a non-finite or negative entry are flagged and take the f32 scan.
 // ---------------------------------------------------------------------------------------------------
+// Code rows are 160 B apart (m = 320): with one lane per row a 16-B code-word load of a wave touches 64 different
+// 128-B lines, and the 1024 rows of a workgroup iteration (160 KB) do not fit the L1, so every line came from L2 up to 8
+// times.  The scan therefore reads a word-major mirror of the codes: tile of 64 rows x word w x lane -> one wave load
+// = 1 KB contiguous, every line fetched once.  Built once per table (the codes are immutable until the next build).
+__global__ __launch_bounds__(256) void k_pq_tile_codes(const uint4 *__restrict__ codes, uint64_t n, uint32_t nwords,
+                                                       uint4 *__restrict__ tiled) {
+    const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;  // output entry: ((tile * nwords) + w) * 64 + lane
+    const uint64_t total = (n + 63) / 64 * 64 * nwords;
+    if (i >= total) return;
+    const uint64_t lane = i & 63, tw = i >> 6, tile = tw / nwords, w = tw - tile * nwords;
+    const uint64_t row = tile * 64 + lane;
+    tiled[i] = row < n ? codes[row * nwords + w] : make_uint4(0, 0, 0, 0);
+}
+
 constexpr uint32_t ADC16_Q = 8;          // queries per workgroup pass
 constexpr uint32_t ADC16_WGBUF = 2048;   // LDS hit buffer entries per workgroup
 
@@ -392,7 +406,7 @@ __global__ __launch_bounds__(256) void k_pq_quant16(const float *__restrict__ lu
 }
 
 struct Adc16Args {
-    const uint8_t *codes;
+    const uint4 *codes_t;    // word-major mirror of the code rows (k_pq_tile_codes)
     uint64_t n;
     uint32_t enc_dim, m;
     const uint4 *img;        // [ceil(nq/8)][m*16] 16-B entries
@@ -406,6 +420,12 @@ struct Adc16Args {
     uint32_t cap;
 };
 
+// NW = 16-B code words per row (enc_dim / 16) as a compile-time constant: the row loop is fully unrolled, every
+// group's table offset is an instruction immediate and the address register of a lookup is ONE v_perm_b32 (byte b of
+// the packed nibble offsets, plus bit 16 for the groups beyond the 16-bit immediate range).  NW = 0: runtime count,
+// one extra add per lookup.  (Shift + mask + base add per lookup made the loop VALU-bound: 154 vector instructions
+// per 32 lookups against 128 LDS cycles.)
+template <int NW>
 __global__ __launch_bounds__(1024) void k_pq_adc16(Adc16Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
     const uint32_t tid = threadIdx.x;
@@ -416,6 +436,12 @@ __global__ __launch_bounds__(1024) void k_pq_adc16(Adc16Args a) {
     uint32_t *hit_row = reinterpret_cast<uint32_t *>(thr + 8);        // [ADC16_WGBUF]
     uint32_t *hit_q = hit_row + ADC16_WGBUF;                          // [ADC16_WGBUF] slot | rank << 8
     uint32_t *hit_n = hit_q + ADC16_WGBUF;                            // [0] entries, [1..8] per-slot counts, [9..16] bases
+    // the lookups address the table with absolute LDS offsets from 0: the dynamic segment is the kernel's only LDS
+    // object, so it starts there; if a toolchain ever places it elsewhere the queries go to the f32 scan
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem16 != 0u) {
+        if (tid < ADC16_Q && q0 + tid < a.nq) atomicAdd(&a.cnt[q0 + tid], a.cap + 1);
+        return;
+    }
     {
         const uint4 *src = a.img + uint64_t(blockIdx.y) * m * 16;
         for (uint32_t i = tid; i < m * 16; i += 1024) tab[i] = src[i];
@@ -440,32 +466,64 @@ __global__ __launch_bounds__(1024) void k_pq_adc16(Adc16Args a) {
     for (int b = 0; b < (int)ADC16_Q; b++) T[b] = thr[b];
     const uint64_t r_begin = uint64_t(blockIdx.x) * a.rows_per_wg;
     const uint64_t r_end = r_begin + a.rows_per_wg < a.n ? r_begin + a.rows_per_wg : a.n;
-    const uint32_t nwords = a.enc_dim / 16;
-    const char *lbase = reinterpret_cast<const char *>(tab);
+    const uint32_t nwords = NW ? (uint32_t)NW : a.enc_dim / 16;
+    typedef __attribute__((address_space(3))) uint4 lds_u4;
     for (uint64_t rb = r_begin; rb < r_end; rb += 1024) {
         const uint64_t row = rb + tid;
         const bool valid = row < r_end;
-        const uint4 *cw = reinterpret_cast<const uint4 *>(a.codes + (valid ? row : r_end - 1) * a.enc_dim);
+        // word w of row (rb + tid): tile = row / 64 (uniform in the wave: rb is a multiple of 64), lane = row % 64; rows
+        // past n inside the last tile are zero padding
+        const uint4 *cw = a.codes_t + (row >> 6) * nwords * 64 + (row & 63);
         uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        uint4 v = cw[0];
-        for (uint32_t w = 0; w < nwords; w++) {
-            const uint32_t words[4] = {v.x, v.y, v.z, v.w};
-            if (w + 1 < nwords) v = cw[w + 1];  // next code word while this one is looked up
-            const char *wb = lbase + w * (32 * 256);
+        // one 16-B code word = 32 groups.  Byte b of a 32-bit word: low nibble = group 8wi + 2b, high nibble the next one;
+        // their byte offsets inside the group's 256-B block (code * 16) sit packed in the bytes of e4 / o4.
+        // gbyte = byte offset of the word's first group block, folded into the instructions' immediates; the table
+        // starts at LDS address 0 (checked at kernel entry), so a lookup's address register is the permute alone
+        auto word16 = [&](const uint4 &cv, uint32_t gbyte, uint32_t hi /* 0 or 0x04: adds bit 16 through the permute */) {
+            const uint32_t words[4] = {cv.x, cv.y, cv.z, cv.w};
 #pragma unroll
             for (int wi = 0; wi < 4; wi++) {
-                // byte b of the word: low nibble = group 32w + 8wi + 2b, high nibble = the next one; as byte offsets
-                // (code * 16) inside the group's 256-B block: packed in the bytes of e4 / o4
                 const uint32_t e4 = (words[wi] & 0x0f0f0f0fu) << 4, o4 = words[wi] & 0xf0f0f0f0u;
+                uint4 E[4], O[4];
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
-                    const uint4 E = *reinterpret_cast<const uint4 *>(wb + (wi * 8 + 2 * b) * 256 + ((e4 >> (8 * b)) & 0xffu));
-                    const uint4 O = *reinterpret_cast<const uint4 *>(wb + (wi * 8 + 2 * b + 1) * 256 + ((o4 >> (8 * b)) & 0xffu));
-                    a0 = a0 + E.x + O.x;
-                    a1 = a1 + E.y + O.y;
-                    a2 = a2 + E.z + O.z;
-                    a3 = a3 + E.w + O.w;
+                    const uint32_t sel = 0x0c000c00u | (hi << 16) | (uint32_t)b | (hi ? 0u : 0x000c0000u);
+                    const uint32_t oe = __builtin_amdgcn_perm(1u, e4, sel), oo = __builtin_amdgcn_perm(1u, o4, sel);
+#if defined(__HIP_DEVICE_COMPILE__)
+                    E[b] = *reinterpret_cast<const lds_u4 *>(oe + gbyte + (wi * 8 + 2 * b) * 256);
+                    O[b] = *reinterpret_cast<const lds_u4 *>(oo + gbyte + (wi * 8 + 2 * b + 1) * 256);
+#else
+                    E[b] = O[b] = make_uint4(oe, oo, gbyte, 0);  // (host pass of the single-source compile: never runs)
+#endif
                 }
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    a0 = a0 + E[b].x + O[b].x;
+                    a1 = a1 + E[b].y + O[b].y;
+                    a2 = a2 + E[b].z + O[b].z;
+                    a3 = a3 + E[b].w + O[b].w;
+                }
+                // pin the four running sums here: left alone, the optimiser re-associates the unrolled row into four
+                // separate 320-term chains, finishes one and parks the other three components of every table entry
+                // in scratch (measured: 1.7 - 7.8 KB of spills per lane)
+                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+            }
+        };
+        if (NW) {
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                // groups 32w .. 32w+31 at byte offset w * 8192: beyond 65535 the immediate cannot hold it -> bit 16 rides
+                // in the address register (sel byte 2 = 4 picks the 0x01 of the constant operand)
+                const uint4 cv = cw[w * 64];
+                if (w < 8) word16(cv, w * 8192, 0u);
+                else word16(cv, (w - 8) * 8192, 0x04u);
+            }
+        } else {
+            uint4 v = cw[0];
+            for (uint32_t w = 0; w < nwords; w++) {
+                const uint4 cur = v;
+                if (w + 1 < nwords) v = cw[(w + 1) * 64];  // next code word while this one is looked up
+                word16(cur, w * 8192, 0u);
             }
         }
         const int32_t s[ADC16_Q] = {int32_t(a0 & 0xffffu), int32_t(a0 >> 16), int32_t(a1 & 0xffffu), int32_t(a1 >> 16),
@@ -711,7 +769,9 @@ static float host_dist(int dist, const float *a, const float *b, size_t n) {
 void pq_clear(Index &ix) {
     ix.pq.present = false;
     ix.pq.n_coded = 0;
+    ix.pq.codes_t_valid = false;
     ix.pq.d_codes.release();
+    ix.pq.d_codes_t.release();
 }
 
 static void pq_install(Index &ix, uint64_t n_bits, uint64_t m, const float *centroids) {
@@ -745,6 +805,21 @@ static void pq_install(Index &ix, uint64_t n_bits, uint64_t m, const float *cent
     pq.d_codes.reserve(std::max<uint64_t>(ix.n, 1) * pq.enc_dim);
 }
 
+// word-major mirror of the codes for the quantised scan (4-bit tables with whole 16-B code words only)
+static void pq_tile_codes(Index &ix) {
+    PQState &pq = ix.pq;
+    pq.codes_t_valid = false;
+    if (pq.n_bits != 4 || (pq.enc_dim % 16) != 0 || pq.m != 2 * pq.enc_dim || ix.n == 0) return;
+    const uint32_t nwords = (uint32_t)(pq.enc_dim / 16);
+    const uint64_t total = (ix.n + 63) / 64 * 64 * nwords;
+    pq.d_codes_t.reserve(total * sizeof(uint4));
+    WsLease ws(ix);
+    hipLaunchKernelGGL(k_pq_tile_codes, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ws->stream, pq.d_codes.as<uint4>(), ix.n,
+                       nwords, pq.d_codes_t.as<uint4>());
+    VDB_SYNC(ws->stream);
+    pq.codes_t_valid = true;
+}
+
 static void pq_encode_all(Index &ix) {
     PQState &pq = ix.pq;
     if (ix.n == 0) return;
@@ -763,6 +838,7 @@ void pq_attach(Index &ix, uint64_t n_bits, uint64_t m, const float *centroids, c
     } else {
         pq_encode_all(ix);
     }
+    pq_tile_codes(ix);
     ix.pq.n_coded = ix.n;
     ix.pq.present = true;
 }
@@ -904,8 +980,29 @@ void pq_build(Index &ix, uint64_t n_bits, uint64_t m, uint64_t train_n, uint64_t
     for (auto &t : th) t.join();
     pq_install(ix, n_bits, m, cent.data());
     pq_encode_all(ix);
+    pq_tile_codes(ix);
     ix.pq.n_coded = ix.n;
     ix.pq.present = true;
+}
+
+template <int NW>
+static void adc16_launch_nw(const Adc16Args &a, dim3 grid, size_t lds, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pq_adc16<NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_pq_adc16<NW>, grid, dim3(1024), lds, s, a);
+}
+static void adc16_launch(const Adc16Args &a, uint32_t nwords, dim3 grid, size_t lds, hipStream_t s) {
+    switch (nwords) {  // m = 32 * nwords groups: 128 / 256 / 320 (Gist1M, dim / 3) / 512
+        case 4: adc16_launch_nw<4>(a, grid, lds, s); break;
+        case 8: adc16_launch_nw<8>(a, grid, lds, s); break;
+        case 10: adc16_launch_nw<10>(a, grid, lds, s); break;
+        case 16: adc16_launch_nw<16>(a, grid, lds, s); break;
+        default: adc16_launch_nw<0>(a, grid, lds, s); break;
+    }
 }
 
 // ---- FlatIndex::knn_pq (flat_index.rs:84-104) --------------------------------------------------------
@@ -1052,7 +1149,7 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
     // q16: the scan runs on the 16-bit quantised tables, 8 queries per pass (k_pq_adc16), and the exact f32 sums are
     // computed for its candidates only (k_pq_adc_exact); otherwise the f32 scan itself filters (k_pq_adc MODE 1).
     const size_t lds16 = size_t(pq.m) * 256 + 32 + ADC16_WGBUF * 8 + (1 + 2 * ADC16_Q) * 4;
-    const bool q16 = g_adc16 != 1 && pq.n_bits == 4 && ix.dist == 0 && (pq.enc_dim % 16) == 0 && pq.m == 2 * pq.enc_dim &&
+    const bool q16 = g_adc16 != 1 && pq.codes_t_valid && pq.n_bits == 4 && ix.dist == 0 && (pq.enc_dim % 16) == 0 && pq.m == 2 * pq.enc_dim &&
                      lds16 <= 150 * 1024 && BQ == 4 && nt == 1024;
     const uint64_t ld_s = (n_s + 63) & ~63ull;
     const uint32_t nl_s = topk_num_lists(n_s);
@@ -1070,12 +1167,6 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
     double *d_qM = nullptr, *d_qD = nullptr;
     uint32_t *d_qflag = nullptr;
     if (q16) {
-        static bool attr = false;
-        if (!attr) {
-            VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pq_adc16), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        160 * 1024));
-            attr = true;
-        }
         const uint64_t ngrp = (nq + ADC16_Q - 1) / ADC16_Q;
         ws.qfrag_g.reserve(ngrp * pq.m * 256);
         ws.qaux.reserve(nq * (2 * sizeof(double) + sizeof(uint32_t)));
@@ -1108,7 +1199,7 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
         uint64_t *d_cand = ws.lists.as<uint64_t>();  // the sample lists are dead now
         if (q16) {
             Adc16Args a{};
-            a.codes = pq.d_codes.as<uint8_t>();
+            a.codes_t = pq.d_codes_t.as<uint4>();
             a.n = n;
             a.enc_dim = (uint32_t)pq.enc_dim;
             a.m = (uint32_t)pq.m;
@@ -1125,7 +1216,7 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
             const uint32_t nwg = (uint32_t)((n + a.rows_per_wg - 1) / a.rows_per_wg);
             const uint32_t ngrp = (uint32_t)((gn + ADC16_Q - 1) / ADC16_Q);
             ix.prof_begin(ws, "pq_adc", double(ngrp) * double(n) * pq.enc_dim);
-            hipLaunchKernelGGL(k_pq_adc16, dim3(nwg, ngrp), dim3(1024), lds16, s, a);
+            adc16_launch(a, (uint32_t)(pq.enc_dim / 16), dim3(nwg, ngrp), lds16, s);
             ix.prof_end(ws);
             hipLaunchKernelGGL(k_pq_adc_exact, dim3((unsigned)gn), dim3(256), lsz * sizeof(float), s, pq.d_codes.as<uint8_t>(),
                                (uint32_t)pq.enc_dim, (uint32_t)pq.m, ws.lut.as<float>() + g0 * lsz, d_tau + g0, d_cand,
