@@ -477,53 +477,69 @@ __global__ __launch_bounds__(1024) void k_pq_adc16(Adc16Args a) {
         uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         // one 16-B code word = 32 groups.  Byte b of a 32-bit word: low nibble = group 8wi + 2b, high nibble the next one;
         // their byte offsets inside the group's 256-B block (code * 16) sit packed in the bytes of e4 / o4.
-        // gbyte = byte offset of the word's first group block, folded into the instructions' immediates; the table
-        // starts at LDS address 0 (checked at kernel entry), so a lookup's address register is the permute alone
-        auto word16 = [&](const uint4 &cv, uint32_t gbyte, uint32_t hi /* 0 or 0x04: adds bit 16 through the permute */) {
-            const uint32_t words[4] = {cv.x, cv.y, cv.z, cv.w};
+        // A step = the 8 groups of one 32-bit code word: byte b holds group 2b (low nibble) and 2b+1 (high nibble); their
+        // byte offsets inside a group's 256-B block (code * 16) sit packed in the bytes of e4 / o4.  gbyte = byte offset
+        // of the step's first group block, folded into the instructions' immediates; the table starts at LDS address 0
+        // (checked at kernel entry), so a lookup's address register is the permute alone.
+        auto issue = [&](uint32_t word, uint32_t gbyte, uint32_t hi /* 0 or 0x04: adds bit 16 through the permute */, uint4 *E, uint4 *O) {
+            const uint32_t e4 = (word & 0x0f0f0f0fu) << 4, o4 = word & 0xf0f0f0f0u;
 #pragma unroll
-            for (int wi = 0; wi < 4; wi++) {
-                const uint32_t e4 = (words[wi] & 0x0f0f0f0fu) << 4, o4 = words[wi] & 0xf0f0f0f0u;
-                uint4 E[4], O[4];
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const uint32_t sel = 0x0c000c00u | (hi << 16) | (uint32_t)b | (hi ? 0u : 0x000c0000u);
-                    const uint32_t oe = __builtin_amdgcn_perm(1u, e4, sel), oo = __builtin_amdgcn_perm(1u, o4, sel);
+            for (int b = 0; b < 4; b++) {
+                const uint32_t sel = 0x0c000c00u | (hi << 16) | (uint32_t)b | (hi ? 0u : 0x000c0000u);
+                const uint32_t oe = __builtin_amdgcn_perm(1u, e4, sel), oo = __builtin_amdgcn_perm(1u, o4, sel);
 #if defined(__HIP_DEVICE_COMPILE__)
-                    E[b] = *reinterpret_cast<const lds_u4 *>(oe + gbyte + (wi * 8 + 2 * b) * 256);
-                    O[b] = *reinterpret_cast<const lds_u4 *>(oo + gbyte + (wi * 8 + 2 * b + 1) * 256);
+                E[b] = *reinterpret_cast<const lds_u4 *>(oe + gbyte + (2 * b) * 256);
+                O[b] = *reinterpret_cast<const lds_u4 *>(oo + gbyte + (2 * b + 1) * 256);
 #else
-                    E[b] = O[b] = make_uint4(oe, oo, gbyte, 0);  // (host pass of the single-source compile: never runs)
+                E[b] = O[b] = make_uint4(oe, oo, gbyte, 0);  // (host pass of the single-source compile: never runs)
 #endif
-                }
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    a0 = a0 + E[b].x + O[b].x;
-                    a1 = a1 + E[b].y + O[b].y;
-                    a2 = a2 + E[b].z + O[b].z;
-                    a3 = a3 + E[b].w + O[b].w;
-                }
-                // pin the four running sums here: left alone, the optimiser re-associates the unrolled row into four
-                // separate 320-term chains, finishes one and parks the other three components of every table entry
-                // in scratch (measured: 1.7 - 7.8 KB of spills per lane)
-                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
             }
         };
-        if (NW) {
+        auto consume = [&](const uint4 *E, const uint4 *O) {
 #pragma unroll
-            for (int w = 0; w < NW; w++) {
-                // groups 32w .. 32w+31 at byte offset w * 8192: beyond 65535 the immediate cannot hold it -> bit 16 rides
-                // in the address register (sel byte 2 = 4 picks the 0x01 of the constant operand)
-                const uint4 cv = cw[w * 64];
-                if (w < 8) word16(cv, w * 8192, 0u);
-                else word16(cv, (w - 8) * 8192, 0x04u);
+            for (int b = 0; b < 4; b++) {
+                a0 = a0 + E[b].x + O[b].x;
+                a1 = a1 + E[b].y + O[b].y;
+                a2 = a2 + E[b].z + O[b].z;
+                a3 = a3 + E[b].w + O[b].w;
+            }
+            // pin the four running sums here: left alone, the optimiser re-associates the unrolled row into four
+            // separate 320-term chains, finishes one and parks the other three components of every table entry
+            // in scratch (measured: 1.7 - 7.8 KB of spills per lane)
+            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        };
+        if (NW) {
+            // software pipeline over the 4 NW steps of the row: the lookups of step i+1 are issued before the sums of
+            // step i are taken, so 8 - 16 ds_read_b128 per wave are in flight while the adds run
+            uint4 cv[NW ? NW : 1];
+#pragma unroll
+            for (int w = 0; w < NW; w++) cv[w] = cw[w * 64];
+            uint4 E[2][4], O[2][4];
+            issue(cv[0].x, 0u, 0u, E[0], O[0]);
+#pragma unroll
+            for (int st = 0; st < 4 * NW; st++) {
+                if (st + 1 < 4 * NW) {
+                    const int w = (st + 1) >> 2, wi = (st + 1) & 3;
+                    const uint32_t word = wi == 0 ? cv[w].x : (wi == 1 ? cv[w].y : (wi == 2 ? cv[w].z : cv[w].w));
+                    // groups 32w .. 32w+31 at byte offset w * 8192: beyond 65535 the immediate cannot hold it -> bit 16
+                    // rides in the address register (sel byte 2 = 4 picks the 0x01 of the constant operand)
+                    issue(word, (w < 8 ? w : w - 8) * 8192 + wi * 2048, w < 8 ? 0u : 0x04u, E[(st + 1) & 1], O[(st + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks these reads below the adds of step st)
+                }
+                consume(E[st & 1], O[st & 1]);
             }
         } else {
             uint4 v = cw[0];
             for (uint32_t w = 0; w < nwords; w++) {
                 const uint4 cur = v;
                 if (w + 1 < nwords) v = cw[(w + 1) * 64];  // next code word while this one is looked up
-                word16(cur, w * 8192, 0u);
+                const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+                for (int wi = 0; wi < 4; wi++) {
+                    uint4 E[4], O[4];
+                    issue(words[wi], w * 8192 + wi * 2048, 0u, E, O);
+                    consume(E, O);
+                }
             }
         }
         const int32_t s[ADC16_Q] = {int32_t(a0 & 0xffffu), int32_t(a0 >> 16), int32_t(a1 & 0xffffu), int32_t(a1 >> 16),
