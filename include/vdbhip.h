@@ -119,6 +119,8 @@ int vdb_flat_fallback_count(const vdb_index *idx, uint64_t *out);
  *   "flat_half_valid"    1 when the index holds the fp16 mirror,
  *   "flat_bf16_mirror"   1 once the split-bf16 mirror (4 B/element) has been built -- lazily, by the first search that
  *                        needs it (redo tier, flat_half = 1, calls without an fp16 mirror),
+ *   "hnsw_heap_walk_queries"  HNSW queries answered by the any-size heap walk (max(ef, k) > 1024, or the LDS candidate
+ *                        pool of the fast walk overflowed),
  *   "hbm_bytes_per_row"  resident HBM bytes per row over all per-row buffers (rows, norms, mirrors, PQ codes, level-0 links). */
 int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out);
 

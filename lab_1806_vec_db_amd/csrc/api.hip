@@ -358,6 +358,8 @@ int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out) {
         *out = idx->ix.half_valid ? 1 : 0;
     else if (n == "flat_bf16_mirror")
         *out = idx->ix.tiled_built ? 1 : 0;
+    else if (n == "hnsw_heap_walk_queries")
+        *out = idx->ix.hnsw.heap_walk_queries.load();
     else if (n == "hbm_bytes_per_row")
         *out = idx->ix.hbm_bytes_per_row();
     else

@@ -27,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include "heap.hpp"
 #include "pq_hnsw.hpp"
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -461,9 +462,148 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswDev g, const float *__re
             }
         }
     }
-    if (overflow && lane == 0) atomicOr(err, 1u);
+    if (overflow && lane == 0) err[q] = 1u;  // this query is answered again by k_hnsw_search_big
 #pragma unroll
     for (int r = 0; r < R; r++) out[uint64_t(q) * (64 * R) + r * 64 + lane] = rv[r];
+    if (lane == 0 && !overflow) {  // (an overflowed walk is repeated by k_hnsw_search_big, which counts it)
+        atomicAdd(&stats[0], n_dist);
+        atomicAdd(&stats[1], n_exp);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same walk without size limits: ef beyond the 1024 pairs of the register list, candidate pools beyond the LDS
+// pool.  The reference keeps both sets in BTreeSets (hnsw_index.rs:266-268); here the result set is a max-heap and the
+// candidate queue a min-heap in global memory, both driven by lane 0 (O(log n) per operation), while the distances of
+// a node's links are still computed one per lane.  A node enters the queue at most once (visited set), so n entries
+// per query bound it.  Same replay rules as k_hnsw_search: stored link order, check_candidate by the full order at pop
+// time, ResultSet::add by distance only; the work counters are the same ones.  The result heap leaves the kernel
+// unsorted (PAIR_NONE padded); a row sort follows.
+// ---------------------------------------------------------------------------------------------------
+template <bool ADC>
+__global__ __launch_bounds__(64) void k_hnsw_search_big(HnswDev g, const float *__restrict__ Q, const float *__restrict__ qsq_all,
+                                                        const float *__restrict__ lut_all, uint32_t lut_in_lds, uint32_t ef,
+                                                        uint32_t *__restrict__ visited, uint64_t visited_words,
+                                                        const uint32_t *__restrict__ qlist, uint64_t *__restrict__ cand_heap,
+                                                        uint64_t cand_cap, uint64_t *__restrict__ res_heap, uint32_t res_ld,
+                                                        unsigned long long *__restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_big[];
+    float *fl = reinterpret_cast<float *>(smem_big);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t slot = blockIdx.x;
+    const uint32_t q = qlist[slot];
+    const float qsq = qsq_all[q];
+    uint32_t *vis = visited + uint64_t(slot) * visited_words;
+    uint64_t *ch = cand_heap + uint64_t(slot) * cand_cap;
+    uint64_t *rh = res_heap + uint64_t(slot) * res_ld;
+    for (uint32_t j = lane; j < res_ld; j += 64) rh[j] = PAIR_NONE;
+    const float *lut = nullptr;
+    if (ADC) {
+        const float *lg = lut_all + uint64_t(q) * g.pq_m * g.pq_kc;
+        if (lut_in_lds) {
+            for (uint32_t i = lane; i < g.pq_m * g.pq_kc; i += 64) fl[i] = lg[i];
+            lut = fl;
+        } else {
+            lut = lg;
+        }
+    } else {
+        for (uint32_t i = lane; i < g.dim; i += 64) fl[i] = Q[uint64_t(q) * g.dim + i];
+    }
+    __syncthreads();
+    auto dist_of = [&](uint32_t idx) -> float { return ADC ? hnsw_adc_dist(g, lut, qsq, idx) : hnsw_exact_dist(g, fl, qsq, idx); };
+    unsigned long long n_dist = 0, n_exp = 0;
+
+    // greedy descent, levels enter_level .. 1 (hnsw_index.rs:306-350): as in k_hnsw_search
+    uint32_t cur = g.enter_point;
+    float cur_d = 0.0f;
+    {
+        float d = 0.0f;
+        if (lane == 0) d = dist_of(cur);
+        cur_d = __shfl(d, 0);
+        n_dist++;
+    }
+    for (uint32_t level = g.enter_level; level >= 1; level--) {
+        n_dist++;
+        for (;;) {
+            const uint64_t sl = g.upper_off[cur] + level - 1;
+            const uint32_t len = g.upper_len[sl];
+            const uint32_t *lk = g.upper + sl * g.m;
+            bool moved = false;
+            for (uint32_t base = 0; base < len; base += 64) {
+                const uint32_t j = base + lane;
+                const uint32_t nb = j < len ? lk[j] : 0;
+                float d = 0.0f;
+                if (j < len) d = dist_of(nb);
+                const uint32_t cnt = len - base < 64 ? len - base : 64;
+                n_dist += cnt;
+                for (uint32_t t = 0; t < cnt; t++) {
+                    const float dt = __shfl(d, t);
+                    const uint32_t nt = __shfl(nb, t);
+                    if (dt < cur_d) {
+                        cur_d = dt;
+                        cur = nt;
+                        moved = true;
+                    }
+                }
+            }
+            if (!moved) break;
+        }
+    }
+
+    // level 0 (hnsw_index.rs:258-291)
+    uint32_t cn = 0, rn = 0;       // heap sizes (lane 0's copies are the live ones)
+    uint64_t tau = PAIR_NONE;      // results.last() once the set is full (uniform across the wave)
+    {
+        const uint64_t e = pair_key(cur_d, cur);
+        if (lane == 0) {
+            atomicOr(&vis[cur >> 5], 1u << (cur & 31));
+            (void)result_heap_add(rh, rn, ef, e);
+            heap_min_push(ch, cn, e);
+            cn++;
+            tau = rn == ef ? rh[0] : PAIR_NONE;
+        }
+        tau = __shfl(tau, 0);
+    }
+    for (;;) {
+        uint64_t best = PAIR_NONE;
+        if (lane == 0 && cn > 0 && ch[0] < tau) best = heap_min_pop(ch, cn);  // check_candidate (candidate_pair.rs:55-57)
+        best = __shfl(best, 0);
+        if (best == PAIR_NONE) break;  // queue empty, or its smallest pair is not < the worst result
+        n_exp++;
+        const uint32_t p = uint32_t(best);
+        const uint32_t len = g.len0[p];
+        const uint32_t *lk = g.level0 + uint64_t(p) * g.max_m0;
+        for (uint32_t base = 0; base < len; base += 64) {
+            const uint32_t j = base + lane;
+            uint32_t nb = 0;
+            bool fresh = false;
+            if (j < len) {
+                nb = lk[j];
+                const uint32_t bit = 1u << (nb & 31);
+                const uint32_t old = atomicOr(&vis[nb >> 5], bit);
+                fresh = (old & bit) == 0;
+            }
+            uint64_t fm = __ballot(fresh);
+            float d = 0.0f;
+            if (fresh) d = dist_of(nb);
+            n_dist += __builtin_popcountll(fm);
+            while (fm) {  // stored order
+                const uint32_t t = (uint32_t)__builtin_ctzll(fm);
+                fm &= fm - 1;
+                const uint64_t e = pair_key(__shfl(d, t), __shfl(nb, t));
+                if (lane == 0) {
+                    const bool cand = e < tau;  // check_candidate against the set BEFORE this add (never true later if false now)
+                    (void)result_heap_add(rh, rn, ef, e);
+                    if (cand && cn < cand_cap) {
+                        heap_min_push(ch, cn, e);
+                        cn++;
+                    }
+                    tau = rn == ef ? rh[0] : PAIR_NONE;
+                }
+                tau = __shfl(tau, 0);
+            }
+        }
+    }
     if (lane == 0) {
         atomicAdd(&stats[0], n_dist);
         atomicAdd(&stats[1], n_exp);
@@ -1101,29 +1241,34 @@ void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, ui
     VDB_REQUIRE(h.len0.size() == ix.n, "HNSW graph does not cover every row (rebuild or re-attach it)");
     hnsw_upload(ix);
     const uint64_t n = ix.n;
-    const uint64_t efk64 = std::max(ef, k);  // ef.max(k) :628
-    VDB_REQUIRE(efk64 <= 1024, "hnsw knn: max(ef, k) must be <= 1024 in this build");
+    // ef.max(k) :628.  A set of more than n pairs never fills, so n + 1 stands for every larger capacity (same walk, same
+    // counters: the reference keeps expanding until the queue is empty)
+    const uint64_t efk64 = std::min<uint64_t>(std::max(ef, k), n + 1);
     const uint32_t efk = (uint32_t)efk64;
-    const uint32_t cape = topk_capacity(efk);
+    const bool big_all = efk > 1024;  // beyond the register-resident result list: every query takes the heap walk
+    const uint32_t cape = big_all ? 64 : topk_capacity(efk);
     const uint32_t ksel = (uint32_t)std::min<uint64_t>(k, efk);
-    const uint32_t capk = topk_capacity(ksel);
+    const uint32_t capk = ksel <= 1024 ? topk_capacity(ksel) : 64;
     VDB_HIP(hipMemsetAsync(d_idx, 0, nq * k * sizeof(uint64_t), s));
     VDB_HIP(hipMemsetAsync(d_dist, 0, nq * k * sizeof(float), s));
 
     ws.qsq.reserve(nq * sizeof(float));
     launch_row_sqnorm(d_q, nq, (uint32_t)ix.dim, ws.qsq.as<float>(), s);
     PQState &pq = ix.pq;
+    if (use_pq) VDB_REQUIRE(pq.present && pq.n_coded == n, "PQ table does not cover the rows of the index (rebuild it after add)");
     uint32_t lut_in_lds = 0;
-    size_t lds = HNSW_POOL * sizeof(uint64_t);
+    size_t lds = HNSW_POOL * sizeof(uint64_t), lds_big = 0;
     if (use_pq) {
         pq_make_luts(ix, ws, d_q, nq);
         size_t lb = pq.m * pq.kc * sizeof(float);
         if (lb <= 32 * 1024) {
             lut_in_lds = 1;
             lds += lb;
+            lds_big = lb;
         }
     } else {
         lds += ix.dim * sizeof(float);
+        lds_big = ix.dim * sizeof(float);
     }
     const bool dma = !use_pq && g_hnsw_dma && h.max_m0 <= 32 && ix.dim % 32 == 0;
     if (dma) lds = ((lds + 511) & ~size_t(511)) + HNSW_DMA_BYTES;
@@ -1153,56 +1298,132 @@ void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, ui
     }
     const uint64_t vwords = (n + 31) / 32;
     constexpr uint64_t QB = 1024;  // queries per launch (bounds the visited bitmaps: QB * n/8 bytes)
-    ws.misc.reserve(QB * vwords * sizeof(uint32_t) + 64);
-    ws.keys_a.reserve(nq * cape * sizeof(uint64_t));
-    ws.keys_b.reserve(nq * cape * sizeof(uint64_t));
-    ws.keys_c.reserve(nq * capk * sizeof(uint64_t));
-    ws.flags.reserve(64);
-    VDB_HIP(hipMemsetAsync(ws.flags.p, 0, 64, s));
-    unsigned long long *stats = reinterpret_cast<unsigned long long *>(ws.flags.as<uint8_t>() + 16);
-    uint32_t *err = reinterpret_cast<uint32_t *>(ws.flags.p);
-    for (uint64_t q0 = 0; q0 < nq; q0 += QB) {
-        uint32_t nb = (uint32_t)std::min<uint64_t>(QB, nq - q0);
-        VDB_HIP(hipMemsetAsync(ws.misc.p, 0, uint64_t(nb) * vwords * sizeof(uint32_t), s));
-        const float *lut = use_pq ? ws.lut.as<float>() + q0 * pq.m * pq.kc : nullptr;
-        uint64_t *outk = ws.keys_a.as<uint64_t>() + q0 * cape;
-        ix.prof_begin(ws, "hnsw", 0.0);
+    // flags: [0,16) work counters (n_dist, n_expanded), [64, 64 + 4 nq) per-query "candidate pool overflowed"
+    ws.flags.reserve(64 + nq * sizeof(uint32_t));
+    VDB_HIP(hipMemsetAsync(ws.flags.p, 0, 64 + nq * sizeof(uint32_t), s));
+    unsigned long long *stats = reinterpret_cast<unsigned long long *>(ws.flags.p);
+    uint32_t *err = reinterpret_cast<uint32_t *>(ws.flags.as<uint8_t>() + 64);
+    if (!big_all) {
+        ws.misc.reserve(QB * vwords * sizeof(uint32_t) + 64);
+        ws.keys_a.reserve(nq * cape * sizeof(uint64_t));
+        ws.keys_b.reserve(nq * cape * sizeof(uint64_t));
+        ws.keys_c.reserve(nq * capk * sizeof(uint64_t));
+        for (uint64_t q0 = 0; q0 < nq; q0 += QB) {
+            uint32_t nb = (uint32_t)std::min<uint64_t>(QB, nq - q0);
+            VDB_HIP(hipMemsetAsync(ws.misc.p, 0, uint64_t(nb) * vwords * sizeof(uint32_t), s));
+            const float *lut = use_pq ? ws.lut.as<float>() + q0 * pq.m * pq.kc : nullptr;
+            uint64_t *outk = ws.keys_a.as<uint64_t>() + q0 * cape;
+            ix.prof_begin(ws, "hnsw", 0.0);
 #define HL(R)                                                                                                          \
     if (use_pq)                                                                                                        \
         hnsw_launch<R, true>(g, d_q + q0 * ix.dim, ws.qsq.as<float>() + q0, lut, lut_in_lds, efk, ws.misc.as<uint32_t>(), \
-                             vwords, outk, stats, err, nb, lds, s);                                                    \
+                             vwords, outk, stats, err + q0, nb, lds, s);                                               \
     else                                                                                                               \
         hnsw_launch<R, false>(g, d_q + q0 * ix.dim, ws.qsq.as<float>() + q0, lut, lut_in_lds, efk, ws.misc.as<uint32_t>(), \
-                              vwords, outk, stats, err, nb, lds, s);
-        switch (cape / 64) {
-            case 1: HL(1); break;
-            case 2: HL(2); break;
-            case 4: HL(4); break;
-            case 8: HL(8); break;
-            case 16: HL(16); break;
-            default: throw Error(1, "hnsw knn: ef too large");
-        }
+                              vwords, outk, stats, err + q0, nb, lds, s);
+            switch (cape / 64) {
+                case 1: HL(1); break;
+                case 2: HL(2); break;
+                case 4: HL(4); break;
+                case 8: HL(8); break;
+                case 16: HL(16); break;
+                default: throw Error(1, "hnsw knn: unexpected result-list capacity");
+            }
 #undef HL
-        ix.prof_end(ws);
+            ix.prof_end(ws);
+        }
+        if (use_pq) {
+            // pq_resort with the cached-form distance (hnsw_index.rs:693-695)
+            VDB_HIP(hipMemsetAsync(ws.keys_b.p, 0xff, nq * cape * sizeof(uint64_t), s));
+            launch_rerank(ix.d_rows.as<float>(), (uint32_t)ix.dim, d_q, (uint32_t)nq, ix.dist == 0 ? MET_L2_CACHED : MET_COSINE,
+                          ix.d_sq.as<float>(), ws.qsq.as<float>(), ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), efk, cape, s);
+            pq_resort_launch(ws.keys_b.as<uint64_t>(), efk, cape, (uint32_t)nq, ksel, ws.keys_c.as<uint64_t>(), s);
+            launch_finalize(ws.keys_c.as<uint64_t>(), capk, (uint32_t)nq, ksel, (uint32_t)k, ix.id_offset, d_idx, d_dist, d_cnt, s);
+        } else {
+            // into_sorted_vec_limit(k) (:632)
+            launch_finalize(ws.keys_a.as<uint64_t>(), cape, (uint32_t)nq, ksel, (uint32_t)k, ix.id_offset, d_idx, d_dist, d_cnt, s);
+        }
     }
-    if (use_pq) {
-        // pq_resort with the cached-form distance (hnsw_index.rs:693-695)
-        VDB_HIP(hipMemsetAsync(ws.keys_b.p, 0xff, nq * cape * sizeof(uint64_t), s));
-        launch_rerank(ix.d_rows.as<float>(), (uint32_t)ix.dim, d_q, (uint32_t)nq, ix.dist == 0 ? MET_L2_CACHED : MET_COSINE,
-                      ix.d_sq.as<float>(), ws.qsq.as<float>(), ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), efk, cape, s);
-        pq_resort_launch(ws.keys_b.as<uint64_t>(), efk, cape, (uint32_t)nq, ksel, ws.keys_c.as<uint64_t>(), s);
-        launch_finalize(ws.keys_c.as<uint64_t>(), capk, (uint32_t)nq, ksel, (uint32_t)k, ix.id_offset, d_idx, d_dist, d_cnt, s);
+    // queries for the heap walk: all of them (ef > 1024), or those whose LDS candidate pool overflowed (graphs of
+    // near-duplicates keep thousands of live candidates); the work counters of an overflowed walk are dropped first
+    std::vector<uint32_t> redo;
+    unsigned long long st[2] = {0, 0};
+    auto read_stats = [&]() {
+        unsigned char *hb = static_cast<unsigned char *>(ws.pinned(64 + nq * sizeof(uint32_t)));
+        VDB_HIP(hipMemcpyAsync(hb, ws.flags.p, 64 + nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        VDB_SYNC(s);
+        std::memcpy(st, hb, 16);
+        return reinterpret_cast<const uint32_t *>(hb + 64);
+    };
+    if (big_all) {
+        redo.resize(nq);
+        for (uint64_t q = 0; q < nq; q++) redo[q] = (uint32_t)q;
     } else {
-        // into_sorted_vec_limit(k) (:632)
-        launch_finalize(ws.keys_a.as<uint64_t>(), cape, (uint32_t)nq, ksel, (uint32_t)k, ix.id_offset, d_idx, d_dist, d_cnt, s);
+        const uint32_t *e = read_stats();
+        for (uint64_t q = 0; q < nq; q++)
+            if (e[q]) redo.push_back((uint32_t)q);
     }
-    unsigned char hostbuf[64];
-    VDB_HIP(hipMemcpyAsync(hostbuf, ws.flags.p, 64, hipMemcpyDeviceToHost, s));
-    VDB_SYNC(s);
-    uint32_t e;
-    std::memcpy(&e, hostbuf, 4);
-    unsigned long long st[2];
-    std::memcpy(st, hostbuf + 16, 16);
+    if (!redo.empty()) {
+        h.heap_walk_queries += redo.size();
+        const uint32_t res_ld = (efk + 63) & ~63u;
+        // per slot: visited bitmap + candidate heap (n pairs) + result heap, its sorted copy and (PQ) the exact keys
+        const uint64_t per_q = vwords * 4 + n * 8 + uint64_t(res_ld) * 24;
+        const uint64_t QBB = std::max<uint64_t>(1, std::min<uint64_t>(256, (size_t(3) << 29) / per_q));
+        const size_t tb = sort_rows_temp_bytes(QBB, res_ld);
+        DevBuf b_vis, b_cand, b_res, b_sorted, b_exact, b_tmp, b_ql;  // rare path: allocated on demand
+        b_vis.reserve(QBB * vwords * 4);
+        b_cand.reserve(QBB * n * 8);
+        b_res.reserve(QBB * res_ld * 8);
+        b_sorted.reserve(QBB * res_ld * 8);
+        if (use_pq) b_exact.reserve(QBB * res_ld * 8);
+        b_tmp.reserve(tb);
+        b_ql.reserve(QBB * 4);
+        static bool attr = false;
+        if (!attr) {
+            VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hnsw_search_big<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hnsw_search_big<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            attr = true;
+        }
+        for (size_t c0 = 0; c0 < redo.size(); c0 += QBB) {
+            const uint32_t nb = (uint32_t)std::min<size_t>(QBB, redo.size() - c0);
+            VDB_HIP(hipMemcpyAsync(b_ql.p, redo.data() + c0, nb * 4, hipMemcpyHostToDevice, s));
+            VDB_HIP(hipMemsetAsync(b_vis.p, 0, uint64_t(nb) * vwords * 4, s));
+            ix.prof_begin(ws, "hnsw", 0.0);
+            if (use_pq)
+                hipLaunchKernelGGL((k_hnsw_search_big<true>), dim3(nb), dim3(64), lds_big, s, g, d_q, ws.qsq.as<float>(),
+                                   ws.lut.as<float>(), lut_in_lds, efk, b_vis.as<uint32_t>(), vwords, b_ql.as<uint32_t>(),
+                                   b_cand.as<uint64_t>(), n, b_res.as<uint64_t>(), res_ld, stats);
+            else
+                hipLaunchKernelGGL((k_hnsw_search_big<false>), dim3(nb), dim3(64), lds_big, s, g, d_q, ws.qsq.as<float>(),
+                                   (const float *)nullptr, 0u, efk, b_vis.as<uint32_t>(), vwords, b_ql.as<uint32_t>(),
+                                   b_cand.as<uint64_t>(), n, b_res.as<uint64_t>(), res_ld, stats);
+            ix.prof_end(ws);
+            launch_sort_rows(b_res.as<uint64_t>(), b_sorted.as<uint64_t>(), nb, res_ld, b_tmp.p, tb, s);
+            // outputs per run of consecutive query ids (the whole chunk when every query takes this path)
+            for (uint32_t j0 = 0; j0 < nb;) {
+                uint32_t j1 = j0 + 1;
+                while (j1 < nb && redo[c0 + j1] == redo[c0 + j1 - 1] + 1) j1++;
+                const uint64_t q = redo[c0 + j0], run = j1 - j0;
+                const uint64_t *srt = b_sorted.as<uint64_t>() + uint64_t(j0) * res_ld;
+                if (use_pq) {
+                    uint64_t *ex = b_exact.as<uint64_t>() + uint64_t(j0) * res_ld;
+                    VDB_HIP(hipMemsetAsync(ex, 0xff, run * res_ld * 8, s));
+                    launch_rerank(ix.d_rows.as<float>(), (uint32_t)ix.dim, d_q + q * ix.dim, (uint32_t)run,
+                                  ix.dist == 0 ? MET_L2_CACHED : MET_COSINE, ix.d_sq.as<float>(), ws.qsq.as<float>() + q, srt, ex, efk,
+                                  res_ld, s);
+                    pq_resort_finalize(ix, ws, ex, efk, res_ld, run, ksel, k, ix.id_offset, d_idx + q * k, d_dist + q * k, d_cnt + q);
+                } else {
+                    launch_finalize(srt, res_ld, (uint32_t)run, ksel, (uint32_t)k, ix.id_offset, d_idx + q * k, d_dist + q * k,
+                                    d_cnt + q, s);
+                }
+                j0 = j1;
+            }
+            VDB_SYNC(s);  // the next chunk reuses the buffers (and they are freed on return)
+        }
+        (void)read_stats();
+    }
     h.last_n_dist = st[0];
     h.last_n_expanded = st[1];
     if (!ws.pending.empty()) {
@@ -1211,7 +1432,6 @@ void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, ui
         const double row_bytes = use_pq ? double(pq.enc_dim) : double(ix.dim) * sizeof(float) + sizeof(float);
         ws.pending.back().bytes += double(st[0]) * row_bytes + double(st[1]) * double(h.max_m0) * sizeof(uint32_t);
     }
-    VDB_REQUIRE(e == 0, "hnsw search: candidate pool overflow (more than 2048 live candidates; degenerate duplicates)");
 }
 
 }  // namespace vdb

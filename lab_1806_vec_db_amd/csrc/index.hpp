@@ -122,6 +122,7 @@ struct HNSWState {
     bool dev_dirty = true;
     DevBuf d_level0, d_len0, d_upper, d_upper_len, d_upper_off;
     std::atomic<uint64_t> last_n_dist{0}, last_n_expanded{0};
+    std::atomic<uint64_t> heap_walk_queries{0};  // queries answered by k_hnsw_search_big (ef > 1024 or LDS pool overflow)
 };
 
 struct Index;

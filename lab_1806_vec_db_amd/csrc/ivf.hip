@@ -185,20 +185,34 @@ void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uin
         VDB_HIP(hipMemsetAsync(d_cnt, 0, nq * sizeof(uint64_t), s));
         return;
     }
-    VDB_REQUIRE(k <= 1024, "ivf knn: k must be <= 1024 in this build");
     const uint64_t np = std::min<uint64_t>(n_probes, iv.k);
-    VDB_REQUIRE(np <= 1024, "ivf knn: at most 1024 probes in this build");
+    {   // the candidate rows of a call are nq x (rows of the np largest clusters) pair keys, twice: bound them
+        uint64_t b = 0;
+        for (uint64_t j = 0; j < np; j++) b += iv.sizes_desc[j];
+        const uint64_t qs = std::max<uint64_t>(1, (size_t(2) << 30) / (std::max<uint64_t>(b, 64) * 16));
+        if (nq > qs) {
+            for (uint64_t q0 = 0; q0 < nq; q0 += qs)
+                ivf_knn_device(ix, ws, d_q + q0 * ix.dim, std::min(qs, nq - q0), k, n_probes, d_idx + q0 * k, d_dist + q0 * k, d_cnt + q0);
+            return;
+        }
+    }
     // (1) probes = find_n_nearest (k_means.rs:174-190): a ResultSet over all centroids in index order keeps, on equal
     // distances, the lower index -- the np smallest (distance, index) pairs.  All centroid distances, then a select.
     ws.qsq.reserve(nq * sizeof(float));
     launch_row_sqnorm(d_q, nq, (uint32_t)ix.dim, ws.qsq.as<float>(), s);
-    const uint32_t ldc = (uint32_t)((iv.k + 63) & ~63ull), capp = topk_capacity((uint32_t)np);
+    const uint32_t ldc = (uint32_t)((iv.k + 63) & ~63ull), capp = np <= 1024 ? topk_capacity((uint32_t)np) : ldc;
     ws.keys_a.reserve(nq * ldc * sizeof(uint64_t));
     ws.keys_b.reserve(nq * ldc * sizeof(uint64_t));
     ws.lut.reserve(nq * capp * sizeof(uint64_t));
     uint64_t *d_probes = ws.lut.as<uint64_t>();
     all_centroid_keys(*iv.cent, d_q, ws.qsq.as<float>(), nq, ldc, ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), s);
-    launch_topk_merge(ws.keys_b.as<uint64_t>(), 1, ldc, (uint32_t)nq, (uint32_t)np, d_probes, s);
+    if (np <= 1024) {
+        launch_topk_merge(ws.keys_b.as<uint64_t>(), 1, ldc, (uint32_t)nq, (uint32_t)np, d_probes, s);
+    } else {  // more probes than the register-resident select holds: every centroid key sorted, the first np taken
+        const size_t tb = sort_rows_temp_bytes(nq, ldc);
+        ws.dense.reserve(tb);
+        launch_sort_rows(ws.keys_b.as<uint64_t>(), d_probes, nq, ldc, ws.dense.p, tb, s);
+    }
     // (2) candidate lists; the np largest clusters bound every query's candidate count
     uint64_t bound = 0;
     for (uint64_t j = 0; j < np; j++) bound += iv.sizes_desc[j];
@@ -207,10 +221,9 @@ void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uin
         return;
     }
     const uint32_t ld = (uint32_t)((bound + 63) & ~63ull);
-    const uint32_t ksel = (uint32_t)std::min<uint64_t>(k, bound), capk = topk_capacity(ksel);
+    const uint32_t ksel = (uint32_t)std::min<uint64_t>(k, bound);
     ws.keys_a.reserve(nq * ld * sizeof(uint64_t));
     ws.keys_b.reserve(nq * ld * sizeof(uint64_t));
-    ws.keys_c.reserve(nq * capk * sizeof(uint64_t));
     ws.misc.reserve(64);
     unsigned long long *d_ncand = ws.misc.as<unsigned long long>();
     VDB_HIP(hipMemsetAsync(d_ncand, 0, sizeof(unsigned long long), s));
@@ -221,12 +234,11 @@ void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uin
     launch_rerank(ix.d_rows.as<float>(), (uint32_t)ix.dim, d_q, (uint32_t)nq, ix.dist == 0 ? MET_L2_DIRECT : MET_COSINE,
                   ix.d_sq.as<float>(), ws.qsq.as<float>(), ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), ld, ld, s);
     ix.prof_end(ws);
-    pq_resort_launch(ws.keys_b.as<uint64_t>(), ld, ld, (uint32_t)nq, ksel, ws.keys_c.as<uint64_t>(), s);
     if (k > ksel) {
         VDB_HIP(hipMemsetAsync(d_idx, 0, nq * k * sizeof(uint64_t), s));
         VDB_HIP(hipMemsetAsync(d_dist, 0, nq * k * sizeof(float), s));
     }
-    launch_finalize(ws.keys_c.as<uint64_t>(), capk, (uint32_t)nq, ksel, (uint32_t)k, ix.id_offset, d_idx, d_dist, d_cnt, s);
+    pq_resort_finalize(ix, ws, ws.keys_b.as<uint64_t>(), ld, ld, nq, ksel, k, ix.id_offset, d_idx, d_dist, d_cnt);
     if (!ws.pending.empty()) {  // measurement on: the scan's algorithmic bytes = scanned rows x (dim*4 + 4), known only now
         unsigned long long total = 0;
         VDB_HIP(hipMemcpyAsync(&total, d_ncand, sizeof(total), hipMemcpyDeviceToHost, s));

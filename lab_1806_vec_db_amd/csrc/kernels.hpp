@@ -112,6 +112,17 @@ size_t sort_pairs_temp_bytes(uint64_t n);
 void launch_sort_pairs(const float *dist, uint64_t n, uint64_t *tmp_keys, uint64_t *out, void *temp, size_t temp_bytes,
                        hipStream_t s);
 
+// any-size fallbacks (k, ef, n_probes beyond the 1024 pairs the register-resident selects hold):
+// every row of pair keys [nq][ld] sorted ascending (in != out); temp = sort_rows_temp_bytes(nq, ld) bytes
+size_t sort_rows_temp_bytes(uint64_t nq, uint64_t ld);
+void launch_sort_rows(const uint64_t *in, uint64_t *out, uint64_t nq, uint64_t ld, void *temp, size_t temp_bytes, hipStream_t s);
+void launch_pair_keys_rows(const float *dist, uint64_t ldd, uint64_t n, uint32_t nq, uint64_t *keys, uint64_t ldk, hipStream_t s);
+void launch_copy_prefix(const uint64_t *in, uint64_t ld_in, uint64_t *out, uint64_t ld_out, uint64_t count, uint32_t nq, hipStream_t s);
+// ResultSet::add replayed over the offers [nq][ldc] (first ncand of every row, in order; PAIR_NONE skipped), set capacity
+// k: out [nq][ldo >= k] = the set, unsorted, PAIR_NONE padded
+void launch_resort_big(const uint64_t *offers, uint32_t ncand, uint32_t ldc, uint32_t nq, uint32_t k, uint64_t *out, uint32_t ldo,
+                       hipStream_t s);
+
 // ---- k_mfma.hip ----------------------------------------------------------------------------
 uint32_t mfma_batch(uint32_t dim);  // queries per workgroup batch: 32 (dim <= 1024), 16 (dim <= 2048), 0 = unsupported
 // Q [nq][dim] -> ceil(nq/32) fragment-ordered split-bf16 images of mfma_qfrag_floats(dim) floats each

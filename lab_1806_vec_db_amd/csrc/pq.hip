@@ -1083,6 +1083,58 @@ void pq_resort_launch(const uint64_t *exact_keys, uint32_t ncand, uint32_t ldc, 
     }
 }
 
+// row stride of the per-query shortlists: the register-resident select writes topk_capacity(efk) entries (efk <= 1024);
+// beyond that the any-size path writes efk rounded up to 64
+static uint32_t pq_list_ld(uint32_t efk) { return efk <= 1024 ? topk_capacity(efk) : ((efk + 63) & ~63u); }
+
+// any ef: every ADC value of every row, a full (adc, idx) sort per query, the first efk pairs (flat_index.rs:96-100
+// with ResultSet::new(ef.max(k)) of any size) -> ws.keys_a [nq][pq_list_ld(efk)]
+static void pq_adc_shortlist_sorted(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint32_t efk) {
+    hipStream_t s = ws.stream;
+    PQState &pq = ix.pq;
+    const uint64_t n = ix.n;
+    ws.qsq.reserve(nq * sizeof(float));
+    launch_row_sqnorm(d_q, nq, (uint32_t)ix.dim, ws.qsq.as<float>(), s);
+    pq_make_luts(ix, ws, d_q, nq);
+    const uint32_t lsz = (uint32_t)(pq.m * pq.kc);
+    const size_t lbytes = size_t(lsz) * sizeof(float), cbytes = ix.dist == 1 ? lbytes : 0;
+    const uint32_t BQ = lbytes * 4 + cbytes <= 120 * 1024 ? 4 : (lbytes * 2 + cbytes <= 120 * 1024 ? 2 : 1);
+    const uint32_t nt = lbytes * BQ + cbytes <= 120 * 1024 ? 1024 : 256;
+    const uint64_t ld = (n + nt + 63) & ~63ull;
+    const uint32_t ldo = pq_list_ld(efk);
+    const uint64_t GQ = std::max<uint64_t>(BQ, std::min<uint64_t>(64, (size_t(1) << 30) / (ld * 20)) / BQ * BQ);
+    const size_t tb = sort_rows_temp_bytes(GQ, ld);
+    ws.keys_a.reserve(nq * ldo * sizeof(uint64_t));
+    ws.keys_b.reserve(nq * ldo * sizeof(uint64_t));
+    ws.dense.reserve(GQ * ld * sizeof(float));
+    ws.lists.reserve(2 * GQ * ld * sizeof(uint64_t) + tb);
+    uint64_t *k_in = ws.lists.as<uint64_t>(), *k_out = k_in + GQ * ld;
+    void *temp = k_out + GQ * ld;
+    for (uint64_t g0 = 0; g0 < nq; g0 += GQ) {
+        const uint64_t gn = std::min<uint64_t>(GQ, nq - g0);
+        AdcArgs a{};
+        a.codes = pq.d_codes.as<uint8_t>();
+        a.n = n;
+        a.enc_dim = (uint32_t)pq.enc_dim;
+        a.m = (uint32_t)pq.m;
+        a.cent_cache = pq.d_cent_cache.as<float>();
+        a.cosine = ix.dist == 1 ? 1 : 0;
+        a.blk_step = 1;
+        a.fast = g_adc_fast;
+        a.nq_total = (uint32_t)gn;
+        a.lut = ws.lut.as<float>() + g0 * lsz;
+        a.qsq = ws.qsq.as<float>() + g0;
+        a.out = ws.dense.as<float>();
+        a.ld = ld;
+        ix.prof_begin(ws, "pq_adc", double((gn + BQ - 1) / BQ) * double(n) * pq.enc_dim);
+        adc_launch<0>(ix, ws, BQ, a);
+        ix.prof_end(ws);
+        launch_pair_keys_rows(ws.dense.as<float>(), ld, n, (uint32_t)gn, k_in, ld, s);
+        launch_sort_rows(k_in, k_out, gn, ld, temp, tb, s);
+        launch_copy_prefix(k_out, ld, ws.keys_a.as<uint64_t>() + g0 * ldo, ldo, efk, (uint32_t)gn, s);
+    }
+}
+
 // ADC scan of the whole code table (pq_table.rs:239-301 through flat_index.rs:96-100): per query the efk smallest
 // (ADC distance, row) pairs, sorted by the CandidatePair order, land in ws.keys_a [nq][topk_capacity(efk)];
 // ws.qsq holds the query norms afterwards.
@@ -1090,6 +1142,10 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
     hipStream_t s = ws.stream;
     PQState &pq = ix.pq;
     VDB_REQUIRE(pq.present && pq.n_coded == ix.n, "PQ table does not cover the rows of the index (rebuild it after add)");
+    if (efk > 1024) {  // beyond the register-resident select
+        pq_adc_shortlist_sorted(ix, ws, d_q, nq, efk);
+        return;
+    }
     const uint64_t n = ix.n;
     ws.qsq.reserve(nq * sizeof(float));
     launch_row_sqnorm(d_q, nq, (uint32_t)ix.dim, ws.qsq.as<float>(), s);
@@ -1327,11 +1383,33 @@ void pq_export_adc_all(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, 
 // ws.keys_a -> ws.keys_b
 static void pq_exact_of_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint32_t efk) {
     hipStream_t s = ws.stream;
-    const uint32_t cape = topk_capacity(efk);
+    const uint32_t cape = pq_list_ld(efk);
     VDB_HIP(hipMemsetAsync(ws.keys_b.p, 0xff, nq * cape * sizeof(uint64_t), s));
     launch_rerank(ix.d_rows.as<float>(), (uint32_t)ix.dim, d_q, (uint32_t)nq, ix.dist == 0 ? MET_L2_DIRECT : MET_COSINE,
                   ix.d_sq.as<float>(), ws.qsq.as<float>(), ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), efk,
                   cape, s);
+}
+
+// ResultSet::pq_resort (candidate_pair.rs:102-108) of the exact keys [nq][ldc] (ADC order, first ncand per row) with set
+// capacity ksel, then the outputs.  ksel <= 1024: the wave-resident replay; beyond: the heap replay + a row sort.
+void pq_resort_finalize(Index &ix, Workspace &ws, const uint64_t *exact_keys, uint32_t ncand, uint32_t ldc, uint64_t nq,
+                               uint32_t ksel, uint64_t k, uint64_t id_offset, uint64_t *d_idx, float *d_dist, uint64_t *d_cnt) {
+    hipStream_t s = ws.stream;
+    if (ksel <= 1024) {
+        const uint32_t capk = topk_capacity(ksel);
+        ws.keys_c.reserve(nq * capk * sizeof(uint64_t));
+        pq_resort_launch(exact_keys, ncand, ldc, (uint32_t)nq, ksel, ws.keys_c.as<uint64_t>(), s);
+        launch_finalize(ws.keys_c.as<uint64_t>(), capk, (uint32_t)nq, ksel, (uint32_t)k, id_offset, d_idx, d_dist, d_cnt, s);
+        return;
+    }
+    const uint32_t ldk = (ksel + 63) & ~63u;
+    const size_t tb = sort_rows_temp_bytes(nq, ldk);
+    ws.keys_c.reserve(nq * ldk * sizeof(uint64_t));
+    ws.lists.reserve(nq * ldk * sizeof(uint64_t) + tb);
+    uint64_t *heap = ws.lists.as<uint64_t>();
+    launch_resort_big(exact_keys, ncand, ldc, (uint32_t)nq, ksel, heap, ldk, s);
+    launch_sort_rows(heap, ws.keys_c.as<uint64_t>(), nq, ldk, heap + nq * ldk, tb, s);
+    launch_finalize(ws.keys_c.as<uint64_t>(), ldk, (uint32_t)nq, ksel, (uint32_t)k, id_offset, d_idx, d_dist, d_cnt, s);
 }
 
 void flat_knn_pq_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef,
@@ -1345,19 +1423,23 @@ void flat_knn_pq_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq,
     const uint64_t n = ix.n;
     const uint64_t efk64 = std::min<uint64_t>(std::max(ef, k), n);  // ResultSet::new(ef.max(k)) flat_index.rs:96
     const uint64_t ksel64 = std::min<uint64_t>(k, n);
-    VDB_REQUIRE(efk64 <= 1024, "knn_pq: min(max(ef, k), len) must be <= 1024 in this build");
+    VDB_REQUIRE(efk64 < (1ull << 31), "knn_pq: ef too large");
     const uint32_t efk = (uint32_t)efk64, ksel = (uint32_t)ksel64;
+    if (efk > 1024) {  // any-size path: bound the per-call buffers (efk keys per query, three times)
+        const uint64_t qs = std::max<uint64_t>(1, (size_t(1) << 30) / (uint64_t(pq_list_ld(efk)) * 32));
+        if (nq > qs) {
+            for (uint64_t q0 = 0; q0 < nq; q0 += qs)
+                flat_knn_pq_device(ix, ws, d_q + q0 * ix.dim, std::min(qs, nq - q0), k, ef, d_idx + q0 * k, d_dist + q0 * k, d_cnt + q0);
+            return;
+        }
+    }
     if (k > ksel) {
         VDB_HIP(hipMemsetAsync(d_idx, 0, nq * k * sizeof(uint64_t), s));
         VDB_HIP(hipMemsetAsync(d_dist, 0, nq * k * sizeof(float), s));
     }
-    const uint32_t cape = topk_capacity(efk), capk = topk_capacity(ksel);
     pq_adc_shortlist(ix, ws, d_q, nq, efk);
     pq_exact_of_shortlist(ix, ws, d_q, nq, efk);
-    ws.keys_c.reserve(nq * capk * sizeof(uint64_t));
-    pq_resort_launch(ws.keys_b.as<uint64_t>(), efk, cape, (uint32_t)nq, ksel, ws.keys_c.as<uint64_t>(), s);
-    launch_finalize(ws.keys_c.as<uint64_t>(), capk, (uint32_t)nq, ksel, (uint32_t)k, ix.id_offset, d_idx, d_dist,
-                    d_cnt, s);
+    pq_resort_finalize(ix, ws, ws.keys_b.as<uint64_t>(), efk, pq_list_ld(efk), nq, ksel, k, ix.id_offset, d_idx, d_dist, d_cnt);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1394,7 +1476,7 @@ void flat_knn_pq_shard_device(Index &ix, Workspace &ws, const float *d_q, uint64
     hipStream_t s = ws.stream;
     if (nq == 0) return;
     const uint64_t efg = std::max(ef, k);
-    VDB_REQUIRE(efg >= 1 && efg <= 1024, "knn_pq shard: max(ef, k) must be in 1..1024 in this build");
+    VDB_REQUIRE(efg >= 1 && efg < (1ull << 31), "knn_pq shard: max(ef, k) must be in 1..2^31");
     VDB_REQUIRE(ix.id_offset + ix.n <= (1ull << 32), "knn_pq shard: global row ids must fit 32 bits");
     if (ix.n == 0) {
         VDB_HIP(hipMemsetAsync(d_adc_keys, 0xff, nq * efg * sizeof(uint64_t), s));
@@ -1405,7 +1487,7 @@ void flat_knn_pq_shard_device(Index &ix, Workspace &ws, const float *d_q, uint64
     pq_adc_shortlist(ix, ws, d_q, nq, efk);
     pq_exact_of_shortlist(ix, ws, d_q, nq, efk);
     hipLaunchKernelGGL(k_pq_export_keys, dim3((unsigned)nq), dim3(256), 0, s, ws.keys_a.as<uint64_t>(),
-                       ws.keys_b.as<uint64_t>(), topk_capacity(efk), efk, (uint32_t)efg, ix.id_offset, d_adc_keys,
+                       ws.keys_b.as<uint64_t>(), pq_list_ld(efk), efk, (uint32_t)efg, ix.id_offset, d_adc_keys,
                        d_exact_keys);
 }
 
@@ -1447,17 +1529,13 @@ void pq_merge_resort_device(Index &ix, Workspace &ws, const uint64_t *d_adc, con
         VDB_HIP(hipMemsetAsync(d_cnt, 0, nq * sizeof(uint64_t), s));
         return;
     }
-    VDB_REQUIRE(efg >= k && efg <= 1024, "pq merge: need k <= max(ef, k) <= 1024");
-    const uint32_t capk = topk_capacity((uint32_t)k);
+    VDB_REQUIRE(efg >= k && efg < (1ull << 31), "pq merge: need k <= max(ef, k) < 2^31");
     ws.keys_b.reserve(nq * efg * sizeof(uint64_t));
-    ws.keys_c.reserve(nq * capk * sizeof(uint64_t));
     hipLaunchKernelGGL(k_pq_shard_merge, dim3((unsigned)nq), dim3(256), 0, s, d_adc, d_exact, (uint32_t)n_shards,
                        (uint32_t)nq, (uint32_t)efg, ws.keys_b.as<uint64_t>());
-    pq_resort_launch(ws.keys_b.as<uint64_t>(), (uint32_t)efg, (uint32_t)efg, (uint32_t)nq, (uint32_t)k,
-                     ws.keys_c.as<uint64_t>(), s);
     VDB_HIP(hipMemsetAsync(d_idx, 0, nq * k * sizeof(uint64_t), s));
     VDB_HIP(hipMemsetAsync(d_dist, 0, nq * k * sizeof(float), s));
-    launch_finalize(ws.keys_c.as<uint64_t>(), capk, (uint32_t)nq, (uint32_t)k, (uint32_t)k, 0, d_idx, d_dist, d_cnt, s);
+    pq_resort_finalize(ix, ws, ws.keys_b.as<uint64_t>(), (uint32_t)efg, (uint32_t)efg, nq, (uint32_t)k, k, 0, d_idx, d_dist, d_cnt);
 }
 
 }  // namespace vdb

@@ -32,6 +32,9 @@ using KMeansAssignFn = std::function<void(const float *cent, uint32_t *assign)>;
 void host_kmeans(const float *train, size_t nt, size_t dim, size_t c0, size_t c1, size_t k, size_t max_iter, float tol,
                  int dist, uint64_t seed, float *cent, const KMeansAssignFn &assign_fn = nullptr);
 uint64_t host_splitmix64(uint64_t &s);
+// ResultSet::add replay over offers [nq][ldc] (first ncand per row) with set capacity ksel (any size), then the outputs
+void pq_resort_finalize(Index &ix, Workspace &ws, const uint64_t *exact_keys, uint32_t ncand, uint32_t ldc, uint64_t nq,
+                        uint32_t ksel, uint64_t k, uint64_t id_offset, uint64_t *d_idx, float *d_dist, uint64_t *d_cnt);
 void pq_resort_launch(const uint64_t *exact_keys, uint32_t ncand, uint32_t ldc, uint32_t nq, uint32_t k,
                       uint64_t *out, hipStream_t s);
 
