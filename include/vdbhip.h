@@ -107,6 +107,8 @@ int vdb_flat_set_mode(vdb_index *idx, int mode);
  *   "flat_tail"        exact stage: 0 fused launch when the shortlist fits 64 rows, 1 separate kernels
  *   "flat_share", "mfma_variant", "flat_sample_thin", "flat_gemm_debug"   small-batch kernel / sample plan / measurement hooks
  *   "pq_adc_fast", "hnsw_dma"   inner-loop variants of the ADC scan and of the HNSW walk
+ *   "hnsw_pool_cap"    live candidates the fast HNSW walk keeps in LDS (default and maximum 2048) before a query is handed to
+ *                      the heap walk; tests lower it to exercise that hand-over
  *   "pq_adc16"         quantised first pass of the threshold-filter ADC scan (16-bit tables, 8 queries per pass; exact f32
  *                      sums for its candidates): 0 auto (4-bit codes, L2Sqr, 16-B code words), 1 off */
 int vdb_set_param(vdb_index *idx, const char *name, int64_t value);
@@ -232,6 +234,39 @@ int vdb_pq_merge_resort(const uint64_t *adc_keys, const uint64_t *exact_keys, ui
 int vdb_pq_merge_resort_device(vdb_index *idx, const void *d_adc_keys, const void *d_exact_keys, uint64_t n_shards,
                                uint64_t nq, uint64_t efk, uint64_t k, void *d_out_idx, void *d_out_dist,
                                void *d_out_count, void *stream);
+
+/* ---- multi-GPU context (vdb_ctx_create; SURVEY 8e: row shards + one RCCL all-gather) ------------------------
+ * The library owns the RCCL communicator and the exchange: a host needs no collective library of its own.
+ *   vdb_ctx_create        ONE process drives n_dev GPUs (ncclCommInitAll): the layout of a Rust host, whose DynamicIndex
+ *                         (dynamic_index.rs:11-94) lives in one process;
+ *   vdb_ctx_create_rank   one process per GPU (ncclCommInitRank): rank 0 obtains a 128-byte id from vdb_ctx_unique_id, the
+ *                         host distributes it (MPI, a file, torch.distributed's store ...), every rank passes it in.
+ * RCCL is loaded at run time (dlopen) by the first context that needs a communicator (world > 1). */
+typedef struct vdb_ctx vdb_ctx;
+typedef struct vdb_sharded vdb_sharded;
+int vdb_ctx_create(const int *device_ids, int n_dev, vdb_ctx **out);
+int vdb_ctx_unique_id(void *out_id, uint64_t out_bytes /* >= 128 */);
+int vdb_ctx_create_rank(int device_id, const void *id, int rank, int world, vdb_ctx **out);
+int vdb_ctx_destroy(vdb_ctx *ctx);
+int vdb_ctx_info(const vdb_ctx *ctx, int *world, int *n_local, int *first_rank, int *has_comm);
+/* DynamicIndex::new(dim, dist) over all GPUs of the context: rank r of S holds rows [r * ceil(N/S), (r+1) * ceil(N/S))
+ * of the corpus handed to vdb_sharded_set_rows (every process passes the same N x dim view) and reports global ids. */
+int vdb_sharded_create(vdb_ctx *ctx, uint64_t dim, int dist, vdb_sharded **out);
+int vdb_sharded_destroy(vdb_sharded *sh);
+int vdb_sharded_set_rows(vdb_sharded *sh, const float *rows, uint64_t n_total);
+int vdb_sharded_len(const vdb_sharded *sh, uint64_t *out);
+/* borrowed handle of this process's i-th shard (statistics, tuning switches, exports); owned by the sharded index */
+int vdb_sharded_local(vdb_sharded *sh, int i, vdb_index **out);
+/* FlatIndex::knn (flat_index.rs:48-57) over the whole corpus: per-shard top-k, ONE all-gather of [nq,k] ids / distances /
+ * counts per rank, exact merge by (distance, index) -- equal to the unsharded answer.  k <= 1024. */
+int vdb_sharded_flat_knn(vdb_sharded *sh, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t *out_idx,
+                         float *out_dist, uint64_t *out_count);
+/* PQTable replicated on every shard (same centroids; codes encoded per shard on its GPU) and FlatIndex::knn_pq
+ * (flat_index.rs:84-104) over the whole corpus: ADC key rows + exact key rows gathered, merged in (adc, idx) order, then
+ * pq_resort (candidate_pair.rs:102-108) -- equal to the unsharded answer. */
+int vdb_sharded_pq_attach(vdb_sharded *sh, uint64_t n_bits, uint64_t m, const float *centroids);
+int vdb_sharded_knn_pq(vdb_sharded *sh, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef,
+                       uint64_t *out_idx, float *out_dist, uint64_t *out_count);
 
 /* ---- measurement hooks -------------------------------------------------------------------
  * When enabled, the dominant kernels are bracketed by HIP events on their own stream and the

@@ -79,6 +79,19 @@ SIGNATURES = {
     "vdb_merge_topk": [f32p, u64p, u64p, u64, u64, u64, u64p, f32p, u64p],
     "vdb_merge_topk_device": [vp, vp, vp, vp, u64, u64, u64, vp, vp, vp, vp],
     "vdb_merge_topk_gathered": [vp, vp, u64, u64, u64, u64, u64, u64, u64, vp, vp, vp, vp],
+    "vdb_ctx_create": [intp, C.c_int, C.POINTER(vp)],
+    "vdb_ctx_unique_id": [vp, u64],
+    "vdb_ctx_create_rank": [C.c_int, vp, C.c_int, C.c_int, C.POINTER(vp)],
+    "vdb_ctx_destroy": [vp],
+    "vdb_ctx_info": [vp, intp, intp, intp, intp],
+    "vdb_sharded_create": [vp, u64, C.c_int, C.POINTER(vp)],
+    "vdb_sharded_destroy": [vp],
+    "vdb_sharded_set_rows": [vp, f32p, u64],
+    "vdb_sharded_len": [vp, u64p],
+    "vdb_sharded_local": [vp, C.c_int, C.POINTER(vp)],
+    "vdb_sharded_flat_knn": [vp, f32p, u64, u64, u64, u64p, f32p, u64p],
+    "vdb_sharded_pq_attach": [vp, u64, u64, f32p],
+    "vdb_sharded_knn_pq": [vp, f32p, u64, u64, u64, u64, u64p, f32p, u64p],
     "vdb_stream_probe": [C.c_int, u64, C.c_int, f64p],
     "vdb_prof_enable": [vp, C.c_int],
     "vdb_prof_reset": [vp],

@@ -3,42 +3,51 @@
 #include <cmath>
 #include <cstring>
 
-#include "../../include/vdbhip.h"
-#include "index.hpp"
+#include "ctx.hpp"
 #include "pq_hnsw.hpp"
 
 using namespace vdb;
 
 static thread_local std::string g_last_error;
-
-struct vdb_index {
-    Index ix;
-    vdb_index(int dev, uint64_t dim, int dist) : ix(dev, dim, dist) {}
-};
-
-#define VDB_API_BEGIN try {
-#define VDB_API_END                                   \
-    return VDB_OK;                                    \
-    }                                                 \
-    catch (const vdb::Error &e) {                     \
-        g_last_error = e.what();                      \
-        return e.code;                                \
-    }                                                 \
-    catch (const std::exception &e) {                 \
-        g_last_error = e.what();                      \
-        return VDB_ERR_INVALID;                       \
-    }                                                 \
-    catch (...) {                                     \
-        g_last_error = "unknown error";               \
-        return VDB_ERR_INVALID;                       \
-    }
-
-static void require_gpu() {
+void vdb::set_last_error(const std::string &m) { g_last_error = m; }
+void vdb::require_gpu() {
     int cnt = 0;
     hipError_t e = hipGetDeviceCount(&cnt);
     if (e != hipSuccess || cnt <= 0)
         throw Error(VDB_ERR_NOGPU, std::string("no usable HIP device (libvdbhip has no CPU fallback): ") +
                                        hipGetErrorString(e));
+}
+
+// device-resident variants: inputs/outputs on the index's GPU, ids < 2^32; synchronous on return
+void vdb::merge_topk_dev(Index &ix, const void *d_dists, const void *d_ids, const void *d_counts, uint64_t stride_d,
+                           uint64_t stride_i, uint64_t stride_c, uint64_t n_shards, uint64_t nq, uint64_t k,
+                           void *d_out_idx, void *d_out_dist, void *d_out_count, void *stream) {
+    VDB_REQUIRE(d_dists && d_ids && d_counts && d_out_idx && d_out_dist && d_out_count, "null argument");
+    VDB_REQUIRE(k >= 1 && k <= 1024, "k must be in 1..1024");
+    VDB_REQUIRE(nq <= 65535 && n_shards <= 65535, "too many queries or shards for one call");
+    ix.use_device();
+    WsLease ws(ix);
+    VDB_SYNC(static_cast<hipStream_t>(stream));
+    if (k <= 64) {  // one launch, no scratch lists
+        launch_merge_shards64(static_cast<const float *>(d_dists), static_cast<const uint64_t *>(d_ids),
+                              static_cast<const uint64_t *>(d_counts), stride_d, stride_i, stride_c, (uint32_t)n_shards,
+                              (uint32_t)nq, (uint32_t)k, static_cast<uint64_t *>(d_out_idx), static_cast<float *>(d_out_dist),
+                              static_cast<uint64_t *>(d_out_count), ws->stream);
+        VDB_SYNC(ws->stream);
+        return;
+    }
+    uint32_t cap = topk_capacity((uint32_t)k);
+    ws->lists.reserve(nq * n_shards * cap * sizeof(uint64_t));
+    ws->keys_c.reserve(nq * cap * sizeof(uint64_t));
+    launch_pack_pairs(static_cast<const float *>(d_dists), static_cast<const uint64_t *>(d_ids),
+                      static_cast<const uint64_t *>(d_counts), stride_d, stride_i, stride_c, (uint32_t)n_shards,
+                      (uint32_t)nq, (uint32_t)k, cap, ws->lists.as<uint64_t>(), ws->stream);
+    launch_topk_merge(ws->lists.as<uint64_t>(), (uint32_t)n_shards, cap, (uint32_t)nq, (uint32_t)k,
+                      ws->keys_c.as<uint64_t>(), ws->stream);
+    launch_finalize(ws->keys_c.as<uint64_t>(), cap, (uint32_t)nq, (uint32_t)k, (uint32_t)k, 0,
+                    static_cast<uint64_t *>(d_out_idx), static_cast<float *>(d_out_dist),
+                    static_cast<uint64_t *>(d_out_count), ws->stream);
+    VDB_SYNC(ws->stream);
 }
 
 extern "C" {
@@ -307,6 +316,8 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         idx->ix.flat_gemm_mode = (int)value;
     else if (n == "hnsw_dma")
         hnsw_set_dma((int)value);
+    else if (n == "hnsw_pool_cap")
+        hnsw_set_pool_cap((int)value);
     else if (n == "pq_adc_fast")
         pq_set_adc_fast((int)value);
     else if (n == "pq_adc16")
@@ -769,37 +780,6 @@ int vdb_merge_topk(const float *dists, const uint64_t *ids, const uint64_t *coun
     VDB_API_END
 }
 
-// device-resident variants: inputs/outputs on the index's GPU, ids < 2^32; synchronous on return
-static void merge_topk_dev(Index &ix, const void *d_dists, const void *d_ids, const void *d_counts, uint64_t stride_d,
-                           uint64_t stride_i, uint64_t stride_c, uint64_t n_shards, uint64_t nq, uint64_t k,
-                           void *d_out_idx, void *d_out_dist, void *d_out_count, void *stream) {
-    VDB_REQUIRE(d_dists && d_ids && d_counts && d_out_idx && d_out_dist && d_out_count, "null argument");
-    VDB_REQUIRE(k >= 1 && k <= 1024, "k must be in 1..1024");
-    VDB_REQUIRE(nq <= 65535 && n_shards <= 65535, "too many queries or shards for one call");
-    ix.use_device();
-    WsLease ws(ix);
-    VDB_SYNC(static_cast<hipStream_t>(stream));
-    if (k <= 64) {  // one launch, no scratch lists
-        launch_merge_shards64(static_cast<const float *>(d_dists), static_cast<const uint64_t *>(d_ids),
-                              static_cast<const uint64_t *>(d_counts), stride_d, stride_i, stride_c, (uint32_t)n_shards,
-                              (uint32_t)nq, (uint32_t)k, static_cast<uint64_t *>(d_out_idx), static_cast<float *>(d_out_dist),
-                              static_cast<uint64_t *>(d_out_count), ws->stream);
-        VDB_SYNC(ws->stream);
-        return;
-    }
-    uint32_t cap = topk_capacity((uint32_t)k);
-    ws->lists.reserve(nq * n_shards * cap * sizeof(uint64_t));
-    ws->keys_c.reserve(nq * cap * sizeof(uint64_t));
-    launch_pack_pairs(static_cast<const float *>(d_dists), static_cast<const uint64_t *>(d_ids),
-                      static_cast<const uint64_t *>(d_counts), stride_d, stride_i, stride_c, (uint32_t)n_shards,
-                      (uint32_t)nq, (uint32_t)k, cap, ws->lists.as<uint64_t>(), ws->stream);
-    launch_topk_merge(ws->lists.as<uint64_t>(), (uint32_t)n_shards, cap, (uint32_t)nq, (uint32_t)k,
-                      ws->keys_c.as<uint64_t>(), ws->stream);
-    launch_finalize(ws->keys_c.as<uint64_t>(), cap, (uint32_t)nq, (uint32_t)k, (uint32_t)k, 0,
-                    static_cast<uint64_t *>(d_out_idx), static_cast<float *>(d_out_dist),
-                    static_cast<uint64_t *>(d_out_count), ws->stream);
-    VDB_SYNC(ws->stream);
-}
 int vdb_merge_topk_device(vdb_index *idx, const void *d_dists, const void *d_ids, const void *d_counts,
                           uint64_t n_shards, uint64_t nq, uint64_t k, void *d_out_idx, void *d_out_dist,
                           void *d_out_count, void *stream) {

@@ -58,6 +58,7 @@ struct HnswDev {
     const float *cent_cache;
     uint32_t enc_dim, pq_m, pq_kc, n_bits;
     int dma;  // exact level-0 distances through LDS-DMA staging (max_m0 <= 32, dim % 32 == 0)
+    uint32_t pool_cap;  // live candidates the LDS pool may hold (<= HNSW_POOL; a test hook lowers it to reach the heap walk)
 };
 
 constexpr uint32_t HNSW_POOL = 2048;  // candidate pool entries per query (LDS)
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswDev g, const float *__re
     uint32_t pool_n = 0;
     bool overflow = false;
     auto pool_push = [&](uint64_t e) {
-        if (pool_n == HNSW_POOL) {
+        if (pool_n == g.pool_cap) {
             // drop pairs that can no longer be expanded (>= worst); they would only ever end the walk
             uint32_t kept = 0;
             for (uint32_t base = 0; base < pool_n; base += 64) {
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswDev g, const float *__re
                 kept += __builtin_popcountll(mask);
             }
             pool_n = kept;
-            if (pool_n == HNSW_POOL) {
+            if (pool_n == g.pool_cap) {
                 overflow = true;
                 return;
             }
@@ -1228,6 +1229,8 @@ static void hnsw_launch(const HnswDev &g, const float *d_q, const float *qsq, co
 
 static int g_hnsw_dma = 1;
 void hnsw_set_dma(int v) { g_hnsw_dma = v; }
+static uint32_t g_hnsw_pool_cap = HNSW_POOL;
+void hnsw_set_pool_cap(int v) { g_hnsw_pool_cap = v < 1 ? 1u : (v > (int)HNSW_POOL ? HNSW_POOL : (uint32_t)v); }
 
 void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef, bool use_pq,
                      uint64_t *d_idx, float *d_dist, uint64_t *d_cnt) {
@@ -1274,6 +1277,7 @@ void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, ui
     if (dma) lds = ((lds + 511) & ~size_t(511)) + HNSW_DMA_BYTES;
     HnswDev g{};
     g.dma = dma ? 1 : 0;
+    g.pool_cap = g_hnsw_pool_cap;
     g.rows = ix.d_rows.as<float>();
     g.xsq = ix.d_sq.as<float>();
     g.level0 = h.d_level0.as<uint32_t>();

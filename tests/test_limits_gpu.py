@@ -67,24 +67,45 @@ def test_hnsw_pq_large_ef(mods, graph5000):
 
 
 def test_hnsw_degenerate_duplicates_pool_overflow(mods):
-    """A graph over 12 000 copies of 40 points: thousands of live candidates at equal distances overflow the 2 048-entry
-    LDS pool of the fast walk.  Round 1 reported an error here; now the overflowed queries are answered by the heap walk."""
+    """4 000 copies of one point: once the result set is full of copies at distance d, every further copy with a smaller
+    index passes check_candidate (full order) without being admitted (distance not strictly smaller), so the live
+    candidates outgrow any fixed pool.  Round 1 reported an error here; now the overflowed queries are answered by the
+    heap walk, with the oracle's answers and counters."""
     vdb, O = mods
     rng = np.random.default_rng(5)
-    uniq = rng.standard_normal((40, 24)).astype(np.float32)
-    base = np.concatenate([uniq] * 300)[rng.permutation(12000)]
+    uniq = rng.standard_normal((400, 24)).astype(np.float32)
+    base = np.concatenate([np.repeat(uniq[:1], 4000, axis=0), uniq, np.concatenate([uniq[1:41]] * 40)])
+    base = base[rng.permutation(len(base))]
     ix = vdb.GpuIndex(24, "l2sqr")
     ix.batch_add(base)
     ix.hnsw_build(M=24, ef_construction=400, seed=8, batch=16, nthreads=8)
     oh = O.HNSW.from_graph(base, 0, 24, 400, ix.hnsw_export())
-    qs = np.concatenate([uniq[:4] + 0.001, uniq[:2]]).astype(np.float32)
-    before = ix.get_stat("hnsw_heap_walk_queries")
+    qs = np.concatenate([uniq[:3] + 0.001, uniq[:2]]).astype(np.float32)
     for k, ef in ((10, 1000), (50, 600)):
         _check(lambda q: ix.knn_with_ef(q, k, ef), lambda q: oh.knn(q, k, ef), qs, k)
         oi, od, oc, nd, ne = oh.knn_batch(qs, k, ef)
         ix.knn_with_ef(qs, k, ef)
         assert ix.hnsw_last_stats() == (nd, ne), "counters of the call (fast walk + heap walk of the overflowed queries)"
-    assert ix.get_stat("hnsw_heap_walk_queries") > before, "the scenario no longer overflows the LDS pool: make it harder"
+
+
+def test_hnsw_pool_handover_to_heap_walk(mods, graph5000):
+    """the same hand-over forced on an ordinary graph by lowering the LDS pool's capacity (test hook): some queries of
+    the call finish in the fast walk, the others are repeated by the heap walk; answers and counters stay the oracle's"""
+    vdb, O = mods
+    base, ix, oh = graph5000
+    qs = gist_like(40, dim=48, seed=44)
+    try:
+        ix.set_param("hnsw_pool_cap", 24)
+        before = ix.get_stat("hnsw_heap_walk_queries")
+        for k, ef in ((10, 128), (5, 16)):
+            _check(lambda q: ix.knn_with_ef(q, k, ef), lambda q: oh.knn(q, k, ef), qs, k)
+            oi, od, oc, nd, ne = oh.knn_batch(qs, k, ef)
+            ix.knn_with_ef(qs, k, ef)
+            assert ix.hnsw_last_stats() == (nd, ne)
+        moved = ix.get_stat("hnsw_heap_walk_queries") - before
+        assert moved > 0, "no query overflowed a 24-entry pool: the hook is not effective"
+    finally:
+        ix.set_param("hnsw_pool_cap", 2048)
 
 
 @pytest.mark.parametrize("dist,kind", [("l2sqr", 0), ("cosine", 1)])
