@@ -90,6 +90,14 @@ int vdb_flat_knn(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim
  * synchronises `stream` once at the end (certification read-back). */
 int vdb_flat_knn_device(vdb_index *idx, const void *d_queries, uint64_t nq, uint64_t dim, uint64_t k,
                         void *d_out_idx, void *d_out_dist, void *d_out_count, void *stream);
+/* the approximate keys the Flat shortlist pass compares with its threshold, for EVERY row, from the same kernel in its dense
+ * mode (test / measurement entry point behind the certification-bound tests): out_keys [nq][len];
+ * L2Sqr: key = |x|^2 - 2 S~, approximate distance = key + |q|^2;  Cosine: key = -S~ / |x|, approximate distance = 1 + key / |q|.
+ * tier 0 = scaled fp16 operands, 1 = split-bf16 operands.  out_qsq [nq] = |q|^2 (strict fold), out_qerr [nq] = measured
+ * |q - q~| of the fp16 query images (0 for tier 1), out_dx4 = {max |dx_r|, max |dx_r| / |x_r|, max |x|^2, min positive |x|^2}.
+ * nq <= 1024; any of the last three outputs may be NULL. */
+int vdb_flat_shortlist_keys(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, int tier, float *out_keys,
+                            float *out_qsq, float *out_qerr, float *out_dx4);
 /* tuning / test hooks for the Flat path:
  *   mode 0 = auto (MFMA shortlist + exact re-rank + certification, exact scan for small inputs),
  *   mode 1 = exact scan only (strict-order f32 fold for every row),

@@ -297,6 +297,21 @@ int vdb_flat_knn_device(vdb_index *idx, const void *d_queries, uint64_t nq, uint
     VDB_API_END
 }
 
+int vdb_flat_shortlist_keys(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, int tier, float *out_keys,
+                            float *out_qsq, float *out_qerr, float *out_dx4) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx && queries && out_keys, "null argument");
+    Index &ix = idx->ix;
+    VDB_REQUIRE(dim == ix.dim, "query dimension mismatch");
+    VDB_REQUIRE(tier == 0 || tier == 1, "tier must be 0 (fp16 operands) or 1 (split-bf16 operands)");
+    ix.use_device();
+    WsLease ws(ix);
+    ws->q.reserve(nq * ix.dim * sizeof(float));
+    VDB_HIP(hipMemcpyAsync(ws->q.p, queries, nq * ix.dim * sizeof(float), hipMemcpyHostToDevice, ws->stream));
+    ix.flat_debug_keys(*ws, ws->q.as<float>(), nq, tier, out_keys, out_qsq, out_qerr, out_dx4);
+    VDB_API_END
+}
+
 int vdb_flat_set_mode(vdb_index *idx, int mode) {
     VDB_API_BEGIN
     VDB_REQUIRE(idx, "null index");

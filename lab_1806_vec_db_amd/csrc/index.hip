@@ -508,4 +508,54 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     VDB_SYNC(s);  // rq..rc are freed on return
 }
 
+// ---- the approximate keys of the Flat shortlist pass, for every row ------------------------------------------------
+// What the filter kernels compare with tau, produced by the SAME kernel in its dense (sample) mode with unit_step = 1:
+// L2Sqr key(r, q) = |x_r|^2 - 2 S~(r, q)  (approximate distance = key + |q|^2);  Cosine key = -S~ / |x_r|  (approximate
+// distance = 1 + key / |q|).  tier 0 = fp16 operands (k_flat_gemm<GEMM_F16>), tier 1 = split-bf16 operands.  Also the
+// quantities the certification bound is built from: |q|^2 (strict fold), the measured |dq| of the fp16 query image and
+// the measured row rounding errors (dx_abs = max |dx_r|, dx_rel = max |dx_r| / |x_r|).  Test / measurement entry point.
+void Index::flat_debug_keys(Workspace &ws, const float *d_q, uint64_t nq, int tier, float *h_keys, float *h_qsq, float *h_qerr,
+                            float *h_dx) {
+    hipStream_t s = ws.stream;
+    VDB_REQUIRE(nq >= 1 && nq <= 1024 && n >= 1, "debug keys: 1..1024 queries on a non-empty index");
+    VDB_REQUIRE(mfma_supported((uint32_t)dim), "debug keys: the dimension has no MFMA shortlist path");
+    const bool half = tier == 0;
+    VDB_REQUIRE(!half || half_valid, "debug keys: the index holds no fp16 mirror");
+    if (!half) ensure_tiled(ws);
+    const int cosine = dist == 1 ? 1 : 0;
+    const uint64_t gq = gemm_group(), ngroups = (nq + gq - 1) / gq, nq_pad = ngroups * gq;
+    const uint64_t n_s = gemm_sample_rows(n, 1), ld = (n_s + 63) & ~63ull;
+    ws.qsq.reserve(nq_pad * sizeof(float));
+    ws.qfrag_g.reserve(nq_pad * size_t(mfma_dim_pad((uint32_t)dim)) * sizeof(float));
+    ws.dense.reserve(nq_pad * ld * sizeof(float));
+    ws.qaux.reserve(3 * nq_pad * sizeof(float));
+    ws.misc.reserve(nq_pad * sizeof(uint32_t));
+    float *d_qscale = ws.qaux.as<float>(), *d_qmul = d_qscale + nq_pad, *d_qerr = d_qmul + nq_pad;
+    if (half) {
+        launch_query_prep_h(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, half_sx(), ws.qsq.as<float>(), d_qscale, d_qmul, d_qerr,
+                            ws.misc.as<uint32_t>(), s);
+        launch_pack_queries_h(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, 8, d_qscale, ws.qfrag_g.p, s);
+    } else {
+        launch_row_sqnorm(d_q, nq, (uint32_t)dim, ws.qsq.as<float>(), s);
+        launch_mfma_pack_queries_nh(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, 8, ws.qfrag_g.as<float>(), s);
+    }
+    launch_flat_gemm_sample(half ? d_tiled_h.as<float>() : d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag_g.as<float>(),
+                            half ? d_qmul : nullptr, (uint32_t)ngroups, d_sq.as<float>(), cosine, 1, ws.dense.as<float>(), ld, num_cu, s);
+    VDB_HIP(hipMemcpy2DAsync(h_keys, n * sizeof(float), ws.dense.p, ld * sizeof(float), n * sizeof(float), nq, hipMemcpyDeviceToHost, s));
+    if (h_qsq) VDB_HIP(hipMemcpyAsync(h_qsq, ws.qsq.p, nq * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (h_qerr) {
+        if (half)
+            VDB_HIP(hipMemcpyAsync(h_qerr, d_qerr, nq * sizeof(float), hipMemcpyDeviceToHost, s));
+        else
+            std::memset(h_qerr, 0, nq * sizeof(float));
+    }
+    VDB_SYNC(s);
+    if (h_dx) {
+        h_dx[0] = half ? half_dx_abs : 0.0f;
+        h_dx[1] = half ? half_dx_rel : 0.0f;
+        h_dx[2] = xsq_max;
+        h_dx[3] = xsq_min_pos;
+    }
+}
+
 }  // namespace vdb

@@ -205,6 +205,8 @@ struct Index {
                          uint64_t *d_cnt, bool allow_half = true, uint32_t kprime_min = 0);
     void flat_sorted_device(Workspace &ws, const float *d_q, uint64_t nq, uint64_t ksel, uint64_t k, uint64_t *d_idx,
                             float *d_dist, uint64_t *d_cnt);
+    void flat_debug_keys(Workspace &ws, const float *d_q, uint64_t nq, int tier, float *h_keys, float *h_qsq, float *h_qerr,
+                         float *h_dx /* [4]: dx_abs, dx_rel, xsq_max, xsq_min_pos */);
     void flat_exact_device(Workspace &ws, const float *d_q, const float *d_qsq, uint64_t nq, uint32_t ksel,
                            uint64_t k, uint64_t *d_idx, float *d_dist, uint64_t *d_cnt);
 };

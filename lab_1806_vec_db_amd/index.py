@@ -235,6 +235,19 @@ class GpuIndex:
                                                   n_shards, nq, k, L.vp(out_idx), L.vp(out_dist), L.vp(out_cnt),
                                                   L.vp(stream)))
 
+    def flat_shortlist_keys(self, queries, tier: int):
+        """approximate keys of the Flat shortlist pass for every row (vdb_flat_shortlist_keys): (keys [nq, len], qsq [nq],
+        qerr [nq], dict(dx_abs, dx_rel, xsq_max, xsq_min_pos)); tier 0 = fp16 operands, 1 = split-bf16 operands"""
+        q = _f32(queries)
+        q = q.reshape(1, -1) if q.ndim == 1 else q
+        keys = np.zeros((q.shape[0], len(self)), dtype=np.float32)
+        qsq = np.zeros(q.shape[0], dtype=np.float32)
+        qerr = np.zeros(q.shape[0], dtype=np.float32)
+        dx = np.zeros(4, dtype=np.float32)
+        L.check(self._lib.vdb_flat_shortlist_keys(self._h, _ptr(q, L.f32p), q.shape[0], q.shape[1], int(tier), _ptr(keys, L.f32p),
+                                                  _ptr(qsq, L.f32p), _ptr(qerr, L.f32p), _ptr(dx, L.f32p)))
+        return keys, qsq, qerr, {"dx_abs": float(dx[0]), "dx_rel": float(dx[1]), "xsq_max": float(dx[2]), "xsq_min_pos": float(dx[3])}
+
     def set_flat_mode(self, mode: int):
         L.check(self._lib.vdb_flat_set_mode(self._h, int(mode)))
 
