@@ -74,7 +74,15 @@ int vdb_calc_dist(int device_id, const float *a, const float *b, uint64_t n, int
 
 /* ---- u8 scalar (DistanceScalar for u8, distance/mod.rs:79-95) ---------------------------
  * Every u8 element is converted with `as f32` (exact) before the f32 folds, so a VecSet<u8> index equals the f32
- * index of the converted rows bit for bit; these entry points convert and forward (rows are held as f32 in HBM). */
+ * index of the converted rows bit for bit.  On an f32 index vdb_index_add_u8 converts and forwards (f32 rows in HBM); on an
+ * index made by vdb_index_create_u8 it stores the bytes as they are. */
+/* VecSet<u8> index (scalar.rs:117-119): rows stay at ONE byte per element in HBM (a quarter of the f32 bytes); the kernels
+ * widen on the fly, the MFMA mirrors hold u8 values exactly.  Serves Flat search (vdb_flat_knn / vdb_flat_knn_u8, swap_remove,
+ * row); PQ / HNSW / IVF need an f32 table, as in the reference (DynamicIndex instantiates f32 only, dynamic_index.rs:11-14).
+ * Rows are added with vdb_index_add_u8; vdb_index_row returns them widened, vdb_index_row_u8 as stored. */
+int vdb_index_create_u8(int device_id, uint64_t dim, int dist, vdb_index **out);
+int vdb_index_row_u8(const vdb_index *idx, uint64_t i, uint8_t *out);
+int vdb_index_is_u8(const vdb_index *idx, int *out);
 int vdb_calc_dist_u8(int device_id, const uint8_t *a, const uint8_t *b, uint64_t n, int dist, float *out);
 int vdb_index_add_u8(vdb_index *idx, const uint8_t *rows, uint64_t n, uint64_t *first_id);
 int vdb_flat_knn_u8(vdb_index *idx, const uint8_t *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t *out_idx,

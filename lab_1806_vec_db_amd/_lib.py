@@ -26,6 +26,9 @@ u64 = C.c_uint64
 SIGNATURES = {
     "vdb_device_count": [intp],
     "vdb_index_create": [C.c_int, u64, C.c_int, C.POINTER(vp)],
+    "vdb_index_create_u8": [C.c_int, u64, C.c_int, C.POINTER(vp)],
+    "vdb_index_row_u8": [vp, u64, u8p],
+    "vdb_index_is_u8": [vp, intp],
     "vdb_index_destroy": [vp],
     "vdb_index_len": [vp, u64p],
     "vdb_index_dim": [vp, u64p],

@@ -73,6 +73,16 @@ int vdb_index_create(int device_id, uint64_t dim, int dist, vdb_index **out) {
     *out = new vdb_index(device_id, dim, dist);
     VDB_API_END
 }
+// VecSet<u8> (scalar.rs:117-119): rows stored at one byte per element; Flat search only
+int vdb_index_create_u8(int device_id, uint64_t dim, int dist, vdb_index **out) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(out, "null out");
+    VDB_REQUIRE(dim > 0 && dim < (1u << 24), "dim must be in 1..2^24");
+    VDB_REQUIRE(dist == VDB_L2SQR || dist == VDB_COSINE, "dist must be 0 (L2Sqr) or 1 (Cosine)");
+    require_gpu();
+    *out = new vdb_index(device_id, dim, dist, true);
+    VDB_API_END
+}
 int vdb_index_destroy(vdb_index *idx) {
     VDB_API_BEGIN
     if (idx) {
@@ -105,12 +115,35 @@ int vdb_index_row(const vdb_index *idx, uint64_t i, float *out) {
     const Index &ix = idx->ix;
     VDB_REQUIRE(i < ix.n, "row index out of bounds");
     ix.use_device();
+    if (ix.elem_u8) {  // widened with `as f32` (exact)
+        std::vector<uint8_t> b(ix.dim);
+        VDB_HIP(hipMemcpy(b.data(), ix.d_rows.as<uint8_t>() + i * ix.dim, ix.dim, hipMemcpyDeviceToHost));
+        for (uint64_t j = 0; j < ix.dim; j++) out[j] = (float)b[j];
+        return VDB_OK;
+    }
     VDB_HIP(hipMemcpy(out, ix.d_rows.as<float>() + i * ix.dim, ix.dim * sizeof(float), hipMemcpyDeviceToHost));
+    VDB_API_END
+}
+int vdb_index_row_u8(const vdb_index *idx, uint64_t i, uint8_t *out) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx && out, "null argument");
+    const Index &ix = idx->ix;
+    VDB_REQUIRE(ix.elem_u8, "not a VecSet<u8> index");
+    VDB_REQUIRE(i < ix.n, "row index out of bounds");
+    ix.use_device();
+    VDB_HIP(hipMemcpy(out, ix.d_rows.as<uint8_t>() + i * ix.dim, ix.dim, hipMemcpyDeviceToHost));
+    VDB_API_END
+}
+int vdb_index_is_u8(const vdb_index *idx, int *out) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx && out, "null argument");
+    *out = idx->ix.elem_u8 ? 1 : 0;
     VDB_API_END
 }
 
 static void add_common(Index &ix, const float *rows, uint64_t n, uint64_t *first_id, bool on_device) {
     VDB_REQUIRE(rows || n == 0, "null rows");
+    VDB_REQUIRE(!ix.elem_u8, "this index stores VecSet<u8> rows: add them with vdb_index_add_u8");
     if (ix.ivf.present && n) ivf_clear(ix);  // IVFIndex has no add (built from_vec_set only): the clusters go stale
     // MetadataVecTable::add / batch_add clear the PQ table before they touch the index (metadata_vec_table.rs:65,77):
     // the codes cover the old rows only, a later knn_pq must fail with "needs a PQ table", not scan past d_codes
@@ -201,6 +234,11 @@ int vdb_index_add_u8(vdb_index *idx, const uint8_t *rows, uint64_t n, uint64_t *
     VDB_API_BEGIN
     VDB_REQUIRE(idx, "null index");
     VDB_REQUIRE(rows || n == 0, "null rows");
+    if (idx->ix.elem_u8) {  // native: one byte per element in HBM
+        if (first_id) *first_id = idx->ix.n;
+        idx->ix.add_rows(rows, n, false);
+        return VDB_OK;
+    }
     std::vector<float> f = widen_u8(rows, n * idx->ix.dim);
     add_common(idx->ix, f.data(), n, first_id, false);
     VDB_API_END

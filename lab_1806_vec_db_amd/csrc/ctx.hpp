@@ -7,7 +7,7 @@
 
 struct vdb_index {
     vdb::Index ix;
-    vdb_index(int dev, uint64_t dim, int dist) : ix(dev, dim, dist) {}
+    vdb_index(int dev, uint64_t dim, int dist, bool u8 = false) : ix(dev, dim, dist, u8) {}
 };
 
 namespace vdb {

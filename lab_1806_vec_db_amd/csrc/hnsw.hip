@@ -1104,6 +1104,7 @@ void hnsw_clear(Index &ix) {
 }
 
 void hnsw_build(Index &ix, uint64_t M, uint64_t ef_construction, uint64_t seed, uint64_t batch, int nthreads) {
+    VDB_REQUIRE(!ix.elem_u8, "PQ / HNSW / IVF are built over f32 tables (DynamicIndex, dynamic_index.rs:11-14): a VecSet<u8> index serves Flat search");
     VDB_REQUIRE(M >= 2, "M must be >= 2");
     HNSWState &h = ix.hnsw;
     h.present = false;
@@ -1137,6 +1138,7 @@ void hnsw_build(Index &ix, uint64_t M, uint64_t ef_construction, uint64_t seed, 
 void hnsw_attach(Index &ix, uint64_t M, uint64_t ef_construction, const uint32_t *level0, const uint64_t *len0,
                  const uint64_t *vec_level, const uint32_t *upper, const uint64_t *upper_len, int has_enter,
                  uint64_t enter_point, uint64_t enter_level) {
+    VDB_REQUIRE(!ix.elem_u8, "PQ / HNSW / IVF are built over f32 tables (DynamicIndex, dynamic_index.rs:11-14): a VecSet<u8> index serves Flat search");
     VDB_REQUIRE(M >= 2, "M must be >= 2");
     HNSWState &h = ix.hnsw;
     h.present = false;

@@ -7,7 +7,7 @@
 
 namespace vdb {
 
-Index::Index(int dev, uint64_t d, int ds) : device(dev), dim(d), dist(ds) {
+Index::Index(int dev, uint64_t d, int ds, bool u8) : device(dev), dim(d), dist(ds), elem_u8(u8) {
     use_device();
     hipDeviceProp_t prop;
     VDB_HIP(hipGetDeviceProperties(&prop, dev));
@@ -35,7 +35,14 @@ void Index::release_ws(std::unique_ptr<Workspace> ws) {
     ws_free.push_back(std::move(ws));
 }
 
+const float *Index::rows_f32_view(DevBuf &scratch, uint64_t r0, uint64_t r1, hipStream_t s) const {
+    if (!elem_u8) return d_rows.as<float>();
+    scratch.reserve(std::max<uint64_t>(r1 - r0, 1) * dim * sizeof(float));
+    launch_widen_u8(d_rows.as<uint8_t>() + r0 * dim, (r1 - r0) * dim, scratch.as<float>(), s);
+    return reinterpret_cast<const float *>(reinterpret_cast<uintptr_t>(scratch.p) - r0 * dim * sizeof(float));
+}
 const float *Index::host_rows() const {
+    VDB_REQUIRE(!elem_u8, "this operation needs f32 rows: a VecSet<u8> index serves Flat search only");
     std::lock_guard<std::mutex> g(host_mu);
     if (!host_valid) {
         use_device();
@@ -47,26 +54,31 @@ const float *Index::host_rows() const {
 }
 
 // VecSet::push (vec_set.rs:113-118) for `count` rows + dist_cache (hnsw_index.rs:251-254)
-void Index::add_rows(const float *rows, uint64_t count, bool on_device) {
+void Index::add_rows(const void *rows, uint64_t count, bool on_device) {
     if (count == 0) return;
     use_device();
     VDB_REQUIRE(n + count < (1ull << 32), "a shard holds at most 2^32-1 rows (ids are u32 on the device)");
     WsLease ws(*this);
     hipStream_t s = ws->stream;
-    size_t row_bytes = size_t(dim) * sizeof(float);
-    d_rows.grow((n + count) * row_bytes, n * row_bytes, s);
+    size_t row_bytes = size_t(dim) * elem_size();
+    d_rows.grow((n + count) * row_bytes + 16, n * row_bytes, s);  // +16: the u8 kernels may read a 16-B word at the last row's end
     d_sq.grow((n + count + 128) * sizeof(float), n * sizeof(float), s);  // +128: kernels may read a few entries past n
-    float *dst = d_rows.as<float>() + n * dim;
+    char *dst = d_rows.as<char>() + n * row_bytes;
     VDB_HIP(hipMemcpyAsync(dst, rows, count * row_bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
-    launch_row_sqnorm(dst, count, (uint32_t)dim, d_sq.as<float>() + n, s);
-    if (mfma_supported((uint32_t)dim) && tiled_built) {
-        // refresh the fragment-ordered mirror for every 16-row tile that received rows
-        uint64_t tiles_new = ((n + count + 15) / 16 + 11) / 12 * 12;  // whole 64-row items (k_flat_mfma) and whole 2/3-tile units (k_flat_gemm)
-        uint64_t tiles_old = n / 16;                                // the partially filled tile is rewritten
+    const bool mirror = mfma_supported((uint32_t)dim) && tiled_built;
+    uint64_t tiles_new = ((n + count + 15) / 16 + 11) / 12 * 12;  // whole 64-row items (k_flat_mfma) and whole 2/3-tile units (k_flat_gemm)
+    uint64_t tiles_old = n / 16;                                // the partially filled tile is rewritten
+    if (mirror) {
         uint64_t tile_bytes = 16 * size_t(mfma_dim_pad((uint32_t)dim)) * sizeof(float);
         d_tiled.grow(tiles_new * tile_bytes, tiles_old * tile_bytes, s);
-        launch_tile_rows(d_rows.as<float>(), n + count, (uint32_t)dim, tiles_old, tiles_new, d_tiled.as<float>(), s);
     }
+    // row norms of the new rows and the fragment-ordered mirror of every 16-row tile that received rows (a u8 index feeds
+    // these f32 build kernels widened chunks; the rows themselves stay at one byte per element)
+    for_tile_chunks(*ws, tiles_old, tiles_new, n + count, [&](const float *v, uint64_t ta, uint64_t tb, uint64_t ra, uint64_t rb) {
+        const uint64_t a = std::max(ra, n);
+        if (rb > a) launch_row_sqnorm(v + a * dim, rb - a, (uint32_t)dim, d_sq.as<float>() + a, s);
+        if (mirror) launch_tile_rows(v, n + count, (uint32_t)dim, ta, tb, d_tiled.as<float>(), s);
+    });
     std::vector<float> sq(count);
     VDB_HIP(hipMemcpyAsync(sq.data(), d_sq.as<float>() + n, count * sizeof(float), hipMemcpyDeviceToHost, s));
     VDB_SYNC(s);
@@ -78,10 +90,11 @@ void Index::add_rows(const float *rows, uint64_t count, bool on_device) {
     half_refresh(*ws, n, n + count);  // needs the new xsq_max
     {
         std::lock_guard<std::mutex> g(host_mu);
-        if (on_device) {
+        if (on_device || elem_u8) {
             host_valid = false;
         } else if (host_valid) {
-            h_rows.insert(h_rows.end(), rows, rows + count * dim);
+            const float *fr = static_cast<const float *>(rows);
+            h_rows.insert(h_rows.end(), fr, fr + count * dim);
         }
     }
     n += count;
@@ -94,25 +107,23 @@ void Index::swap_remove(uint64_t i) {
     WsLease ws(*this);
     hipStream_t s = ws->stream;
     uint64_t last = n - 1;
+    const size_t row_bytes = size_t(dim) * elem_size();
     if (i < last) {
-        VDB_HIP(hipMemcpyAsync(d_rows.as<float>() + i * dim, d_rows.as<float>() + last * dim, dim * sizeof(float),
-                               hipMemcpyDeviceToDevice, s));
+        VDB_HIP(hipMemcpyAsync(d_rows.as<char>() + i * row_bytes, d_rows.as<char>() + last * row_bytes, row_bytes, hipMemcpyDeviceToDevice, s));
         VDB_HIP(hipMemcpyAsync(d_sq.as<float>() + i, d_sq.as<float>() + last, sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     if (mfma_supported((uint32_t)dim)) {  // rewrite the tiles of the moved row and of the removed last row
-        if (tiled_built) {
-            launch_tile_rows(d_rows.as<float>(), last, (uint32_t)dim, i / 16, i / 16 + 1, d_tiled.as<float>(), s);
-            launch_tile_rows(d_rows.as<float>(), last, (uint32_t)dim, last / 16, last / 16 + 1, d_tiled.as<float>(), s);
-        }
-        if (half_valid) {  // same scale; the moved row's rounding error is already part of half_dx_*
-            launch_tile_rows_h(d_rows.as<float>(), last, (uint32_t)dim, i / 16, i / 16 + 1, half_sx(), d_tiled_h.p, s);
-            launch_tile_rows_h(d_rows.as<float>(), last, (uint32_t)dim, last / 16, last / 16 + 1, half_sx(), d_tiled_h.p, s);
-        }
+        for (uint64_t t : {i / 16, last / 16})
+            for_tile_chunks(*ws, t, t + 1, last, [&](const float *v, uint64_t ta, uint64_t tb, uint64_t, uint64_t) {
+                if (tiled_built) launch_tile_rows(v, last, (uint32_t)dim, ta, tb, d_tiled.as<float>(), s);
+                // same scale; the moved row's rounding error is already part of half_dx_*
+                if (half_valid) launch_tile_rows_h(v, last, (uint32_t)dim, ta, tb, half_sx(), d_tiled_h.p, s);
+            });
     }
     VDB_SYNC(s);
     {
         std::lock_guard<std::mutex> g(host_mu);
-        if (host_valid) {
+        if (host_valid && !elem_u8) {
             if (i < last) std::memcpy(h_rows.data() + i * dim, h_rows.data() + last * dim, dim * sizeof(float));
             h_rows.resize(last * dim);
         }
@@ -130,13 +141,15 @@ void Index::ensure_tiled(Workspace &ws) {
     const uint64_t tiles = ((n + 15) / 16 + 11) / 12 * 12;  // whole 64-row items (k_flat_mfma) and whole 2/3-tile units (k_flat_gemm)
     const uint64_t tile_bytes = 16 * size_t(mfma_dim_pad((uint32_t)dim)) * sizeof(float);
     d_tiled.reserve(tiles * tile_bytes);
-    launch_tile_rows(d_rows.as<float>(), n, (uint32_t)dim, 0, tiles, d_tiled.as<float>(), ws.stream);
+    for_tile_chunks(ws, 0, tiles, n, [&](const float *v, uint64_t ta, uint64_t tb, uint64_t, uint64_t) {
+        launch_tile_rows(v, n, (uint32_t)dim, ta, tb, d_tiled.as<float>(), ws.stream);
+    });
     VDB_SYNC(ws.stream);
     tiled_built = true;
 }
 
 uint64_t Index::hbm_bytes_per_row() const {
-    uint64_t b = dim * sizeof(float) + sizeof(float);  // VecSet row + dist_cache entry
+    uint64_t b = dim * elem_size() + sizeof(float);  // VecSet row + dist_cache entry
     if (mfma_supported((uint32_t)dim)) {
         if (tiled_built) b += uint64_t(mfma_dim_pad((uint32_t)dim)) * sizeof(float);
         if (half_valid) b += uint64_t(mfma_dim_pad((uint32_t)dim)) * sizeof(uint16_t);
@@ -173,8 +186,11 @@ void Index::half_refresh(Workspace &ws, uint64_t n_old, uint64_t n_new) {
     d_tiled_h.grow(tiles_new * tile_bytes, t0 * tile_bytes, s);
     d_half_err.reserve(2 * sizeof(uint32_t));
     VDB_HIP(hipMemsetAsync(d_half_err.p, 0, 2 * sizeof(uint32_t), s));
-    launch_tile_rows_h(d_rows.as<float>(), n_new, (uint32_t)dim, t0, tiles_new, half_sx(), d_tiled_h.p, s);
-    launch_row_split_err(d_rows.as<float>(), d_sq.as<float>(), r0, n_new, (uint32_t)dim, half_sx(), d_half_err.as<uint32_t>(), s);
+    for_tile_chunks(ws, t0, tiles_new, n_new, [&](const float *v, uint64_t ta, uint64_t tb, uint64_t ra, uint64_t rb) {
+        launch_tile_rows_h(v, n_new, (uint32_t)dim, ta, tb, half_sx(), d_tiled_h.p, s);
+        const uint64_t a = std::max(ra, r0);
+        if (rb > a) launch_row_split_err(v, d_sq.as<float>(), a, rb, (uint32_t)dim, half_sx(), d_half_err.as<uint32_t>(), s);
+    });
     uint32_t *h = static_cast<uint32_t *>(ws.pinned(2 * sizeof(uint32_t)));
     VDB_HIP(hipMemcpyAsync(h, d_half_err.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     VDB_SYNC(s);
@@ -218,6 +234,22 @@ void Index::prof_collect(Workspace &ws) {
     ws.ev_used = 0;
 }
 
+// the two search-time readers of the row-major rows, by element type
+void Index::scan_rows(uint64_t nrows, uint32_t d, const float *Q, uint32_t nq, int metric, const float *xsq, const float *qsq,
+                      float *out, uint64_t ld, bool use_lds, hipStream_t s) const {
+    if (elem_u8)
+        launch_scan_exact_u8(d_rows.as<uint8_t>(), nrows, d, Q, nq, metric, xsq, qsq, out, ld, s);
+    else
+        launch_scan_exact(d_rows.as<float>(), nrows, d, Q, nq, metric, xsq, qsq, out, ld, use_lds, s);
+}
+void Index::rerank_rows(uint32_t d, const float *Q, uint32_t nq, int metric, const float *xsq, const float *qsq, const uint64_t *cand,
+                        uint64_t *out, uint32_t ncand, uint32_t ldc, hipStream_t s) const {
+    if (elem_u8)
+        launch_rerank_u8(d_rows.as<uint8_t>(), d, Q, nq, metric, xsq, qsq, cand, out, ncand, ldc, s);
+    else
+        launch_rerank(d_rows.as<float>(), d, Q, nq, metric, xsq, qsq, cand, out, ncand, ldc, s);
+}
+
 // ---- Flat: exact scan path -----------------------------------------------------------------------
 // FlatIndex::knn (flat_index.rs:48-57) for nq queries: strict-order distances for every row, then the
 // k smallest pairs by (distance, index).
@@ -246,7 +278,7 @@ void Index::flat_exact_device(Workspace &ws, const float *d_q, const float *d_qs
             const uint32_t nb = (uint32_t)std::min<uint64_t>(qch, nq - q0);
             launch_iota_keys(ws.keys_a.as<uint64_t>(), nb, (uint32_t)n, (uint32_t)ld, s);
             prof_begin(ws, "flat_exact", double(n) * dim * sizeof(float));
-            launch_rerank(d_rows.as<float>(), (uint32_t)dim, d_q + q0 * dim, nb, metric, d_sq.as<float>(),
+            rerank_rows((uint32_t)dim, d_q + q0 * dim, nb, metric, d_sq.as<float>(),
                           d_qsq ? d_qsq + q0 : nullptr, ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), (uint32_t)n,
                           (uint32_t)ld, s);
             prof_end(ws);
@@ -260,7 +292,7 @@ void Index::flat_exact_device(Workspace &ws, const float *d_q, const float *d_qs
     for (uint64_t q0 = 0; q0 < nq; q0 += BQ) {
         uint32_t nb = (uint32_t)std::min<uint64_t>(BQ, nq - q0);
         prof_begin(ws, "flat_exact", double(n) * dim * sizeof(float));
-        launch_scan_exact(d_rows.as<float>(), n, (uint32_t)dim, d_q + q0 * dim, nb, metric, d_sq.as<float>(),
+        scan_rows(n, (uint32_t)dim, d_q + q0 * dim, nb, metric, d_sq.as<float>(),
                           d_qsq ? d_qsq + q0 : nullptr, ws.dense.as<float>(), ld, use_lds, s);
         prof_end(ws);
         launch_topk_dense(ws.dense.as<float>(), ld, n, nb, ksel, ws.lists.as<uint64_t>(), s);
@@ -291,7 +323,7 @@ void Index::flat_sorted_device(Workspace &ws, const float *d_q, uint64_t nq, uin
     }
     for (uint64_t q0 = 0; q0 < nq; q0 += BQ) {
         uint32_t nb = (uint32_t)std::min<uint64_t>(BQ, nq - q0);
-        launch_scan_exact(d_rows.as<float>(), n, (uint32_t)dim, d_q + q0 * dim, nb, metric, d_sq.as<float>(),
+        scan_rows(n, (uint32_t)dim, d_q + q0 * dim, nb, metric, d_sq.as<float>(),
                           ws.qsq.as<float>() + q0, ws.dense.as<float>(), ld, n >= 4096, s);
         for (uint32_t b = 0; b < nb; b++) {
             launch_sort_pairs(ws.dense.as<float>() + b * ld, n, ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(),
@@ -435,7 +467,7 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
         se.dx_abs = half_dx_abs;
         se.dx_rel = half_dx_rel;
     }
-    if (flat_tail_mode != 1 && flat_tail64_supported((uint32_t)dim, kprime, ksel)) {
+    if (flat_tail_mode != 1 && !elem_u8 && flat_tail64_supported((uint32_t)dim, kprime, ksel)) {
         FlatTailArgs t{};
         t.cand = d_cand;
         t.cap = CAND_CAP;
@@ -462,7 +494,7 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
         launch_flat_tail64(t, (uint32_t)nq, s);
     } else {
         launch_topk_merge_counted(d_cand, CAND_CAP, d_hits, (uint32_t)nq, kprime, ws.keys_a.as<uint64_t>(), s);
-        launch_rerank(d_rows.as<float>(), (uint32_t)dim, d_q, (uint32_t)nq, cosine ? MET_COSINE : MET_L2_DIRECT, d_sq.as<float>(),
+        rerank_rows((uint32_t)dim, d_q, (uint32_t)nq, cosine ? MET_COSINE : MET_L2_DIRECT, d_sq.as<float>(),
                       ws.qsq.as<float>(), ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), kprime, capp, s);  // pads its rows
         launch_topk_merge(ws.keys_b.as<uint64_t>(), 1, capp, (uint32_t)nq, ksel, ws.keys_c.as<uint64_t>(), s);
         launch_flat_finish(ws.keys_c.as<uint64_t>(), capk, ws.keys_a.as<uint64_t>(), capp, (uint32_t)nq, ksel, (uint32_t)k, kprime,

@@ -1,5 +1,6 @@
 // index.hpp -- the HBM-resident index object behind the C ABI (include/vdbhip.h).
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <map>
@@ -144,6 +145,29 @@ struct Index {
     int dist = 0;
     uint64_t n = 0;
     uint64_t id_offset = 0;
+    // VecSet<T>: T = f32 (the DynamicIndex case) or u8 (scalar.rs:117-119): d_rows holds n * dim elements of elem_size()
+    // bytes.  A u8 index serves Flat search (exact scan, MFMA shortlist over mirrors that hold u8 values exactly, native
+    // u8 re-rank); PQ / HNSW / IVF are built over f32 tables only, as DynamicIndex instantiates them (dynamic_index.rs:11-14).
+    bool elem_u8 = false;
+    size_t elem_size() const { return elem_u8 ? 1 : sizeof(float); }
+    // f32 view of rows [r0, r1) for the build-time kernels: base pointer B with B + r * dim = row r (the rows themselves,
+    // or a widened copy of the chunk in `scratch` for a u8 index)
+    const float *rows_f32_view(DevBuf &scratch, uint64_t r0, uint64_t r1, hipStream_t s) const;
+    // fn(view, tile_a, tile_b, row_a, row_b) over the 16-row tiles [t_begin, t_end), rows clipped to n_rows: one call on
+    // the rows themselves (f32), or one per widened chunk (u8); view + r * dim addresses row r for row_a <= r < row_b
+    template <class F>
+    void for_tile_chunks(Workspace &ws, uint64_t t_begin, uint64_t t_end, uint64_t n_rows, F fn) const {
+        if (!elem_u8) {
+            fn(d_rows.as<float>(), t_begin, t_end, std::min(t_begin * 16, n_rows), n_rows);
+            return;
+        }
+        constexpr uint64_t CH = 12 * 64;  // tiles per chunk (whole mirror units): 12 288 rows
+        ws.dense.reserve(CH * 16 * dim * sizeof(float));  // before the loop: a later, larger reserve would free a buffer in use
+        for (uint64_t t = t_begin; t < t_end; t += CH) {
+            const uint64_t tb = std::min(t_end, t + CH), ra = std::min(t * 16, n_rows), rb = std::min(tb * 16, n_rows);
+            fn(rows_f32_view(ws.dense, ra, rb, ws.stream), t, tb, ra, rb);
+        }
+    }
     DevBuf d_rows, d_sq;
     // MFMA-fragment-ordered split-bf16 mirror of d_rows (k_mfma.hip; 4 B/element), only when mfma_supported(dim).  Built
     // LAZILY by the first search that needs it (the redo tier of the fp16 pass, calls without an fp16 mirror,
@@ -186,13 +210,13 @@ struct Index {
     std::mutex prof_mu;
     std::map<std::string, ProfEntry> prof;
 
-    Index(int dev, uint64_t d, int ds);
+    Index(int dev, uint64_t d, int ds, bool u8 = false);
     void use_device() const { VDB_HIP(hipSetDevice(device)); }
     std::unique_ptr<Workspace> acquire_ws();
     void release_ws(std::unique_ptr<Workspace> ws);
     const float *host_rows() const;  // materialise the host mirror if needed
 
-    void add_rows(const float *rows, uint64_t count, bool on_device);
+    void add_rows(const void *rows, uint64_t count, bool on_device);  // elements of elem_size() bytes
     void swap_remove(uint64_t i);
 
     // timing hooks
@@ -205,6 +229,10 @@ struct Index {
                          uint64_t *d_cnt, bool allow_half = true, uint32_t kprime_min = 0);
     void flat_sorted_device(Workspace &ws, const float *d_q, uint64_t nq, uint64_t ksel, uint64_t k, uint64_t *d_idx,
                             float *d_dist, uint64_t *d_cnt);
+    void scan_rows(uint64_t nrows, uint32_t d, const float *Q, uint32_t nq, int metric, const float *xsq, const float *qsq, float *out,
+                   uint64_t ld, bool use_lds, hipStream_t s) const;
+    void rerank_rows(uint32_t d, const float *Q, uint32_t nq, int metric, const float *xsq, const float *qsq, const uint64_t *cand,
+                     uint64_t *out, uint32_t ncand, uint32_t ldc, hipStream_t s) const;
     void flat_debug_keys(Workspace &ws, const float *d_q, uint64_t nq, int tier, float *h_keys, float *h_qsq, float *h_qerr,
                          float *h_dx /* [4]: dx_abs, dx_rel, xsq_max, xsq_min_pos */);
     void flat_exact_device(Workspace &ws, const float *d_q, const float *d_qsq, uint64_t nq, uint32_t ksel,

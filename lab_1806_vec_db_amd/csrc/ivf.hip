@@ -101,6 +101,7 @@ static void ivf_install(Index &ix, uint64_t k, const float *centroids, const uin
 }
 
 void ivf_attach(Index &ix, uint64_t k_clusters, const float *centroids, const uint64_t *assign) {
+    VDB_REQUIRE(!ix.elem_u8, "PQ / HNSW / IVF are built over f32 tables (DynamicIndex, dynamic_index.rs:11-14): a VecSet<u8> index serves Flat search");
     VDB_REQUIRE(centroids, "null centroids");
     ix.use_device();
     ivf_install(ix, k_clusters, centroids, assign);
@@ -108,6 +109,7 @@ void ivf_attach(Index &ix, uint64_t k_clusters, const float *centroids, const ui
 
 // IVFIndex::from_vec_set (ivf_index.rs:66-118): sample (vec_set.rs:154-163), k-means, assignment
 void ivf_build(Index &ix, uint64_t k_clusters, uint64_t train_n, uint64_t max_iter, float tol, uint64_t seed) {
+    VDB_REQUIRE(!ix.elem_u8, "PQ / HNSW / IVF are built over f32 tables (DynamicIndex, dynamic_index.rs:11-14): a VecSet<u8> index serves Flat search");
     VDB_REQUIRE(ix.n > 0, "Cannot build an IVF index for an empty table");
     VDB_REQUIRE(k_clusters >= 1, "The number of centroids should be greater than 0.");
     ix.use_device();

@@ -103,6 +103,13 @@ void launch_pack_pairs(const float *dists, const uint64_t *ids, const uint64_t *
                        uint64_t stride_i, uint64_t stride_c /* bytes between shards */, uint32_t S, uint32_t nq, uint32_t k,
                        uint32_t cap_in, uint64_t *lists, hipStream_t s);
 
+// ---- k_u8.hip: VecSet<u8> rows at one byte per element (scalar.rs:117-119, distance/mod.rs:79-95) -------------------
+void launch_widen_u8(const uint8_t *in, uint64_t count, float *out, hipStream_t s);
+void launch_scan_exact_u8(const uint8_t *X, uint64_t n, uint32_t dim, const float *Q, uint32_t nq, int metric, const float *xsq,
+                          const float *qsq, float *out, uint64_t ld, hipStream_t s);
+void launch_rerank_u8(const uint8_t *X, uint32_t dim, const float *Q, uint32_t nq, int metric, const float *xsq, const float *qsq,
+                      const uint64_t *cand, uint64_t *out, uint32_t ncand, uint32_t ldc, hipStream_t s);
+
 // ---- k_probe.hip ---------------------------------------------------------------------------
 // attainable HBM read bandwidth in GB/s: pure streaming read of `bytes`, `iters` timed passes, best of two patterns
 double stream_probe(int device, uint64_t bytes, int iters);

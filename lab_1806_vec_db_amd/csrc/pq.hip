@@ -848,6 +848,7 @@ static void pq_encode_all(Index &ix) {
 }
 
 void pq_attach(Index &ix, uint64_t n_bits, uint64_t m, const float *centroids, const uint8_t *codes) {
+    VDB_REQUIRE(!ix.elem_u8, "PQ / HNSW / IVF are built over f32 tables (DynamicIndex, dynamic_index.rs:11-14): a VecSet<u8> index serves Flat search");
     pq_install(ix, n_bits, m, centroids);
     if (codes) {
         if (ix.n) VDB_HIP(hipMemcpy(ix.pq.d_codes.p, codes, ix.n * ix.pq.enc_dim, hipMemcpyHostToDevice));
@@ -960,6 +961,7 @@ uint64_t host_splitmix64(uint64_t &s) { return splitmix64(s); }
 void pq_build(Index &ix, uint64_t n_bits, uint64_t m, uint64_t train_n, uint64_t max_iter, float tol,
               uint64_t seed) {
     VDB_REQUIRE(n_bits == 4 || n_bits == 8, "n_bits must be 4 or 8 in PQTable.");
+    VDB_REQUIRE(!ix.elem_u8, "PQ / HNSW / IVF are built over f32 tables (DynamicIndex, dynamic_index.rs:11-14): a VecSet<u8> index serves Flat search");
     VDB_REQUIRE(m > 0 && m <= ix.dim, "m must be in 1..=dim");
     VDB_REQUIRE(ix.n > 0, "Cannot build PQ table for an empty table");  // metadata_vec_table.rs:120-122
     const float *rows = ix.host_rows();
@@ -984,16 +986,79 @@ void pq_build(Index &ix, uint64_t n_bits, uint64_t m, uint64_t train_n, uint64_t
     std::vector<float> cent(kc * dim);
     unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     unsigned nth = (unsigned)std::min<uint64_t>(hw, m);
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nth; t++)
-        th.emplace_back([&, t]() {
-            for (uint64_t g = t; g < m; g += nth) {
-                uint64_t gseed = seed ^ (0xD1B54A32D192ED03ull * (g + 1));
-                kmeans_group(train, nt, dim, gs[g], gs[g + 1], kc, max_iter, tol, ix.dist, gseed,
-                             cent.data() + kc * gs[g]);
-            }
-        });
-    for (auto &t : th) t.join();
+    auto par_groups = [&](const std::function<void(uint64_t)> &fn) {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nth; t++)
+            th.emplace_back([&, t]() {
+                for (uint64_t g = t; g < m; g += nth) fn(g);
+            });
+        for (auto &t : th) t.join();
+    };
+    // (1) k-means++ seeding per group on the host (k_means.rs:61-87: a sequential weighted draw per centroid)
+    par_groups([&](uint64_t g) {
+        uint64_t gseed = seed ^ (0xD1B54A32D192ED03ull * (g + 1));
+        kmeans_group(train, nt, dim, gs[g], gs[g + 1], kc, /*max_iter=*/0, tol, ix.dist, gseed, cent.data() + kc * gs[g]);
+    });
+    // (2) Lloyd (k_means.rs:95-162) for ALL groups together: the assignment step (:117-120) -- nt x m x kc strict-order
+    // sub-vector distances per iteration -- is find_nearest_base of every training row against the current centroids,
+    // i.e. exactly the encoder: one k_pq_encode launch on the training rows per iteration.  The update (sums in row
+    // order, empty clusters keep their centroid, max shift against tol) stays on the host, per group in parallel; a
+    // group that has converged is frozen, as its own loop would have stopped.
+    {
+        ix.use_device();
+        const uint64_t enc = n_bits == 4 ? (m + 1) / 2 : m;
+        DevBuf d_train, d_cent, d_csq, d_gs, d_codes;
+        d_train.reserve(nt * dim * sizeof(float));
+        d_cent.reserve(kc * dim * sizeof(float));
+        d_csq.reserve(m * kc * sizeof(float));
+        d_gs.reserve((m + 1) * sizeof(uint64_t));
+        d_codes.reserve(nt * enc);
+        VDB_HIP(hipMemcpy(d_train.p, train, nt * dim * sizeof(float), hipMemcpyHostToDevice));
+        VDB_HIP(hipMemcpy(d_gs.p, gs.data(), (m + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+        std::vector<uint8_t> codes(nt * enc);
+        std::vector<float> csq(m * kc);
+        std::vector<char> active(m, 1);
+        WsLease ws(ix);
+        for (uint64_t it = 0; it < max_iter; it++) {
+            for (uint64_t g = 0; g < m; g++)
+                for (uint64_t c = 0; c < kc; c++) {
+                    const float *cc = cent.data() + kc * gs[g] + c * (gs[g + 1] - gs[g]);
+                    csq[g * kc + c] = host_dot(cc, cc, gs[g + 1] - gs[g]);
+                }
+            VDB_HIP(hipMemcpyAsync(d_cent.p, cent.data(), kc * dim * sizeof(float), hipMemcpyHostToDevice, ws->stream));
+            VDB_HIP(hipMemcpyAsync(d_csq.p, csq.data(), m * kc * sizeof(float), hipMemcpyHostToDevice, ws->stream));
+            hipLaunchKernelGGL(k_pq_encode, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ws->stream, d_train.as<float>(), (uint64_t)nt,
+                               (uint32_t)dim, d_cent.as<float>(), d_csq.as<float>(), d_gs.as<uint64_t>(), (uint32_t)m, (uint32_t)kc,
+                               (uint32_t)n_bits, ix.dist == 1 ? 1 : 0, (uint32_t)enc, d_codes.as<uint8_t>());
+            VDB_HIP(hipMemcpyAsync(codes.data(), d_codes.p, nt * enc, hipMemcpyDeviceToHost, ws->stream));
+            VDB_SYNC(ws->stream);
+            par_groups([&](uint64_t g) {
+                if (!active[g]) return;
+                const size_t c0 = gs[g], gd = gs[g + 1] - gs[g];
+                float *cg = cent.data() + kc * c0;
+                std::vector<float> sums(kc * gd, 0.0f);
+                std::vector<size_t> cnt(kc, 0);
+                for (size_t i = 0; i < nt; i++) {
+                    const size_t c = n_bits == 4 ? ((codes[i * enc + g / 2] >> (4 * (g & 1))) & 0xf) : codes[i * enc + g];
+                    cnt[c]++;
+                    const float *v = train + i * dim + c0;
+                    for (size_t j = 0; j < gd; j++) sums[c * gd + j] += v[j];
+                }
+                float max_diff = -INFINITY;
+                for (size_t c = 0; c < kc; c++) {
+                    if (cnt[c] == 0)
+                        std::memcpy(&sums[c * gd], cg + c * gd, gd * sizeof(float));
+                    else
+                        for (size_t j = 0; j < gd; j++) sums[c * gd + j] /= float(cnt[c]);
+                    const float d = host_l2(cg + c * gd, &sums[c * gd], gd);
+                    if (!std::isnan(d) && d > max_diff) max_diff = d;
+                }
+                std::memcpy(cg, sums.data(), kc * gd * sizeof(float));
+                if (max_diff < tol) active[g] = 0;
+            });
+            if (std::none_of(active.begin(), active.end(), [](char a) { return a != 0; })) break;
+        }
+    }
     pq_install(ix, n_bits, m, cent.data());
     pq_encode_all(ix);
     pq_tile_codes(ix);

@@ -58,11 +58,15 @@ def calc_dist_u8(a, b, dist="cosine", device: int = 0) -> float:
 class GpuIndex:
     """One HBM-resident VecSet<f32> with optional PQ table and HNSW graph (DynamicIndex + PQTable)."""
 
-    def __init__(self, dim: int, dist="cosine", device: int = 0):
+    def __init__(self, dim: int, dist="cosine", device: int = 0, scalar: str = "f32"):
+        """scalar = "f32" (DynamicIndex) or "u8": a VecSet<u8> held at one byte per element (Flat search only)"""
         self._lib = L.load()
         self._h = L.vp()
         self.device = device
-        L.check(self._lib.vdb_index_create(device, int(dim), parse_dist(dist), C.byref(self._h)))
+        if scalar not in ("f32", "u8"):
+            raise ValueError(f"Invalid scalar type: {scalar}")
+        create = self._lib.vdb_index_create_u8 if scalar == "u8" else self._lib.vdb_index_create
+        L.check(create(device, int(dim), parse_dist(dist), C.byref(self._h)))
 
     # -- lifetime ---------------------------------------------------------------------------------
     def close(self):
@@ -129,6 +133,11 @@ class GpuIndex:
         first = C.c_uint64()
         L.check(self._lib.vdb_index_add_u8(self._h, _ptr(r, L.u8p), r.shape[0], C.byref(first)))
         return int(first.value)
+
+    def row_u8(self, i: int) -> np.ndarray:
+        out = np.empty(self.dim, dtype=np.uint8)
+        L.check(self._lib.vdb_index_row_u8(self._h, int(i), _ptr(out, L.u8p)))
+        return out
 
     def flat_knn_u8(self, queries, k: int):
         q = np.ascontiguousarray(queries, dtype=np.uint8)

@@ -243,3 +243,29 @@ def test_attach_rejects_wrong_sizes(mods):
     with pytest.raises(vdb.VdbError):
         ix.hnsw_attach(4, 16, bad)
     ix.hnsw_attach(4, 16, g)  # the untouched export still attaches
+
+
+@pytest.mark.parametrize("dist,kind", [("l2sqr", 0), ("cosine", 1)])
+@pytest.mark.parametrize("n_bits", [4, 8])
+def test_pq_training_gpu_assignment_equals_host_kmeans(mods, dist, kind, n_bits):
+    """PQ training runs Lloyd's assignment step (k_means.rs:117-120) on the GPU for all groups at once (the encoder
+    kernel on the training rows) and the update on the host.  Given the same seeding stream the centroids must equal
+    the oracle's all-host k-means bit for bit: same (distance, index) argmin, same row-order sums, same stopping rule.
+    (The stream itself is this build's -- splitmix64 per group -- the reference's ChaCha stream is unpinned)"""
+    vdb, O = mods
+    n, dim, m = 700, 30, 7   # uneven groups: 5,5,4,4,4,4,4
+    base = gist_like(n, dim=dim, seed=33)
+    base[100:120] = base[:20]  # duplicate rows: equal distances in the argmin
+    ix = vdb.GpuIndex(dim, dist)
+    ix.batch_add(base)
+    seed = 12345
+    ix.pq_build(n_bits=n_bits, m=m, train_n=0, max_iter=6, tol=1e-6, seed=seed)
+    got = ix.pq_export()["centroids"]
+    gs = O.pq_groups(dim, m)
+    kc = 1 << n_bits
+    for g in range(m):
+        gseed = (seed ^ (0xD1B54A32D192ED03 * (g + 1))) & ((1 << 64) - 1)
+        c0, c1 = gs[g]
+        want = O.kmeans(base, c0, c1, kc, 6, 1e-6, kind, gseed)
+        have = got[kc * c0: kc * c1].reshape(kc, -1)
+        assert np.array_equal(have.view(np.uint32), np.asarray(want, dtype=np.float32).reshape(kc, -1).view(np.uint32)), g
