@@ -563,7 +563,14 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable
             leg["hnsw_work_per_query"] = {"n_dist": round(nd / nq, 1), "n_expanded": round(ne / nq, 1)}
             leg["roofline"]["units_per_launch"] = "n_dist x (dim*4 + 4) + n_expanded x max_m0*4 bytes, counted by the kernel (SURVEY 8d)"
         else:
-            leg["roofline"]["units_per_launch"] = "rows x ceil(m*n_bits/8) code bytes per scan; one scan serves the queries whose LUTs share LDS"
+            r = leg["roofline"]
+            r["units_per_launch"] = ("rows x ceil(m*n_bits/8) code bytes per scan; one scan (k_pq_adc16) serves the 8 queries whose "
+                                     "16-bit tables share LDS; the 160-MB code mirror is re-read from the Infinity Cache, not HBM")
+            # the scan's own bound is the LDS gather rate: one 16-B table entry per (row, group, 8 queries)
+            lds_bytes = r["bytes_per_launch"] * 32.0  # m * 16 B per row = 32 x the row's m/2 code bytes (4-bit codes)
+            lds_tbps = lds_bytes / (r["avg_launch_ms"] * 1e-3) / 1e12
+            r["lds_gather"] = {"achieved_TBps": round(lds_tbps, 1), "peak_TBps": 150.0, "frac": round(lds_tbps / 150.0, 4),
+                               "note": "ds_read_b128 aggregate of 256 CUs (MI355X_MICROARCH.md, LDS section); the kernel's binding resource"}
         if O is not None and ncpu > 0:
             ix.flat_knn_device(queries.data_ptr(), nq, k, t_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr())  # Flat ground truth
             gt = t_idx.cpu().numpy().astype(np.uint64)

@@ -381,6 +381,8 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         gemm_set_tw((int)value);
     else if (n == "flat_gemm_nt")
         gemm_set_nt((int)value);
+    else if (n == "flat_gemm_zigzag")
+        gemm_set_zigzag((int)value);
     else if (n == "flat_gemm_block_rows") {
         VDB_REQUIRE(value >= 0, "flat_gemm_block_rows must be >= 0");
         gemm_set_block_rows((uint64_t)value);

@@ -40,6 +40,8 @@ static int g_gemm_tw = 3;
 void gemm_set_tw(int v) { g_gemm_tw = v == 2 ? 2 : 3; }
 static int g_gemm_nt = 0;  // 0 auto (by mirror size), 1 never, 2 always
 void gemm_set_nt(int v) { g_gemm_nt = v; }
+static int g_gemm_zigzag = 0;  // 0 auto, 1 never, 2 always
+void gemm_set_zigzag(int v) { g_gemm_zigzag = v; }
 static uint64_t g_gemm_block_rows = 0;  // 0 auto; n: scan in blocks of n rows (rounded to whole workgroup steps), one launch each
 void gemm_set_block_rows(uint64_t v) { g_gemm_block_rows = v; }
 static int g_gemm_stagger = 0;  // measured: no effect (the epilogue cost is per CU, not a chip-wide HBM gap), kept as a switch
@@ -64,6 +66,7 @@ struct GemmArgs {
     uint32_t debug;
     uint32_t stagger;  // GEMM_FILTER: one unit step in 10-ns ticks (0: start all workgroups together), see the kernel
     uint32_t nt;       // GEMM_FILTER: non-temporal X loads (host-side choice, see GEMM_NT_BIT)
+    uint32_t zigzag;   // GEMM_FILTER: odd query groups walk their full steps in reverse (the rows the previous pass read last are still in the Infinity Cache)
     uint32_t row_base; // GEMM_FILTER: first row of the block this launch scans (XT, xsq and n are the block's; ids are global)
 };
 
@@ -136,8 +139,11 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
         if (S0 == 0) return 1;
         return S0 + (slot < rem_wg ? 1u : 0u);
     };
-    auto unit_of = [&](uint32_t slot, uint32_t st) -> uint32_t {  // may be >= n_units (idle wave of the window's tail)
-        return st < S0 ? st * nwaves + gw : S0 * nwaves + slot * NW + wave;
+    // Odd query groups may walk the full steps backwards (a.zigzag): a pass then starts on the rows the previous pass
+    // read last -- up to an Infinity Cache worth of the mirror is still resident -- instead of on the rows it evicted first.
+    auto unit_of = [&](uint32_t slot, uint32_t st, uint32_t g) -> uint32_t {  // may be >= n_units (idle wave of the window's tail)
+        const uint32_t sw = (MODE == GEMM_FILTER && a.zigzag && (g & 1)) ? S0 - 1 - st : st;
+        return st < S0 ? sw * nwaves + gw : S0 * nwaves + slot * NW + wave;
     };
     auto unit_ptr = [&](uint32_t u) -> const char * {  // wave-uniform
         if (u >= a.n_units) u = a.n_units - 1;  // idle waves re-read the last unit (L2 hits, results masked)
@@ -152,8 +158,9 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
         while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
     }
     uint32_t slot_cur = blockIdx.x, slot_nxt = adv(slot_cur);  // of the current and of the next query group
-    const char *cp_cur = unit_ptr(unit_of(slot_cur, 0)),
-               *cp_nxt = unit_ptr(1 < steps_of(slot_cur) ? unit_of(slot_cur, 1) : unit_of(slot_nxt, 0));
+    const uint32_t g0 = MODE == GEMM_SAMPLE ? blockIdx.y : 0;
+    const char *cp_cur = unit_ptr(unit_of(slot_cur, 0, g0)),
+               *cp_nxt = unit_ptr(1 < steps_of(slot_cur) ? unit_of(slot_cur, 1, g0) : unit_of(slot_nxt, 0, g0 + 1));
     uint32_t voff[TW];  // this lane's byte offset inside a unit, per tile
 #pragma unroll
     for (int t = 0; t < TW; t++) voff[t] = lane * 16 + t * KB * 2048;
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
         if (PREC == GEMM_F16 && threadIdx.x < GEMM_BQ) qm_s[threadIdx.x] = a.qmul[grp * GEMM_BQ + threadIdx.x];
         const uint32_t steps = steps_of(slot_cur);
         for (uint32_t st = 0; st < steps; st++) {
-            const uint32_t u_raw = unit_of(slot_cur, st);
+            const uint32_t u_raw = unit_of(slot_cur, st, grp);
             const uint32_t u = u_raw < a.n_units ? u_raw : a.n_units - 1;
             f32x4 acc[TW][NH];
 #pragma unroll
@@ -286,11 +293,11 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
                 // sequence just continues: those loads are never used)
                 uint32_t un;
                 if (st + 2 < steps)
-                    un = unit_of(slot_cur, st + 2);
+                    un = unit_of(slot_cur, st + 2, grp);
                 else if (st + 1 < steps)
-                    un = unit_of(slot_nxt, 0);
+                    un = unit_of(slot_nxt, 0, grp + 1);
                 else
-                    un = 1 < steps_of(slot_nxt) ? unit_of(slot_nxt, 1) : unit_of(adv(slot_nxt), 0);
+                    un = 1 < steps_of(slot_nxt) ? unit_of(slot_nxt, 1, grp + 1) : unit_of(adv(slot_nxt), 0, grp + 2);
                 cp_nxt = unit_ptr(un);
             }
             // ---- epilogue: lane holds rows 4*g4..4*g4+3 of each tile for query r of each half ----
@@ -581,6 +588,7 @@ void launch_flat_gemm_filter(const float *XT, uint64_t n, uint32_t dim, const fl
     {   // mirror bytes of this shard against the Infinity Cache (256 MB): stream past it, or let it serve passes 2..
         const double mirror_bytes = double((n + 15) / 16 * 16) * mfma_dim_pad(dim) * (qmul ? 2 : 4);
         a.nt = g_gemm_nt == 2 || (g_gemm_nt == 0 && mirror_bytes > 384.0 * 1024 * 1024) ? 1u : 0u;
+        a.zigzag = g_gemm_zigzag == 2 ? 1u : 0u;
     }
     if (g_gemm_stagger) {  // one unit step of a workgroup at ~6 TB/s spread over the CUs, in 10-ns ticks (wall_clock64 runs at 100 MHz)
         const double unit_bytes = 8.0 * g_gemm_tw * 16 * mfma_dim_pad(dim) * (qmul ? 2 : 4);

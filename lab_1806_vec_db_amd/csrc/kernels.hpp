@@ -163,6 +163,7 @@ void launch_flat_gemm_sample(const float *XT, uint64_t n, uint32_t dim, const fl
                              const float *xsq, int cosine, uint32_t unit_step, float *out, uint64_t ld, int num_cu,
                              hipStream_t s);
 void gemm_set_tw(int v);
+void gemm_set_zigzag(int v);   // odd query groups walk the corpus backwards: 0 auto, 1 off, 2 on
 void gemm_set_nt(int v);       // X-stream cache policy of the filter pass: 0 auto (non-temporal when the mirror exceeds the Infinity Cache), 1 default policy, 2 non-temporal
 void gemm_set_block_rows(uint64_t v);  // filter pass in row blocks (one launch per block, all query groups): 0 off (default), n rows
 void gemm_set_stagger(int v);  // 0 (default): workgroups start together; n: start delays of up to n unit steps
