@@ -3,7 +3,9 @@ derived.  For every (query, row) pair of adversarial corpora the approximate dis
 (vdb_flat_shortlist_keys: the production kernel in its dense mode) and the strict-order f32 distance the library returns
 are compared with the distance in float64:
 
-        |a(r, q) - d64(r, q)| <= E(|x_r|, q)        |e(r, q) - d64(r, q)| <= E(|x_r|, q)
+        |a(r, q) - d64(r, q)| + |e(r, q) - d64(r, q)| <= E(|x_r|, q)
+
+(a row outside the shortlist has a >= kappa + |q|^2, hence e >= a - |a - d64| - |e - d64| >= kappa + |q|^2 - E)
 
 with E evaluated exactly as flat_certify_flag does (k_exact.hip), at the row's own norm -- the certification evaluates it
 at a norm bound that is at least as large, and E grows with the norm.  Both tiers (fp16 operands with their measured
@@ -98,8 +100,7 @@ def test_error_bound_holds_with_margin(dist, kind, dim):
             re = np.abs(e - d64) / E
             assert np.isfinite(ra).all() and np.isfinite(re).all(), (name, tier)
             worst[(name, tier)] = (float(ra.max()), float(re.max()))
-            assert ra.max() <= 1.0, (name, tier, "approximate key outside the certification bound", ra.max())
-            assert re.max() <= 1.0, (name, tier, "strict fold outside the certification bound", re.max())
+            assert (ra + re).max() <= 1.0, (name, tier, "key error + fold error exceed the certification bound", (ra + re).max())
         ix.close()
     print(f"\ncertification bound, {dist} dim {dim}: max |err| / E per corpus and tier (approximate key, strict fold)")
     for (name, tier), (ma, me) in sorted(worst.items()):
