@@ -188,8 +188,12 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # VDB_FORCE_EXCHANGE=1: a single rank still forms the RCCL process group and runs the per-step all-gather + gathered
+    # merge (the N > 1 code path with one rank): lets a one-GPU box execute the nccl calls of the exchange
+    force_x = world == 1 and backend == "nccl" and os.environ.get("VDB_FORCE_EXCHANGE") == "1"
+    if world > 1 or force_x:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29655")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -253,7 +257,7 @@ def main():
     torch.cuda.empty_cache()
 
     # the local results live in the send block of the per-step exchange (typed views, no packing)
-    ex = ShardExchange(nq, k, device, world if backend == "nccl" else 1)
+    ex = ShardExchange(nq, k, device, world if backend == "nccl" else 1, force=force_x)
     o_idx, o_dist, o_cnt = ex.idx, ex.dist, ex.cnt
 
     host_xchg = backend != "nccl" and world > 1
@@ -398,7 +402,7 @@ def main():
         legs.update(legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable))
         out["legs"] = legs
     print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_x:
         dist.destroy_process_group()
 
 

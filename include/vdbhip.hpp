@@ -153,6 +153,58 @@ private:
     DistanceAlgorithm dist_;
 };
 
+// The same index over ALL GPUs of one host process (vdb_ctx_create + vdb_sharded_*): rows in contiguous blocks, per-shard
+// top-k, ONE RCCL all-gather inside the library, exact merge.  What a multi-GPU `DynamicIndex::Gpu`
+// arm forwards to; answers equal the single-GPU index's.
+class ShardedIndex {
+public:
+    ShardedIndex(uint64_t dim, DistanceAlgorithm dist, const std::vector<int> &devices) : dim_(dim) {
+        check(vdb_ctx_create(devices.data(), (int)devices.size(), &ctx_));
+        int rc = vdb_sharded_create(ctx_, dim, (int)dist, &h_);
+        if (rc != VDB_OK) {
+            std::string msg = vdb_last_error();
+            vdb_ctx_destroy(ctx_);
+            throw Error(rc, msg);
+        }
+    }
+    ~ShardedIndex() {
+        if (h_) vdb_sharded_destroy(h_);
+        if (ctx_) vdb_ctx_destroy(ctx_);
+    }
+    ShardedIndex(const ShardedIndex &) = delete;
+    ShardedIndex &operator=(const ShardedIndex &) = delete;
+    void set_rows(const float *rows, uint64_t n) { check(vdb_sharded_set_rows(h_, rows, n)); }
+    uint64_t len() const {
+        uint64_t n = 0;
+        check(vdb_sharded_len(h_, &n));
+        return n;
+    }
+    std::vector<std::vector<CandidatePair>> knn_batch(const float *queries, uint64_t nq, uint64_t k) const {
+        return run(nq, k, [&](uint64_t *i, float *d, uint64_t *c) { return vdb_sharded_flat_knn(h_, queries, nq, dim_, k, i, d, c); });
+    }
+    void attach_pq(uint64_t n_bits, uint64_t m, const std::vector<float> &centroids) {
+        check(vdb_sharded_pq_attach(h_, n_bits, m, centroids.data()));
+    }
+    std::vector<std::vector<CandidatePair>> knn_pq_batch(const float *queries, uint64_t nq, uint64_t k, uint64_t ef) const {
+        return run(nq, k, [&](uint64_t *i, float *d, uint64_t *c) { return vdb_sharded_knn_pq(h_, queries, nq, dim_, k, ef, i, d, c); });
+    }
+
+private:
+    template <class F>
+    std::vector<std::vector<CandidatePair>> run(uint64_t nq, uint64_t k, F fn) const {
+        std::vector<uint64_t> idx(nq * (k ? k : 1)), cnt(nq);
+        std::vector<float> d(nq * (k ? k : 1));
+        check(fn(idx.data(), d.data(), cnt.data()));
+        std::vector<std::vector<CandidatePair>> out(nq);
+        for (uint64_t q = 0; q < nq; q++)
+            for (uint64_t j = 0; j < cnt[q]; j++) out[q].push_back({idx[q * k + j], d[q * k + j]});
+        return out;
+    }
+    vdb_ctx *ctx_ = nullptr;
+    vdb_sharded *h_ = nullptr;
+    uint64_t dim_;
+};
+
 // calc_dist (pyo3/mod.rs:43-48)
 inline float calc_dist(const std::vector<float> &a, const std::vector<float> &b, DistanceAlgorithm dist, int device = 0) {
     float out = 0;

@@ -643,20 +643,44 @@ __global__ __launch_bounds__(256) void k_flat_tail64(FlatTailArgs a) {
     const uint32_t total = cnt_q <= a.cap ? cnt_q : 0;  // cnt > cap: slots are not all written, the query is redone
     const uint64_t best = block_top64(a.cand + uint64_t(q) * a.cap, total, sbest);  // (its barrier also covers qs4)
     if (threadIdx.x >= 64) return;
-    const uint64_t ak = __shfl(best, a.kprime - 1);
     const uint64_t c = lane < a.kprime ? best : PAIR_NONE;
     const bool live = c != PAIR_NONE;
     const uint32_t idx = live ? uint32_t(c) : 0u;
-    const float acc = wave_rerank_fold<FOLD, 2>(a.X, a.dim, idx, live, qs4, tile, lane);
-    uint64_t r = PAIR_NONE;
-    if (live) {
+    const uint32_t kk = a.ksel < a.kprime ? a.ksel : a.kprime;
+    auto exact_key = [&](float acc) -> uint64_t {
         const float xs = (a.metric == MET_L2_DIRECT) ? 0.0f : a.xsq[idx];
         const float qs = (a.metric == MET_L2_DIRECT) ? 0.0f : a.qsq[q];
-        r = pair_key(epilogue(a.metric, acc, xs, qs), idx);
+        return pair_key(epilogue(a.metric, acc, xs, qs), idx);
+    };
+    // Two stages when the shortlist is longer than 32 rows: the 32 best approximate candidates are re-ranked first and
+    // certified against the 33rd-smallest approximate key (every row outside those 32 -- the other shortlisted rows
+    // included -- has a key at least that large); only a query that fails this test pays for the other rows' gathers.
+    // The exact stage is bound by those gathers (64 rows x dim x 4 B per query), so most queries now cost half.
+    uint64_t r = PAIR_NONE, sorted;
+    uint8_t flag = 1;
+    const bool two_stage = a.kprime > 32 && kk <= 32 && cnt_q <= a.cap;
+    if (two_stage) {
+        const bool l1 = live && lane < 32;
+        const float acc1 = wave_rerank_fold<FOLD, 2>(a.X, a.dim, idx, l1, qs4, tile, lane);
+        if (l1) r = exact_key(acc1);
+        sorted = sort64(r, lane);
+        const uint64_t ek1 = __shfl(sorted, kk - 1), ak1 = __shfl(best, 32);  // the smallest key outside the first 32
+        uint8_t f1 = 1;
+        if (lane == 0)
+            f1 = flat_certify_flag(ek1, ak1, q, 32, a.n_rows, a.qsq, a.xsq_max, a.xsq_min_pos, a.cosine, a.dim, a.se, cnt_q, a.cap);
+        flag = (uint8_t)__shfl((int)f1, 0);
     }
-    const uint64_t sorted = sort64(r, lane);  // (distance, index) order, PAIR_NONE last
-    const uint32_t kk = a.ksel < a.kprime ? a.ksel : a.kprime;
-    const uint64_t ek = __shfl(sorted, kk - 1);
+    if (flag) {  // wave-uniform: the rest of the shortlist (all of it without the first stage)
+        const bool l2 = live && (!two_stage || lane >= 32);
+        const float acc2 = wave_rerank_fold<FOLD, 2>(a.X, a.dim, idx, l2, qs4, tile, lane);
+        if (l2) r = exact_key(acc2);
+        sorted = sort64(r, lane);  // (distance, index) order, PAIR_NONE last
+        const uint64_t ek = __shfl(sorted, kk - 1), ak = __shfl(best, a.kprime - 1);
+        uint8_t f2 = 1;
+        if (lane == 0)
+            f2 = flat_certify_flag(ek, ak, q, a.kprime, a.n_rows, a.qsq, a.xsq_max, a.xsq_min_pos, a.cosine, a.dim, a.se, cnt_q, a.cap);
+        flag = (uint8_t)__shfl((int)f2, 0);
+    }
     const bool ok = lane < a.ksel && sorted != PAIR_NONE;
     if (lane < a.ksel) {
         a.out_idx[uint64_t(q) * a.kstride + lane] = ok ? uint64_t(uint32_t(sorted)) + a.id_offset : 0;
@@ -665,7 +689,7 @@ __global__ __launch_bounds__(256) void k_flat_tail64(FlatTailArgs a) {
     const uint32_t count = __builtin_popcountll(__ballot(ok));
     if (lane == 0) {
         if (a.out_count) a.out_count[q] = count;
-        a.flags[q] = flat_certify_flag(ek, ak, q, a.kprime, a.n_rows, a.qsq, a.xsq_max, a.xsq_min_pos, a.cosine, a.dim, a.se, cnt_q, a.cap);
+        a.flags[q] = flag;
     }
 }
 bool flat_tail64_supported(uint32_t dim, uint32_t kprime, uint32_t ksel) {

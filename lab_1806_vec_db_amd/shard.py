@@ -140,10 +140,13 @@ class ShardExchange:
     collective per step), and `vdb_merge_topk_gathered` reads the S blocks of the receive buffer in place.
     """
 
-    def __init__(self, nq: int, k: int, device, world: int):
+    def __init__(self, nq: int, k: int, device, world: int, force: bool = False):
+        """force: run the collective and the gathered merge even for one rank (a 1-rank RCCL all-gather: the only way to
+        execute this path's nccl calls on a one-GPU box)"""
         import torch
 
         self.nq, self.k, self.world = nq, k, world
+        self.force = force
         self.off_ids = 0
         self.off_dists = nq * k * 8
         self.off_counts = (nq * k * 12 + 7) // 8 * 8
@@ -152,7 +155,7 @@ class ShardExchange:
         self.idx = self.send[self.off_ids:self.off_dists].view(torch.int64).view(nq, k)
         self.dist = self.send[self.off_dists:self.off_dists + nq * k * 4].view(torch.float32).view(nq, k)
         self.cnt = self.send[self.off_counts:self.block].view(torch.int64)
-        if world > 1:
+        if world > 1 or force:
             self.recv = torch.empty(world * self.block, dtype=torch.uint8, device=device)
             self.m_idx = torch.empty((nq, k), dtype=torch.int64, device=device)
             self.m_dist = torch.empty((nq, k), dtype=torch.float32, device=device)
@@ -160,7 +163,7 @@ class ShardExchange:
 
     def exchange_merge(self, gpu_index, group=None):
         """After the local search has filled idx / dist / cnt: returns the merged (idx, dist, cnt) on every rank."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return self.idx, self.dist, self.cnt
         import torch
         import torch.distributed as dist

@@ -60,6 +60,15 @@ int main(int argc, char **argv) {
     EXPECT(threw);
     auto b = ix.knn_batch(ix.row(0).data(), 1, 2);
     EXPECT(b.size() == 1 && b[0].size() == 2 && b[0][0].index == 0);
+    {   // the same corpus behind the multi-GPU context (one GPU here: no communicator needed, same code path otherwise)
+        ShardedIndex sh(4, DistanceAlgorithm::Cosine, {0});
+        const float rows[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        sh.set_rows(rows, 3);
+        EXPECT(sh.len() == 3);
+        const float q[4] = {0, 0, 1, 0};
+        auto s1 = sh.knn_batch(q, 1, 2);
+        EXPECT(s1.size() == 1 && s1[0].size() == 2 && s1[0][0].index == 2 && s1[0][0].distance == 0.0f);
+    }
     std::printf("cpp host ok\n");
     return 0;
 }

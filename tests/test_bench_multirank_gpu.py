@@ -41,6 +41,31 @@ def test_sharded_bench_equals_single(tmp_path):
         assert np.array_equal(a["cnt"], b["cnt"])
 
 
+def test_one_rank_rccl_exchange(tmp_path):
+    """The per-step exchange of bench.py's N > 1 path -- torch.distributed `nccl` (= RCCL) all_gather_into_tensor on the
+    send block + vdb_merge_topk_gathered on the receive buffer -- executed for real with ONE rank (VDB_FORCE_EXCHANGE=1):
+    the only way to run those calls on a one-GPU box.  Results must equal the plain single-GPU run."""
+    r0 = _run(1, str(tmp_path / "plain.npz"), 29631)
+    env_backup = os.environ.get("VDB_FORCE_EXCHANGE")
+    os.environ["VDB_FORCE_EXCHANGE"] = "1"
+    os.environ.pop("VDB_DIST_BACKEND", None)
+    try:
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29632", VDB_FORCE_EXCHANGE="1")
+        env.pop("VDB_DIST_BACKEND", None)
+        args = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--rows", "60000", "--nq", "96", "--cpu-queries", "0", "--dump",
+                str(tmp_path / "x.npz")]
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+    finally:
+        if env_backup is None:
+            os.environ.pop("VDB_FORCE_EXCHANGE", None)
+        else:
+            os.environ["VDB_FORCE_EXCHANGE"] = env_backup
+    a, b = np.load(tmp_path / "plain.npz"), np.load(tmp_path / "x.npz")
+    assert r0["n_gpus"] == 1
+    assert np.array_equal(a["idx"], b["idx"]) and np.array_equal(a["dist"], b["dist"]) and np.array_equal(a["cnt"], b["cnt"])
+
+
 @pytest.mark.parametrize("workload,rows,dim", [("pq_flat", "70000", "96"), ("hnsw", "3000", "48")])
 def test_sharded_other_workloads_equal_single(tmp_path, workload, rows, dim):
     """pq_flat: row shards + ADC-order merge + re-sort; hnsw: replicas with split queries."""
