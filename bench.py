@@ -25,7 +25,7 @@ At N=1 (default flags) the same run also reports, under "legs", every other item
   config1_gist_1000  BASELINE config 1: the reference's own data/gist_1000.bin x data/gist_test.bin, Flat, L2Sqr, k=10,
                      GPU beside the CPU oracle serial and on all cores (protocol of examples/bench.rs:403-433)
   pq_flat            PQ-Flat ADC (4-bit, m=320, ef=100) on a 1M low-rank gist-like corpus
-  hnsw               HNSW (M=16, efc=200, ef=128) on the first --hnsw-rows rows of that corpus (host build time bounds it)
+  hnsw               HNSW (M=16, efc=200, ef=128) on the first --hnsw-rows rows of that corpus (default: all 1M)
 each with its own roofline / cpu_baseline / parity, plus `attainable_peak_GBps` from a streaming-read probe in this run.
 `--legs none` prints the headline only (what N>1 runs always do).
 """
@@ -164,9 +164,11 @@ def main():
     ap.add_argument("--legs", choices=["auto", "all", "none"], default="auto",
                     help="the SURVEY 8(d) report items beside the headline (N=1, flat): auto = all when the headline runs at its "
                          "default size, none = headline only")
-    ap.add_argument("--hnsw-rows", type=int, default=500_000,
-                    help="rows of the hnsw leg: the host build (hnsw_index.rs:391-457 batches) takes ~100 s for 500k and ~210 s for "
-                         "1M rows on 16 cores; the default keeps the whole run inside the driver's limit")
+    ap.add_argument("--hnsw-rows", type=int, default=1_000_000,
+                    help="rows of the hnsw leg (BASELINE config 3 names Gist1M); the build -- batches of 1024 points as "
+                         "add_parallel forms them (hnsw_index.rs:391-457), their candidate phase on the GPU -- takes ~55 s for 1M rows")
+    ap.add_argument("--hnsw-batch", type=int, default=1024,
+                    help="points per builder batch (the reference uses 4 x rayon threads); >= 256 puts the candidate phase on the GPU")
     args = ap.parse_args()
 
     import torch
@@ -202,7 +204,7 @@ def main():
     wl = args.workload
     default_size = args.rows <= 0 and args.dim == 960 and args.nq == 1000
     if args.rows <= 0:
-        args.rows = 1_000_000  # hnsw: the host builder (hnsw_index.rs:391-457 batches) takes ~3-4 min for this graph
+        args.rows = 1_000_000
     legs_on = world == 1 and wl == "flat" and (args.legs == "all" or (args.legs == "auto" and default_size))
     ef = args.ef or {"pq_flat": 100, "hnsw": 128, "hnsw_pq": 128, "ivf": 4}.get(wl, 0)
     n, dim, nq, k = args.rows, args.dim, args.nq, args.k
@@ -251,7 +253,7 @@ def main():
         build_s = time.perf_counter() - t_b
     if wl in ("hnsw", "hnsw_pq"):
         t_b = time.perf_counter()
-        ix.hnsw_build(M=16, ef_construction=200, seed=42, batch=64, nthreads=threads)
+        ix.hnsw_build(M=16, ef_construction=200, seed=42, batch=args.hnsw_batch, nthreads=threads)
         build_s = time.perf_counter() - t_b
     del base, shard
     torch.cuda.empty_cache()
@@ -607,12 +609,14 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable
     ix = vdb.GpuIndex(dim, "l2sqr", device=local_rank)
     ix.add_device(base.data_ptr(), hr)
     t_b = time.perf_counter()
-    ix.hnsw_build(M=16, ef_construction=200, seed=42, batch=64, nthreads=threads)
+    ix.hnsw_build(M=16, ef_construction=200, seed=42, batch=args.hnsw_batch, nthreads=threads)
     hb_s = time.perf_counter() - t_b
     legs["hnsw"] = run(ix, "hnsw", hr, 128,
                        lambda: ix.hnsw_knn_device(queries.data_ptr(), nq, k, 128, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr()),
-                       {"workload": f"hnsw_knn_gistlike_{hr}", "M": 16, "ef_construction": 200, "host_build_s": round(hb_s, 1),
-                        "rows_note": "the host builder bounds the size a default run can afford (--hnsw-rows); 1M-row lines: profiles/"})
+                       {"workload": f"hnsw_knn_gistlike_{hr}", "M": 16, "ef_construction": 200, "build_s": round(hb_s, 1),
+                        "build_batch": args.hnsw_batch,
+                        "build_note": "HNSWIndex::add_parallel batches; candidate phase of a batch on the GPU (k_hnsw_search, k = ef = "
+                                      "ef_construction, over the device mirror of the graph), linking on host threads; the graph equals the all-host builder's"})
     ix.close()
     return legs
 

@@ -123,6 +123,8 @@ int vdb_flat_set_mode(vdb_index *idx, int mode);
  *   "flat_tail"        exact stage: 0 fused launch when the shortlist fits 64 rows, 1 separate kernels
  *   "flat_share", "mfma_variant", "flat_sample_thin", "flat_gemm_debug"   small-batch kernel / sample plan / measurement hooks
  *   "pq_adc_fast", "hnsw_dma"   inner-loop variants of the ADC scan and of the HNSW walk
+ *   "hnsw_build_gpu"   candidate phase of batched HNSW builds (vdb_hnsw_build with batch >= 256): 0 auto = the level-0 searches of a
+ *                      batch and the distances between its members run on the GPU (same graph as the all-host builder), 1 off
  *   "hnsw_pool_cap"    live candidates the fast HNSW walk keeps in LDS (default and maximum 2048) before a query is handed to
  *                      the heap walk; tests lower it to exercise that hand-over
  *   "pq_adc16"         quantised first pass of the threshold-filter ADC scan (16-bit tables, 8 queries per pass; exact f32

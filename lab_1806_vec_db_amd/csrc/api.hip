@@ -369,6 +369,8 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         idx->ix.flat_gemm_mode = (int)value;
     else if (n == "hnsw_dma")
         hnsw_set_dma((int)value);
+    else if (n == "hnsw_build_gpu")
+        hnsw_set_build_gpu((int)value);
     else if (n == "hnsw_pool_cap")
         hnsw_set_pool_cap((int)value);
     else if (n == "pq_adc_fast")

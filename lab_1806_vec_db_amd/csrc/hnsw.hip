@@ -737,6 +737,19 @@ struct Builder {
     };
     CacheView cache{nullptr, 0};
     double t_search = 0, t_connect = 0;  // wall seconds of the parallel candidate phase / the serial linking phase
+    // GPU assistance of add_batch (hnsw_build): the level-0 candidate search of a whole batch against the pre-batch
+    // graph IS HNSWIndex::knn_with_ef(k = ef = ef_construction) -- one k_hnsw_search launch over the device mirror of
+    // the graph -- and the distances between batch members are one all-pairs launch.  Same values, same sets as the
+    // host search (the kernel is bit-exact against the oracle's search), so the graph does not change.
+    struct GpuAssist {
+        uint64_t min_batch = 256;  // smaller batches cannot fill the GPU: one query is one wave
+        // keys [nb][cape]: the sorted result set of every batch member (PAIR_NONE padded); ok[i] = 0: search it on the host
+        // (pool overflow); cross [nb][ldx]: pair keys (distance of member i to member r, first + r)
+        std::function<void(uint64_t first, uint64_t nb, uint64_t enter_point, uint64_t enter_level, std::vector<uint64_t> &keys,
+                           uint32_t &cape, std::vector<uint64_t> &cross, uint32_t &ldx, std::vector<uint8_t> &ok)> search;
+        std::function<void(const std::vector<uint64_t> &dirty /* (owner << 8) | level */)> sync;
+    };
+    GpuAssist *gpu = nullptr;
     Builder(HNSWState &hh, const float *r, const float *s, uint64_t d, int ds)
         : h(hh), rows(r), sq(s), dim(d), dist(ds), cache{s, ds} {}
 
@@ -966,8 +979,26 @@ struct Builder {
         const uint64_t enter_point = h.enter_point, enter_level = h.enter_level;
         const auto t_begin = std::chrono::steady_clock::now();
         std::vector<std::vector<RSet>> cands(nb);
+        std::vector<uint64_t> gkeys, gcross;
+        std::vector<uint8_t> gok;
+        uint32_t gcape = 0, gld = 0;
+        const bool use_gpu = gpu && nb >= gpu->min_batch;
+        if (use_gpu) gpu->search(first, nb, enter_point, enter_level, gkeys, gcape, gcross, gld, gok);
         auto work = [&](uint64_t i, Scratch &s) {
             uint64_t idx = first + i, level = h.vec_level[idx];
+            if (use_gpu && level == 0 && gok[i]) {
+                // search_on_level(greedy_until(0), 0, ef_construction) from the GPU, then the earlier batch members
+                // (:431-437; every member has level >= 0) offered in order, exactly as below
+                RSet c(h.ef_construction);
+                const uint64_t *kr = gkeys.data() + i * gcape;
+                // (the kernel's register list is 64 R entries wide: positions past ef hold pairs that were pushed out of the set)
+                for (uint32_t j = 0; j < gcape && j < h.ef_construction && kr[j] != PAIR_NONE; j++)
+                    c.v.push_back(Pair{f32_from_orderable(uint32_t(kr[j] >> 32)), uint64_t(uint32_t(kr[j]))});
+                const uint64_t *xr = gcross.data() + i * gld;
+                for (uint64_t r = 0; r < i; r++) c.add(Pair{f32_from_orderable(uint32_t(xr[r] >> 32)), first + r});
+                cands[i].push_back(std::move(c));
+                return;
+            }
             const float *q = rows + idx * dim;
             float qc = cache[idx];
             uint64_t cur = level < enter_level ? greedy_until(level, q, qc) : enter_point;
@@ -1049,6 +1080,11 @@ struct Builder {
                     arrange_links(owner, l, evs[e].v);
             }
         });
+        if (gpu) {  // the lists this batch rewrote, for the device mirror of the graph
+            std::vector<uint64_t> dirty;
+            for (size_t g = 0; g + 1 < gstart.size(); g++) dirty.push_back(evs[gstart[g]].key);
+            gpu->sync(dirty);
+        }
         const auto t_end = std::chrono::steady_clock::now();
         t_search += std::chrono::duration<double>(t_mid - t_begin).count();
         t_connect += std::chrono::duration<double>(t_end - t_mid).count();
@@ -1103,6 +1139,13 @@ void hnsw_clear(Index &ix) {
     ix.hnsw.d_upper.release();
 }
 
+// device mirror of the graph under construction + the GPU side of Builder::GpuAssist (defined behind the search kernels'
+// launchers, below)
+struct BuildDev;
+static std::shared_ptr<BuildDev> hnsw_build_gpu_assist(Index &ix, Builder::GpuAssist &ga, const std::vector<uint64_t> &levels);
+static int g_hnsw_build_gpu = 0;  // 0 auto (batches of >= 256 points, ef_construction <= 1024), 1 off
+void hnsw_set_build_gpu(int v) { g_hnsw_build_gpu = v; }
+
 void hnsw_build(Index &ix, uint64_t M, uint64_t ef_construction, uint64_t seed, uint64_t batch, int nthreads) {
     VDB_REQUIRE(!ix.elem_u8, "PQ / HNSW / IVF are built over f32 tables (DynamicIndex, dynamic_index.rs:11-14): a VecSet<u8> index serves Flat search");
     VDB_REQUIRE(M >= 2, "M must be >= 2");
@@ -1116,6 +1159,12 @@ void hnsw_build(Index &ix, uint64_t M, uint64_t ef_construction, uint64_t seed, 
     uint64_t n = ix.n;
     std::vector<uint64_t> levels(n);
     for (uint64_t i = 0; i < n; i++) levels[i] = rand_level(h.rng_state, h.inv_log_m);
+    Builder::GpuAssist ga;
+    std::shared_ptr<BuildDev> bdev;
+    if (g_hnsw_build_gpu != 1 && batch >= ga.min_batch && h.ef_construction <= 1024 && n >= 4 * ga.min_batch) {
+        bdev = hnsw_build_gpu_assist(ix, ga, levels);
+        b.gpu = &ga;
+    }
     Scratch s;
     uint64_t cur = 0;
     while (cur < n) {
@@ -1233,6 +1282,174 @@ static int g_hnsw_dma = 1;
 void hnsw_set_dma(int v) { g_hnsw_dma = v; }
 static uint32_t g_hnsw_pool_cap = HNSW_POOL;
 void hnsw_set_pool_cap(int v) { g_hnsw_pool_cap = v < 1 ? 1u : (v > (int)HNSW_POOL ? HNSW_POOL : (uint32_t)v); }
+
+// ---------------------------------------------------------------------------------------------------
+// GPU side of the builder's candidate phase (Builder::GpuAssist).  The device mirror of the graph is full-size from the
+// start (offsets of the upper lists follow from the pre-drawn levels); after every batch only the lists that batch
+// rewrote are sent over (a few thousand 128-B rows) and scattered into place.
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_scatter_lists(uint32_t *__restrict__ dst, uint32_t *__restrict__ dst_len, const uint64_t *__restrict__ slots,
+                                const uint32_t *__restrict__ src, const uint32_t *__restrict__ src_len, uint32_t row_words,
+                                uint32_t count) {
+    const uint32_t i = blockIdx.x;  // one list per block
+    if (i >= count) return;
+    const uint64_t slot = slots[i];
+    for (uint32_t j = threadIdx.x; j < row_words; j += blockDim.x) dst[slot * row_words + j] = src[uint64_t(i) * row_words + j];
+    if (threadIdx.x == 0) dst_len[slot] = src_len[i];
+}
+__global__ void k_iota_offset_keys(uint64_t *__restrict__ rows, uint32_t n, uint32_t ld, uint32_t first) {
+    uint64_t *row = rows + uint64_t(blockIdx.x) * ld;
+    for (uint32_t j = threadIdx.x; j < ld; j += blockDim.x) row[j] = j < n ? uint64_t(first + j) : PAIR_NONE;
+}
+
+struct BuildDev {
+    DevBuf d_level0, d_len0, d_upper, d_upper_len, d_upper_off;  // the graph, sized for all n rows
+    DevBuf d_vis, d_keys, d_flags, d_cross_in, d_cross_out, d_stage_slots, d_stage_rows, d_stage_len;
+    bool mirror_valid = false;
+    std::vector<uint64_t> upper_off;  // [n + 1] from the pre-drawn levels
+    hipStream_t stream = nullptr;
+    ~BuildDev() {
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+static std::shared_ptr<BuildDev> hnsw_build_gpu_assist(Index &ix, Builder::GpuAssist &ga, const std::vector<uint64_t> &levels) {
+    auto bd = std::make_shared<BuildDev>();
+    HNSWState &h = ix.hnsw;
+    const uint64_t n = ix.n;
+    ix.use_device();
+    VDB_HIP(hipStreamCreateWithFlags(&bd->stream, hipStreamNonBlocking));
+    bd->upper_off.assign(n + 1, 0);
+    for (uint64_t i = 0; i < n; i++) bd->upper_off[i + 1] = bd->upper_off[i] + levels[i];
+    const uint64_t tot = bd->upper_off[n];
+    bd->d_level0.reserve(std::max<uint64_t>(n * h.max_m0, 1) * 4);
+    bd->d_len0.reserve(std::max<uint64_t>(n, 1) * 4);
+    bd->d_upper.reserve(std::max<uint64_t>(tot * h.m, 1) * 4);
+    bd->d_upper_len.reserve(std::max<uint64_t>(tot, 1) * 4);
+    bd->d_upper_off.reserve((n + 1) * 8);
+    VDB_HIP(hipMemcpy(bd->d_upper_off.p, bd->upper_off.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+
+    Index *ixp = &ix;
+    BuildDev *b = bd.get();
+    ga.search = [ixp, b](uint64_t first, uint64_t nb, uint64_t enter_point, uint64_t enter_level, std::vector<uint64_t> &keys,
+                         uint32_t &cape, std::vector<uint64_t> &cross, uint32_t &ldx, std::vector<uint8_t> &ok) {
+        Index &ix = *ixp;
+        HNSWState &h = ix.hnsw;
+        ix.use_device();
+        hipStream_t s = b->stream;
+        const uint64_t n = ix.n, have = h.len0.size();  // rows whose lists exist on the host so far (incl. this batch, all empty)
+        if (!b->mirror_valid) {  // first GPU batch: everything built so far, the rest zero (no links, length 0)
+            VDB_HIP(hipMemsetAsync(b->d_len0.p, 0, std::max<uint64_t>(n, 1) * 4, s));
+            VDB_HIP(hipMemsetAsync(b->d_upper_len.p, 0, std::max<uint64_t>(b->upper_off[n], 1) * 4, s));
+            VDB_HIP(hipMemcpyAsync(b->d_level0.p, h.level0.data(), have * h.max_m0 * 4, hipMemcpyHostToDevice, s));
+            std::vector<uint32_t> l0(have), ul(h.upper_len.size());
+            for (uint64_t i = 0; i < have; i++) l0[i] = (uint32_t)h.len0[i];
+            for (size_t i = 0; i < ul.size(); i++) ul[i] = (uint32_t)h.upper_len[i];
+            VDB_HIP(hipMemcpyAsync(b->d_len0.p, l0.data(), have * 4, hipMemcpyHostToDevice, s));
+            if (!h.upper.empty()) VDB_HIP(hipMemcpyAsync(b->d_upper.p, h.upper.data(), h.upper.size() * 4, hipMemcpyHostToDevice, s));
+            if (!ul.empty()) VDB_HIP(hipMemcpyAsync(b->d_upper_len.p, ul.data(), ul.size() * 4, hipMemcpyHostToDevice, s));
+            VDB_SYNC(s);
+            b->mirror_valid = true;
+        }
+        const uint32_t efk = (uint32_t)std::min<uint64_t>(h.ef_construction, n + 1);
+        cape = topk_capacity(efk);
+        const bool dma = g_hnsw_dma && h.max_m0 <= 32 && ix.dim % 32 == 0;
+        size_t lds = HNSW_POOL * sizeof(uint64_t) + ix.dim * sizeof(float);
+        if (dma) lds = ((lds + 511) & ~size_t(511)) + HNSW_DMA_BYTES;
+        HnswDev g{};
+        g.dma = dma ? 1 : 0;
+        g.pool_cap = g_hnsw_pool_cap;
+        g.rows = ix.d_rows.as<float>();
+        g.xsq = ix.d_sq.as<float>();
+        g.level0 = b->d_level0.as<uint32_t>();
+        g.len0 = b->d_len0.as<uint32_t>();
+        g.upper = b->d_upper.as<uint32_t>();
+        g.upper_len = b->d_upper_len.as<uint32_t>();
+        g.upper_off = b->d_upper_off.as<uint64_t>();
+        g.n = n;
+        g.dim = (uint32_t)ix.dim;
+        g.m = (uint32_t)h.m;
+        g.max_m0 = (uint32_t)h.max_m0;
+        g.enter_point = (uint32_t)enter_point;
+        g.enter_level = (uint32_t)enter_level;
+        g.cosine = ix.dist == 1 ? 1 : 0;
+        const uint64_t vwords = (n + 31) / 32;
+        constexpr uint64_t QB = 1024;
+        b->d_vis.reserve(QB * vwords * 4);
+        b->d_keys.reserve(nb * cape * 8);
+        b->d_flags.reserve(64 + nb * 4);
+        VDB_HIP(hipMemsetAsync(b->d_flags.p, 0, 64 + nb * 4, s));
+        unsigned long long *stats = reinterpret_cast<unsigned long long *>(b->d_flags.p);
+        uint32_t *err = reinterpret_cast<uint32_t *>(b->d_flags.as<uint8_t>() + 64);
+        const float *d_q = ix.d_rows.as<float>() + first * ix.dim, *d_qsq = ix.d_sq.as<float>() + first;
+        for (uint64_t q0 = 0; q0 < nb; q0 += QB) {
+            const uint32_t nq = (uint32_t)std::min<uint64_t>(QB, nb - q0);
+            VDB_HIP(hipMemsetAsync(b->d_vis.p, 0, uint64_t(nq) * vwords * 4, s));
+            uint64_t *outk = b->d_keys.as<uint64_t>() + q0 * cape;
+#define HLB(R) hnsw_launch<R, false>(g, d_q + q0 * ix.dim, d_qsq + q0, nullptr, 0u, efk, b->d_vis.as<uint32_t>(), vwords, outk, stats, err + q0, nq, lds, s)
+            switch (cape / 64) {
+                case 1: HLB(1); break;
+                case 2: HLB(2); break;
+                case 4: HLB(4); break;
+                case 8: HLB(8); break;
+                case 16: HLB(16); break;
+                default: throw Error(1, "hnsw build: unexpected result-list capacity");
+            }
+#undef HLB
+        }
+        // all-pairs cached-form distances inside the batch (the `rhs_idx < idx` offers of add_parallel, :431-437)
+        ldx = (uint32_t)((nb + 63) & ~63ull);
+        b->d_cross_in.reserve(nb * ldx * 8);
+        b->d_cross_out.reserve(nb * ldx * 8);
+        hipLaunchKernelGGL(k_iota_offset_keys, dim3((unsigned)nb), dim3(256), 0, s, b->d_cross_in.as<uint64_t>(), (uint32_t)nb, ldx,
+                           (uint32_t)first);
+        launch_rerank(ix.d_rows.as<float>(), (uint32_t)ix.dim, d_q, (uint32_t)nb, ix.dist == 0 ? MET_L2_CACHED : MET_COSINE,
+                      ix.d_sq.as<float>(), d_qsq, b->d_cross_in.as<uint64_t>(), b->d_cross_out.as<uint64_t>(), (uint32_t)nb, ldx, s);
+        keys.resize(nb * cape);
+        cross.resize(nb * uint64_t(ldx));
+        std::vector<uint32_t> e(nb);
+        VDB_HIP(hipMemcpyAsync(keys.data(), b->d_keys.p, nb * cape * 8, hipMemcpyDeviceToHost, s));
+        VDB_HIP(hipMemcpyAsync(cross.data(), b->d_cross_out.p, nb * uint64_t(ldx) * 8, hipMemcpyDeviceToHost, s));
+        VDB_HIP(hipMemcpyAsync(e.data(), err, nb * 4, hipMemcpyDeviceToHost, s));
+        VDB_SYNC(s);
+        ok.resize(nb);
+        for (uint64_t i = 0; i < nb; i++) ok[i] = e[i] ? 0 : 1;  // an overflowed LDS pool: that member is searched on the host
+    };
+    ga.sync = [ixp, b](const std::vector<uint64_t> &dirty) {
+        if (!b->mirror_valid || dirty.empty()) return;
+        Index &ix = *ixp;
+        HNSWState &h = ix.hnsw;
+        ix.use_device();
+        hipStream_t s = b->stream;
+        for (int upper = 0; upper < 2; upper++) {
+            const uint32_t words = upper ? (uint32_t)h.m : (uint32_t)h.max_m0;
+            std::vector<uint64_t> slots;
+            std::vector<uint32_t> rows, lens;
+            for (uint64_t key : dirty) {
+                const uint64_t owner = key >> 8, level = key & 0xff;
+                if ((level != 0) != (upper != 0)) continue;
+                const uint64_t slot = upper ? h.upper_off[owner] + level - 1 : owner;
+                const uint32_t *src = upper ? h.upper.data() + slot * h.m : h.level0.data() + owner * h.max_m0;
+                slots.push_back(slot);
+                rows.insert(rows.end(), src, src + words);
+                lens.push_back((uint32_t)(upper ? h.upper_len[slot] : h.len0[owner]));
+            }
+            if (slots.empty()) continue;
+            b->d_stage_slots.reserve(slots.size() * 8);
+            b->d_stage_rows.reserve(rows.size() * 4);
+            b->d_stage_len.reserve(lens.size() * 4);
+            VDB_HIP(hipMemcpyAsync(b->d_stage_slots.p, slots.data(), slots.size() * 8, hipMemcpyHostToDevice, s));
+            VDB_HIP(hipMemcpyAsync(b->d_stage_rows.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, s));
+            VDB_HIP(hipMemcpyAsync(b->d_stage_len.p, lens.data(), lens.size() * 4, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_scatter_lists, dim3((unsigned)slots.size()), dim3(64), 0, s,
+                               upper ? b->d_upper.as<uint32_t>() : b->d_level0.as<uint32_t>(),
+                               upper ? b->d_upper_len.as<uint32_t>() : b->d_len0.as<uint32_t>(), b->d_stage_slots.as<uint64_t>(),
+                               b->d_stage_rows.as<uint32_t>(), b->d_stage_len.as<uint32_t>(), words, (uint32_t)slots.size());
+            VDB_SYNC(s);  // the staging vectors are reused by the other pass
+        }
+    };
+    return bd;
+}
 
 void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef, bool use_pq,
                      uint64_t *d_idx, float *d_dist, uint64_t *d_cnt) {

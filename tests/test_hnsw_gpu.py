@@ -188,3 +188,35 @@ def test_gistlike_batch_built_graph(mods):
     fi, _, _ = ix.flat_knn(qs, 10)
     rec = np.mean([O.recall(fi[q], idx[q]) for q in range(qs.shape[0])])
     assert rec > 0.9
+
+
+@pytest.mark.parametrize("dist,kind", [("l2sqr", 0), ("cosine", 1)])
+def test_gpu_assisted_builder_matches_oracle_builder(mods, dist, kind):
+    """Batches of >= 256 points run their candidate phase on the GPU (the level-0 search of every batch member against the
+    pre-batch graph = k_hnsw_search with k = ef = ef_construction over the device mirror of the graph; distances between
+    batch members = one all-pairs launch).  The graph must equal the oracle's all-host builder with the same level stream
+    and batch size, list by list -- and the all-host run of this library's builder (hnsw_build_gpu = 1)."""
+    vdb, O = mods
+    from conftest import gist_like
+    base = gist_like(6000, dim=64, seed=77)
+    base[3000:3010] = base[:10]  # exact duplicates: distance ties inside the candidate sets
+    ix = vdb.GpuIndex(64, dist)
+    ix.batch_add(base)
+    ix.hnsw_build(M=8, ef_construction=48, seed=11, batch=300, nthreads=8)   # batches reach 300 once 2 400 rows are in
+    g_gpu = ix.hnsw_export()
+    oh = O.HNSW.build(base, kind, M=8, ef_construction=48, seed=11, batch=300)
+    ok, key = _graphs_equal(g_gpu, oh.graph())
+    assert ok, f"GPU-assisted graph differs from the oracle's in {key}"
+    try:
+        ix.set_param("hnsw_build_gpu", 1)
+        ix.hnsw_build(M=8, ef_construction=48, seed=11, batch=300, nthreads=8)
+    finally:
+        ix.set_param("hnsw_build_gpu", 0)
+    ok, key = _graphs_equal(g_gpu, ix.hnsw_export())
+    assert ok, f"GPU-assisted graph differs from the all-host graph in {key}"
+    # and the graph is searchable
+    qs = gist_like(8, dim=64, seed=78)
+    idx, d, cnt = ix.knn_with_ef(qs, 5, 40)
+    for q in range(8):
+        oi, od = oh.knn(qs[q], 5, 40)
+        assert idx[q, :len(oi)].tolist() == oi.tolist() and np.array_equal(d[q, :len(od)], od)
