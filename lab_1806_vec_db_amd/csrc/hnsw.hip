@@ -58,6 +58,7 @@ struct HnswDev {
     const float *cent_cache;
     uint32_t enc_dim, pq_m, pq_kc, n_bits;
     int dma;  // exact level-0 distances through LDS-DMA staging (max_m0 <= 32, dim % 32 == 0)
+    const uint32_t *entry0;  // optional, per query of the launch: level-0 entry point (the builder's searches of members above level 0); 0xFFFFFFFF / null = greedy descent from the enter point
     uint32_t pool_cap;  // live candidates the LDS pool may hold (<= HNSW_POOL; a test hook lowers it to reach the heap walk)
 };
 
@@ -298,6 +299,11 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswDev g, const float *__re
 
     // ---- greedy descent, levels enter_level .. 1 (hnsw_index.rs:306-350) ---------------------------
     uint32_t cur = g.enter_point;
+    uint32_t top_level = g.enter_level;
+    if (g.entry0 != nullptr && g.entry0[q] != 0xFFFFFFFFu) {  // block-uniform: start level 0 at the given node
+        cur = g.entry0[q];
+        top_level = 0;
+    }
     float cur_d = 0.0f;
     {
         float d = 0.0f;
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswDev g, const float *__re
         cur_d = __shfl(d, 0);
         n_dist++;
     }
-    for (uint32_t level = g.enter_level; level >= 1; level--) {
+    for (uint32_t level = top_level; level >= 1; level--) {
         n_dist++;  // the reference re-scores the current node at the start of every level (:313)
         for (;;) {
             uint64_t slot = g.upper_off[cur] + level - 1;
@@ -737,6 +743,7 @@ struct Builder {
     };
     CacheView cache{nullptr, 0};
     double t_search = 0, t_connect = 0;  // wall seconds of the parallel candidate phase / the serial linking phase
+    double t_gpu = 0, t_sync = 0;        // of which: inside GpuAssist::search / ::sync
     // GPU assistance of add_batch (hnsw_build): the level-0 candidate search of a whole batch against the pre-batch
     // graph IS HNSWIndex::knn_with_ef(k = ef = ef_construction) -- one k_hnsw_search launch over the device mirror of
     // the graph -- and the distances between batch members are one all-pairs launch.  Same values, same sets as the
@@ -745,8 +752,10 @@ struct Builder {
         uint64_t min_batch = 256;  // smaller batches cannot fill the GPU: one query is one wave
         // keys [nb][cape]: the sorted result set of every batch member (PAIR_NONE padded); ok[i] = 0: search it on the host
         // (pool overflow); cross [nb][ldx]: pair keys (distance of member i to member r, first + r)
-        std::function<void(uint64_t first, uint64_t nb, uint64_t enter_point, uint64_t enter_level, std::vector<uint64_t> &keys,
-                           uint32_t &cape, std::vector<uint64_t> &cross, uint32_t &ldx, std::vector<uint8_t> &ok)> search;
+        // entry0 [nb]: level-0 entry of a member whose upper levels were searched on the host, 0xFFFFFFFF = greedy descent
+        std::function<void(uint64_t first, uint64_t nb, uint64_t enter_point, uint64_t enter_level, const std::vector<uint32_t> &entry0,
+                           std::vector<uint64_t> &keys, uint32_t &cape, std::vector<uint64_t> &cross, uint32_t &ldx,
+                           std::vector<uint8_t> &ok)> search;
         std::function<void(const std::vector<uint64_t> &dirty /* (owner << 8) | level */)> sync;
     };
     GpuAssist *gpu = nullptr;
@@ -981,52 +990,75 @@ struct Builder {
         std::vector<std::vector<RSet>> cands(nb);
         std::vector<uint64_t> gkeys, gcross;
         std::vector<uint8_t> gok;
+        std::vector<uint32_t> entry0(nb, 0xFFFFFFFFu);
         uint32_t gcape = 0, gld = 0;
         const bool use_gpu = gpu && nb >= gpu->min_batch;
-        if (use_gpu) gpu->search(first, nb, enter_point, enter_level, gkeys, gcape, gcross, gld, gok);
-        auto work = [&](uint64_t i, Scratch &s) {
-            uint64_t idx = first + i, level = h.vec_level[idx];
-            if (use_gpu && level == 0 && gok[i]) {
-                // search_on_level(greedy_until(0), 0, ef_construction) from the GPU, then the earlier batch members
-                // (:431-437; every member has level >= 0) offered in order, exactly as below
+        int nt = std::max(1, std::min<int>(nthreads, (int)nb));
+        auto for_members = [&](const std::function<void(uint64_t, Scratch &)> &fn) {
+            if (nt == 1) {
+                for (uint64_t i = 0; i < nb; i++) fn(i, s0);
+                return;
+            }
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; t++)
+                th.emplace_back([&, t]() {
+                    Scratch s;
+                    for (uint64_t i = t; i < nb; i += nt) fn(i, s);
+                });
+            for (auto &x : th) x.join();
+        };
+        // one level of one member: search_on_level from cur, then the earlier batch members of that level offered in order
+        // (rhs_idx < idx && vec_level[rhs] >= level, :431-437); returns the next level's entry (taken before the offers)
+        auto level_step = [&](uint64_t i, uint64_t l, uint64_t cur, Scratch &s) -> uint64_t {
+            const uint64_t idx = first + i;
+            const float *q = rows + idx * dim;
+            const float qc = cache[idx];
+            RSet c = search_on_level(cur, l, h.ef_construction, q, qc, s);
+            const uint64_t nxt = c.v.front().i;
+            std::vector<uint32_t> rhs;
+            for (uint64_t r = 0; r < i; r++)
+                if (h.vec_level[first + r] >= l) rhs.push_back((uint32_t)(first + r));
+            std::vector<float> rd(rhs.size());
+            dist_many(q, qc, rhs.data(), rhs.size(), rd.data());
+            for (size_t r = 0; r < rhs.size(); r++) c.add(Pair{rd[r], rhs[r]});
+            cands[i].push_back(std::move(c));
+            return nxt;
+        };
+        auto upper_levels = [&](uint64_t i, Scratch &s) -> uint64_t {  // levels top .. 1 on the host; returns the level-0 entry
+            const uint64_t idx = first + i, level = h.vec_level[idx];
+            uint64_t cur = level < enter_level ? greedy_until(level, rows + idx * dim, cache[idx]) : enter_point;
+            for (uint64_t l = std::min(level, enter_level); l >= 1; l--) cur = level_step(i, l, cur, s);
+            return cur;
+        };
+        if (use_gpu) {
+            // (A) members above level 0: their upper-level searches (small graphs) on the host, which yields their level-0
+            // entry; (B) ONE launch searches level 0 for every member -- greedy descent for the level-0 members, the given
+            // entry for the others -- and one launch gives the distances between members; (C) the sets are assembled.
+            for_members([&](uint64_t i, Scratch &s) {
+                if (h.vec_level[first + i] >= 1) entry0[i] = (uint32_t)upper_levels(i, s);
+            });
+            const auto tg = std::chrono::steady_clock::now();
+            gpu->search(first, nb, enter_point, enter_level, entry0, gkeys, gcape, gcross, gld, gok);
+            t_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg).count();
+            for_members([&](uint64_t i, Scratch &s) {
+                const uint64_t idx = first + i;
+                if (!gok[i]) {  // the LDS pool of the GPU walk overflowed: this member's level 0 on the host
+                    const uint64_t cur = entry0[i] != 0xFFFFFFFFu ? entry0[i]
+                                                                  : (0 < enter_level ? greedy_until(0, rows + idx * dim, cache[idx]) : enter_point);
+                    (void)level_step(i, 0, cur, s);
+                    return;
+                }
                 RSet c(h.ef_construction);
                 const uint64_t *kr = gkeys.data() + i * gcape;
                 // (the kernel's register list is 64 R entries wide: positions past ef hold pairs that were pushed out of the set)
                 for (uint32_t j = 0; j < gcape && j < h.ef_construction && kr[j] != PAIR_NONE; j++)
                     c.v.push_back(Pair{f32_from_orderable(uint32_t(kr[j] >> 32)), uint64_t(uint32_t(kr[j]))});
-                const uint64_t *xr = gcross.data() + i * gld;
+                const uint64_t *xr = gcross.data() + i * gld;  // every earlier member has level >= 0
                 for (uint64_t r = 0; r < i; r++) c.add(Pair{f32_from_orderable(uint32_t(xr[r] >> 32)), first + r});
                 cands[i].push_back(std::move(c));
-                return;
-            }
-            const float *q = rows + idx * dim;
-            float qc = cache[idx];
-            uint64_t cur = level < enter_level ? greedy_until(level, q, qc) : enter_point;
-            uint64_t top = std::min(level, enter_level);
-            for (uint64_t l = top + 1; l-- > 0;) {
-                RSet c = search_on_level(cur, l, h.ef_construction, q, qc, s);
-                cur = c.v.front().i;
-                // rhs_idx < idx && vec_level[rhs] >= level (:431-437)
-                std::vector<uint32_t> rhs;
-                for (uint64_t r = 0; r < i; r++)
-                    if (h.vec_level[first + r] >= l) rhs.push_back((uint32_t)(first + r));
-                std::vector<float> rd(rhs.size());
-                dist_many(q, qc, rhs.data(), rhs.size(), rd.data());
-                for (size_t r = 0; r < rhs.size(); r++) c.add(Pair{rd[r], rhs[r]});
-                cands[i].push_back(std::move(c));
-            }
-        };
-        int nt = std::max(1, std::min<int>(nthreads, (int)nb));
-        if (nt == 1) {
-            for (uint64_t i = 0; i < nb; i++) work(i, s0);
+            });
         } else {
-            std::vector<std::thread> th;
-            for (int t = 0; t < nt; t++)
-                th.emplace_back([&, t]() {
-                    Scratch s;
-                    for (uint64_t i = t; i < nb; i += nt) work(i, s);
-                });
-            for (auto &x : th) x.join();
+            for_members([&](uint64_t i, Scratch &s) { (void)level_step(i, 0, upper_levels(i, s), s); });
         }
         const auto t_mid = std::chrono::steady_clock::now();
         // Linking (hnsw_index.rs:446-450 runs connect_new_links node by node).  Everything it computes is a function of
@@ -1083,7 +1115,9 @@ struct Builder {
         if (gpu) {  // the lists this batch rewrote, for the device mirror of the graph
             std::vector<uint64_t> dirty;
             for (size_t g = 0; g + 1 < gstart.size(); g++) dirty.push_back(evs[gstart[g]].key);
+            const auto ts = std::chrono::steady_clock::now();
             gpu->sync(dirty);
+            t_sync += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
         }
         const auto t_end = std::chrono::steady_clock::now();
         t_search += std::chrono::duration<double>(t_mid - t_begin).count();
@@ -1178,8 +1212,8 @@ void hnsw_build(Index &ix, uint64_t M, uint64_t ef_construction, uint64_t seed, 
         cur = next;
     }
     if (std::getenv("VDB_HNSW_PROF"))
-        std::fprintf(stderr, "hnsw_build: n=%llu candidate phase %.1f s (%d threads), linking phase %.1f s\n",
-                     (unsigned long long)n, b.t_search, nthreads, b.t_connect);
+        std::fprintf(stderr, "hnsw_build: n=%llu candidate phase %.1f s (%d threads; %.1f s of it GPU searches), linking phase %.1f s (%.1f s of it mirror updates)\n",
+                     (unsigned long long)n, b.t_search, nthreads, b.t_gpu, b.t_connect, b.t_sync);
     h.present = true;
     h.dev_dirty = true;
 }
@@ -1304,7 +1338,7 @@ __global__ void k_iota_offset_keys(uint64_t *__restrict__ rows, uint32_t n, uint
 
 struct BuildDev {
     DevBuf d_level0, d_len0, d_upper, d_upper_len, d_upper_off;  // the graph, sized for all n rows
-    DevBuf d_vis, d_keys, d_flags, d_cross_in, d_cross_out, d_stage_slots, d_stage_rows, d_stage_len;
+    DevBuf d_vis, d_keys, d_flags, d_entry, d_cross_in, d_cross_out, d_stage_slots, d_stage_rows, d_stage_len;
     bool mirror_valid = false;
     std::vector<uint64_t> upper_off;  // [n + 1] from the pre-drawn levels
     hipStream_t stream = nullptr;
@@ -1331,8 +1365,9 @@ static std::shared_ptr<BuildDev> hnsw_build_gpu_assist(Index &ix, Builder::GpuAs
 
     Index *ixp = &ix;
     BuildDev *b = bd.get();
-    ga.search = [ixp, b](uint64_t first, uint64_t nb, uint64_t enter_point, uint64_t enter_level, std::vector<uint64_t> &keys,
-                         uint32_t &cape, std::vector<uint64_t> &cross, uint32_t &ldx, std::vector<uint8_t> &ok) {
+    ga.search = [ixp, b](uint64_t first, uint64_t nb, uint64_t enter_point, uint64_t enter_level, const std::vector<uint32_t> &entry0,
+                         std::vector<uint64_t> &keys, uint32_t &cape, std::vector<uint64_t> &cross, uint32_t &ldx,
+                         std::vector<uint8_t> &ok) {
         Index &ix = *ixp;
         HNSWState &h = ix.hnsw;
         ix.use_device();
@@ -1378,6 +1413,8 @@ static std::shared_ptr<BuildDev> hnsw_build_gpu_assist(Index &ix, Builder::GpuAs
         b->d_vis.reserve(QB * vwords * 4);
         b->d_keys.reserve(nb * cape * 8);
         b->d_flags.reserve(64 + nb * 4);
+        b->d_entry.reserve(nb * 4);
+        VDB_HIP(hipMemcpyAsync(b->d_entry.p, entry0.data(), nb * 4, hipMemcpyHostToDevice, s));
         VDB_HIP(hipMemsetAsync(b->d_flags.p, 0, 64 + nb * 4, s));
         unsigned long long *stats = reinterpret_cast<unsigned long long *>(b->d_flags.p);
         uint32_t *err = reinterpret_cast<uint32_t *>(b->d_flags.as<uint8_t>() + 64);
@@ -1386,6 +1423,7 @@ static std::shared_ptr<BuildDev> hnsw_build_gpu_assist(Index &ix, Builder::GpuAs
             const uint32_t nq = (uint32_t)std::min<uint64_t>(QB, nb - q0);
             VDB_HIP(hipMemsetAsync(b->d_vis.p, 0, uint64_t(nq) * vwords * 4, s));
             uint64_t *outk = b->d_keys.as<uint64_t>() + q0 * cape;
+            g.entry0 = b->d_entry.as<uint32_t>() + q0;
 #define HLB(R) hnsw_launch<R, false>(g, d_q + q0 * ix.dim, d_qsq + q0, nullptr, 0u, efk, b->d_vis.as<uint32_t>(), vwords, outk, stats, err + q0, nq, lds, s)
             switch (cape / 64) {
                 case 1: HLB(1); break;
