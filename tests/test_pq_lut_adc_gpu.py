@@ -91,3 +91,36 @@ def test_shard_key_rows_equal_oracle_adc(mods, dist, kind, n, dim, m, n_bits, ef
         sel = (ok & np.uint64(0xFFFFFFFF)).astype(np.int64) - off
         ex = np.array([O.dist(kind, base[i], qs[q]) for i in sel], dtype=np.float32)
         assert np.array_equal(e[q], O.pair_keys(ex, (sel + off).astype(np.uint64))), q
+
+
+@pytest.mark.parametrize("dist,kind", [("l2sqr", 0)])
+def test_quantised_scan_fallbacks_on_degenerate_queries(mods, dist, kind):
+    """The 16-bit first pass of the ADC scan (k_pq_adc16) only handles tables of finite non-negative entries; queries whose
+    table holds a NaN / inf (NaN or huge query components), constant tables (all centroids of every group equal -> step
+    D = 1) and thresholds of +inf must take the f32 scan per query -- while the ordinary queries of the same call stay on
+    the fast path.  Answers equal the oracle's either way."""
+    vdb, O = mods
+    n, dim, m = 70000, 64, 16
+    base = gist_like(n, dim=dim, seed=41)
+    ix, opq = _build(vdb, O, base, dist, kind, 4, m)
+    qs = gist_like(12, dim=dim, seed=42)
+    qs[1, 5] = np.nan
+    qs[2, :] = 0.0
+    qs[3, 7] = 3.0e19          # (x - c)^2 overflows to +inf in the table
+    qs[4, :] = 1.0e-30         # denormal-scale products
+    qs[5] = base[123]
+    qs[6, 9] = -np.inf
+    for k, ef in ((10, 100), (5, 1000)):
+        idx, d, cnt = ix.knn_pq(qs, k, ef)
+        for q in range(len(qs)):
+            oi, od = O.flat_knn_pq(base, opq, qs[q], k, ef, kind)
+            assert idx[q, :len(oi)].tolist() == oi.tolist(), (k, ef, q)
+            assert np.array_equal(d[q, :len(od)], od, equal_nan=True), (k, ef, q)
+    # the A/B switch: same answers with the quantised pass off
+    a = ix.knn_pq(qs[7:], 10, 64)
+    try:
+        ix.set_param("pq_adc16", 1)
+        b = ix.knn_pq(qs[7:], 10, 64)
+    finally:
+        ix.set_param("pq_adc16", 0)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
