@@ -128,7 +128,7 @@ int vdb_flat_set_mode(vdb_index *idx, int mode);
  *   "hnsw_pool_cap"    live candidates the fast HNSW walk keeps in LDS (default and maximum 2048) before a query is handed to
  *                      the heap walk; tests lower it to exercise that hand-over
  *   "pq_adc16"         quantised first pass of the threshold-filter ADC scan (16-bit tables, 8 queries per pass; exact f32
- *                      sums for its candidates): 0 auto (4-bit codes, L2Sqr, 16-B code words), 1 off */
+ *                      sums for its candidates): 0 auto (4-bit codes, whole 16-B code words; L2Sqr 8 and Cosine 7 queries per pass), 1 off */
 int vdb_set_param(vdb_index *idx, const char *name, int64_t value);
 /* number of queries whose MFMA shortlist failed certification and were redone by the exact scan */
 int vdb_flat_fallback_count(const vdb_index *idx, uint64_t *out);

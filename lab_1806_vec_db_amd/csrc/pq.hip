@@ -347,60 +347,113 @@ __global__ __launch_bounds__(256) void k_pq_tile_codes(const uint4 *__restrict__
 constexpr uint32_t ADC16_Q = 8;          // queries per workgroup pass
 constexpr uint32_t ADC16_WGBUF = 2048;   // LDS hit buffer entries per workgroup
 
-// one workgroup per query: table -> 16-bit image [q / 8][g][c][q % 8], offset M and step D
-__global__ __launch_bounds__(256) void k_pq_quant16(const float *__restrict__ lut, uint32_t m, uint32_t nq,
-                                                    uint16_t *__restrict__ img, double *__restrict__ qM,
-                                                    double *__restrict__ qD, uint32_t *__restrict__ qflag) {
+// one workgroup per query: table -> 16-bit image [q / NQ][g][c][q % NQ], offset M and step D.
+// L2Sqr (NQ = 8): entries floor((lut - mn_g) / D), D = sum_g range_g / 65000: a LOWER bound of the sum.
+// Cosine (NQ = 7): the ADC value is 1 - S / max(sqrt(C) |q|, 1e-10) with S = sum of dot-product entries (any sign) and
+// C = sum of |centroid|^2 entries (pq_table.rs:262-299).  Slots 0..6 hold ceil((lut - mn_g) / D), D = sum range / 64000
+// -- an UPPER bound of S --, slot 7 of every entry holds floor((cc - mnc_g) / DC): a lower bound of C, the same for all
+// queries (written by the block of the group's first query).  A row survives when S_ub >= 0 and
+// S_ub^2 >= rho^2 |q|^2 C_lb with rho = 1 - tau (less slack), see k_pq_adc16.
+__global__ __launch_bounds__(256) void k_pq_quant16(const float *__restrict__ lut, const float *__restrict__ cent_cache, uint32_t m,
+                                                    uint32_t nq, int cosine, uint16_t *__restrict__ img, double *__restrict__ qM,
+                                                    double *__restrict__ qD, double *__restrict__ qMC, double *__restrict__ qDC,
+                                                    uint32_t *__restrict__ qflag) {
     const uint32_t q = blockIdx.x, t = threadIdx.x;
-    __shared__ double sR[256], sM[256];
+    const uint32_t NQ = cosine ? 7u : 8u;
+    __shared__ double sR[256], sM[256], sA[256];
     __shared__ uint32_t sbad;
     if (t == 0) sbad = 0;
     __syncthreads();
+    auto reduce3 = [&](double &a, double &b, double &c) {
+        sR[t] = a;
+        sM[t] = b;
+        sA[t] = c;
+        __syncthreads();
+        for (uint32_t s = 128; s > 0; s >>= 1) {
+            if (t < s) {
+                sR[t] += sR[t + s];
+                sM[t] += sM[t + s];
+                sA[t] += sA[t + s];
+            }
+            __syncthreads();
+        }
+        a = sR[0];
+        b = sM[0];
+        c = sA[0];
+        __syncthreads();
+    };
     const float *lq = lut + uint64_t(q) * m * 16;
-    double R = 0.0, M = 0.0;
+    double R = 0.0, M = 0.0, A = 0.0;  // sum of ranges, of minima, of the largest magnitudes (rounding slack of a mixed-sign sum)
     bool bad = false;
     for (uint32_t g = t; g < m; g += 256) {
-        float mn = INFINITY, mx = -INFINITY;
+        float mn = INFINITY, mx = -INFINITY, am = 0.0f;
 #pragma unroll
         for (int c = 0; c < 16; c++) {
             const float v = lq[g * 16 + c];
-            if (!(v >= 0.0f) || v > 3.0e38f) bad = true;  // NaN, negative, inf
+            if (cosine ? !(fabsf(v) <= 3.0e38f) : (!(v >= 0.0f) || v > 3.0e38f)) bad = true;  // NaN, inf (L2Sqr: negative)
             mn = fminf(mn, v);
             mx = fmaxf(mx, v);
+            am = fmaxf(am, fabsf(v));
         }
         R += double(mx) - double(mn);
         M += double(mn);
+        A += double(am);
     }
     if (bad) atomicOr(&sbad, 1u);
-    sR[t] = R;
-    sM[t] = M;
-    __syncthreads();
-    for (uint32_t s = 128; s > 0; s >>= 1) {
-        if (t < s) {
-            sR[t] += sR[t + s];
-            sM[t] += sM[t + s];
-        }
-        __syncthreads();
-    }
-    R = sR[0];
-    M = sM[0];
-    const bool flag = sbad != 0 || !(R < 1.0e300) || !(M < 1.0e300);
-    const double D = (!flag && R > 0.0) ? R / 65000.0 : 1.0;
-    uint16_t *dst = img + uint64_t(q / ADC16_Q) * m * 16 * ADC16_Q + (q % ADC16_Q);
+    reduce3(R, M, A);
+    const bool flag = sbad != 0 || !(R < 1.0e300) || !(fabs(M) < 1.0e300);
+    const double D = (!flag && R > 0.0) ? R / (cosine ? 64000.0 : 65000.0) : 1.0;
+    uint16_t *dst = img + uint64_t(q / NQ) * m * 16 * 8 + (q % NQ);
     for (uint32_t g = t; g < m; g += 256) {
         float mn = INFINITY;
 #pragma unroll
         for (int c = 0; c < 16; c++) mn = fminf(mn, lq[g * 16 + c]);
 #pragma unroll
         for (int c = 0; c < 16; c++) {
-            double x = flag ? 0.0 : floor((double(lq[g * 16 + c]) - double(mn)) / D);
-            x = x < 0.0 ? 0.0 : (x > 65000.0 ? 65000.0 : x);  // (unreachable clamps: x <= range_g / D <= 65000)
-            dst[(g * 16 + c) * ADC16_Q] = (uint16_t)x;
+            const double y = (double(lq[g * 16 + c]) - double(mn)) / D;
+            double x = flag ? 0.0 : (cosine ? ceil(y) : floor(y));
+            x = x < 0.0 ? 0.0 : (x > 65000.0 ? 65000.0 : x);  // (unreachable clamps: sum of the maxima <= 64000 + m)
+            dst[(g * 16 + c) * 8] = (uint16_t)x;
+        }
+    }
+    double MC = 0.0, DC = 1.0;
+    if (cosine) {  // the |centroid|^2 table: the same numbers in every block; the group's first query writes slot 7
+        double RC = 0.0, Z = 0.0;
+        MC = 0.0;
+        for (uint32_t g = t; g < m; g += 256) {
+            float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const float v = cent_cache[g * 16 + c];
+                mn = fminf(mn, v);
+                mx = fmaxf(mx, v);
+            }
+            RC += double(mx) - double(mn);
+            MC += double(mn);
+        }
+        reduce3(RC, MC, Z);
+        DC = RC > 0.0 && RC < 1.0e300 ? RC / 65000.0 : 1.0;
+        if (q % NQ == 0) {
+            uint16_t *dc = img + uint64_t(q / NQ) * m * 16 * 8 + 7;
+            for (uint32_t g = t; g < m; g += 256) {
+                float mn = INFINITY;
+#pragma unroll
+                for (int c = 0; c < 16; c++) mn = fminf(mn, cent_cache[g * 16 + c]);
+#pragma unroll
+                for (int c = 0; c < 16; c++) {
+                    double x = floor((double(cent_cache[g * 16 + c]) - double(mn)) / DC);
+                    x = x < 0.0 ? 0.0 : (x > 65000.0 ? 65000.0 : x);
+                    dc[(g * 16 + c) * 8] = (uint16_t)x;
+                }
+            }
         }
     }
     if (t == 0) {
-        qM[q] = M;
+        // Cosine: the f32 left fold of mixed-sign terms errs by at most gamma_m * sum |t_g| <= m 2^-23 * A: part of the upper bound
+        qM[q] = cosine ? M + 2.0 * double(m) * 0x1p-24 * A : M;
         qD[q] = D;
+        qMC[q] = MC;
+        qDC[q] = DC;
         qflag[q] = flag ? 1u : 0u;
     }
 }
@@ -411,6 +464,8 @@ struct Adc16Args {
     uint32_t enc_dim, m;
     const uint4 *img;        // [ceil(nq/8)][m*16] 16-B entries
     const double *qM, *qD;   // [nq]
+    const double *qMC, *qDC; // [nq] Cosine: offset / step of the |centroid|^2 table (identical for all queries)
+    const float *qsq;        // [nq] Cosine: |q|^2
     const uint32_t *qflag;   // [nq]
     const float *tau;        // [nq]
     uint32_t nq;
@@ -425,28 +480,29 @@ struct Adc16Args {
 // the packed nibble offsets, plus bit 16 for the groups beyond the 16-bit immediate range).  NW = 0: runtime count,
 // one extra add per lookup.  (Shift + mask + base add per lookup made the loop VALU-bound: 154 vector instructions
 // per 32 lookups against 128 LDS cycles.)
-template <int NW>
+template <int NW, bool COS>
 __global__ __launch_bounds__(1024) void k_pq_adc16(Adc16Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+    constexpr uint32_t NQ = COS ? 7 : 8;  // query slots of an entry (Cosine: slot 7 = the |centroid|^2 table)
     const uint32_t tid = threadIdx.x;
     const uint32_t m = a.m;
-    const uint32_t q0 = blockIdx.y * ADC16_Q;
+    const uint32_t q0 = blockIdx.y * NQ;
     uint4 *tab = reinterpret_cast<uint4 *>(smem16);                   // [m*16] entries of 8 x u16
-    int32_t *thr = reinterpret_cast<int32_t *>(tab + m * 16);         // [8] T16 per query slot (-1: slot unused / flagged)
-    uint32_t *hit_row = reinterpret_cast<uint32_t *>(thr + 8);        // [ADC16_WGBUF]
+    int32_t *thr = reinterpret_cast<int32_t *>(tab + m * 16);         // L2Sqr: [8] T16 per slot (-1: unused / flagged); Cosine: [8][4] floats
+    uint32_t *hit_row = reinterpret_cast<uint32_t *>(thr + 32);       // [ADC16_WGBUF]
     uint32_t *hit_q = hit_row + ADC16_WGBUF;                          // [ADC16_WGBUF] slot | rank << 8
     uint32_t *hit_n = hit_q + ADC16_WGBUF;                            // [0] entries, [1..8] per-slot counts, [9..16] bases
     // the lookups address the table with absolute LDS offsets from 0: the dynamic segment is the kernel's only LDS
     // object, so it starts there; if a toolchain ever places it elsewhere the queries go to the f32 scan
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem16 != 0u) {
-        if (tid < ADC16_Q && q0 + tid < a.nq) atomicAdd(&a.cnt[q0 + tid], a.cap + 1);
+        if (tid < NQ && q0 + tid < a.nq) atomicAdd(&a.cnt[q0 + tid], a.cap + 1);
         return;
     }
     {
         const uint4 *src = a.img + uint64_t(blockIdx.y) * m * 16;
         for (uint32_t i = tid; i < m * 16; i += 1024) tab[i] = src[i];
         if (tid < 1 + 2 * ADC16_Q) hit_n[tid] = 0;
-        if (tid < ADC16_Q) {
+        if (!COS && tid < NQ) {
             int32_t T = -1;
             const uint32_t q = q0 + tid;
             if (q < a.nq && a.qflag[q] == 0) {
@@ -459,11 +515,51 @@ __global__ __launch_bounds__(1024) void k_pq_adc16(Adc16Args a) {
             }
             thr[tid] = T;
         }
+        if (COS && tid < 8) {
+            // per query slot: S_ub = Ms + Ds * s16 (constants rounded up), test S_ub >= 0 && S_ub^2 (1 + 1e-6) >= K * C_lb with
+            // K = rho^2 |q|^2 (1 - 1e-5), rho = (1 - tau) - 1e-6 (2 - tau): d_f32 <= tau implies S_f32 / den_f32 >= rho.
+            // rho <= 0 (tau >= 1: rows of the opposite half-space qualify), a tiny |q| (the 1e-10 clamp of the reference can
+            // act) or a flagged table: Ms = -inf, the query takes the f32 scan (too few hits).  Slot 7: the C table's constants.
+            float *f = reinterpret_cast<float *>(thr) + tid * 4;
+            float Ms = -INFINITY, Ds = 0.0f, K = INFINITY, tq = -1.0f;  // (unused / unsupported slot: neither test can pass)
+            const uint32_t q = q0 + tid;
+            if (tid < NQ && q < a.nq && a.qflag[q] == 0) {
+                const double tau = double(a.tau[q]), qs = double(a.qsq[q]);
+                const double rho = (1.0 - tau) - 1e-6 * (2.0 + fabs(tau));
+                if (rho > 0.0 && rho <= 2.0 && qs > 1e-30 && qs < 1e30) {
+                    Ms = float(a.qM[q] + fabs(a.qM[q]) * 1e-6 + 1e-30);
+                    Ds = float(a.qD[q] * (1.0 + 1e-6));
+                    K = float(rho * rho * qs * (1.0 - 1e-5));
+                    tq = float(4e-20 / qs);  // C below this: |centroid sum| |q| may be under the reference's 1e-10 clamp
+                }
+            }
+            if (tid == 7 && a.nq > 0) {  // C_lb = (MC + DC * c16) (1 - 4 m 2^-24 - 1e-6): the f32 fold of C and this evaluation round
+                const double g1 = 1.0 - 4.0 * double(m) * 0x1p-24 - 1e-6;
+                Ms = float(fmax(a.qMC[0], 0.0) * g1);
+                Ds = float(a.qDC[0] * g1);
+                K = 0.0f;
+                tq = 0.0f;
+            }
+            f[0] = Ms;
+            f[1] = Ds;
+            f[2] = K;
+            f[3] = tq;
+        }
     }
     __syncthreads();
-    int32_t T[ADC16_Q];
+    int32_t T[8];
+    float cMs[8], cDs[8], cK[8], cT[8];
 #pragma unroll
-    for (int b = 0; b < (int)ADC16_Q; b++) T[b] = thr[b];
+    for (int b = 0; b < 8; b++) {
+        T[b] = thr[b];
+        if (COS) {
+            const float *f = reinterpret_cast<const float *>(thr) + b * 4;
+            cMs[b] = f[0];
+            cDs[b] = f[1];
+            cK[b] = f[2];
+            cT[b] = f[3];
+        }
+    }
     const uint64_t r_begin = uint64_t(blockIdx.x) * a.rows_per_wg;
     const uint64_t r_end = r_begin + a.rows_per_wg < a.n ? r_begin + a.rows_per_wg : a.n;
     const uint32_t nwords = NW ? (uint32_t)NW : a.enc_dim / 16;
@@ -542,11 +638,21 @@ __global__ __launch_bounds__(1024) void k_pq_adc16(Adc16Args a) {
                 }
             }
         }
-        const int32_t s[ADC16_Q] = {int32_t(a0 & 0xffffu), int32_t(a0 >> 16), int32_t(a1 & 0xffffu), int32_t(a1 >> 16),
-                                    int32_t(a2 & 0xffffu), int32_t(a2 >> 16), int32_t(a3 & 0xffffu), int32_t(a3 >> 16)};
+        const int32_t s[8] = {int32_t(a0 & 0xffffu), int32_t(a0 >> 16), int32_t(a1 & 0xffffu), int32_t(a1 >> 16),
+                              int32_t(a2 & 0xffffu), int32_t(a2 >> 16), int32_t(a3 & 0xffffu), int32_t(a3 >> 16)};
+        float c_lb = 0.0f;
+        if (COS) c_lb = fmaxf(cMs[7] + cDs[7] * float(s[7]), 0.0f);
 #pragma unroll
-        for (int b = 0; b < (int)ADC16_Q; b++) {
-            if (valid && s[b] <= T[b]) {
+        for (int b = 0; b < (int)NQ; b++) {
+            bool pass;
+            if (COS) {
+                const float sub = cMs[b] + cDs[b] * float(s[b]);
+                // (second term: even the lower bound of C cannot rule out the reference's 1e-10 clamp -> the exact stage decides)
+                pass = (sub >= 0.0f && sub * sub * 1.000001f >= cK[b] * c_lb) || c_lb <= cT[b];
+            } else {
+                pass = s[b] <= T[b];
+            }
+            if (valid && pass) {
                 const uint32_t pos = atomicAdd(hit_n, 1u);
                 if (pos < ADC16_WGBUF) {
                     hit_row[pos] = uint32_t(row);
@@ -565,7 +671,7 @@ __global__ __launch_bounds__(1024) void k_pq_adc16(Adc16Args a) {
         hit_q[i] |= r_ << 8;
     }
     __syncthreads();
-    if (tid < ADC16_Q && hit_n[1 + tid] > 0) hit_n[1 + ADC16_Q + tid] = atomicAdd(&a.cnt[q0 + tid], hit_n[1 + tid]);
+    if (tid < NQ && hit_n[1 + tid] > 0) hit_n[1 + ADC16_Q + tid] = atomicAdd(&a.cnt[q0 + tid], hit_n[1 + tid]);
     __syncthreads();
     for (uint32_t i = tid; i < total; i += 1024) {
         const uint32_t b = hit_q[i] & 0xffu, r_ = hit_q[i] >> 8;
@@ -576,16 +682,21 @@ __global__ __launch_bounds__(1024) void k_pq_adc16(Adc16Args a) {
 
 // exact f32 ADC sums (strict group order, pq_table.rs:254-292) of the candidates of every query: row ids in, pair keys
 // out (PAIR_NONE for sums above tau); valid[q] counts the pairs kept.  One workgroup per query, its f32 table in LDS.
+template <bool COS>
 __global__ __launch_bounds__(256) void k_pq_adc_exact(const uint8_t *__restrict__ codes, uint32_t enc_dim, uint32_t m,
-                                                      const float *__restrict__ lut, const float *__restrict__ tau,
+                                                      const float *__restrict__ lut, const float *__restrict__ cent_cache,
+                                                      const float *__restrict__ qsq, const float *__restrict__ tau,
                                                       uint64_t *__restrict__ cand, const uint32_t *__restrict__ cnt,
                                                       uint32_t cap, uint32_t *__restrict__ valid) {
-    extern __shared__ __attribute__((aligned(16))) float slut[];
+    extern __shared__ __attribute__((aligned(16))) float slut[];  // the query's table; Cosine: the |centroid|^2 table behind it
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const uint32_t total = cnt[q];
     if (total > cap) return;  // overflowed list: the query is redone by the f32 scan
     const float *lq = lut + uint64_t(q) * m * 16;
     for (uint32_t i = tid; i < m * 16; i += 256) slut[i] = lq[i];
+    const float *scc = slut + m * 16;
+    if (COS)
+        for (uint32_t i = tid; i < m * 16; i += 256) slut[m * 16 + i] = cent_cache[i];
     __syncthreads();
     const float t = tau[q];
     uint64_t *cq = cand + uint64_t(q) * cap;
@@ -593,19 +704,33 @@ __global__ __launch_bounds__(256) void k_pq_adc_exact(const uint8_t *__restrict_
     for (uint32_t i = tid; i < total; i += 256) {
         const uint32_t row = uint32_t(cq[i]);
         const uint4 *cw = reinterpret_cast<const uint4 *>(codes + uint64_t(row) * enc_dim);
-        float sum = 0.0f;
+        float sum = 0.0f, cdp = 0.0f;
         uint4 v = cw[0];
         for (uint32_t w = 0; w < enc_dim / 16; w++) {
             const uint32_t words[4] = {v.x, v.y, v.z, v.w};
             if (w + 1 < enc_dim / 16) v = cw[w + 1];
 #pragma unroll
             for (int wi = 0; wi < 4; wi++) {
-                float e[8];
+                float e[8], c[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) e[j] = slut[(w * 32 + 8 * wi + j) * 16 + ((words[wi] >> (4 * j)) & 0xf)];
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t at = (w * 32 + 8 * wi + j) * 16 + ((words[wi] >> (4 * j)) & 0xf);
+                    e[j] = slut[at];
+                    if (COS) c[j] = scc[at];
+                }
 #pragma unroll
-                for (int j = 0; j < 8; j++) sum = sum + e[j];
+                for (int j = 0; j < 8; j++) {
+                    sum = sum + e[j];
+                    if (COS) cdp = cdp + c[j];
+                }
             }
+        }
+        if (COS) {  // pq_table.rs:294-299, the operation order of k_pq_adc
+            float norm0 = sqrtf(cdp);
+            float norm1 = sqrtf(qsq[q]);
+            float den = fmaxf(norm0 * norm1, 1e-10f);
+            float r = sum / den;
+            sum = 1.0f - r;
         }
         const bool keep = sum <= t;
         cq[i] = keep ? pair_key(sum, row) : PAIR_NONE;
@@ -1066,24 +1191,31 @@ void pq_build(Index &ix, uint64_t n_bits, uint64_t m, uint64_t train_n, uint64_t
     ix.pq.present = true;
 }
 
-template <int NW>
+template <int NW, bool COS>
 static void adc16_launch_nw(const Adc16Args &a, dim3 grid, size_t lds, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pq_adc16<NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pq_adc16<NW, COS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL(k_pq_adc16<NW>, grid, dim3(1024), lds, s, a);
+    hipLaunchKernelGGL((k_pq_adc16<NW, COS>), grid, dim3(1024), lds, s, a);
 }
-static void adc16_launch(const Adc16Args &a, uint32_t nwords, dim3 grid, size_t lds, hipStream_t s) {
+template <bool COS>
+static void adc16_launch_c(const Adc16Args &a, uint32_t nwords, dim3 grid, size_t lds, hipStream_t s) {
     switch (nwords) {  // m = 32 * nwords groups: 128 / 256 / 320 (Gist1M, dim / 3) / 512
-        case 4: adc16_launch_nw<4>(a, grid, lds, s); break;
-        case 8: adc16_launch_nw<8>(a, grid, lds, s); break;
-        case 10: adc16_launch_nw<10>(a, grid, lds, s); break;
-        case 16: adc16_launch_nw<16>(a, grid, lds, s); break;
-        default: adc16_launch_nw<0>(a, grid, lds, s); break;
+        case 4: adc16_launch_nw<4, COS>(a, grid, lds, s); break;
+        case 8: adc16_launch_nw<8, COS>(a, grid, lds, s); break;
+        case 10: adc16_launch_nw<10, COS>(a, grid, lds, s); break;
+        case 16: adc16_launch_nw<16, COS>(a, grid, lds, s); break;
+        default: adc16_launch_nw<0, COS>(a, grid, lds, s); break;
     }
+}
+static void adc16_launch(const Adc16Args &a, bool cosine, uint32_t nwords, dim3 grid, size_t lds, hipStream_t s) {
+    if (cosine)
+        adc16_launch_c<true>(a, nwords, grid, lds, s);
+    else
+        adc16_launch_c<false>(a, nwords, grid, lds, s);
 }
 
 // ---- FlatIndex::knn_pq (flat_index.rs:84-104) --------------------------------------------------------
@@ -1285,14 +1417,17 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
     // fused path: tau[q] from a strided row-block sample (exact f32 ADC values), then one filtered scan of all rows.
     // q16: the scan runs on the 16-bit quantised tables, 8 queries per pass (k_pq_adc16), and the exact f32 sums are
     // computed for its candidates only (k_pq_adc_exact); otherwise the f32 scan itself filters (k_pq_adc MODE 1).
-    const size_t lds16 = size_t(pq.m) * 256 + 32 + ADC16_WGBUF * 8 + (1 + 2 * ADC16_Q) * 4;
-    const bool q16 = g_adc16 != 1 && pq.codes_t_valid && pq.n_bits == 4 && ix.dist == 0 && (pq.enc_dim % 16) == 0 && pq.m == 2 * pq.enc_dim &&
-                     lds16 <= 150 * 1024 && BQ == 4 && nt == 1024;
+    const size_t lds16 = size_t(pq.m) * 256 + 128 + ADC16_WGBUF * 8 + (1 + 2 * ADC16_Q) * 4;
+    const bool q16 = g_adc16 != 1 && pq.codes_t_valid && pq.n_bits == 4 && (pq.enc_dim % 16) == 0 && pq.m == 2 * pq.enc_dim &&
+                     lds16 <= 150 * 1024 && nt == 1024 && (ix.dist == 0 ? BQ == 4 : true);
+    const bool cos16 = q16 && ix.dist == 1;
+    const uint32_t NQ16 = cos16 ? 7 : 8;  // queries per pass of the quantised scan (Cosine: slot 7 of an entry is the |centroid|^2 table)
     const uint64_t ld_s = (n_s + 63) & ~63ull;
     const uint32_t nl_s = topk_num_lists(n_s);
     const uint32_t cap = (uint32_t)std::min<uint64_t>(65536, std::max<uint64_t>(4096, 4ull * s_rank * step));
     // queries per round: bounded by the sample matrix (GQ x ld_s floats) and the candidate lists (GQ x cap keys)
-    const uint64_t GQ = q16 ? std::max<uint64_t>(64, std::min<uint64_t>(2048, (size_t(256) << 20) / (ld_s * sizeof(float))) / 64 * 64) : 64;
+    // (q16: a multiple of 448 = 7 * 64, so that a round starts on a whole image group for either metric)
+    const uint64_t GQ = q16 ? std::max<uint64_t>(448, std::min<uint64_t>(1792, (size_t(256) << 20) / (ld_s * sizeof(float))) / 448 * 448) : 64;
     const uint64_t gq_max = std::min<uint64_t>(GQ, nq);
     ws.dense.reserve(gq_max * ld_s * sizeof(float));
     ws.lists.reserve(std::max<size_t>(gq_max * nl_s * cape, gq_max * size_t(cap)) * sizeof(uint64_t));
@@ -1301,18 +1436,20 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
     uint32_t *d_hits = reinterpret_cast<uint32_t *>(d_tau + nq);
     uint32_t *d_valid = d_hits + nq;
     VDB_HIP(hipMemsetAsync(d_hits, 0, 2 * nq * sizeof(uint32_t), s));
-    double *d_qM = nullptr, *d_qD = nullptr;
+    double *d_qM = nullptr, *d_qD = nullptr, *d_qMC = nullptr, *d_qDC = nullptr;
     uint32_t *d_qflag = nullptr;
     if (q16) {
-        const uint64_t ngrp = (nq + ADC16_Q - 1) / ADC16_Q;
+        const uint64_t ngrp = (nq + NQ16 - 1) / NQ16;
         ws.qfrag_g.reserve(ngrp * pq.m * 256);
-        ws.qaux.reserve(nq * (2 * sizeof(double) + sizeof(uint32_t)));
+        ws.qaux.reserve(nq * (4 * sizeof(double) + sizeof(uint32_t)));
         d_qM = ws.qaux.as<double>();
         d_qD = d_qM + nq;
-        d_qflag = reinterpret_cast<uint32_t *>(d_qD + nq);
-        // slots of the last image group beyond nq keep whatever the buffer held: their thresholds are -1 (never hit)
-        hipLaunchKernelGGL(k_pq_quant16, dim3((unsigned)nq), dim3(256), 0, s, ws.lut.as<float>(), (uint32_t)pq.m, (uint32_t)nq,
-                           ws.qfrag_g.as<uint16_t>(), d_qM, d_qD, d_qflag);
+        d_qMC = d_qD + nq;
+        d_qDC = d_qMC + nq;
+        d_qflag = reinterpret_cast<uint32_t *>(d_qDC + nq);
+        // slots of the last image group beyond nq keep whatever the buffer held: their thresholds never hit
+        hipLaunchKernelGGL(k_pq_quant16, dim3((unsigned)nq), dim3(256), 0, s, ws.lut.as<float>(), pq.d_cent_cache.as<float>(),
+                           (uint32_t)pq.m, (uint32_t)nq, cos16 ? 1 : 0, ws.qfrag_g.as<uint16_t>(), d_qM, d_qD, d_qMC, d_qDC, d_qflag);
     }
     for (uint64_t g0 = 0; g0 < nq; g0 += GQ) {
         const uint64_t gn = std::min<uint64_t>(GQ, nq - g0);
@@ -1340,9 +1477,12 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
             a.n = n;
             a.enc_dim = (uint32_t)pq.enc_dim;
             a.m = (uint32_t)pq.m;
-            a.img = reinterpret_cast<const uint4 *>(ws.qfrag_g.as<uint8_t>() + (g0 / ADC16_Q) * pq.m * 256);  // GQ % 8 == 0
+            a.img = reinterpret_cast<const uint4 *>(ws.qfrag_g.as<uint8_t>() + (g0 / NQ16) * pq.m * 256);  // GQ % 56 == 0
             a.qM = d_qM + g0;
             a.qD = d_qD + g0;
+            a.qMC = d_qMC + g0;
+            a.qDC = d_qDC + g0;
+            a.qsq = ws.qsq.as<float>() + g0;
             a.qflag = d_qflag + g0;
             a.tau = d_tau + g0;
             a.nq = (uint32_t)gn;
@@ -1351,13 +1491,18 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
             a.cnt = d_hits + g0;
             a.cap = cap;
             const uint32_t nwg = (uint32_t)((n + a.rows_per_wg - 1) / a.rows_per_wg);
-            const uint32_t ngrp = (uint32_t)((gn + ADC16_Q - 1) / ADC16_Q);
+            const uint32_t ngrp = (uint32_t)((gn + NQ16 - 1) / NQ16);
             ix.prof_begin(ws, "pq_adc", double(ngrp) * double(n) * pq.enc_dim);
-            adc16_launch(a, (uint32_t)(pq.enc_dim / 16), dim3(nwg, ngrp), lds16, s);
+            adc16_launch(a, cos16, (uint32_t)(pq.enc_dim / 16), dim3(nwg, ngrp), lds16, s);
             ix.prof_end(ws);
-            hipLaunchKernelGGL(k_pq_adc_exact, dim3((unsigned)gn), dim3(256), lsz * sizeof(float), s, pq.d_codes.as<uint8_t>(),
-                               (uint32_t)pq.enc_dim, (uint32_t)pq.m, ws.lut.as<float>() + g0 * lsz, d_tau + g0, d_cand,
-                               d_hits + g0, cap, d_valid + g0);
+            if (cos16)
+                hipLaunchKernelGGL(k_pq_adc_exact<true>, dim3((unsigned)gn), dim3(256), 2 * lsz * sizeof(float), s, pq.d_codes.as<uint8_t>(),
+                                   (uint32_t)pq.enc_dim, (uint32_t)pq.m, ws.lut.as<float>() + g0 * lsz, pq.d_cent_cache.as<float>(),
+                                   ws.qsq.as<float>() + g0, d_tau + g0, d_cand, d_hits + g0, cap, d_valid + g0);
+            else
+                hipLaunchKernelGGL(k_pq_adc_exact<false>, dim3((unsigned)gn), dim3(256), lsz * sizeof(float), s, pq.d_codes.as<uint8_t>(),
+                                   (uint32_t)pq.enc_dim, (uint32_t)pq.m, ws.lut.as<float>() + g0 * lsz, (const float *)nullptr,
+                                   (const float *)nullptr, d_tau + g0, d_cand, d_hits + g0, cap, d_valid + g0);
         } else {
             AdcArgs a = base;
             a.nq_total = (uint32_t)gn;

@@ -93,7 +93,7 @@ def test_shard_key_rows_equal_oracle_adc(mods, dist, kind, n, dim, m, n_bits, ef
         assert np.array_equal(e[q], O.pair_keys(ex, (sel + off).astype(np.uint64))), q
 
 
-@pytest.mark.parametrize("dist,kind", [("l2sqr", 0)])
+@pytest.mark.parametrize("dist,kind", [("l2sqr", 0), ("cosine", 1)])
 def test_quantised_scan_fallbacks_on_degenerate_queries(mods, dist, kind):
     """The 16-bit first pass of the ADC scan (k_pq_adc16) only handles tables of finite non-negative entries; queries whose
     table holds a NaN / inf (NaN or huge query components), constant tables (all centroids of every group equal -> step
@@ -110,6 +110,8 @@ def test_quantised_scan_fallbacks_on_degenerate_queries(mods, dist, kind):
     qs[4, :] = 1.0e-30         # denormal-scale products
     qs[5] = base[123]
     qs[6, 9] = -np.inf
+    qs[8] = -base[77]          # Cosine: every row lies in the opposite half-space (tau >= 1: the f32 scan answers)
+    qs[9] = base[5] * 1e-25    # Cosine: |q| so small that the reference's 1e-10 clamp acts
     for k, ef in ((10, 100), (5, 1000)):
         idx, d, cnt = ix.knn_pq(qs, k, ef)
         for q in range(len(qs)):

@@ -5,11 +5,12 @@ import lab_1806_vec_db_amd as vdb
 from bench import gist_like_gpu, gist_lowrank_gpu
 n, dim, nq, k = 1_000_000, 960, 1000, 10
 gen = gist_lowrank_gpu if (len(sys.argv) > 1 and sys.argv[1] == 'lowrank') else gist_like_gpu
+metric = sys.argv[2] if len(sys.argv) > 2 else 'l2sqr'
 dev = torch.device('cuda', 0)
 base = gen(torch, n, dim, 1806, dev); qt = gen(torch, nq, dim, 1807, dev); qs = qt.cpu().numpy()
-tr = vdb.GpuIndex(dim, 'l2sqr'); tr.add_device(base.data_ptr(), 10000); tr.pq_build(n_bits=4, m=320, train_n=0, max_iter=20, seed=42)
+tr = vdb.GpuIndex(dim, metric); tr.add_device(base.data_ptr(), 10000); tr.pq_build(n_bits=4, m=320, train_n=0, max_iter=20, seed=42)
 cent = tr.pq_export()['centroids']; del tr
-ix = vdb.GpuIndex(dim, 'l2sqr'); ix.add_device(base.data_ptr(), n); ix.pq_attach(4, 320, cent, None)
+ix = vdb.GpuIndex(dim, metric); ix.add_device(base.data_ptr(), n); ix.pq_attach(4, 320, cent, None)
 oi = torch.zeros((nq, k), dtype=torch.int64, device=dev); od = torch.zeros((nq, k), dtype=torch.float32, device=dev); oc = torch.zeros((nq,), dtype=torch.int64, device=dev)
 ix.prof_enable(True)
 for ef in (100, 200):
