@@ -26,6 +26,7 @@ At N=1 (default flags) the same run also reports, under "legs", every other item
                      GPU beside the CPU oracle serial and on all cores (protocol of examples/bench.rs:403-433)
   pq_flat            PQ-Flat ADC (4-bit, m=320, ef=100) on a 1M low-rank gist-like corpus
   hnsw               HNSW (M=16, efc=200, ef=128) on the first --hnsw-rows rows of that corpus (default: all 1M)
+  hnsw_pq            the same graph walked with ADC distances + cached-form re-sort (HNSWIndex::knn_pq)
 each with its own roofline / cpu_baseline / parity, plus `attainable_peak_GBps` from a streaming-read probe in this run.
 `--legs none` prints the headline only (what N>1 runs always do).
 """
@@ -559,15 +560,16 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable
 
     def run(ix, wl, rows, ef, fn, extra_cfg):
         el, _ = timed(ix, fn, args.steps, max(1, min(args.warmup, 2)))
-        kernel = {"pq_flat": "pq_adc", "hnsw": "hnsw"}[wl]
+        kernel = {"pq_flat": "pq_adc", "hnsw": "hnsw", "hnsw_pq": "hnsw"}[wl]
         leg = {"value": round(nq * args.steps / el, 1), "unit": "queries/s", "steps": args.steps,
                "ms_per_step": round(el / args.steps * 1e3, 3), "data": "synthetic (low-rank gist-like)",
                "config": dict({"rows": rows, "dim": dim, "queries_per_step": nq, "k": k, "dist": "L2Sqr", "ef": ef}, **extra_cfg),
                "roofline": with_attainable(hbm_roofline(kernel, ix.prof_get(kernel)), attainable)}
-        if wl == "hnsw":
+        if wl in ("hnsw", "hnsw_pq"):
             nd, ne = ix.hnsw_last_stats()
             leg["hnsw_work_per_query"] = {"n_dist": round(nd / nq, 1), "n_expanded": round(ne / nq, 1)}
-            leg["roofline"]["units_per_launch"] = "n_dist x (dim*4 + 4) + n_expanded x max_m0*4 bytes, counted by the kernel (SURVEY 8d)"
+            leg["roofline"]["units_per_launch"] = ("n_dist x (dim*4 + 4) + n_expanded x max_m0*4 bytes, counted by the kernel (SURVEY 8d)" if wl == "hnsw" else
+                                                   "n_dist x 160-B code rows + n_expanded x max_m0*4 bytes (ADC walk: latency-bound by construction), counted by the kernel")
         else:
             r = leg["roofline"]
             r["units_per_launch"] = ("rows x ceil(m*n_bits/8) code bytes per scan; one scan (k_pq_adc16) serves the 8 queries whose "
@@ -617,6 +619,13 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable
                         "build_batch": args.hnsw_batch,
                         "build_note": "HNSWIndex::add_parallel batches; candidate phase of a batch on the GPU (k_hnsw_search, k = ef = "
                                       "ef_construction, over the device mirror of the graph), linking on host threads; the graph equals the all-host builder's"})
+    # -- HNSW + PQ (hnsw_index.rs:672-697; config/bench_pq_hnsw.toml: the reference's fastest published point): the same graph,
+    #    the PQ leg's centroids, codes encoded on the GPU; ADC walk + cached-form re-sort
+    ix.pq_attach(4, dim // 3, cent, None)
+    legs["hnsw_pq"] = run(ix, "hnsw_pq", hr, 128,
+                          lambda: ix.hnsw_knn_device(queries.data_ptr(), nq, k, 128, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr(),
+                                                     use_pq=True),
+                          {"workload": f"hnsw_pq_knn_gistlike_{hr}", "M": 16, "ef_construction": 200, "n_bits": 4, "m": dim // 3})
     ix.close()
     return legs
 
