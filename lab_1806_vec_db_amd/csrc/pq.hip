@@ -563,7 +563,9 @@ __global__ __launch_bounds__(1024) void k_pq_adc16(Adc16Args a) {
     const uint64_t r_begin = uint64_t(blockIdx.x) * a.rows_per_wg;
     const uint64_t r_end = r_begin + a.rows_per_wg < a.n ? r_begin + a.rows_per_wg : a.n;
     const uint32_t nwords = NW ? (uint32_t)NW : a.enc_dim / 16;
+#if defined(__HIP_DEVICE_COMPILE__)
     typedef __attribute__((address_space(3))) uint4 lds_u4;
+#endif
     for (uint64_t rb = r_begin; rb < r_end; rb += 1024) {
         const uint64_t row = rb + tid;
         const bool valid = row < r_end;
