@@ -747,7 +747,7 @@ struct Builder {
     // GPU assistance of add_batch (hnsw_build): the level-0 candidate search of a whole batch against the pre-batch
     // graph IS HNSWIndex::knn_with_ef(k = ef = ef_construction) -- one k_hnsw_search launch over the device mirror of
     // the graph -- and the distances between batch members are one all-pairs launch.  Same values, same sets as the
-    // host search (the kernel is bit-exact against the oracle's search), so the graph does not change.
+    // host search (the kernel replays the reference's search bit for bit, asserted by the GPU parity tests), so the graph does not change.
     struct GpuAssist {
         uint64_t min_batch = 256;  // smaller batches cannot fill the GPU: one query is one wave
         // keys [nb][cape]: the sorted result set of every batch member (PAIR_NONE padded); ok[i] = 0: search it on the host
