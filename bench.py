@@ -568,6 +568,10 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable
         if wl in ("hnsw", "hnsw_pq"):
             nd, ne = ix.hnsw_last_stats()
             leg["hnsw_work_per_query"] = {"n_dist": round(nd / nq, 1), "n_expanded": round(ne / nq, 1)}
+            if wl == "hnsw":
+                # random whole-row gathers do not reach the streaming peak: MI355X_MICROARCH.md measures 5.5 - 5.8 TB/s for them
+                leg["roofline"]["gather_peak_GBps"] = 5500.0
+                leg["roofline"]["frac_of_gather_peak"] = round(leg["roofline"]["achieved"] / 5500.0, 4)
             leg["roofline"]["units_per_launch"] = ("n_dist x (dim*4 + 4) + n_expanded x max_m0*4 bytes, counted by the kernel (SURVEY 8d)" if wl == "hnsw" else
                                                    "n_dist x 160-B code rows + n_expanded x max_m0*4 bytes (ADC walk: latency-bound by construction), counted by the kernel")
         else:
