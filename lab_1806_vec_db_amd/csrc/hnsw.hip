@@ -62,7 +62,8 @@ struct HnswDev {
     uint32_t pool_cap;  // live candidates the LDS pool may hold (<= HNSW_POOL; a test hook lowers it to reach the heap walk)
 };
 
-constexpr uint32_t HNSW_POOL = 2048;  // candidate pool entries per query (LDS)
+constexpr uint32_t HNSW_POOL = 2048;  // most candidate pool entries per query (LDS)
+__host__ __device__ inline uint32_t hnsw_lds_query_off(uint32_t pool_cap) { return (pool_cap * 8u + 15u) & ~15u; }
 
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
 #pragma unroll
@@ -71,6 +72,15 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
         v = o < v ? o : v;
     }
     return v;
+}
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 // exact cached-form distance of row idx to the query held in LDS (strict left fold over the dimension)
@@ -116,26 +126,40 @@ __device__ __forceinline__ float hnsw_adc_dist(const HnswDev &g, const float *lu
         // every nibble is a group (the Gist1M table: 160-B code rows): 16-B code loads, the 8 lookups of a code word
         // issued together, then the strict-order adds (pq_table.rs:254-292).  The byte-at-a-time loop below costs 160
         // dependent byte loads and 320 branches per neighbour (measured 43 us per expansion).
-        const uint4 *cw = reinterpret_cast<const uint4 *>(cr);
-        uint4 v = cw[0];
-        for (uint32_t w = 0; w < g.enc_dim / 16; w++) {
-            const uint32_t words[4] = {v.x, v.y, v.z, v.w};
-            if (w + 1 < g.enc_dim / 16) v = cw[w + 1];
+        // all code words of the row are requested before the first lookup (10 words for the Gist1M table): one round trip
+        // instead of one per word (measured 11.4 us of distance evaluation per expansion with a one-word look-ahead)
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+        constexpr int CW = 10;
+        const v4u *cw = reinterpret_cast<const v4u *>(cr);
+        const uint32_t nw = g.enc_dim / 16;
+        for (uint32_t w0 = 0; w0 < nw; w0 += CW) {
+            v4u cv[CW];
+            static_for<CW>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                cv[i] = cw[w0 + i < nw ? w0 + i : nw - 1];
+            });
+            static_for<CW>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const uint32_t w = w0 + i;
+                if (w < nw) {  // uniform
+                    const uint32_t words[4] = {cv[i].x, cv[i].y, cv[i].z, cv[i].w};
 #pragma unroll
-            for (int wi = 0; wi < 4; wi++) {
-                float t[8], c[8];
+                    for (int wi = 0; wi < 4; wi++) {
+                        float t[8], c[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) {  // nibble j of the word = group 32w + 8wi + j (low nibble of a byte first)
-                    const uint32_t at = (w * 32 + 8 * wi + j) * 16 + ((words[wi] >> (4 * j)) & 0xf);
-                    t[j] = lut[at];
-                    if (g.cosine) c[j] = g.cent_cache[at];
+                        for (int j = 0; j < 8; j++) {  // nibble j of the word = group 32w + 8wi + j (low nibble of a byte first)
+                            const uint32_t at = (w * 32 + 8 * wi + j) * 16 + ((words[wi] >> (4 * j)) & 0xf);
+                            t[j] = lut[at];
+                            if (g.cosine) c[j] = g.cent_cache[at];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            sum = sum + t[j];
+                            if (g.cosine) cdp = cdp + c[j];
+                        }
+                    }
                 }
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    sum = sum + t[j];
-                    if (g.cosine) cdp = cdp + c[j];
-                }
-            }
+            });
         }
         if (!g.cosine) return sum;
         float den0 = fmaxf(sqrtf(cdp) * sqrtf(qsq), 1e-10f);
@@ -258,8 +282,106 @@ __device__ __forceinline__ float hnsw_exact_dists_dma(const HnswDev &g, const fl
     return s2 - t2;
 }
 
+// ---- the same, rows staged through REGISTERS -------------------------------------------------------------------
+// What bounds the walk is memory latency per wave, not a rate: 256 queries (one wave per CU) take 2.98 ms, 1024 queries
+// (four per CU, all the LDS staging above allows) 3.45 ms, and from 2048 queries on the rate is flat (tools/
+// probe_hnsw_batch.py); phase stamps put 13.7 of the 20 us of an expansion in these 30 dependent line waits.  The
+// bytes in flight per CU are what to raise, and LDS is the small memory for that (a line of 32 rows is 4 KB): the
+// vector registers hold 512 KB per CU.  Here the lines are fetched to registers, HNSW_REG_DEPTH lines (16 registers
+// each) in flight per wave, and only the line being folded passes through a 4-KB LDS block to be transposed to the
+// lane-per-row layout of the strict fold.  With the candidate pool sized by ef a query needs ~10 KB of LDS, so the
+// register file bounds the residency: 2 waves per SIMD x 8 lines = 64 lines in flight per CU against 12 above.
+// Loads are line-major (lanes 8g .. 8g+7 fetch the 8 chunks of one row's line: one L1 access per line; a chunk-major
+// form like the DMA's touches every line 8 times -- with LDS-DMA that made no difference, 3.58 vs 3.57 ms).  The fresh
+// rows are compacted to lanes 0 .. nfresh-1 first, so ceil(nfresh/8) load instructions per line are issued.  LDS
+// layout of a line: row (k, g) = 8k + g owns slots 8g .. 8g+7 of block k, chunk c in slot 8g + ((c - g - (k & 1)) mod 8):
+// the writes are linear (lane l writes slot l of block k: lane 8g+j fetched chunk (j + g + (k & 1)) mod 8), and for any
+// c the 16 rows of a ds_read_b128 lane group sit in 16 different 4-bank groups.
+#ifndef HNSW_REG_DEPTH
+#define HNSW_REG_DEPTH 8
+#endif
+constexpr uint32_t HNSW_REG_STAGE = 4096;
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float hnsw_exact_dists_regs(const HnswDev &g, const float *qlds, float qsq, uint32_t nb, bool fresh,
+                                                       unsigned char *stage, uint32_t lane) {
+    constexpr int D = HNSW_REG_DEPTH;
+    const uint32_t nlines = g.dim / 32;
+    const uint64_t fm = __ballot(fresh);
+    const uint32_t nfresh = (uint32_t)__builtin_popcountll(fm);  // <= 32: the fresh lanes are all below max_m0 <= 32
+    const uint32_t rank = (uint32_t)__builtin_popcountll(fm & ((1ull << lane) - 1));
+    // a permutation of the lanes that brings the r-th fresh neighbour to lane r
+    const uint32_t cnb = (uint32_t)__builtin_amdgcn_ds_permute(int((fresh ? rank : nfresh + (lane - rank)) * 4), int(nb));
+    const uint32_t gg = lane >> 3, jj = lane & 7;
+    // Straight-line code from here on: no lane or line is predicated.  (With `if (fresh)` / `if (L < nlines)` around the
+    // loads hipcc's wait-count insertion gave up and put vmcnt(0) before every use: one line in flight, 2x slower than
+    // the DMA form.)  Lanes beyond the last fresh row fetch the first fresh row's line again (an L1 hit), line indices
+    // are clamped to the last line (the tail refills are L1 hits too) and the fold of a padding line is computed and
+    // dropped by a select.
+    // (native vectors: with HIP's float4 struct the copies become memcpys the optimiser leaves in scratch)
+    const v4f *rp[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t src = 8 * k + gg;
+        const uint32_t nbk = __shfl(cnb, src < nfresh ? src : 0u);
+        rp[k] = reinterpret_cast<const v4f *>(g.rows + uint64_t(nbk) * g.dim) + ((jj + gg + (k & 1)) & 7);
+    }
+    const float xs = g.xsq[cnb];  // (lanes >= nfresh hold other valid row numbers: visited neighbours or 0)
+    const uint32_t last = nlines - 1;
+    v4f buf[D][4];
+    static_for<D>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const uint32_t Li = (uint32_t)i < last ? (uint32_t)i : last;
+#pragma unroll
+        for (int k = 0; k < 4; k++) buf[i][k] = rp[k][Li * 8];
+        __builtin_amdgcn_sched_barrier(0);  // loads return in issue order: line 0 has to be the first one issued
+    });
+    float acc = 0.0f;
+    const v4f *q4 = reinterpret_cast<const v4f *>(qlds);
+    // reader: lane r < 32 folds compacted row r = 8 kr + gr (lanes >= 32 mirror them, their result is not used)
+    const uint32_t kr = (lane >> 3) & 3, gr = lane & 7, rot = (gr + (kr & 1)) & 7;
+    uint32_t off[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) off[c] = kr * 1024 + (8 * gr + ((c + 8 - rot) & 7)) * 16;
+    for (uint32_t L0 = 0; L0 < nlines; L0 += D) {
+        static_for<D>([&](auto ic) {  // (a `#pragma unroll` loop was left rolled here and the line buffers went to scratch)
+            constexpr int i = decltype(ic)::value;
+            const uint32_t L = L0 + i;
+            const uint32_t Lc = L < last ? L : last, Ln = L + D < last ? L + D : last;
+#pragma unroll
+            for (int k = 0; k < 4; k++) *reinterpret_cast<v4f *>(stage + k * 1024 + 16 * lane) = buf[i][k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) buf[i][k] = rp[k][Ln * 8];
+            __builtin_amdgcn_sched_barrier(0);
+            float a = acc;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const v4f v = *reinterpret_cast<const v4f *>(stage + off[c]);
+                const v4f qq = q4[Lc * 8 + c];
+                float p;
+                p = v.x * qq.x; a = a + p;
+                p = v.y * qq.y; a = a + p;
+                p = v.z * qq.z; a = a + p;
+                p = v.w * qq.w; a = a + p;
+            }
+            acc = L < nlines ? a : acc;
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    float d;
+    if (g.cosine) {
+        float den = fmaxf(sqrtf(xs) * sqrtf(qsq), 1e-10f);
+        float r = acc / den;
+        d = 1.0f - r;
+    } else {
+        float s2 = xs + qsq;
+        float t2 = 2.0f * acc;
+        d = s2 - t2;
+    }
+    return __shfl(d, rank);  // back to the lane the neighbour came from
+}
+
 template <int R, bool ADC>
-__global__ __launch_bounds__(64) void k_hnsw_search(HnswDev g, const float *__restrict__ Q,
+__global__ __launch_bounds__(64, 2) void k_hnsw_search(HnswDev g, const float *__restrict__ Q,
                                                     const float *__restrict__ qsq_all,
                                                     const float *__restrict__ lut_all, uint32_t lut_in_lds,
                                                     uint32_t ef, uint32_t *__restrict__ visited,
@@ -267,10 +389,11 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswDev g, const float *__re
                                                     unsigned long long *__restrict__ stats /*[2]*/,
                                                     uint32_t *__restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // [ candidate pool: pool_cap pairs | query (or the ADC table) | staging of the exact walk's row lines, 512-B aligned ]
     uint64_t *pool = reinterpret_cast<uint64_t *>(smem_raw);
-    float *fl = reinterpret_cast<float *>(smem_raw + HNSW_POOL * sizeof(uint64_t));
-    // DMA staging behind the query (exact walk only, see hnsw_exact_dists_dma); 512-B aligned for the line buffers
-    unsigned char *stage = smem_raw + ((HNSW_POOL * sizeof(uint64_t) + g.dim * sizeof(float) + 511) & ~size_t(511));
+    const uint32_t fl_off = hnsw_lds_query_off(g.pool_cap);
+    float *fl = reinterpret_cast<float *>(smem_raw + fl_off);
+    unsigned char *stage = smem_raw + ((fl_off + g.dim * sizeof(float) + 511) & ~size_t(511));
     const bool dma = !ADC && g.dma != 0;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t q = blockIdx.x;
@@ -399,7 +522,21 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswDev g, const float *__re
         rs_insert(e);
         pool_push(e);
     }
+#ifdef HNSW_STAMP  // measurement build: wall-clock ticks (100 MHz) per phase of the level-0 loop, summed into stats[2..6]
+    unsigned long long tk_pop = 0, tk_links = 0, tk_dist = 0, tk_ins = 0;
+#define HNSW_TICK(acc, t_prev)                         \
+    {                                                  \
+        const unsigned long long _n = wall_clock64();  \
+        acc += _n - t_prev;                            \
+        t_prev = _n;                                   \
+    }
+#else
+#define HNSW_TICK(acc, t_prev)
+#endif
     while (pool_n > 0 && !overflow) {
+#ifdef HNSW_STAMP
+        unsigned long long t_prev = wall_clock64();
+#endif
         __builtin_amdgcn_wave_barrier();
         // pop_first: smallest pair in the pool.  The same pass drops the pairs that can no longer be expanded (>= worst:
         // popping one of them would only end the walk, and only when nothing better is left), so the pool stays at the
@@ -437,27 +574,40 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswDev g, const float *__re
         }
         pool_n--;
         n_exp++;
+        HNSW_TICK(tk_pop, t_prev)
         const uint32_t p = uint32_t(best);
-        const uint32_t len = g.len0[p];
         const uint32_t *lk = g.level0 + uint64_t(p) * g.max_m0;
+        // the link row is fetched whole, in the same round trip as its length (every row has max_m0 slots): a load guarded
+        // by `j < len` would wait for the length first -- one more dependent trip in a loop that is a chain of them
+        const uint32_t nb0 = lane < g.max_m0 ? lk[lane] : 0u;
+        const uint32_t len = g.len0[p];
         for (uint32_t base = 0; base < len && !overflow; base += 64) {
             uint32_t j = base + lane;
             uint32_t nb = 0;
             bool fresh = false;
             if (j < len) {
-                nb = lk[j];
+                nb = base == 0 ? nb0 : lk[j];
                 uint32_t bit = 1u << (nb & 31);
                 uint32_t old = atomicOr(&vis[nb >> 5], bit);
                 fresh = (old & bit) == 0;
             }
             uint64_t fm = __ballot(fresh);
+            HNSW_TICK(tk_links, t_prev)
             float d = 0.0f;
             if (dma) {
-                if (fm) d = hnsw_exact_dists_dma(g, fl, qsq, nb, fresh, stage, lane);  // wave-uniform branch
+                if (fm)  // wave-uniform branches
+                    d = g.dma == 2 ? hnsw_exact_dists_dma(g, fl, qsq, nb, fresh, stage, lane)
+                                   : hnsw_exact_dists_regs(g, fl, qsq, nb, fresh, stage, lane);
             } else if (fresh) {
                 d = dist_of(nb);
             }
+#ifdef HNSW_STAMP
+            d = __shfl(d, lane);  // (the value must have arrived before the clock is read)
+#endif
+            HNSW_TICK(tk_dist, t_prev)
             n_dist += __builtin_popcountll(fm);
+            // the worst pair only ever moves down, so a neighbour that fails check_candidate now fails it at its turn too
+            fm = __ballot(fresh && pair_key(d, nb) < tau);
             while (fm) {  // stored order
                 uint32_t t = (uint32_t)__builtin_ctzll(fm);
                 fm &= fm - 1;
@@ -467,8 +617,17 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswDev g, const float *__re
                 if (admit) rs_insert(e);
                 if (cand) pool_push(e);
             }
+            HNSW_TICK(tk_ins, t_prev)
         }
     }
+#ifdef HNSW_STAMP
+    if (lane == 0) {
+        atomicAdd(&stats[2], tk_pop);
+        atomicAdd(&stats[3], tk_links);
+        atomicAdd(&stats[4], tk_dist);
+        atomicAdd(&stats[5], tk_ins);
+    }
+#endif
     if (overflow && lane == 0) err[q] = 1u;  // this query is answered again by k_hnsw_search_big
 #pragma unroll
     for (int r = 0; r < R; r++) out[uint64_t(q) * (64 * R) + r * 64 + lane] = rv[r];
@@ -1316,6 +1475,20 @@ static int g_hnsw_dma = 1;
 void hnsw_set_dma(int v) { g_hnsw_dma = v; }
 static uint32_t g_hnsw_pool_cap = HNSW_POOL;
 void hnsw_set_pool_cap(int v) { g_hnsw_pool_cap = v < 1 ? 1u : (v > (int)HNSW_POOL ? HNSW_POOL : (uint32_t)v); }
+// Candidate pool entries of a walk.  Every expansion starts by dropping the pairs at or above the worst result, which
+// leaves pairs that are also in the result list (< ef of them) or tie its worst distance with a smaller index; until the
+// next expansion at most max_m0 pairs join.  ef + max_m0 + 64 therefore only overflows (-> k_hnsw_search_big) on
+// near-duplicate data, and 2 KB instead of 16 KB of LDS per query is what lets 8 walks share a CU.
+static uint32_t hnsw_pool_slots(uint32_t ef, uint32_t max_m0) {
+    const uint64_t want = (uint64_t(ef) + max_m0 + 64 + 63) / 64 * 64;
+    return (uint32_t)std::min<uint64_t>(std::min<uint64_t>(want, HNSW_POOL), g_hnsw_pool_cap);
+}
+// dynamic LDS of k_hnsw_search: pool | payload (query or ADC table) | row staging of the exact walk (mode 1: registers, 2: DMA)
+static size_t hnsw_lds_bytes(uint32_t pool_cap, size_t payload, int dma_mode) {
+    size_t lds = hnsw_lds_query_off(pool_cap) + payload;
+    if (dma_mode) lds = ((lds + 511) & ~size_t(511)) + (dma_mode == 2 ? HNSW_DMA_BYTES : HNSW_REG_STAGE);
+    return lds;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // GPU side of the builder's candidate phase (Builder::GpuAssist).  The device mirror of the graph is full-size from the
@@ -1389,11 +1562,10 @@ static std::shared_ptr<BuildDev> hnsw_build_gpu_assist(Index &ix, Builder::GpuAs
         const uint32_t efk = (uint32_t)std::min<uint64_t>(h.ef_construction, n + 1);
         cape = topk_capacity(efk);
         const bool dma = g_hnsw_dma && h.max_m0 <= 32 && ix.dim % 32 == 0;
-        size_t lds = HNSW_POOL * sizeof(uint64_t) + ix.dim * sizeof(float);
-        if (dma) lds = ((lds + 511) & ~size_t(511)) + HNSW_DMA_BYTES;
         HnswDev g{};
-        g.dma = dma ? 1 : 0;
-        g.pool_cap = g_hnsw_pool_cap;
+        g.dma = dma ? (g_hnsw_dma == 2 ? 2 : 1) : 0;
+        g.pool_cap = hnsw_pool_slots(efk, (uint32_t)h.max_m0);
+        const size_t lds = hnsw_lds_bytes(g.pool_cap, ix.dim * sizeof(float), g.dma);
         g.rows = ix.d_rows.as<float>();
         g.xsq = ix.d_sq.as<float>();
         g.level0 = b->d_level0.as<uint32_t>();
@@ -1517,24 +1689,22 @@ void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, ui
     PQState &pq = ix.pq;
     if (use_pq) VDB_REQUIRE(pq.present && pq.n_coded == n, "PQ table does not cover the rows of the index (rebuild it after add)");
     uint32_t lut_in_lds = 0;
-    size_t lds = HNSW_POOL * sizeof(uint64_t), lds_big = 0;
+    size_t lds_big = 0;
     if (use_pq) {
         pq_make_luts(ix, ws, d_q, nq);
         size_t lb = pq.m * pq.kc * sizeof(float);
         if (lb <= 32 * 1024) {
             lut_in_lds = 1;
-            lds += lb;
             lds_big = lb;
         }
     } else {
-        lds += ix.dim * sizeof(float);
         lds_big = ix.dim * sizeof(float);
     }
     const bool dma = !use_pq && g_hnsw_dma && h.max_m0 <= 32 && ix.dim % 32 == 0;
-    if (dma) lds = ((lds + 511) & ~size_t(511)) + HNSW_DMA_BYTES;
     HnswDev g{};
-    g.dma = dma ? 1 : 0;
-    g.pool_cap = g_hnsw_pool_cap;
+    g.dma = dma ? (g_hnsw_dma == 2 ? 2 : 1) : 0;  // 1: rows staged through registers, 2: through LDS by DMA (the round-1 form, kept for A/B)
+    g.pool_cap = hnsw_pool_slots(efk, (uint32_t)h.max_m0);
+    const size_t lds = hnsw_lds_bytes(g.pool_cap, lds_big, g.dma);
     g.rows = ix.d_rows.as<float>();
     g.xsq = ix.d_sq.as<float>();
     g.level0 = h.d_level0.as<uint32_t>();
@@ -1558,7 +1728,9 @@ void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, ui
         g.n_bits = (uint32_t)pq.n_bits;
     }
     const uint64_t vwords = (n + 31) / 32;
-    constexpr uint64_t QB = 1024;  // queries per launch (bounds the visited bitmaps: QB * n/8 bytes)
+    // queries per launch: what bounds it is the visited bitmaps (QB * n/8 bytes, <= 2 GiB); a launch should hold several
+    // times the 2048 walks the chip keeps resident, so that finished walks are replaced while the long ones run
+    const uint64_t QB = std::min<uint64_t>(8192, std::max<uint64_t>(1024, (uint64_t(2) << 30) / (vwords * 4)));
     // flags: [0,16) work counters (n_dist, n_expanded), [64, 64 + 4 nq) per-query "candidate pool overflowed"
     ws.flags.reserve(64 + nq * sizeof(uint32_t));
     VDB_HIP(hipMemsetAsync(ws.flags.p, 0, 64 + nq * sizeof(uint32_t), s));
@@ -1687,6 +1859,15 @@ void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, ui
     }
     h.last_n_dist = st[0];
     h.last_n_expanded = st[1];
+#ifdef HNSW_STAMP
+    {
+        unsigned long long tk[4];
+        VDB_HIP(hipMemcpy(tk, reinterpret_cast<const char *>(ws.flags.p) + 16, sizeof(tk), hipMemcpyDeviceToHost));
+        const double per = st[1] ? 1.0 / double(st[1]) * 0.01 : 0.0;  // 100 MHz ticks -> us per expansion
+        std::fprintf(stderr, "hnsw stamps (us per expansion): pop %.2f, links + visited %.2f, distances %.2f, inserts %.2f\n", tk[0] * per,
+                     tk[1] * per, tk[2] * per, tk[3] * per);
+    }
+#endif
     if (!ws.pending.empty()) {
         // algorithmic bytes are data-dependent: n_dist row fetches (+ cached norm) and n_expanded link rows,
         // known only now -- credited to the call's last launch record

@@ -11,7 +11,7 @@ ix = vdb.GpuIndex(dim, 'l2sqr'); ix.add_device(base.data_ptr(), n)
 t = time.time(); ix.hnsw_build(M=16, ef_construction=200, seed=42, batch=64, nthreads=16); print(f"build {time.time()-t:.1f} s", flush=True)
 ref = None
 for rnd in range(2):
-    for v in (0, 1):
+    for v in (0, 2, 1):
         ix.set_param('hnsw_dma', v)
         ix.knn_with_ef(qs, 10, 128)
         t = time.perf_counter(); idx, d, c = ix.knn_with_ef(qs, 10, 128); dt = time.perf_counter() - t
