@@ -168,6 +168,9 @@ def main():
     ap.add_argument("--hnsw-rows", type=int, default=1_000_000,
                     help="rows of the hnsw leg (BASELINE config 3 names Gist1M); the build -- batches of 1024 points as "
                          "add_parallel forms them (hnsw_index.rs:391-457), their candidate phase on the GPU -- takes ~55 s for 1M rows")
+    ap.add_argument("--hnsw-queries", type=int, default=8192,
+                    help="queries per step of the hnsw / hnsw_pq legs: a walk is one wavefront and the chip keeps 2048 of them "
+                         "resident, so the rate is flat from ~4096 queries per call on (a 1000-query call is reported beside it)")
     ap.add_argument("--hnsw-batch", type=int, default=1024,
                     help="points per builder batch (the reference uses 4 x rayon threads); >= 256 puts the candidate phase on the GPU")
     args = ap.parse_args()
@@ -558,7 +561,8 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable
     ncpu = min(args.cpu_queries, nq)
     okind = O.L2SQR if O is not None else 0
 
-    def run(ix, wl, rows, ef, fn, extra_cfg):
+    def run(ix, wl, rows, ef, fn, extra_cfg, nq=nq, queries=queries, outs=(o_idx, o_dist, o_cnt), t_idx=t_idx):
+        o_idx, o_dist, o_cnt = outs
         el, _ = timed(ix, fn, args.steps, max(1, min(args.warmup, 2)))
         kernel = {"pq_flat": "pq_adc", "hnsw": "hnsw", "hnsw_pq": "hnsw"}[wl]
         leg = {"value": round(nq * args.steps / el, 1), "unit": "queries/s", "steps": args.steps,
@@ -588,9 +592,15 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable
             gt = t_idx.cpu().numpy().astype(np.uint64)
             fn()
             hb = base[:rows].cpu().numpy()
-            leg.update(cpu_and_parity(O, wl, ix, hb, queries, (o_idx, o_dist, o_cnt), gt, ncpu, k, ef, okind, threads, rows, dim, nq))
+            leg.update(cpu_and_parity(O, wl, ix, hb, queries, (o_idx, o_dist, o_cnt), gt, min(ncpu, nq), k, ef, okind, threads, rows, dim, nq))
             del hb
         return leg
+
+    def small_call(ix, fn1000):
+        """the same search as ONE 1000-query call (the size of the other legs' steps): bounded by the longest walk, not a rate"""
+        el, _ = timed(ix, fn1000, args.steps, 1)
+        return {"queries_per_step": 1000, "value": round(1000 * args.steps / el, 1), "unit": "queries/s",
+                "ms_per_step": round(el / args.steps * 1e3, 3)}
 
     # -- PQ-Flat: config/bench_pq_hnsw.toml:16-23 (n_bits 4, m = dim/3, k_means_size 10000, max_iter 20, tol 1e-6), ef = 100
     ix = vdb.GpuIndex(dim, "l2sqr", device=local_rank)
@@ -617,19 +627,31 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable
     t_b = time.perf_counter()
     ix.hnsw_build(M=16, ef_construction=200, seed=42, batch=args.hnsw_batch, nthreads=threads)
     hb_s = time.perf_counter() - t_b
+    hq = max(1000, args.hnsw_queries)
+    queries_h = gist_lowrank_gpu(torch, hq, dim, 1807, device)
+    h_idx = torch.zeros((hq, k), dtype=torch.int64, device=device)
+    h_dist = torch.zeros((hq, k), dtype=torch.float32, device=device)
+    h_cnt = torch.zeros((hq,), dtype=torch.int64, device=device)
+    ht_idx = torch.zeros((hq, k), dtype=torch.int64, device=device)
+    hkw = {"nq": hq, "queries": queries_h, "outs": (h_idx, h_dist, h_cnt), "t_idx": ht_idx}
     legs["hnsw"] = run(ix, "hnsw", hr, 128,
-                       lambda: ix.hnsw_knn_device(queries.data_ptr(), nq, k, 128, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr()),
+                       lambda: ix.hnsw_knn_device(queries_h.data_ptr(), hq, k, 128, h_idx.data_ptr(), h_dist.data_ptr(), h_cnt.data_ptr()),
                        {"workload": f"hnsw_knn_gistlike_{hr}", "M": 16, "ef_construction": 200, "build_s": round(hb_s, 1),
                         "build_batch": args.hnsw_batch,
                         "build_note": "HNSWIndex::add_parallel batches; candidate phase of a batch on the GPU (k_hnsw_search, k = ef = "
-                                      "ef_construction, over the device mirror of the graph), linking on host threads; the graph equals the all-host builder's"})
+                                      "ef_construction, over the device mirror of the graph), linking on host threads; the graph equals the all-host builder's"},
+                       **hkw)
+    legs["hnsw"]["one_call_of_1000"] = small_call(
+        ix, lambda: ix.hnsw_knn_device(queries_h.data_ptr(), 1000, k, 128, h_idx.data_ptr(), h_dist.data_ptr(), h_cnt.data_ptr()))
     # -- HNSW + PQ (hnsw_index.rs:672-697; config/bench_pq_hnsw.toml: the reference's fastest published point): the same graph,
     #    the PQ leg's centroids, codes encoded on the GPU; ADC walk + cached-form re-sort
     ix.pq_attach(4, dim // 3, cent, None)
     legs["hnsw_pq"] = run(ix, "hnsw_pq", hr, 128,
-                          lambda: ix.hnsw_knn_device(queries.data_ptr(), nq, k, 128, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr(),
+                          lambda: ix.hnsw_knn_device(queries_h.data_ptr(), hq, k, 128, h_idx.data_ptr(), h_dist.data_ptr(), h_cnt.data_ptr(),
                                                      use_pq=True),
-                          {"workload": f"hnsw_pq_knn_gistlike_{hr}", "M": 16, "ef_construction": 200, "n_bits": 4, "m": dim // 3})
+                          {"workload": f"hnsw_pq_knn_gistlike_{hr}", "M": 16, "ef_construction": 200, "n_bits": 4, "m": dim // 3}, **hkw)
+    legs["hnsw_pq"]["one_call_of_1000"] = small_call(
+        ix, lambda: ix.hnsw_knn_device(queries_h.data_ptr(), 1000, k, 128, h_idx.data_ptr(), h_dist.data_ptr(), h_cnt.data_ptr(), use_pq=True))
     ix.close()
     return legs
 
