@@ -574,9 +574,20 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable
             leg["hnsw_work_per_query"] = {"n_dist": round(nd / nq, 1), "n_expanded": round(ne / nq, 1)}
             if wl == "hnsw":
                 # random whole-row gathers do not reach the streaming peak: MI355X_MICROARCH.md measures 5.5 - 5.8 TB/s for them
-                leg["roofline"]["gather_peak_GBps"] = 5500.0
-                leg["roofline"]["frac_of_gather_peak"] = round(leg["roofline"]["achieved"] / 5500.0, 4)
-            leg["roofline"]["units_per_launch"] = ("n_dist x (dim*4 + 4) + n_expanded x max_m0*4 bytes, counted by the kernel (SURVEY 8d)" if wl == "hnsw" else
+                r = leg["roofline"]
+                r["gather_peak_GBps"] = 5500.0
+                r["frac_of_gather_peak"] = round(r["achieved"] / 5500.0, 4)
+                # n_dist f32 rows (+ cached norm) + n_expanded link rows.  The walk's certified half-precision
+                # pre-pass reads 2 B/element for every row and the f32 row only when it cannot rule the row out, so the
+                # bytes it asks for (`achieved`) are fewer than 8(d)'s; both rates are given
+                dropped = ix.get_stat("hnsw_half_dropped")
+                alg = nd * (dim * 4 + 4) + ne * 32 * 4
+                r["algorithmic_bytes_8d"] = alg
+                r["achieved_8d"] = round(alg / (r["avg_launch_ms"] * 1e-3) / 1e9, 1)
+                r["frac_8d"] = round(r["achieved_8d"] / HBM_PEAK_GBS, 4)
+                r["frac_of"] = "bytes requested: fp16 image rows for all scored neighbours + f32 rows for those not ruled out"
+                leg["hnsw_work_per_query"]["ruled_out_by_half_precision_pre_pass"] = round(dropped / nq, 1)
+            leg["roofline"]["units_per_launch"] = ("n_half x dim*2 + (n_dist - ruled_out) x dim*4 + n_dist x 4 + n_expanded x max_m0*4 bytes, counted by the kernel" if wl == "hnsw" else
                                                    "n_dist x 160-B code rows + n_expanded x max_m0*4 bytes (ADC walk: latency-bound by construction), counted by the kernel")
         else:
             r = leg["roofline"]

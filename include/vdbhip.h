@@ -122,10 +122,13 @@ int vdb_flat_set_mode(vdb_index *idx, int mode);
  *   "flat_gemm_nt"     cache policy of the row stream: 0 auto (non-temporal when the mirror exceeds the Infinity Cache), 1 default, 2 non-temporal
  *   "flat_tail"        exact stage: 0 fused launch when the shortlist fits 64 rows, 1 separate kernels
  *   "flat_share", "mfma_variant", "flat_sample_thin", "flat_gemm_debug"   small-batch kernel / sample plan / measurement hooks
- *   "pq_adc_fast", "hnsw_dma"   inner-loop variants of the ADC scan and of the HNSW walk
+ *   "pq_adc_fast", "hnsw_dma"   inner-loop variants of the ADC scan and of the HNSW walk (hnsw_dma: 1 rows staged through
+ *                      registers (default), 2 through LDS by DMA, 0 plain per-lane loads)
+ *   "hnsw_half"        certified half-precision pre-pass of the exact HNSW walk (a row-major fp16 image of the rows, 2 B per
+ *                      element, built on first use; rows it cannot rule out are scored exactly as always): 1 on (default), 0 off
  *   "hnsw_build_gpu"   candidate phase of batched HNSW builds (vdb_hnsw_build with batch >= 256): 0 auto = the level-0 searches of a
  *                      batch and the distances between its members run on the GPU (same graph as the all-host builder), 1 off
- *   "hnsw_pool_cap"    live candidates the fast HNSW walk keeps in LDS (default and maximum 2048) before a query is handed to
+ *   "hnsw_pool_cap"    most live candidates the fast HNSW walk keeps in LDS (it uses min(this, ef + max_m0 + 64); maximum 2048) before a query is handed to
  *                      the heap walk; tests lower it to exercise that hand-over
  *   "pq_adc16"         quantised first pass of the threshold-filter ADC scan (16-bit tables, 8 queries per pass; exact f32
  *                      sums for its candidates): 0 auto (4-bit codes, whole 16-B code words; L2Sqr 8 and Cosine 7 queries per pass), 1 off */
@@ -141,6 +144,8 @@ int vdb_flat_fallback_count(const vdb_index *idx, uint64_t *out);
  *                        needs it (redo tier, flat_half = 1, calls without an fp16 mirror),
  *   "hnsw_heap_walk_queries"  HNSW queries answered by the any-size heap walk (max(ef, k) > 1024, or the LDS candidate
  *                        pool of the fast walk overflowed),
+ *   "hnsw_half_dropped"  of the last HNSW call's distance evaluations (vdb_hnsw_last_stats), the rows its certified
+ *                        half-precision pre-pass ruled out without fetching the f32 row,
  *   "hbm_bytes_per_row"  resident HBM bytes per row over all per-row buffers (rows, norms, mirrors, PQ codes, level-0 links). */
 int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out);
 

@@ -59,6 +59,8 @@ struct HnswDev {
     uint32_t enc_dim, pq_m, pq_kc, n_bits;
     int dma;  // exact level-0 distances through LDS-DMA staging (max_m0 <= 32, dim % 32 == 0)
     const uint32_t *entry0;  // optional, per query of the launch: level-0 entry point (the builder's searches of members above level 0); 0xFFFFFFFF / null = greedy descent from the enter point
+    const uint16_t *rows_h;  // row-major fp16 image of the rows (null: no pre-pass), values fp16(x / inv_sx)
+    float inv_sx, dx_abs, dx_rel;  // its scale and measured rounding error (Index::half_dx_*)
     uint32_t pool_cap;  // live candidates the LDS pool may hold (<= HNSW_POOL; a test hook lowers it to reach the heap walk)
 };
 
@@ -302,6 +304,9 @@ __device__ __forceinline__ float hnsw_exact_dists_dma(const HnswDev &g, const fl
 #endif
 constexpr uint32_t HNSW_REG_STAGE = 4096;
 typedef float v4f __attribute__((ext_vector_type(4)));
+// NG = groups of 8 compacted rows that are fetched (ceil(nfresh / 8) <= NG): after the half-precision pre-pass most
+// expansions are left with a handful of rows, and a whole-instruction `if` would cost the counted waits (see below)
+template <int NG>
 __device__ __forceinline__ float hnsw_exact_dists_regs(const HnswDev &g, const float *qlds, float qsq, uint32_t nb, bool fresh,
                                                        unsigned char *stage, uint32_t lane) {
     constexpr int D = HNSW_REG_DEPTH;
@@ -318,21 +323,21 @@ __device__ __forceinline__ float hnsw_exact_dists_regs(const HnswDev &g, const f
     // are clamped to the last line (the tail refills are L1 hits too) and the fold of a padding line is computed and
     // dropped by a select.
     // (native vectors: with HIP's float4 struct the copies become memcpys the optimiser leaves in scratch)
-    const v4f *rp[4];
+    const v4f *rp[NG];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < NG; k++) {
         const uint32_t src = 8 * k + gg;
         const uint32_t nbk = __shfl(cnb, src < nfresh ? src : 0u);
         rp[k] = reinterpret_cast<const v4f *>(g.rows + uint64_t(nbk) * g.dim) + ((jj + gg + (k & 1)) & 7);
     }
     const float xs = g.xsq[cnb];  // (lanes >= nfresh hold other valid row numbers: visited neighbours or 0)
     const uint32_t last = nlines - 1;
-    v4f buf[D][4];
+    v4f buf[D][NG];
     static_for<D>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const uint32_t Li = (uint32_t)i < last ? (uint32_t)i : last;
 #pragma unroll
-        for (int k = 0; k < 4; k++) buf[i][k] = rp[k][Li * 8];
+        for (int k = 0; k < NG; k++) buf[i][k] = rp[k][Li * 8];
         __builtin_amdgcn_sched_barrier(0);  // loads return in issue order: line 0 has to be the first one issued
     });
     float acc = 0.0f;
@@ -343,14 +348,14 @@ __device__ __forceinline__ float hnsw_exact_dists_regs(const HnswDev &g, const f
 #pragma unroll
     for (int c = 0; c < 8; c++) off[c] = kr * 1024 + (8 * gr + ((c + 8 - rot) & 7)) * 16;
     for (uint32_t L0 = 0; L0 < nlines; L0 += D) {
-        static_for<D>([&](auto ic) {  // (a `#pragma unroll` loop was left rolled here and the line buffers went to scratch)
+        static_for<D>([&](auto ic) {  // (compile-time indices: the line buffers must stay in registers)
             constexpr int i = decltype(ic)::value;
             const uint32_t L = L0 + i;
             const uint32_t Lc = L < last ? L : last, Ln = L + D < last ? L + D : last;
 #pragma unroll
-            for (int k = 0; k < 4; k++) *reinterpret_cast<v4f *>(stage + k * 1024 + 16 * lane) = buf[i][k];
+            for (int k = 0; k < NG; k++) *reinterpret_cast<v4f *>(stage + k * 1024 + 16 * lane) = buf[i][k];
 #pragma unroll
-            for (int k = 0; k < 4; k++) buf[i][k] = rp[k][Ln * 8];
+            for (int k = 0; k < NG; k++) buf[i][k] = rp[k][Ln * 8];
             __builtin_amdgcn_sched_barrier(0);
             float a = acc;
 #pragma unroll
@@ -378,6 +383,111 @@ __device__ __forceinline__ float hnsw_exact_dists_regs(const HnswDev &g, const f
         d = s2 - t2;
     }
     return __shfl(d, rank);  // back to the lane the neighbour came from
+}
+
+
+// ---- certified half-precision pre-pass ---------------------------------------------------------------------------
+// Large calls are bound by the bytes of the row gathers, and 85 % of the rows an expansion scores fail check_candidate
+// (measured: 498k of 3.3M pass at ef = 128).  For those the exact value is never used -- only the fact that it is not below
+// the worst result.  hnsw_half_dots returns S~ = sum fp16(x_i sx) q_i / sx from the row-major fp16 image (half the bytes;
+// any order, fused multiply-adds, all 64 lanes: lane 8g+j takes chunk j of its group's row, partial sums are reduced over j
+// at the end -- no LDS transpose, no strict chain), and a row is dropped when even the bound says it cannot qualify:
+//
+//   L2Sqr  a = fl(s - 2 S~), e = fl(s - 2 acc) with the SAME s = fl(|x|^2 + |q|^2):  |a - e| <= 2 B + u (|a| + |e|)
+//   Cosine a = fl(1 - fl(S~/den)), e likewise with the SAME den:                     |a - e| <= B/den + u (|S~|/den + ...) + u (|a| + |e|)
+//   B >= |S~ - acc| = (gamma_m + gamma_d) |x||q| + |dx||q| (1 + gamma_m): accumulation error of both sums (m, d terms) and
+//   the MEASURED rounding of the image, |dx| <= min(dx_abs, dx_rel |x|) (k_row_split_err, the figures of the Flat fp16 tier).
+//
+// e > worst distance  <=  a - E > worst distance, so the reference rejects the row too (check_candidate and add both fail,
+// distance/index ties included since the inequality is strict), and tau only moves down while the expansion is replayed.
+// Rows that survive are scored exactly below; the counters count every fresh row as before.
+constexpr int HNSW_HALF_DEPTH = 5;  // lines (64 columns of 32 rows: 4 KB) in flight per wave
+__device__ __forceinline__ float hnsw_half_dots(const HnswDev &g, const float *qlds, uint32_t nb, bool fresh, uint32_t lane) {
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    constexpr int D = HNSW_HALF_DEPTH;
+    const uint32_t nlines = g.dim / 64, last = nlines - 1;
+    const uint64_t fm = __ballot(fresh);
+    const uint32_t nfresh = (uint32_t)__builtin_popcountll(fm);
+    const uint32_t rank = (uint32_t)__builtin_popcountll(fm & ((1ull << lane) - 1));
+    const uint32_t cnb = (uint32_t)__builtin_amdgcn_ds_permute(int((fresh ? rank : nfresh + (lane - rank)) * 4), int(nb));
+    const uint32_t gg = lane >> 3, jj = lane & 7;
+    const v4u *rp[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t src = 8 * k + gg;
+        const uint32_t nbk = __shfl(cnb, src < nfresh ? src : 0u);
+        rp[k] = reinterpret_cast<const v4u *>(g.rows_h + uint64_t(nbk) * g.dim) + jj;
+    }
+    v4u buf[D][4];
+    static_for<D>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const uint32_t Li = (uint32_t)i < last ? (uint32_t)i : last;
+#pragma unroll
+        for (int k = 0; k < 4; k++) buf[i][k] = rp[k][Li * 8];
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const v4f *q4 = reinterpret_cast<const v4f *>(qlds) + jj * 2;  // the 8 query columns of this lane's chunk
+    for (uint32_t L0 = 0; L0 < nlines; L0 += D) {
+        static_for<D>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const uint32_t L = L0 + i;
+            const uint32_t Lc = L < last ? L : last, Ln = L + D < last ? L + D : last;
+            v4u cur[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) cur[k] = buf[i][k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) buf[i][k] = rp[k][Ln * 8];
+            __builtin_amdgcn_sched_barrier(0);
+            const v4f qa = q4[Lc * 16], qb = q4[Lc * 16 + 1];
+            const float qv[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float a = acc[k];
+                const uint32_t w[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const h2 h = __builtin_bit_cast(h2, w[e]);
+                    a = __builtin_fmaf((float)h.x, qv[2 * e], a);
+                    a = __builtin_fmaf((float)h.y, qv[2 * e + 1], a);
+                }
+                acc[k] = L < nlines ? a : acc[k];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        acc[k] += __shfl_xor(acc[k], 1);
+        acc[k] += __shfl_xor(acc[k], 2);
+        acc[k] += __shfl_xor(acc[k], 4);
+    }
+    // compacted row r = 8k + g: its sum sits in acc[k] of the lanes of group g
+    const uint32_t src = 8 * (lane & 7), kr = (lane >> 3) & 3;
+    const float s0 = __shfl(acc[0], src), s1 = __shfl(acc[1], src), s2 = __shfl(acc[2], src), s3 = __shfl(acc[3], src);
+    const float sr = kr == 0 ? s0 : (kr == 1 ? s1 : (kr == 2 ? s2 : s3));
+    return __shfl(sr, rank) * g.inv_sx;  // back to the lane the neighbour came from; the scale is a power of two
+}
+
+// true: the reference's distance of row nb is certainly above `worst` (see above).  xs = |x|^2 as cached, S = hnsw_half_dots
+__device__ __forceinline__ bool hnsw_half_rejects(const HnswDev &g, float S, float xs, float qsq, float worst) {
+    constexpr float u = 0x1p-24f;
+    const float nx = sqrtf(xs) * 1.001f, nq = sqrtf(qsq) * 1.001f;  // (cached norms: strict folds, relative error gamma_d << 1e-3)
+    const float dxa = fminf(g.dx_abs, g.dx_rel * nx);
+    const float B = 1.002f * (2.0f * float(g.dim + 2) * u * nx * nq + dxa * nq);
+    float a, E;
+    if (g.cosine) {
+        const float den = fmaxf(sqrtf(xs) * sqrtf(qsq), 1e-10f);
+        const float t = S / den;
+        a = 1.0f - t;
+        E = 1.01f * (B / den + 2.0f * u * (fabsf(t) + fabsf(a) + B / den + 1.0f));
+    } else {
+        const float s2 = xs + qsq;
+        a = s2 - 2.0f * S;
+        E = 1.01f * (2.0f * B + 2.0f * u * (fabsf(a) + 2.0f * B));
+    }
+    return a - E > worst && E < INFINITY;  // (NaN compares false: such rows take the exact path)
 }
 
 template <int R, bool ADC>
@@ -418,7 +528,7 @@ __global__ __launch_bounds__(64, 2) void k_hnsw_search(HnswDev g, const float *_
         return ADC ? hnsw_adc_dist(g, lut, qsq, idx) : hnsw_exact_dist(g, fl, qsq, idx);
     };
 
-    unsigned long long n_dist = 0, n_exp = 0;
+    unsigned long long n_dist = 0, n_exp = 0, n_drop = 0, n_half = 0;  // (n_half: rows scored by the half-precision pre-pass, n_drop: ruled out by it)
 
     // ---- greedy descent, levels enter_level .. 1 (hnsw_index.rs:306-350) ---------------------------
     uint32_t cur = g.enter_point;
@@ -522,7 +632,7 @@ __global__ __launch_bounds__(64, 2) void k_hnsw_search(HnswDev g, const float *_
         rs_insert(e);
         pool_push(e);
     }
-#ifdef HNSW_STAMP  // measurement build: wall-clock ticks (100 MHz) per phase of the level-0 loop, summed into stats[2..6]
+#ifdef HNSW_STAMP  // measurement build: wall-clock ticks (100 MHz) per phase of the level-0 loop, summed into stats[4..7]
     unsigned long long tk_pop = 0, tk_links = 0, tk_dist = 0, tk_ins = 0;
 #define HNSW_TICK(acc, t_prev)                         \
     {                                                  \
@@ -595,9 +705,30 @@ __global__ __launch_bounds__(64, 2) void k_hnsw_search(HnswDev g, const float *_
             HNSW_TICK(tk_links, t_prev)
             float d = 0.0f;
             if (dma) {
-                if (fm)  // wave-uniform branches
-                    d = g.dma == 2 ? hnsw_exact_dists_dma(g, fl, qsq, nb, fresh, stage, lane)
-                                   : hnsw_exact_dists_regs(g, fl, qsq, nb, fresh, stage, lane);
+                if (fm) {  // wave-uniform branches
+                    if (g.dma == 2) {
+                        d = hnsw_exact_dists_dma(g, fl, qsq, nb, fresh, stage, lane);
+                    } else {
+                        bool need = fresh;
+                        if (g.rows_h != nullptr && tau != PAIR_NONE) {  // (until the result list is full every row is admitted)
+                            const float S = hnsw_half_dots(g, fl, nb, fresh, lane);
+                            const float xs = g.xsq[nb];
+                            need = fresh && !hnsw_half_rejects(g, S, xs, qsq, f32_from_orderable(uint32_t(tau >> 32)));
+                            n_drop += (uint32_t)__builtin_popcountll(__ballot(fresh && !need));
+                            n_half += (uint32_t)__builtin_popcountll(fm);
+                            d = INFINITY;  // a dropped row fails check_candidate below, as its exact distance would
+                        }
+                        const uint32_t nneed = (uint32_t)__builtin_popcountll(__ballot(need));
+                        float de = 0.0f;
+                        if (nneed > 16)
+                            de = hnsw_exact_dists_regs<4>(g, fl, qsq, nb, need, stage, lane);
+                        else if (nneed > 8)
+                            de = hnsw_exact_dists_regs<2>(g, fl, qsq, nb, need, stage, lane);
+                        else if (nneed > 0)
+                            de = hnsw_exact_dists_regs<1>(g, fl, qsq, nb, need, stage, lane);
+                        if (need) d = de;
+                    }
+                }
             } else if (fresh) {
                 d = dist_of(nb);
             }
@@ -622,10 +753,10 @@ __global__ __launch_bounds__(64, 2) void k_hnsw_search(HnswDev g, const float *_
     }
 #ifdef HNSW_STAMP
     if (lane == 0) {
-        atomicAdd(&stats[2], tk_pop);
-        atomicAdd(&stats[3], tk_links);
-        atomicAdd(&stats[4], tk_dist);
-        atomicAdd(&stats[5], tk_ins);
+        atomicAdd(&stats[4], tk_pop);
+        atomicAdd(&stats[5], tk_links);
+        atomicAdd(&stats[6], tk_dist);
+        atomicAdd(&stats[7], tk_ins);
     }
 #endif
     if (overflow && lane == 0) err[q] = 1u;  // this query is answered again by k_hnsw_search_big
@@ -634,6 +765,10 @@ __global__ __launch_bounds__(64, 2) void k_hnsw_search(HnswDev g, const float *_
     if (lane == 0 && !overflow) {  // (an overflowed walk is repeated by k_hnsw_search_big, which counts it)
         atomicAdd(&stats[0], n_dist);
         atomicAdd(&stats[1], n_exp);
+        if (n_half) {
+            atomicAdd(&stats[2], n_drop);
+            atomicAdd(&stats[3], n_half);
+        }
     }
 }
 
@@ -1473,6 +1608,8 @@ static void hnsw_launch(const HnswDev &g, const float *d_q, const float *qsq, co
 
 static int g_hnsw_dma = 1;
 void hnsw_set_dma(int v) { g_hnsw_dma = v; }
+static int g_hnsw_half = 1;  // certified half-precision pre-pass of the exact walk (0: off)
+void hnsw_set_half(int v) { g_hnsw_half = v; }
 static uint32_t g_hnsw_pool_cap = HNSW_POOL;
 void hnsw_set_pool_cap(int v) { g_hnsw_pool_cap = v < 1 ? 1u : (v > (int)HNSW_POOL ? HNSW_POOL : (uint32_t)v); }
 // Candidate pool entries of a walk.  Every expansion starts by dropping the pairs at or above the worst result, which
@@ -1513,6 +1650,7 @@ struct BuildDev {
     DevBuf d_level0, d_len0, d_upper, d_upper_len, d_upper_off;  // the graph, sized for all n rows
     DevBuf d_vis, d_keys, d_flags, d_entry, d_cross_in, d_cross_out, d_stage_slots, d_stage_rows, d_stage_len;
     bool mirror_valid = false;
+    bool use_half = false;  // the index holds the row-major fp16 image: the searches run the certified pre-pass
     std::vector<uint64_t> upper_off;  // [n + 1] from the pre-drawn levels
     hipStream_t stream = nullptr;
     ~BuildDev() {
@@ -1536,6 +1674,10 @@ static std::shared_ptr<BuildDev> hnsw_build_gpu_assist(Index &ix, Builder::GpuAs
     bd->d_upper_off.reserve((n + 1) * 8);
     VDB_HIP(hipMemcpy(bd->d_upper_off.p, bd->upper_off.data(), (n + 1) * 8, hipMemcpyHostToDevice));
 
+    {  // the walk's half-precision pre-pass serves the builder's searches as well (all rows are in the index already)
+        WsLease ws(ix);
+        bd->use_half = g_hnsw_half && ix.ensure_rows_h(*ws);
+    }
     Index *ixp = &ix;
     BuildDev *b = bd.get();
     ga.search = [ixp, b](uint64_t first, uint64_t nb, uint64_t enter_point, uint64_t enter_level, const std::vector<uint32_t> &entry0,
@@ -1565,6 +1707,12 @@ static std::shared_ptr<BuildDev> hnsw_build_gpu_assist(Index &ix, Builder::GpuAs
         HnswDev g{};
         g.dma = dma ? (g_hnsw_dma == 2 ? 2 : 1) : 0;
         g.pool_cap = hnsw_pool_slots(efk, (uint32_t)h.max_m0);
+        if (g.dma == 1 && b->use_half) {
+            g.rows_h = ix.d_rows_h.as<uint16_t>();
+            g.inv_sx = 1.0f / ix.half_sx();
+            g.dx_abs = ix.half_dx_abs;
+            g.dx_rel = ix.half_dx_rel;
+        }
         const size_t lds = hnsw_lds_bytes(g.pool_cap, ix.dim * sizeof(float), g.dma);
         g.rows = ix.d_rows.as<float>();
         g.xsq = ix.d_sq.as<float>();
@@ -1703,6 +1851,12 @@ void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, ui
     const bool dma = !use_pq && g_hnsw_dma && h.max_m0 <= 32 && ix.dim % 32 == 0;
     HnswDev g{};
     g.dma = dma ? (g_hnsw_dma == 2 ? 2 : 1) : 0;  // 1: rows staged through registers, 2: through LDS by DMA (the round-1 form, kept for A/B)
+    if (g.dma == 1 && g_hnsw_half && ix.ensure_rows_h(ws)) {
+        g.rows_h = ix.d_rows_h.as<uint16_t>();
+        g.inv_sx = 1.0f / ix.half_sx();
+        g.dx_abs = ix.half_dx_abs;
+        g.dx_rel = ix.half_dx_rel;
+    }
     g.pool_cap = hnsw_pool_slots(efk, (uint32_t)h.max_m0);
     const size_t lds = hnsw_lds_bytes(g.pool_cap, lds_big, g.dma);
     g.rows = ix.d_rows.as<float>();
@@ -1780,12 +1934,12 @@ void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, ui
     // queries for the heap walk: all of them (ef > 1024), or those whose LDS candidate pool overflowed (graphs of
     // near-duplicates keep thousands of live candidates); the work counters of an overflowed walk are dropped first
     std::vector<uint32_t> redo;
-    unsigned long long st[2] = {0, 0};
+    unsigned long long st[4] = {0, 0, 0, 0};
     auto read_stats = [&]() {
         unsigned char *hb = static_cast<unsigned char *>(ws.pinned(64 + nq * sizeof(uint32_t)));
         VDB_HIP(hipMemcpyAsync(hb, ws.flags.p, 64 + nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         VDB_SYNC(s);
-        std::memcpy(st, hb, 16);
+        std::memcpy(st, hb, 32);
         return reinterpret_cast<const uint32_t *>(hb + 64);
     };
     if (big_all) {
@@ -1859,11 +2013,13 @@ void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, ui
     }
     h.last_n_dist = st[0];
     h.last_n_expanded = st[1];
+    h.last_half_dropped = st[2];
 #ifdef HNSW_STAMP
     {
         unsigned long long tk[4];
-        VDB_HIP(hipMemcpy(tk, reinterpret_cast<const char *>(ws.flags.p) + 16, sizeof(tk), hipMemcpyDeviceToHost));
+        VDB_HIP(hipMemcpy(tk, reinterpret_cast<const char *>(ws.flags.p) + 32, sizeof(tk), hipMemcpyDeviceToHost));
         const double per = st[1] ? 1.0 / double(st[1]) * 0.01 : 0.0;  // 100 MHz ticks -> us per expansion
+        std::fprintf(stderr, "hnsw stamps: %llu distance evaluations, %llu through the half-precision pre-pass, %llu ruled out by it\n", st[0], st[3], st[2]);
         std::fprintf(stderr, "hnsw stamps (us per expansion): pop %.2f, links + visited %.2f, distances %.2f, inserts %.2f\n", tk[0] * per,
                      tk[1] * per, tk[2] * per, tk[3] * per);
     }
@@ -1871,8 +2027,11 @@ void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, ui
     if (!ws.pending.empty()) {
         // algorithmic bytes are data-dependent: n_dist row fetches (+ cached norm) and n_expanded link rows,
         // known only now -- credited to the call's last launch record
-        const double row_bytes = use_pq ? double(pq.enc_dim) : double(ix.dim) * sizeof(float) + sizeof(float);
-        ws.pending.back().bytes += double(st[0]) * row_bytes + double(st[1]) * double(h.max_m0) * sizeof(uint32_t);
+        // (SURVEY 8d's figure, n_dist f32 rows, is what vdb_hnsw_last_stats lets a caller compute; the record holds the bytes
+        // the walk asked for: with the pre-pass a scored row is dim*2 B of the fp16 image, plus dim*4 B unless it was ruled out)
+        double row_bytes = use_pq ? double(pq.enc_dim) * double(st[0]) : (double(ix.dim) * sizeof(float)) * double(st[0] - st[2]) + sizeof(float) * double(st[0]);
+        if (!use_pq) row_bytes += double(ix.dim) * sizeof(uint16_t) * double(st[3]);
+        ws.pending.back().bytes += row_bytes + double(st[1]) * double(h.max_m0) * sizeof(uint32_t);
     }
 }
 

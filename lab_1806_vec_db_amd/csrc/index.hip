@@ -131,6 +131,7 @@ void Index::swap_remove(uint64_t i) {
     if (i < last) h_sq[i] = h_sq[last];
     h_sq.resize(last);
     n = last;
+    rows_h_n = 0;  // (rebuilt by the next walk that uses it)
     // xsq_max stays an upper bound (certification only needs a bound)
 }
 
@@ -154,6 +155,7 @@ uint64_t Index::hbm_bytes_per_row() const {
         if (tiled_built) b += uint64_t(mfma_dim_pad((uint32_t)dim)) * sizeof(float);
         if (half_valid) b += uint64_t(mfma_dim_pad((uint32_t)dim)) * sizeof(uint16_t);
     }
+    if (rows_h_n) b += dim * sizeof(uint16_t);
     if (pq.present) b += pq.enc_dim * (pq.codes_t_valid ? 2 : 1);
     if (hnsw.present) b += hnsw.max_m0 * sizeof(uint32_t) + sizeof(uint32_t);
     return b;
@@ -199,6 +201,20 @@ void Index::half_refresh(Workspace &ws, uint64_t n_old, uint64_t n_new) {
     half_dx_abs = std::max(half_dx_abs, std::sqrt(e2[0]) * 1.001f);  // the kernel's f32 sums: relative error << 1e-3
     half_dx_rel = std::max(half_dx_rel, std::sqrt(e2[1]) * 1.001f);
     half_valid = true;
+}
+
+bool Index::ensure_rows_h(Workspace &ws) {
+    if (elem_u8 || !half_valid || dim % 64 != 0 || dim > 4096 || n == 0) return false;
+    std::lock_guard<std::mutex> g(rows_h_mu);
+    if (rows_h_n == n && rows_h_exp == half_exp) return true;
+    uint64_t r0 = rows_h_n;
+    if (rows_h_exp != half_exp || rows_h_n > n) r0 = 0;
+    d_rows_h.grow(n * dim * sizeof(uint16_t) + 16, r0 * dim * sizeof(uint16_t), ws.stream);
+    launch_rows_to_half(d_rows.as<float>() + r0 * dim, (n - r0) * dim, half_sx(), d_rows_h.as<uint16_t>() + r0 * dim, ws.stream);
+    VDB_SYNC(ws.stream);
+    rows_h_n = n;
+    rows_h_exp = half_exp;
+    return true;
 }
 
 // ---- timing hooks ------------------------------------------------------------------------------

@@ -123,6 +123,7 @@ struct HNSWState {
     bool dev_dirty = true;
     DevBuf d_level0, d_len0, d_upper, d_upper_len, d_upper_off;
     std::atomic<uint64_t> last_n_dist{0}, last_n_expanded{0};
+    std::atomic<uint64_t> last_half_dropped{0};  // of last_n_dist: rows the certified half-precision pre-pass ruled out (last call)
     std::atomic<uint64_t> heap_walk_queries{0};  // queries answered by k_hnsw_search_big (ef > 1024 or LDS pool overflow)
 };
 
@@ -188,6 +189,14 @@ struct Index {
     std::atomic<uint64_t> half_queries{0}, half_redo{0};  // queries through the fp16 pass / redone with split-bf16
     void half_refresh(Workspace &ws, uint64_t n_old, uint64_t n_new);  // after rows [n_old, n_new) changed
     float half_sx() const { return std::ldexp(1.0f, 13 - half_exp); }
+    // Row-major fp16 image of the rows, same scale and rounding as d_tiled_h (so half_dx_* bound its error as well): the
+    // operand of the HNSW walk's certified pre-pass (hnsw.hip, hnsw_half_dots).  Built on the first walk that wants it,
+    // extended when rows were added since, rebuilt when the scale changed.
+    DevBuf d_rows_h;
+    uint64_t rows_h_n = 0;
+    int rows_h_exp = 0;
+    std::mutex rows_h_mu;
+    bool ensure_rows_h(Workspace &ws);  // false: this index has no fp16 image (dim, element type, extreme norms)
     std::vector<float> h_sq;  // host mirror of d_sq (4 B/row), kept in step by add_rows / swap_remove
     float xsq_max = 0.0f;
     float xsq_min_pos = 3.4e38f;  // smallest positive row |x|^2 seen (cosine certification: clamp check)

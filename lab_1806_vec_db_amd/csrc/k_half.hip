@@ -64,6 +64,18 @@ void launch_tile_rows_h(const float *X, uint64_t n, uint32_t dim, uint64_t tile0
                        reinterpret_cast<uint4 *>(T));
 }
 
+// the same rounding, row-major: H[i] = fp16(X[i] * sx) (the HNSW walk's pre-pass gathers whole rows; count % 8 == 0)
+__global__ __launch_bounds__(256) void k_rows_to_half(const float4 *__restrict__ X, uint64_t n8, float sx, uint4 *__restrict__ H) {
+    const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n8) H[i] = pack8h(X[2 * i], X[2 * i + 1], sx);
+}
+void launch_rows_to_half(const float *X, uint64_t count, float sx, uint16_t *H, hipStream_t s) {
+    if (count == 0) return;
+    const uint64_t n8 = count / 8;
+    hipLaunchKernelGGL(k_rows_to_half, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float4 *>(X), n8, sx,
+                       reinterpret_cast<uint4 *>(H));
+}
+
 // |v - fp16(v * scale) / scale|^2 summed over a vector by one wave (all differences are exact in f32: v~ is v rounded
 // to 11 bits, or a subnormal / zero whose distance to v is representable)
 __device__ __forceinline__ float wave_round_err2(const float *v, uint32_t dim, float scale, float inv_scale, uint32_t lane) {

@@ -9,10 +9,15 @@ dev = torch.device('cuda', 0)
 base = gist_lowrank_gpu(torch, n, 960, 1806, dev)
 ix = vdb.GpuIndex(960, 'l2sqr'); ix.add_device(base.data_ptr(), n)
 t = time.time(); ix.hnsw_build(M=16, ef_construction=200, seed=42, batch=1024, nthreads=16); print(f"build {time.time()-t:.1f} s", flush=True)
-for nq in (256, 512, 1024, 2048, 4096, 8192, 16384):
+ref = {}
+for half, nq in [(h, q) for h in (0, 1) for q in (256, 1024, 2048, 4096, 8192, 16384)]:
+    ix.set_param('hnsw_half', half)
     qs = gist_lowrank_gpu(torch, nq, 960, 1807, dev).cpu().numpy()
     best = 1e9
     for it in range(4):
         t = time.perf_counter(); idx, d, c = ix.knn_with_ef(qs, 10, 128); best = min(best, time.perf_counter() - t)
     st = ix.hnsw_last_stats()
-    print(f"nq={nq}: {best*1e3:.2f} ms -> {nq/best:.0f} QPS, {st[0]*3840/best/1e12:.2f} TB/s of row gathers, stats/query=({st[0]/nq:.0f}, {st[1]/nq:.1f})", flush=True)
+    same = True
+    if half == 0: ref[nq] = (idx.copy(), d.copy(), st)
+    else: same = bool((ref[nq][0] == idx).all() and (ref[nq][1] == d).all() and ref[nq][2] == st)
+    print(f"half={half} same={same} nq={nq}: {best*1e3:.2f} ms -> {nq/best:.0f} QPS, {st[0]*3840/best/1e12:.2f} TB/s of row gathers, stats/query=({st[0]/nq:.0f}, {st[1]/nq:.1f})", flush=True)
