@@ -274,6 +274,24 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
 #pragma unroll
                             for (int t = 0; t < TW; t++)
                                 acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xl[t]), __builtin_bit_cast(f16x8, ql), acc[t][h], 0, 0, 0);
+                            if (GEMM_ABLATE & 8) {  // measurement: the matrix work and B-fragment reads of 256 queries per pass
+                                typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+                                const volatile u32x4v *qv = reinterpret_cast<const volatile u32x4v *>(qcur);
+                                u32x4v e0, e1;
+                                if (GEMM_ABLATE & 16) {  // (16: the matrix work only, B fragments reused -- what wider row units would do)
+                                    e0 = __builtin_bit_cast(u32x4v, qh);
+                                    e1 = __builtin_bit_cast(u32x4v, ql);
+                                } else {
+                                    e0 = qv[((p * NH + h) * 2 + 0) * 64];
+                                    e1 = qv[((p * NH + h) * 2 + 1) * 64];
+                                }
+#pragma unroll
+                                for (int t = 0; t < TW; t++)
+                                    acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xh[t]), __builtin_bit_cast(f16x8, e0), acc[t][h], 0, 0, 0);
+#pragma unroll
+                                for (int t = 0; t < TW; t++)
+                                    acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xl[t]), __builtin_bit_cast(f16x8, e1), acc[t][h], 0, 0, 0);
+                            }
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
