@@ -125,7 +125,8 @@ int vdb_flat_set_mode(vdb_index *idx, int mode);
  *   "pq_adc_fast", "hnsw_dma"   inner-loop variants of the ADC scan and of the HNSW walk (hnsw_dma: 1 rows staged through
  *                      registers (default), 2 through LDS by DMA, 0 plain per-lane loads)
  *   "hnsw_half"        certified half-precision pre-pass of the exact HNSW walk (a row-major fp16 image of the rows, 2 B per
- *                      element, built on first use; rows it cannot rule out are scored exactly as always): 1 on (default), 0 off
+ *                      element, built on first use; rows it cannot rule out are scored exactly as always): 1 auto (default: calls of >= 768
+ *                      queries, where the walk is bound by bytes rather than by latency), 0 off, 2 always
  *   "hnsw_build_gpu"   candidate phase of batched HNSW builds (vdb_hnsw_build with batch >= 256): 0 auto = the level-0 searches of a
  *                      batch and the distances between its members run on the GPU (same graph as the all-host builder), 1 off
  *   "hnsw_pool_cap"    most live candidates the fast HNSW walk keeps in LDS (it uses min(this, ef + max_m0 + 64); maximum 2048) before a query is handed to

@@ -302,14 +302,14 @@ __device__ __forceinline__ float hnsw_exact_dists_dma(const HnswDev &g, const fl
 #ifndef HNSW_REG_DEPTH
 #define HNSW_REG_DEPTH 8
 #endif
-constexpr uint32_t HNSW_REG_STAGE = 4096;
+constexpr uint32_t HNSW_REG_STAGE = 2 * 4096;  // two line blocks: the transpose runs one line ahead of the fold
 typedef float v4f __attribute__((ext_vector_type(4)));
 // NG = groups of 8 compacted rows that are fetched (ceil(nfresh / 8) <= NG): after the half-precision pre-pass most
 // expansions are left with a handful of rows, and a whole-instruction `if` would cost the counted waits (see below)
 template <int NG>
 __device__ __forceinline__ float hnsw_exact_dists_regs(const HnswDev &g, const float *qlds, float qsq, uint32_t nb, bool fresh,
                                                        unsigned char *stage, uint32_t lane) {
-    constexpr int D = HNSW_REG_DEPTH;
+    constexpr int D = NG == 4 ? HNSW_REG_DEPTH / 2 : HNSW_REG_DEPTH;  // 16 NG D registers of lines in flight + 64 of the line being folded
     const uint32_t nlines = g.dim / 32;
     const uint64_t fm = __ballot(fresh);
     const uint32_t nfresh = (uint32_t)__builtin_popcountll(fm);  // <= 32: the fresh lanes are all below max_m0 <= 32
@@ -347,29 +347,51 @@ __device__ __forceinline__ float hnsw_exact_dists_regs(const HnswDev &g, const f
     uint32_t off[8];
 #pragma unroll
     for (int c = 0; c < 8; c++) off[c] = kr * 1024 + (8 * gr + ((c + 8 - rot) & 7)) * 16;
+    // The fold of a line is a chain of 32 dependent adds (~256 cycles); an LDS write -> read round trip in front of every
+    // line costs about as much again (measured: ~10 us of an expansion's 18 for 30 lines).  So the transpose runs one line
+    // ahead through two LDS blocks: while line L is folded from registers (cur / qv), line L+1 is written to the other block
+    // and every chunk register is re-read for line L+1 right after its last use.
+    static_assert(D % 2 == 0, "the LDS block of a line is chosen by the parity of its ring slot");
+    v4f cur[8], qv[8];
+    {
+#pragma unroll
+        for (int k = 0; k < NG; k++) *reinterpret_cast<v4f *>(stage + k * 1024 + 16 * lane) = buf[0][k];
+        const uint32_t Ld = (uint32_t)D < last ? (uint32_t)D : last;
+#pragma unroll
+        for (int k = 0; k < NG; k++) buf[0][k] = rp[k][Ld * 8];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            cur[c] = *reinterpret_cast<const v4f *>(stage + off[c]);
+            qv[c] = q4[c];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     for (uint32_t L0 = 0; L0 < nlines; L0 += D) {
         static_for<D>([&](auto ic) {  // (compile-time indices: the line buffers must stay in registers)
-            constexpr int i = decltype(ic)::value;
+            constexpr int i = decltype(ic)::value, in = (i + 1) % D;
             const uint32_t L = L0 + i;
-            const uint32_t Lc = L < last ? L : last, Ln = L + D < last ? L + D : last;
+            const uint32_t L1 = L + 1 < last ? L + 1 : last, Lr = L + 1 + D < last ? L + 1 + D : last;
+            unsigned char *sb = stage + ((i + 1) & 1) * 4096;  // block of line L+1
 #pragma unroll
-            for (int k = 0; k < NG; k++) *reinterpret_cast<v4f *>(stage + k * 1024 + 16 * lane) = buf[i][k];
+            for (int k = 0; k < NG; k++) *reinterpret_cast<v4f *>(sb + k * 1024 + 16 * lane) = buf[in][k];
 #pragma unroll
-            for (int k = 0; k < NG; k++) buf[i][k] = rp[k][Ln * 8];
+            for (int k = 0; k < NG; k++) buf[in][k] = rp[k][Lr * 8];
             __builtin_amdgcn_sched_barrier(0);
             float a = acc;
 #pragma unroll
             for (int c = 0; c < 8; c++) {
-                const v4f v = *reinterpret_cast<const v4f *>(stage + off[c]);
-                const v4f qq = q4[Lc * 8 + c];
+                const v4f v = cur[c], qq = qv[c];
                 float p;
                 p = v.x * qq.x; a = a + p;
                 p = v.y * qq.y; a = a + p;
                 p = v.z * qq.z; a = a + p;
                 p = v.w * qq.w; a = a + p;
+                cur[c] = *reinterpret_cast<const v4f *>(sb + off[c]);
+                qv[c] = q4[L1 * 8 + c];
+                __builtin_amdgcn_sched_barrier(0);
             }
             acc = L < nlines ? a : acc;
-            __builtin_amdgcn_sched_barrier(0);
         });
     }
     float d;
@@ -1608,7 +1630,7 @@ static void hnsw_launch(const HnswDev &g, const float *d_q, const float *qsq, co
 
 static int g_hnsw_dma = 1;
 void hnsw_set_dma(int v) { g_hnsw_dma = v; }
-static int g_hnsw_half = 1;  // certified half-precision pre-pass of the exact walk (0: off)
+static int g_hnsw_half = 1;  // certified half-precision pre-pass of the exact walk: 1 auto (calls of >= 768 queries), 0 off, 2 always
 void hnsw_set_half(int v) { g_hnsw_half = v; }
 static uint32_t g_hnsw_pool_cap = HNSW_POOL;
 void hnsw_set_pool_cap(int v) { g_hnsw_pool_cap = v < 1 ? 1u : (v > (int)HNSW_POOL ? HNSW_POOL : (uint32_t)v); }
@@ -1851,7 +1873,9 @@ void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, ui
     const bool dma = !use_pq && g_hnsw_dma && h.max_m0 <= 32 && ix.dim % 32 == 0;
     HnswDev g{};
     g.dma = dma ? (g_hnsw_dma == 2 ? 2 : 1) : 0;  // 1: rows staged through registers, 2: through LDS by DMA (the round-1 form, kept for A/B)
-    if (g.dma == 1 && g_hnsw_half && ix.ensure_rows_h(ws)) {
+    // (auto: calls of fewer than 768 queries are a fraction of one round of walks -- latency, not bytes, is what they wait for,
+    // and the pre-pass is one more dependent gather per expansion: 2.23 vs 2.07 ms at 256 queries, 2.74 vs 2.89 ms at 1024)
+    if (g.dma == 1 && (g_hnsw_half == 2 || (g_hnsw_half == 1 && nq >= 768)) && ix.ensure_rows_h(ws)) {
         g.rows_h = ix.d_rows_h.as<uint16_t>();
         g.inv_sx = 1.0f / ix.half_sx();
         g.dx_abs = ix.half_dx_abs;

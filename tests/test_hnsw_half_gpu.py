@@ -45,7 +45,7 @@ def _corpus(kind, n, seed):
 
 def _check(vdb, O, ix, base, qs, kind, k, ef, M, efc):
     oh = O.HNSW.from_graph(base, kind, M, efc, ix.hnsw_export())
-    ix.set_param("hnsw_half", 1)
+    ix.set_param("hnsw_half", 2)  # (2: also for calls of a few queries; 1 = auto leaves those to the exact stage alone)
     idx, d, cnt = ix.knn_with_ef(qs, k, ef)
     st_on = ix.hnsw_last_stats()
     dropped = ix.get_stat("hnsw_half_dropped")

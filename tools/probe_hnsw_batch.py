@@ -10,7 +10,7 @@ base = gist_lowrank_gpu(torch, n, 960, 1806, dev)
 ix = vdb.GpuIndex(960, 'l2sqr'); ix.add_device(base.data_ptr(), n)
 t = time.time(); ix.hnsw_build(M=16, ef_construction=200, seed=42, batch=1024, nthreads=16); print(f"build {time.time()-t:.1f} s", flush=True)
 ref = {}
-for half, nq in [(h, q) for h in (0, 1) for q in (256, 1024, 2048, 4096, 8192, 16384)]:
+for half, nq in [(h, q) for h in (0, 2) for q in (256, 1024, 2048, 4096, 8192, 16384)]:
     ix.set_param('hnsw_half', half)
     qs = gist_lowrank_gpu(torch, nq, 960, 1807, dev).cpu().numpy()
     best = 1e9
