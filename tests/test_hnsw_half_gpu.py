@@ -99,3 +99,27 @@ def test_image_follows_added_rows_and_scale_changes(mods):
     allrows = np.concatenate([base, big])
     _check(vdb, O, ix, allrows, qs, 0, 8, 32, 12, 40)
     _check(vdb, O, ix, allrows, big[:8] + np.float32(0.5), 0, 8, 32, 12, 40)
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_prepass_random_configuration(mods, seed):
+    """random dims (multiples of 64), per-dimension scales, duplicates, graph widths and result-list sizes"""
+    vdb, O = mods
+    rng = np.random.default_rng(8800 + seed)
+    dim = int(rng.choice([64, 128, 192, 320]))
+    n = int(rng.integers(600, 5000))
+    nq = int(rng.choice([3, 17, 40]))
+    k = int(rng.choice([1, 5, 10, 25]))
+    dist, kind = (("l2sqr", 0), ("cosine", 1))[int(rng.integers(0, 2))]
+    base = (rng.standard_normal((n, dim)) * rng.uniform(0.05, 4.0, dim)).astype(np.float32)
+    if seed % 3 == 0:  # clusters: many near-ties around the worst result
+        base = (base[rng.integers(0, 20, n)] + np.float32(0.02) * rng.standard_normal((n, dim))).astype(np.float32)
+    base[n - 5:] = base[:5]
+    qs = (base[rng.integers(0, n, nq)] + rng.standard_normal((nq, dim)).astype(np.float32) * np.float32(0.1)).astype(np.float32)
+    ix = vdb.GpuIndex(dim, dist)
+    ix.batch_add(base)
+    M = int(rng.choice([4, 8, 16]))
+    efc = int(rng.choice([20, 60]))
+    ix.hnsw_build(M=M, ef_construction=efc, seed=seed, batch=int(rng.choice([1, 16])), nthreads=4)
+    ef = int(rng.choice([k, 40, 200]))
+    _check(vdb, O, ix, base, qs, kind, k, ef, M, efc)
