@@ -166,3 +166,28 @@ def test_vecdb_search_k_ef_len(mods):
     db.build_pq_table("t", train_proportion=0.2)
     hits = db.search("t", base[3], n, ef=n)
     assert len(hits) == len(oi)
+
+
+def test_flat_full_order_many_blocks(mods):
+    """FlatIndex::knn with k = len (flat_index.rs:48-57: the whole (distance, index) order) on 30 000 rows: the radix sort
+    of k_sort.hip runs 8 blocks per pass; duplicated rows give equal distances that the index must order, rows with
+    inf / NaN coordinates sort last (candidate_pair.rs:36-41)."""
+    vdb, O = mods
+    rng = np.random.default_rng(77)
+    n, dim = 30000, 20
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    base[5000:5200] = base[100:300]          # exact duplicates: ties on the distance
+    base[29990, 3] = np.inf
+    base[29995, 0] = np.nan
+    qs = rng.standard_normal((3, dim)).astype(np.float32)
+    for dist, kind in (("l2sqr", 0), ("cosine", 1)):
+        ix = vdb.GpuIndex(dim, dist)
+        ix.batch_add(base)
+        for k in (n, 2500):
+            idx, d, cnt = ix.flat_knn(qs, k)
+            for q in range(qs.shape[0]):
+                oi, od = O.flat_knn(base, qs[q], k, kind)
+                c = int(cnt[q])
+                assert c == len(oi) == k
+                assert idx[q, :c].tolist() == oi.tolist(), (dist, k, q)
+                assert np.array_equal(d[q, :c], od, equal_nan=True), (dist, k, q)
