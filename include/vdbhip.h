@@ -127,6 +127,8 @@ int vdb_flat_set_mode(vdb_index *idx, int mode);
  *   "hnsw_half"        certified half-precision pre-pass of the exact HNSW walk (a row-major fp16 image of the rows, 2 B per
  *                      element, built on first use; rows it cannot rule out are scored exactly as always): 1 auto (default: calls of >= 768
  *                      queries, where the walk is bound by bytes rather than by latency), 0 off, 2 always
+ *   "ivf_half"         the same pre-pass for the IVF probe-list scan (offers that cannot be among the k nearest are dropped before the
+ *                      f32 rows are fetched; same results): 1 auto (default), 0 off
  *   "hnsw_build_gpu"   candidate phase of batched HNSW builds (vdb_hnsw_build with batch >= 256): 0 auto = the level-0 searches of a
  *                      batch and the distances between its members run on the GPU (same graph as the all-host builder), 1 off
  *   "hnsw_pool_cap"    most live candidates the fast HNSW walk keeps in LDS (it uses min(this, ef + max_m0 + 64); maximum 2048) before a query is handed to
@@ -147,6 +149,8 @@ int vdb_flat_fallback_count(const vdb_index *idx, uint64_t *out);
  *                        pool of the fast walk overflowed),
  *   "hnsw_half_dropped"  of the last HNSW call's distance evaluations (vdb_hnsw_last_stats), the rows its certified
  *                        half-precision pre-pass ruled out without fetching the f32 row,
+ *   "ivf_last_offers", "ivf_last_kept"  (while vdb_prof_enable is on) rows the last IVF call offered to its result sets and the
+ *                        ones its certified half-precision pre-pass kept for the exact stage,
  *   "hbm_bytes_per_row"  resident HBM bytes per row over all per-row buffers (rows, norms, mirrors, PQ codes, level-0 links). */
 int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out);
 

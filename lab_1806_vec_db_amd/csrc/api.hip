@@ -371,6 +371,8 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         hnsw_set_dma((int)value);
     else if (n == "hnsw_half")
         hnsw_set_half((int)value);
+    else if (n == "ivf_half")
+        ivf_set_half((int)value);
     else if (n == "hnsw_build_gpu")
         hnsw_set_build_gpu((int)value);
     else if (n == "hnsw_pool_cap")
@@ -432,6 +434,10 @@ int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out) {
         *out = idx->ix.hnsw.heap_walk_queries.load();
     else if (n == "hnsw_half_dropped")
         *out = idx->ix.hnsw.last_half_dropped.load();
+    else if (n == "ivf_last_offers")
+        *out = idx->ix.ivf.last_offers.load();
+    else if (n == "ivf_last_kept")
+        *out = idx->ix.ivf.last_kept.load();
     else if (n == "hbm_bytes_per_row")
         *out = idx->ix.hbm_bytes_per_row();
     else

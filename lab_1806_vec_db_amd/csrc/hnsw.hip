@@ -27,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include "half_rows.hpp"
 #include "heap.hpp"
 #include "pq_hnsw.hpp"
 #if defined(__x86_64__)
@@ -74,15 +75,6 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
         v = o < v ? o : v;
     }
     return v;
-}
-
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 // exact cached-form distance of row idx to the query held in LDS (strict left fold over the dimension)
@@ -303,7 +295,6 @@ __device__ __forceinline__ float hnsw_exact_dists_dma(const HnswDev &g, const fl
 #define HNSW_REG_DEPTH 8
 #endif
 constexpr uint32_t HNSW_REG_STAGE = 2 * 4096;  // two line blocks: the transpose runs one line ahead of the fold
-typedef float v4f __attribute__((ext_vector_type(4)));
 // NG = groups of 8 compacted rows that are fetched (ceil(nfresh / 8) <= NG): after the half-precision pre-pass most
 // expansions are left with a handful of rows, and a whole-instruction `if` would cost the counted waits (see below)
 template <int NG>
@@ -408,109 +399,13 @@ __device__ __forceinline__ float hnsw_exact_dists_regs(const HnswDev &g, const f
 }
 
 
-// ---- certified half-precision pre-pass ---------------------------------------------------------------------------
+// ---- certified half-precision pre-pass (half_rows.hpp) ------------------------------------------------------------
 // Large calls are bound by the bytes of the row gathers, and 85 % of the rows an expansion scores fail check_candidate
-// (measured: 498k of 3.3M pass at ef = 128).  For those the exact value is never used -- only the fact that it is not below
-// the worst result.  hnsw_half_dots returns S~ = sum fp16(x_i sx) q_i / sx from the row-major fp16 image (half the bytes;
-// any order, fused multiply-adds, all 64 lanes: lane 8g+j takes chunk j of its group's row, partial sums are reduced over j
-// at the end -- no LDS transpose, no strict chain), and a row is dropped when even the bound says it cannot qualify:
-//
-//   L2Sqr  a = fl(s - 2 S~), e = fl(s - 2 acc) with the SAME s = fl(|x|^2 + |q|^2):  |a - e| <= 2 B + u (|a| + |e|)
-//   Cosine a = fl(1 - fl(S~/den)), e likewise with the SAME den:                     |a - e| <= B/den + u (|S~|/den + ...) + u (|a| + |e|)
-//   B >= |S~ - acc| = (gamma_m + gamma_d) |x||q| + |dx||q| (1 + gamma_m): accumulation error of both sums (m, d terms) and
-//   the MEASURED rounding of the image, |dx| <= min(dx_abs, dx_rel |x|) (k_row_split_err, the figures of the Flat fp16 tier).
-//
-// e > worst distance  <=  a - E > worst distance, so the reference rejects the row too (check_candidate and add both fail,
-// distance/index ties included since the inequality is strict), and tau only moves down while the expansion is replayed.
-// Rows that survive are scored exactly below; the counters count every fresh row as before.
-constexpr int HNSW_HALF_DEPTH = 5;  // lines (64 columns of 32 rows: 4 KB) in flight per wave
-__device__ __forceinline__ float hnsw_half_dots(const HnswDev &g, const float *qlds, uint32_t nb, bool fresh, uint32_t lane) {
-    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    constexpr int D = HNSW_HALF_DEPTH;
-    const uint32_t nlines = g.dim / 64, last = nlines - 1;
-    const uint64_t fm = __ballot(fresh);
-    const uint32_t nfresh = (uint32_t)__builtin_popcountll(fm);
-    const uint32_t rank = (uint32_t)__builtin_popcountll(fm & ((1ull << lane) - 1));
-    const uint32_t cnb = (uint32_t)__builtin_amdgcn_ds_permute(int((fresh ? rank : nfresh + (lane - rank)) * 4), int(nb));
-    const uint32_t gg = lane >> 3, jj = lane & 7;
-    const v4u *rp[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t src = 8 * k + gg;
-        const uint32_t nbk = __shfl(cnb, src < nfresh ? src : 0u);
-        rp[k] = reinterpret_cast<const v4u *>(g.rows_h + uint64_t(nbk) * g.dim) + jj;
-    }
-    v4u buf[D][4];
-    static_for<D>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        const uint32_t Li = (uint32_t)i < last ? (uint32_t)i : last;
-#pragma unroll
-        for (int k = 0; k < 4; k++) buf[i][k] = rp[k][Li * 8];
-        __builtin_amdgcn_sched_barrier(0);
-    });
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    const v4f *q4 = reinterpret_cast<const v4f *>(qlds) + jj * 2;  // the 8 query columns of this lane's chunk
-    for (uint32_t L0 = 0; L0 < nlines; L0 += D) {
-        static_for<D>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            const uint32_t L = L0 + i;
-            const uint32_t Lc = L < last ? L : last, Ln = L + D < last ? L + D : last;
-            v4u cur[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) cur[k] = buf[i][k];
-#pragma unroll
-            for (int k = 0; k < 4; k++) buf[i][k] = rp[k][Ln * 8];
-            __builtin_amdgcn_sched_barrier(0);
-            const v4f qa = q4[Lc * 16], qb = q4[Lc * 16 + 1];
-            const float qv[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                float a = acc[k];
-                const uint32_t w[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const h2 h = __builtin_bit_cast(h2, w[e]);
-                    a = __builtin_fmaf((float)h.x, qv[2 * e], a);
-                    a = __builtin_fmaf((float)h.y, qv[2 * e + 1], a);
-                }
-                acc[k] = L < nlines ? a : acc[k];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        acc[k] += __shfl_xor(acc[k], 1);
-        acc[k] += __shfl_xor(acc[k], 2);
-        acc[k] += __shfl_xor(acc[k], 4);
-    }
-    // compacted row r = 8k + g: its sum sits in acc[k] of the lanes of group g
-    const uint32_t src = 8 * (lane & 7), kr = (lane >> 3) & 3;
-    const float s0 = __shfl(acc[0], src), s1 = __shfl(acc[1], src), s2 = __shfl(acc[2], src), s3 = __shfl(acc[3], src);
-    const float sr = kr == 0 ? s0 : (kr == 1 ? s1 : (kr == 2 ? s2 : s3));
-    return __shfl(sr, rank) * g.inv_sx;  // back to the lane the neighbour came from; the scale is a power of two
-}
-
-// true: the reference's distance of row nb is certainly above `worst` (see above).  xs = |x|^2 as cached, S = hnsw_half_dots
-__device__ __forceinline__ bool hnsw_half_rejects(const HnswDev &g, float S, float xs, float qsq, float worst) {
-    constexpr float u = 0x1p-24f;
-    const float nx = sqrtf(xs) * 1.001f, nq = sqrtf(qsq) * 1.001f;  // (cached norms: strict folds, relative error gamma_d << 1e-3)
-    const float dxa = fminf(g.dx_abs, g.dx_rel * nx);
-    const float B = 1.002f * (2.0f * float(g.dim + 2) * u * nx * nq + dxa * nq);
-    float a, E;
-    if (g.cosine) {
-        const float den = fmaxf(sqrtf(xs) * sqrtf(qsq), 1e-10f);
-        const float t = S / den;
-        a = 1.0f - t;
-        E = 1.01f * (B / den + 2.0f * u * (fabsf(t) + fabsf(a) + B / den + 1.0f));
-    } else {
-        const float s2 = xs + qsq;
-        a = s2 - 2.0f * S;
-        E = 1.01f * (2.0f * B + 2.0f * u * (fabsf(a) + 2.0f * B));
-    }
-    return a - E > worst && E < INFINITY;  // (NaN compares false: such rows take the exact path)
-}
+// (measured: 498k of 3.3M pass at ef = 128).  Once the result list is full an expansion first scores all fresh neighbours from
+// the row-major fp16 image (half_dots32) and drops every row whose reference distance is certainly above the worst result
+// (half_rules_out: a - E > worst  =>  e > worst, so check_candidate and add both fail in the reference too, distance / index
+// ties included since the inequality is strict; tau only moves down while the expansion is replayed).  Rows that survive are
+// scored exactly (hnsw_exact_dists_regs); the counters count every fresh row as before.
 
 template <int R, bool ADC>
 __global__ __launch_bounds__(64, 2) void k_hnsw_search(HnswDev g, const float *__restrict__ Q,
@@ -733,9 +628,9 @@ __global__ __launch_bounds__(64, 2) void k_hnsw_search(HnswDev g, const float *_
                     } else {
                         bool need = fresh;
                         if (g.rows_h != nullptr && tau != PAIR_NONE) {  // (until the result list is full every row is admitted)
-                            const float S = hnsw_half_dots(g, fl, nb, fresh, lane);
+                            const float S = half_dots32(g.rows_h, g.dim, g.inv_sx, fl, nb, fresh, lane);
                             const float xs = g.xsq[nb];
-                            need = fresh && !hnsw_half_rejects(g, S, xs, qsq, f32_from_orderable(uint32_t(tau >> 32)));
+                            need = fresh && !half_rules_out(g.cosine ? MET_COSINE : MET_L2_CACHED, g.dim, S, xs, qsq, g.dx_abs, g.dx_rel, f32_from_orderable(uint32_t(tau >> 32)));
                             n_drop += (uint32_t)__builtin_popcountll(__ballot(fresh && !need));
                             n_half += (uint32_t)__builtin_popcountll(fm);
                             d = INFINITY;  // a dropped row fails check_candidate below, as its exact distance would

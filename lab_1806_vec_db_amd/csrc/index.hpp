@@ -137,6 +137,8 @@ struct IVFState {
     std::vector<uint32_t> offsets;         // k+1
     std::vector<uint32_t> sizes_desc;      // cluster sizes, descending (bounds the candidates of n probes)
     DevBuf d_offsets, d_members;           // u32 [k+1], u32 [n] (ascending id inside a cluster)
+    std::atomic<uint64_t> last_offers{0}, last_kept{0};  // measurement on: offers of the last call / those its pre-pass kept
+    std::atomic<uint32_t> half_overflows{0};  // calls whose half-precision pre-pass kept more offers than its lists hold (4: stop trying)
 };
 
 struct Index {

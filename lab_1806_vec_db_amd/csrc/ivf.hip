@@ -16,6 +16,7 @@
 #include <cstring>
 #include <numeric>
 
+#include "half_rows.hpp"
 #include "pq_hnsw.hpp"
 
 namespace vdb {
@@ -71,6 +72,7 @@ static void ivf_assign_rows(Index &ix, std::vector<uint64_t> &assign) {
 }
 
 static void ivf_install(Index &ix, uint64_t k, const float *centroids, const uint64_t *assign) {
+    ix.ivf.half_overflows = 0;
     VDB_REQUIRE(k >= 1, "The number of centroids should be greater than 0.");  // k_means.rs:45-48
     VDB_REQUIRE(ix.n < (1ull << 32), "ivf: too many rows");
     ivf_clear(ix);
@@ -177,8 +179,85 @@ __global__ __launch_bounds__(256) void k_ivf_candidates(const uint64_t *__restri
     if (threadIdx.x == 0) atomicAdd(n_cand_total, (unsigned long long)base);  // rows scanned for this query (SURVEY 8d bytes)
 }
 
+// ---- certified half-precision pre-pass of the scan (half_rows.hpp) ------------------------------------------------------
+// The scan keeps k of the thousands of rows in the probed clusters, and the replay of ResultSet::add over the offers gives
+// the same set whether or not rows whose distance is strictly above D_k (the k-th smallest distance among the offers) are
+// offered at all: such a row only ever fills a free slot or replaces a worse one, it is evicted before any row at or below
+// D_k is (the evicted pair is the maximum of the set), and whether a row at D_k is admitted depends only on how many rows at
+// or below D_k the set holds at that moment.  So: (1) lo / hi = a -/+ E for every offer from the fp16 image (half the
+// bytes of the f32 rows); (2) T = k-th smallest hi >= D_k (k offers are at or below their own hi <= T); (3) offers with
+// lo > T are certainly above D_k and are dropped, the others keep their order; (4) exact distances and the replay for
+// what is left.  Offers whose approximation is not finite are kept.  The kept list has a fixed capacity; a query that
+// overflows it sends the call back to the plain scan.
+__global__ __launch_bounds__(64) void k_ivf_half_bounds(const uint16_t *__restrict__ rows_h, uint32_t dim, float inv_sx, float dx_abs,
+                                                        float dx_rel, int metric, const float *__restrict__ Q,
+                                                        const float *__restrict__ xsq, const float *__restrict__ qsq,
+                                                        const uint64_t *__restrict__ cand, uint32_t ld, float *__restrict__ lo,
+                                                        float *__restrict__ hi) {
+    extern __shared__ __attribute__((aligned(16))) float ivf_q[];  // [dim]
+    const uint32_t q = blockIdx.y, lane = threadIdx.x;
+    for (uint32_t i = lane; i < dim; i += 64) ivf_q[i] = Q[uint64_t(q) * dim + i];
+    __syncthreads();
+    const float qs = qsq[q];
+#pragma unroll 1
+    for (uint32_t h = 0; h < 2; h++) {  // half_dots32 scores 32 rows per call, one per lane 0..31
+        const uint32_t j = blockIdx.x * 64 + h * 32 + (lane & 31);
+        const bool mine = lane < 32 && j < ld;
+        const uint64_t c = mine ? cand[uint64_t(q) * ld + j] : PAIR_NONE;
+        const bool live = c != PAIR_NONE;
+        const uint32_t nb = live ? uint32_t(c) : 0u;
+        float l = INFINITY, u = INFINITY;  // empty slot: never kept, never counted
+        if (__ballot(live) != 0) {         // wave-uniform
+            const float S = half_dots32(rows_h, dim, inv_sx, ivf_q, nb, live, lane);
+            float a, E;
+            half_approx(metric, dim, S, xsq[nb], qs, dx_abs, dx_rel, a, E);
+            if (live) {
+                const bool fin = E < INFINITY && a - a == 0.0f;
+                l = fin ? a - E : -INFINITY;
+                u = fin ? a + E : INFINITY;
+            }
+        }
+        if (mine) {
+            lo[uint64_t(q) * ld + j] = l;
+            hi[uint64_t(q) * ld + j] = u;
+        }
+    }
+}
+// out[q][0..ld2) = the offers of query q with lo <= T[q], in offer order, PAIR_NONE padded; flags[q] = 1 when they do not fit
+__global__ __launch_bounds__(256) void k_ivf_keep(const uint64_t *__restrict__ cand, uint32_t ld, const float *__restrict__ lo,
+                                                  const float *__restrict__ T, uint64_t *__restrict__ out, uint32_t ld2,
+                                                  uint8_t *__restrict__ flags, unsigned long long *__restrict__ n_kept_total) {
+    __shared__ uint32_t wcnt[4];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const float t = T[q];
+    uint32_t base = 0;
+    for (uint32_t j0 = 0; j0 < ld; j0 += 256) {  // block-uniform
+        const uint32_t j = j0 + tid;
+        const uint64_t c = j < ld ? cand[uint64_t(q) * ld + j] : PAIR_NONE;
+        const bool keep = c != PAIR_NONE && lo[uint64_t(q) * ld + j] <= t;
+        const uint64_t m = __ballot(keep);
+        if (lane == 0) wcnt[wave] = (uint32_t)__builtin_popcountll(m);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4; w++) {
+            before += w < wave ? wcnt[w] : 0u;
+            total += wcnt[w];
+        }
+        const uint32_t pos = base + before + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1));
+        if (keep && pos < ld2) out[uint64_t(q) * ld2 + pos] = c;
+        base += total;
+        __syncthreads();
+    }
+    for (uint32_t j = base + tid; j < ld2; j += 256) out[uint64_t(q) * ld2 + j] = PAIR_NONE;
+    if (tid == 0 && base > ld2) flags[q] = 1;
+    if (tid == 0) atomicAdd(n_kept_total, (unsigned long long)(base < ld2 ? base : ld2));  // rows the exact stage fetches
+}
+static int g_ivf_half = 1;  // 1 auto, 0 off
+void ivf_set_half(int v) { g_ivf_half = v; }
+
 void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t n_probes,
-                    uint64_t *d_idx, float *d_dist, uint64_t *d_cnt) {
+                    uint64_t *d_idx, float *d_dist, uint64_t *d_cnt, bool use_half) {
     hipStream_t s = ws.stream;
     IVFState &iv = ix.ivf;
     if (nq == 0) return;
@@ -194,7 +273,7 @@ void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uin
         const uint64_t qs = std::max<uint64_t>(1, (size_t(2) << 30) / (std::max<uint64_t>(b, 64) * 16));
         if (nq > qs) {
             for (uint64_t q0 = 0; q0 < nq; q0 += qs)
-                ivf_knn_device(ix, ws, d_q + q0 * ix.dim, std::min(qs, nq - q0), k, n_probes, d_idx + q0 * k, d_dist + q0 * k, d_cnt + q0);
+                ivf_knn_device(ix, ws, d_q + q0 * ix.dim, std::min(qs, nq - q0), k, n_probes, d_idx + q0 * k, d_dist + q0 * k, d_cnt + q0, use_half);
             return;
         }
     }
@@ -228,24 +307,72 @@ void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uin
     ws.keys_b.reserve(nq * ld * sizeof(uint64_t));
     ws.misc.reserve(64);
     unsigned long long *d_ncand = ws.misc.as<unsigned long long>();
-    VDB_HIP(hipMemsetAsync(d_ncand, 0, sizeof(unsigned long long), s));
+    VDB_HIP(hipMemsetAsync(d_ncand, 0, 2 * sizeof(unsigned long long), s));  // [0] offers, [1] offers kept by the pre-pass
     hipLaunchKernelGGL(k_ivf_candidates, dim3((unsigned)nq), dim3(256), 0, s, d_probes, capp, (uint32_t)np,
                        iv.d_offsets.as<uint32_t>(), iv.d_members.as<uint32_t>(), ld, ws.keys_a.as<uint64_t>(), d_ncand);
+    // (2b) the certified half-precision pre-pass: only the offers that may be among the k nearest go on
+    const uint64_t *cand_keys = ws.keys_a.as<uint64_t>();
+    uint64_t *exact_keys = ws.keys_b.as<uint64_t>();
+    uint32_t ldx = ld;
+    const uint32_t ld2 = (uint32_t)((std::min<uint64_t>(ld, std::max<uint64_t>(256, 16ull * ksel)) + 63) & ~63ull);
+    const bool half = use_half && g_ivf_half && iv.half_overflows < 4 && (ld <= select_tau_max_n() || ksel <= 64) && ld2 < ld && ksel >= 1 &&  // (k_select_tau_small takes any length)
+                      ix.ensure_rows_h(ws);
+    double scan_bytes_per_row = double(ix.dim) * sizeof(float) + sizeof(float);
+    uint8_t *flags = nullptr;
+    if (half) {
+        const int metric = ix.dist == 0 ? MET_L2_DIRECT : MET_COSINE;
+        ws.dense.reserve(2 * nq * ld * sizeof(float));
+        ws.qaux.reserve(nq * sizeof(float));
+        ws.lists.reserve(2 * nq * ld2 * sizeof(uint64_t));
+        float *d_lo = ws.dense.as<float>(), *d_hi = d_lo + nq * ld, *d_T = ws.qaux.as<float>();
+        uint64_t *kept = ws.lists.as<uint64_t>();
+        flags = static_cast<uint8_t *>(ws.pinned(nq));
+        std::memset(flags, 0, nq);
+        ix.prof_begin(ws, "ivf_half", 0.0);
+        hipLaunchKernelGGL(k_ivf_half_bounds, dim3(ld / 64, (unsigned)nq), dim3(64), ix.dim * sizeof(float), s, ix.d_rows_h.as<uint16_t>(),
+                           (uint32_t)ix.dim, 1.0f / ix.half_sx(), ix.half_dx_abs, ix.half_dx_rel, metric, d_q, ix.d_sq.as<float>(),
+                           ws.qsq.as<float>(), cand_keys, ld, d_lo, d_hi);
+        ix.prof_end(ws);
+        launch_select_tau(d_hi, ld, ld, (uint32_t)nq, (uint32_t)nq, ksel, d_T, s);
+        hipLaunchKernelGGL(k_ivf_keep, dim3((unsigned)nq), dim3(256), 0, s, cand_keys, ld, d_lo, d_T, kept, ld2, flags, d_ncand + 1);
+        cand_keys = kept;
+        exact_keys = kept + nq * ld2;
+        ldx = ld2;
+    }
     ix.prof_begin(ws, "ivf_rerank", 0.0);
     // (3) exact distances in offer order, (4) ResultSet::add replay, sorted output (into_sorted_vec, :153)
     launch_rerank(ix.d_rows.as<float>(), (uint32_t)ix.dim, d_q, (uint32_t)nq, ix.dist == 0 ? MET_L2_DIRECT : MET_COSINE,
-                  ix.d_sq.as<float>(), ws.qsq.as<float>(), ws.keys_a.as<uint64_t>(), ws.keys_b.as<uint64_t>(), ld, ld, s);
+                  ix.d_sq.as<float>(), ws.qsq.as<float>(), cand_keys, exact_keys, ldx, ldx, s);
     ix.prof_end(ws);
     if (k > ksel) {
         VDB_HIP(hipMemsetAsync(d_idx, 0, nq * k * sizeof(uint64_t), s));
         VDB_HIP(hipMemsetAsync(d_dist, 0, nq * k * sizeof(float), s));
     }
-    pq_resort_finalize(ix, ws, ws.keys_b.as<uint64_t>(), ld, ld, nq, ksel, k, ix.id_offset, d_idx, d_dist, d_cnt);
-    if (!ws.pending.empty()) {  // measurement on: the scan's algorithmic bytes = scanned rows x (dim*4 + 4), known only now
-        unsigned long long total = 0;
-        VDB_HIP(hipMemcpyAsync(&total, d_ncand, sizeof(total), hipMemcpyDeviceToHost, s));
+    pq_resort_finalize(ix, ws, exact_keys, ldx, ldx, nq, ksel, k, ix.id_offset, d_idx, d_dist, d_cnt);
+    if (half) {  // a query whose kept offers did not fit: the whole call again with the plain scan (rare; the index stops trying after four)
         VDB_SYNC(s);
-        ws.pending.back().bytes += double(total) * (double(ix.dim) * sizeof(float) + sizeof(float));
+        bool over = false;
+        for (uint64_t q = 0; q < nq; q++) over |= flags[q] != 0;
+        if (over) {
+            iv.half_overflows++;
+            ivf_knn_device(ix, ws, d_q, nq, k, n_probes, d_idx, d_dist, d_cnt, false);
+            return;
+        }
+    }
+    if (!ws.pending.empty()) {  // measurement on: the scan's algorithmic bytes = scanned rows x (dim*4 + 4), known only now
+        unsigned long long total[2] = {0, 0};
+        VDB_HIP(hipMemcpyAsync(total, d_ncand, sizeof(total), hipMemcpyDeviceToHost, s));
+        VDB_SYNC(s);
+        // (with the pre-pass the two records split the bytes asked for: fp16 rows + norms for every offer, f32 rows for the kept
+        // ones; SURVEY 8(d)'s figure stays offers x (dim*4 + 4))
+        if (half && ws.pending.size() >= 2) {
+            ws.pending[ws.pending.size() - 2].bytes += double(total[0]) * (double(ix.dim) * sizeof(uint16_t) + sizeof(float));
+            ws.pending.back().bytes += double(total[1]) * scan_bytes_per_row;
+        } else {
+            ws.pending.back().bytes += double(total[0]) * scan_bytes_per_row;
+        }
+        iv.last_offers = total[0];
+        iv.last_kept = half ? total[1] : total[0];
     }
 }
 

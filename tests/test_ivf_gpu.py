@@ -91,3 +91,46 @@ def test_ivf_attach_external_and_invalidation(mods):
         ix.ivf_knn(qs[0], 3)
     with pytest.raises(vdb.VdbError):
         ix.ivf_build(0)
+
+
+@pytest.mark.parametrize("dist,kind", [("l2sqr", 0), ("cosine", 1)])
+@pytest.mark.parametrize("data", ["gist", "cancel", "decades", "dups"])
+def test_ivf_half_prepass_keeps_results(mods, data, dist, kind):
+    """The scan's certified half-precision pre-pass (ivf.hip: k_ivf_half_bounds / k_ivf_keep) drops offers that cannot be
+    among the k nearest before the f32 rows are fetched; the ResultSet::add replay over what is left must give the oracle's
+    answer, ties at the cut included (duplicated rows), on the corpora that stress the bound."""
+    vdb, O = mods
+    rng = np.random.default_rng(321)
+    n, dim, nq = 9000, 128, 24
+    if data == "gist":
+        base, qs = gist_like(n, dim=dim, seed=5), gist_like(nq, dim=dim, seed=6)
+    elif data == "cancel":
+        c = rng.standard_normal(dim).astype(np.float32)
+        c *= np.float32(50.0) / np.linalg.norm(c)
+        base = (c[None, :] + np.float32(1e-2) * rng.standard_normal((n, dim))).astype(np.float32)
+        qs = (c[None, :] + np.float32(1e-2) * rng.standard_normal((nq, dim))).astype(np.float32)
+    elif data == "decades":
+        base = (rng.standard_normal((n, dim)) * 10.0 ** rng.uniform(-2, 2, size=(n, 1))).astype(np.float32)
+        qs = (rng.standard_normal((nq, dim)) * 10.0 ** rng.uniform(-2, 2, size=(nq, 1))).astype(np.float32)
+    else:  # every row four times, interleaved: equal distances straddle every cut
+        u = gist_like(n // 4, dim=dim, seed=7)
+        base = np.concatenate([u, u, u, u])
+        qs = gist_like(nq, dim=dim, seed=8)
+    ix = vdb.GpuIndex(dim, dist)
+    ix.batch_add(base)
+    ix.ivf_build(30, train_n=2000, max_iter=5, seed=3)
+    ex = ix.ivf_export()
+    iv = O.IVF(base, ex["centroids"], kind, assign=ex["assign"])
+    for k, npb in ((10, 4), (1, 2), (40, 9)):
+        ix.set_param("ivf_half", 0)
+        try:
+            i0, d0, c0 = ix.ivf_knn(qs, k, npb)
+        finally:
+            ix.set_param("ivf_half", 1)
+        i1, d1, c1 = ix.ivf_knn(qs, k, npb)
+        assert np.array_equal(i0, i1) and np.array_equal(d0, d1) and np.array_equal(c0, c1), (k, npb)
+        for q in range(nq):
+            oi, od = iv.knn(qs[q], k, npb)
+            c = int(c1[q])
+            assert c == len(oi)
+            assert i1[q, :c].tolist() == oi.tolist() and np.array_equal(d1[q, :c], od), (k, npb, q)
