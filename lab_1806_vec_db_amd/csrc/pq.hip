@@ -480,6 +480,13 @@ struct Adc16Args {
 // the packed nibble offsets, plus bit 16 for the groups beyond the 16-bit immediate range).  NW = 0: runtime count,
 // one extra add per lookup.  (Shift + mask + base add per lookup made the loop VALU-bound: 154 vector instructions
 // per 32 lookups against 128 LDS cycles.)
+// Early exit of rows that are out (L2Sqr: the running sums only grow; once all eight are above their thresholds in every lane of
+// a wave, the wave's 64 rows cannot qualify).  Exact, but on the bench corpus (1M low-rank gist-like rows, 4-bit m = 320, ef =
+// 100) it LOSES: 6.04 instead of 5.45 ms per 1000 queries -- the smallest of a wave's 512 (row, query) sums crosses its
+// threshold too late for the skipped lookups to pay for one check per code word.  Measurement switch (make EXTRA=-DADC16_ABANDON=1).
+#ifndef ADC16_ABANDON
+#define ADC16_ABANDON 0
+#endif
 template <int NW, bool COS>
 __global__ __launch_bounds__(1024) void k_pq_adc16(Adc16Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
@@ -560,6 +567,15 @@ __global__ __launch_bounds__(1024) void k_pq_adc16(Adc16Args a) {
             cT[b] = f[3];
         }
     }
+    // (ADC16_ABANDON) Tp = T + 1 per 16-bit half, 0 for an unused slot (always "above"), 65535 when T does not fit (never abandoned);
+    // checked after every code word of the second half: one v_pk_max_u16 + compare per register
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    uint32_t Tp[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int32_t t0 = T[2 * i] + 1, t1 = T[2 * i + 1] + 1;
+        Tp[i] = uint32_t(t0 > 65535 ? 65535 : t0) | (uint32_t(t1 > 65535 ? 65535 : t1) << 16);
+    }
     const uint64_t r_begin = uint64_t(blockIdx.x) * a.rows_per_wg;
     const uint64_t r_end = r_begin + a.rows_per_wg < a.n ? r_begin + a.rows_per_wg : a.n;
     const uint32_t nwords = NW ? (uint32_t)NW : a.enc_dim / 16;
@@ -614,8 +630,10 @@ __global__ __launch_bounds__(1024) void k_pq_adc16(Adc16Args a) {
             for (int w = 0; w < NW; w++) cv[w] = cw[w * 64];
             uint4 E[2][4], O[2][4];
             issue(cv[0].x, 0u, 0u, E[0], O[0]);
+            bool done = false;  // wave-uniform: every row of the wave is out (a `break` would keep the loop from unrolling)
 #pragma unroll
             for (int st = 0; st < 4 * NW; st++) {
+                if (done) continue;
                 if (st + 1 < 4 * NW) {
                     const int w = (st + 1) >> 2, wi = (st + 1) & 3;
                     const uint32_t word = wi == 0 ? cv[w].x : (wi == 1 ? cv[w].y : (wi == 2 ? cv[w].z : cv[w].w));
@@ -625,6 +643,13 @@ __global__ __launch_bounds__(1024) void k_pq_adc16(Adc16Args a) {
                     __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks these reads below the adds of step st)
                 }
                 consume(E[st & 1], O[st & 1]);
+                if (!COS && ADC16_ABANDON && (st & 3) == 3 && st + 1 < 4 * NW && st >= 2 * NW - 1) {
+                    auto above = [](uint32_t acc, uint32_t tp) {
+                        return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, acc), __builtin_bit_cast(u16x2, tp))) == acc;
+                    };
+                    const bool out = !valid || (above(a0, Tp[0]) && above(a1, Tp[1]) && above(a2, Tp[2]) && above(a3, Tp[3]));
+                    done = __ballot(!out) == 0;  // the threshold test below then sees sums that are already above
+                }
             }
         } else {
             uint4 v = cw[0];
