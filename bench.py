@@ -44,6 +44,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_SUSTAINED = None  # (TFLOP/s, GHz) of vdb_mfma_probe in this run
 
 
 def gist_like_gpu(torch, n, dim, seed, device, chunk=131072):
@@ -134,6 +135,15 @@ def flat_roofline(ix, rows, dim, nq):
     if kernel == "flat_half":
         extra["frac_of"] = "operand bytes: the scaled fp16 mirror of the rows (2 B/element) the first pass streams; exact f32 re-rank + certification downstream"
         extra["operand_bytes"] = bpl
+        # the filter is a dense contraction too: 2 flops per (row, column, query slot) with 128 slots per pass
+        tf = passes * rows * ((dim + 63) // 64 * 64) * 128 * 2 / avg_s / 1e12
+        extra["matrix_pipe"] = {"achieved_TFLOPs": round(tf, 1), "nominal_peak_TFLOPs": 2500.0, "frac_of_nominal": round(tf / 2500.0, 4),
+                                "instruction": "v_mfma_f32_16x16x32_f16"}
+        if MFMA_SUSTAINED:
+            extra["matrix_pipe"].update({"sustained_peak_TFLOPs": MFMA_SUSTAINED[0], "clock_GHz_at_sustained_peak": MFMA_SUSTAINED[1],
+                                         "frac_of_sustained": round(tf / MFMA_SUSTAINED[0], 4),
+                                         "note": "sustained peak = vdb_mfma_probe in this run: the same instruction back to back on every SIMD, "
+                                                 "4 waves per SIMD; the chip lowers its clock under that load"})
     else:
         extra["frac_of"] = "SURVEY 8(d) algorithmic bytes (the kernel streams 4 B/element)"
     return hbm_roofline(kernel, p, extra)
@@ -219,6 +229,11 @@ def main():
         from lab_1806_vec_db_amd.index import stream_probe
 
         attainable = round(stream_probe(local_rank, 3_840_000_000, 5), 1)  # before the corpus exists: 3.84 GB of its own
+        global MFMA_SUSTAINED
+        from lab_1806_vec_db_amd.index import mfma_probe
+
+        # the matrix pipe's rate under sustained load on this box (the chip is power-limited well below the nominal 2.5 PFLOP/s)
+        MFMA_SUSTAINED = tuple(round(v, 2) for v in mfma_probe(local_rank, 4, 200_000))
 
     # identical corpus on every rank (same seed), each keeps its row block
     gen = gist_like_gpu if args.data == "gistlike" else gist_lowrank_gpu

@@ -303,6 +303,10 @@ int vdb_prof_enable(vdb_index *idx, int on);
 /* attainable HBM read bandwidth of this box: a pure streaming read of `bytes` (> the 256-MB Infinity Cache)
  * repeated `iters` times, best of two access patterns, in GB/s (1e9 B/s).  Allocates and frees its own buffer. */
 int vdb_stream_probe(int device_id, uint64_t bytes, int iters, double *out_gbps);
+/* matrix-pipe rate of this box under sustained load: v_mfma_f32_16x16x32_f16 (the Flat filter's instruction) issued back to back
+ * by `waves_per_simd` waves on every SIMD, `iters` x 8 independent tiles per wave; dense TFLOP/s of the launch and the shader
+ * clock (GHz) the chip held meanwhile.  Measurement hook. */
+int vdb_mfma_probe(int device_id, int waves_per_simd, int iters, double *out_tflops, double *out_clock_ghz);
 int vdb_prof_reset(vdb_index *idx);
 int vdb_prof_get(vdb_index *idx, const char *kernel, double *total_ms, uint64_t *launches, double *bytes);
 

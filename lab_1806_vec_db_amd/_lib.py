@@ -97,6 +97,7 @@ SIGNATURES = {
     "vdb_sharded_pq_attach": [vp, u64, u64, f32p],
     "vdb_sharded_knn_pq": [vp, f32p, u64, u64, u64, u64, u64p, f32p, u64p],
     "vdb_stream_probe": [C.c_int, u64, C.c_int, f64p],
+    "vdb_mfma_probe": [C.c_int, C.c_int, C.c_int, f64p, f64p],
     "vdb_prof_enable": [vp, C.c_int],
     "vdb_prof_reset": [vp],
     "vdb_prof_get": [vp, C.c_char_p, f64p, u64p, f64p],

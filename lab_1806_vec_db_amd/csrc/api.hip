@@ -879,6 +879,13 @@ int vdb_stream_probe(int device_id, uint64_t bytes, int iters, double *out_gbps)
     *out_gbps = stream_probe(device_id, bytes, iters);
     VDB_API_END
 }
+int vdb_mfma_probe(int device_id, int waves_per_simd, int iters, double *out_tflops, double *out_clock_ghz) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(out_tflops && out_clock_ghz, "null out");
+    require_gpu();
+    mfma_probe(device_id, waves_per_simd, iters, out_tflops, out_clock_ghz);
+    VDB_API_END
+}
 int vdb_prof_enable(vdb_index *idx, int on) {
     VDB_API_BEGIN
     VDB_REQUIRE(idx, "null index");

@@ -100,4 +100,75 @@ double stream_probe(int device, uint64_t bytes, int iters) {
     return best;
 }
 
+// ---- matrix-pipe rate of THIS box under sustained load ------------------------------------------------------------------
+// v_mfma_f32_16x16x32_f16 (the Flat filter's instruction) issued back to back from `waves_per_simd` waves per SIMD on
+// every CU, 8 independent accumulator tiles per wave: TFLOP/s over the whole launch and the shader clock the chip held
+// meanwhile (s_memtime cycles of one wave over the event time).  Measurement hook only.
+typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
+typedef float pf32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_probe_mfma(uint32_t iters, float *out, unsigned long long *cycles) {
+    pf32x4 acc[8];
+    pf16x8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        a[i] = (_Float16)(float(threadIdx.x & 7) * 0.125f + float(i));
+        b[i] = (_Float16)(float(threadIdx.x & 3) * 0.25f - float(i));
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) acc[t] = (pf32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned long long c0 = clock64();
+    for (uint32_t it = 0; it < iters; it++) {
+#pragma unroll
+        for (int t = 0; t < 8; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[t], 0, 0, 0);
+    }
+    const unsigned long long c1 = clock64();
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; t++) sum += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+    if (sum == 12345.678f) out[0] = sum;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cycles[0] = c1 - c0;
+}
+void mfma_probe(int device, int waves_per_simd, int iters, double *tflops, double *clock_ghz) {
+    VDB_HIP(hipSetDevice(device));
+    VDB_REQUIRE(waves_per_simd >= 1 && waves_per_simd <= 8 && iters >= 1 && iters <= (1 << 24), "mfma probe: waves_per_simd in 1..8, iters in 1..2^24");
+    hipDeviceProp_t prop;
+    VDB_HIP(hipGetDeviceProperties(&prop, device));
+    const unsigned grid = (unsigned)prop.multiProcessorCount * (unsigned)waves_per_simd;  // 4 waves per block: one per SIMD
+    void *out = nullptr, *cyc = nullptr;
+    hipStream_t s = nullptr;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    try {
+        VDB_HIP(hipMalloc(&out, 64));
+        VDB_HIP(hipMalloc(&cyc, 64));
+        VDB_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        VDB_HIP(hipEventCreate(&ea));
+        VDB_HIP(hipEventCreate(&eb));
+        hipLaunchKernelGGL(k_probe_mfma, dim3(grid), dim3(256), 0, s, (uint32_t)iters, static_cast<float *>(out), static_cast<unsigned long long *>(cyc));
+        VDB_HIP(hipEventRecord(ea, s));
+        hipLaunchKernelGGL(k_probe_mfma, dim3(grid), dim3(256), 0, s, (uint32_t)iters, static_cast<float *>(out), static_cast<unsigned long long *>(cyc));
+        VDB_HIP(hipEventRecord(eb, s));
+        VDB_HIP(hipEventSynchronize(eb));
+        VDB_HIP(hipGetLastError());
+        float ms = 0;
+        VDB_HIP(hipEventElapsedTime(&ms, ea, eb));
+        unsigned long long c = 0;
+        VDB_HIP(hipMemcpy(&c, cyc, sizeof(c), hipMemcpyDeviceToHost));
+        const double flops = double(grid) * 4.0 * double(iters) * 8.0 * (2.0 * 16 * 16 * 32);
+        *tflops = flops / (double(ms) * 1e-3) / 1e12;
+        *clock_ghz = double(c) / (double(ms) * 1e-3) / 1e9;  // (the timed wave runs for all but the launch overhead of the event window)
+    } catch (...) {
+        if (ea) (void)hipEventDestroy(ea);
+        if (eb) (void)hipEventDestroy(eb);
+        if (s) (void)hipStreamDestroy(s);
+        if (out) (void)hipFree(out);
+        if (cyc) (void)hipFree(cyc);
+        throw;
+    }
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+    (void)hipStreamDestroy(s);
+    (void)hipFree(out);
+    (void)hipFree(cyc);
+}
+
 }  // namespace vdb

@@ -444,6 +444,13 @@ def stream_probe(device: int = 0, nbytes: int = 3_840_000_000, iters: int = 5) -
     return float(v.value)
 
 
+def mfma_probe(device: int = 0, waves_per_simd: int = 2, iters: int = 200_000):
+    """(dense fp16 TFLOP/s, shader clock in GHz) of back-to-back v_mfma_f32_16x16x32_f16 on every SIMD of this box."""
+    t, c = C.c_double(), C.c_double()
+    L.check(L.load().vdb_mfma_probe(int(device), int(waves_per_simd), int(iters), C.byref(t), C.byref(c)))
+    return float(t.value), float(c.value)
+
+
 def merge_topk(dists: np.ndarray, ids: np.ndarray, counts: np.ndarray, k: int):
     """Merge per-shard sorted lists [S][nq][k] into the global top-k by (distance, index)."""
     d = _f32(dists)
