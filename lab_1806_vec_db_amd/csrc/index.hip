@@ -440,8 +440,7 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
             d_qmul = d_qscale + nq_pad;
             d_qerr = d_qmul + nq_pad;
             launch_query_prep_h(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, half_sx(), ws.qsq.as<float>(), d_qscale, d_qmul,
-                                d_qerr, d_hits, s);
-            launch_pack_queries_h(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, 8, d_qscale, ws.qfrag_g.p, s);
+                                d_qerr, d_hits, ws.qfrag_g.p, s);  // norms, scales, rounding errors AND the packed fp16 image
         } else {
             launch_mfma_pack_queries_nh(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, 8, ws.qfrag_g.as<float>(), s);
         }
@@ -581,7 +580,7 @@ void Index::flat_debug_keys(Workspace &ws, const float *d_q, uint64_t nq, int ti
     float *d_qscale = ws.qaux.as<float>(), *d_qmul = d_qscale + nq_pad, *d_qerr = d_qmul + nq_pad;
     if (half) {
         launch_query_prep_h(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, half_sx(), ws.qsq.as<float>(), d_qscale, d_qmul, d_qerr,
-                            ws.misc.as<uint32_t>(), s);
+                            ws.misc.as<uint32_t>(), nullptr, s);  // (the stand-alone packing kernel below: the two must agree)
         launch_pack_queries_h(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, 8, d_qscale, ws.qfrag_g.p, s);
     } else {
         launch_row_sqnorm(d_q, nq, (uint32_t)dim, ws.qsq.as<float>(), s);

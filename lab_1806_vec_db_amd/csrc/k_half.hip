@@ -137,7 +137,7 @@ void launch_row_split_err(const float *X, const float *xsq, uint64_t row0, uint6
 __global__ __launch_bounds__(256) void k_query_prep_h(const float *__restrict__ Q, uint32_t nq, uint32_t nq_pad, uint32_t dim,
                                                       float inv_sx, float *__restrict__ qsq, float *__restrict__ qscale,
                                                       float *__restrict__ qmul, float *__restrict__ qerr,
-                                                      uint32_t *__restrict__ hits) {
+                                                      uint32_t *__restrict__ hits, uint4 *__restrict__ qfrag /* null: no image */) {
     extern __shared__ float qp_smem[];  // [4 waves][dim]
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t q = blockIdx.x * 4 + wave;
@@ -191,12 +191,29 @@ __global__ __launch_bounds__(256) void k_query_prep_h(const float *__restrict__ 
         qerr[q] = err;
         hits[q] = 0;
     }
+    if (qfrag != nullptr) {
+        // the query's B-operand image (the layout of k_pack_queries_h with NH = 8: one launch less per step): piece (kb32, kg) =
+        // 8 columns 32 kb + 8 kg, 16 B at [group][kb64][half][sub][16 kg + (q & 15)]; padding queries and columns are zero
+        constexpr uint32_t NH = 8;
+        const uint32_t KB = ((dim + 63) & ~63u) / 32;
+        const float *sq = qp_smem + size_t(wave) * dim;  // (the wave's own writes: ordered)
+        uint4 *dst = qfrag + uint64_t(q / (16 * NH)) * KB * NH * 64;
+        const uint32_t h = (q % (16 * NH)) / 16, r = q & 15;
+        for (uint32_t p = lane; p < KB * 4; p += 64) {
+            const uint32_t kb = p >> 2, kg = p & 3, c = kb * 32 + 8 * kg;
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = (q < nq && c + i < dim) ? sq[c + i] : 0.0f;
+            dst[(((kb >> 1) * NH + h) * 2 + (kb & 1)) * 64 + 16 * kg + r] =
+                pack8h(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), sc);
+        }
+    }
 }
 void launch_query_prep_h(const float *Q, uint32_t nq, uint32_t nq_pad, uint32_t dim, float sx, float *qsq, float *qscale,
-                         float *qmul, float *qerr, uint32_t *hits, hipStream_t s) {
+                         float *qmul, float *qerr, uint32_t *hits, void *qfrag, hipStream_t s) {
     if (nq_pad == 0) return;
     hipLaunchKernelGGL(k_query_prep_h, dim3((nq_pad + 3) / 4), dim3(256), size_t(4) * dim * sizeof(float), s, Q, nq, nq_pad, dim,
-                       1.0f / sx, qsq, qscale, qmul, qerr, hits);
+                       1.0f / sx, qsq, qscale, qmul, qerr, hits, reinterpret_cast<uint4 *>(qfrag));
 }
 
 // Q [nq][dim] -> per group of 16*NH queries a B-operand image [kb64][half][sub 0|1][lane]: 8 fp16 of query

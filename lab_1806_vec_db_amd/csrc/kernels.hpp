@@ -176,7 +176,8 @@ void launch_row_split_err(const float *X, const float *xsq, uint64_t row0, uint6
                           uint32_t *out2 /* [2] float bits: max |dx|^2, max |dx|^2/|x|^2 (atomicMax) */, hipStream_t s);
 void launch_rows_to_half(const float *X, uint64_t count, float sx, uint16_t *H, hipStream_t s);
 void launch_query_prep_h(const float *Q, uint32_t nq, uint32_t nq_pad, uint32_t dim, float sx, float *qsq /* out: |q|^2, strict order */,
-                         float *qscale, float *qmul, float *qerr, uint32_t *hits /* zeroed */, hipStream_t s);
+                         float *qscale, float *qmul, float *qerr, uint32_t *hits /* zeroed */,
+                         void *qfrag /* non-null: also write the query image of launch_pack_queries_h(.., NH = 8, ..) */, hipStream_t s);
 void launch_pack_queries_h(const float *Q, uint32_t nq, uint32_t nq_cover, uint32_t dim, uint32_t NH, const float *qscale,
                            void *qfrag, hipStream_t s);
 void launch_mfma_pack_queries_nh(const float *Q, uint32_t nq, uint32_t nq_cover, uint32_t dim, uint32_t NH, float *qfrag,
