@@ -290,9 +290,12 @@ def main():
 
     def step():
         if wl == "flat":
-            ix.flat_knn_device(queries.data_ptr(), nq, k, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr())
+            # the step's send block (two rotate: the all-gather + merge of step i run on torch's stream under the search of step
+            # i+1, which the library issues on its own stream; everything is complete at the fence that ends the timed region)
+            b_idx, b_dist, b_cnt = ex.begin_step()
+            ix.flat_knn_device(queries.data_ptr(), nq, k, b_idx.data_ptr(), b_dist.data_ptr(), b_cnt.data_ptr())
             if host_xchg:
-                return allgather_merge(o_idx.cpu(), o_dist.cpu(), o_cnt.cpu(), k)
+                return allgather_merge(b_idx.cpu(), b_dist.cpu(), b_cnt.cpu(), k)
             return ex.exchange_merge(ix)
         if wl == "pq_flat":
             if world == 1:

@@ -229,6 +229,12 @@ int vdb_merge_topk_gathered(vdb_index *idx, const void *d_gathered, uint64_t blo
                             uint64_t off_dists, uint64_t off_counts, uint64_t n_shards, uint64_t nq, uint64_t k,
                             void *d_out_idx, void *d_out_dist, void *d_out_count, void *stream);
 
+/* the same, ENQUEUED on `stream` (the stream the all-gather was issued on) without any host synchronisation, k <= 64: the
+ * exchange of one step can then run under the next step's search (outputs are valid once `stream` has passed this point) */
+int vdb_merge_topk_gathered_async(vdb_index *idx, const void *d_gathered, uint64_t block_bytes, uint64_t off_ids,
+                                  uint64_t off_dists, uint64_t off_counts, uint64_t n_shards, uint64_t nq, uint64_t k,
+                                  void *d_out_idx, void *d_out_dist, void *d_out_count, void *stream);
+
 /* ---- IVFIndex (index_algorithm/ivf_index.rs) ------------------------------
  * from_vec_set (:66-118): k-means over all columns on train_n sampled rows (0 = all; host, RNG = splitmix64(seed),
  * parity unpinned), then every row joins its nearest centroid (k_means.rs:40-57: CandidatePair order) -- computed on

@@ -83,6 +83,7 @@ SIGNATURES = {
     "vdb_merge_topk": [f32p, u64p, u64p, u64, u64, u64, u64p, f32p, u64p],
     "vdb_merge_topk_device": [vp, vp, vp, vp, u64, u64, u64, vp, vp, vp, vp],
     "vdb_merge_topk_gathered": [vp, vp, u64, u64, u64, u64, u64, u64, u64, vp, vp, vp, vp],
+    "vdb_merge_topk_gathered_async": [vp, vp, u64, u64, u64, u64, u64, u64, u64, vp, vp, vp, vp],
     "vdb_ctx_create": [intp, C.c_int, C.POINTER(vp)],
     "vdb_ctx_unique_id": [vp, u64],
     "vdb_ctx_create_rank": [C.c_int, vp, C.c_int, C.c_int, C.POINTER(vp)],

@@ -871,6 +871,25 @@ int vdb_merge_topk_gathered(vdb_index *idx, const void *d_gathered, uint64_t blo
     VDB_API_END
 }
 
+int vdb_merge_topk_gathered_async(vdb_index *idx, const void *d_gathered, uint64_t block_bytes, uint64_t off_ids,
+                                  uint64_t off_dists, uint64_t off_counts, uint64_t n_shards, uint64_t nq, uint64_t k,
+                                  void *d_out_idx, void *d_out_dist, void *d_out_count, void *stream) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx && d_gathered && d_out_idx && d_out_dist && d_out_count, "null argument");
+    VDB_REQUIRE((off_ids & 7) == 0 && (off_counts & 7) == 0 && (off_dists & 3) == 0 && (block_bytes & 7) == 0,
+                "misaligned block layout");
+    VDB_REQUIRE(k >= 1 && k <= 64, "the enqueued merge serves k in 1..64 (one launch, no scratch); use vdb_merge_topk_gathered beyond");
+    VDB_REQUIRE(nq <= 65535 && n_shards <= 65535, "too many queries or shards for one call");
+    idx->ix.use_device();
+    const char *g = static_cast<const char *>(d_gathered);
+    launch_merge_shards64(reinterpret_cast<const float *>(g + off_dists), reinterpret_cast<const uint64_t *>(g + off_ids),
+                          reinterpret_cast<const uint64_t *>(g + off_counts), block_bytes, block_bytes, block_bytes, (uint32_t)n_shards,
+                          (uint32_t)nq, (uint32_t)k, static_cast<uint64_t *>(d_out_idx), static_cast<float *>(d_out_dist),
+                          static_cast<uint64_t *>(d_out_count), static_cast<hipStream_t>(stream));
+    VDB_HIP(hipGetLastError());
+    VDB_API_END
+}
+
 // ---- measurement hooks --------------------------------------------------------------------------------
 int vdb_stream_probe(int device_id, uint64_t bytes, int iters, double *out_gbps) {
     VDB_API_BEGIN

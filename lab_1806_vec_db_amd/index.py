@@ -244,6 +244,13 @@ class GpuIndex:
                                                   n_shards, nq, k, L.vp(out_idx), L.vp(out_dist), L.vp(out_cnt),
                                                   L.vp(stream)))
 
+    def merge_topk_gathered_async(self, d_gathered: int, block_bytes: int, off_ids: int, off_dists: int, off_counts: int,
+                                  n_shards: int, nq: int, k: int, out_idx: int, out_dist: int, out_cnt: int, stream: int):
+        """vdb_merge_topk_gathered_async: the merge enqueued on `stream`, no host synchronisation (k <= 64)"""
+        L.check(self._lib.vdb_merge_topk_gathered_async(self._h, L.vp(d_gathered), block_bytes, off_ids, off_dists, off_counts,
+                                                        n_shards, nq, k, L.vp(out_idx), L.vp(out_dist), L.vp(out_cnt),
+                                                        L.vp(stream)))
+
     def flat_shortlist_keys(self, queries, tier: int):
         """approximate keys of the Flat shortlist pass for every row (vdb_flat_shortlist_keys): (keys [nq, len], qsq [nq],
         qerr [nq], dict(dx_abs, dx_rel, xsq_max, xsq_min_pos)); tier 0 = fp16 operands, 1 = split-bf16 operands"""

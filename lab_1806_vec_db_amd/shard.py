@@ -137,7 +137,13 @@ class ShardExchange:
 
     One rank's block = [nq*k ids i64 | nq*k distances f32 | pad | nq counts i64] in ONE uint8 tensor: the search
     writes straight into typed views of it (no packing kernels), `all_gather_into_tensor` moves the block (one RCCL
-    collective per step), and `vdb_merge_topk_gathered` reads the S blocks of the receive buffer in place.
+    collective per step), and the merge reads the S blocks of the receive buffer in place.
+
+    The exchange is pipelined: there are two sets of buffers, and for k <= 64 the collective and the merge of a step are only
+    ENQUEUED on torch's current stream (`vdb_merge_topk_gathered_async`, no host synchronisation), so they run under the next
+    step's search, which the library issues on its own stream.  `begin_step()` hands out the buffers of the step and first
+    waits until the exchange that used them two steps ago is done; the merged results of a step are valid once torch's stream
+    has passed its exchange (the caller's fence, or `wait()`).
     """
 
     def __init__(self, nq: int, k: int, device, world: int, force: bool = False):
@@ -151,27 +157,62 @@ class ShardExchange:
         self.off_dists = nq * k * 8
         self.off_counts = (nq * k * 12 + 7) // 8 * 8
         self.block = self.off_counts + nq * 8
-        self.send = torch.zeros(self.block, dtype=torch.uint8, device=device)
-        self.idx = self.send[self.off_ids:self.off_dists].view(torch.int64).view(nq, k)
-        self.dist = self.send[self.off_dists:self.off_dists + nq * k * 4].view(torch.float32).view(nq, k)
-        self.cnt = self.send[self.off_counts:self.block].view(torch.int64)
-        if world > 1 or force:
-            self.recv = torch.empty(world * self.block, dtype=torch.uint8, device=device)
-            self.m_idx = torch.empty((nq, k), dtype=torch.int64, device=device)
-            self.m_dist = torch.empty((nq, k), dtype=torch.float32, device=device)
-            self.m_cnt = torch.empty((nq,), dtype=torch.int64, device=device)
+        self.active = world > 1 or force
+        self.depth = 2 if self.active else 1
+        self._bufs = []
+        for _ in range(self.depth):
+            send = torch.zeros(self.block, dtype=torch.uint8, device=device)
+            b = {"send": send,
+                 "idx": send[self.off_ids:self.off_dists].view(torch.int64).view(nq, k),
+                 "dist": send[self.off_dists:self.off_dists + nq * k * 4].view(torch.float32).view(nq, k),
+                 "cnt": send[self.off_counts:self.block].view(torch.int64), "event": None}
+            if self.active:
+                b["recv"] = torch.empty(world * self.block, dtype=torch.uint8, device=device)
+                b["m_idx"] = torch.empty((nq, k), dtype=torch.int64, device=device)
+                b["m_dist"] = torch.empty((nq, k), dtype=torch.float32, device=device)
+                b["m_cnt"] = torch.empty((nq,), dtype=torch.int64, device=device)
+            self._bufs.append(b)
+        self._cur = 0
+        self._set_views()
+
+    def _set_views(self):
+        b = self._bufs[self._cur]
+        self.send, self.idx, self.dist, self.cnt = b["send"], b["idx"], b["dist"], b["cnt"]
+
+    def begin_step(self):
+        """buffers of the next step: (idx, dist, cnt) views the local search writes into"""
+        if self.depth > 1:
+            self._cur = (self._cur + 1) % self.depth
+            ev = self._bufs[self._cur]["event"]
+            if ev is not None:
+                ev.synchronize()  # the exchange that last read / wrote these buffers
+            self._set_views()
+        return self.idx, self.dist, self.cnt
 
     def exchange_merge(self, gpu_index, group=None):
-        """After the local search has filled idx / dist / cnt: returns the merged (idx, dist, cnt) on every rank."""
-        if self.world == 1 and not self.force:
+        """After the local search has filled idx / dist / cnt: the merged (idx, dist, cnt), the same on every rank.  For k <= 64
+        they are valid once torch's current stream has passed this point (see the class comment)."""
+        if not self.active:
             return self.idx, self.dist, self.cnt
         import torch
         import torch.distributed as dist
 
-        dist.all_gather_into_tensor(self.recv, self.send, group=group)
-        # the collective is ordered on torch's current stream; the merge waits for that stream itself (one host
-        # synchronisation per exchange, inside the library call)
-        gpu_index.merge_topk_gathered(self.recv.data_ptr(), self.block, self.off_ids, self.off_dists, self.off_counts,
-                                      self.world, self.nq, self.k, self.m_idx.data_ptr(), self.m_dist.data_ptr(),
-                                      self.m_cnt.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
-        return self.m_idx, self.m_dist, self.m_cnt
+        b = self._bufs[self._cur]
+        dist.all_gather_into_tensor(b["recv"], b["send"], group=group)
+        stream = torch.cuda.current_stream()
+        args = (b["recv"].data_ptr(), self.block, self.off_ids, self.off_dists, self.off_counts, self.world, self.nq, self.k,
+                b["m_idx"].data_ptr(), b["m_dist"].data_ptr(), b["m_cnt"].data_ptr())
+        if self.k <= 64:
+            gpu_index.merge_topk_gathered_async(*args, stream=stream.cuda_stream)
+            if b["event"] is None:
+                b["event"] = torch.cuda.Event()
+            b["event"].record(stream)
+        else:  # the scratch-list merge: waits for the collective's stream itself and returns synchronised
+            gpu_index.merge_topk_gathered(*args, stream=stream.cuda_stream)
+        return b["m_idx"], b["m_dist"], b["m_cnt"]
+
+    def wait(self):
+        """host wait for every enqueued exchange"""
+        for b in self._bufs:
+            if b["event"] is not None:
+                b["event"].synchronize()

@@ -418,3 +418,60 @@ def test_merge_topk_gathered_blocks(mods):
     for q in range(nq):
         oi, od = O.flat_knn(base, qs[q], k)
         assert hi[q].tolist() == oi.tolist() and np.array_equal(hd[q], od)
+
+
+def test_merge_topk_gathered_async_and_pipelined_exchange(mods):
+    """vdb_merge_topk_gathered_async enqueues the same merge on the caller's stream without a host synchronisation; the
+    pipelined ShardExchange (two rotating sets of buffers, exchange of step i under the search of step i+1) returns, for
+    every step, what the synchronous merge returns."""
+    import torch
+    vdb, O = mods
+    from lab_1806_vec_db_amd.shard import ShardExchange
+    rng = np.random.default_rng(13)
+    n, dim, nq, k = 20000, 64, 130, 10
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    ix = vdb.GpuIndex(dim, "l2sqr")
+    ix.batch_add(base)
+    dev = torch.device("cuda", 0)
+    ex = ShardExchange(nq, k, dev, 1)
+    qsets = [torch.from_numpy(rng.standard_normal((nq, dim)).astype(np.float32)).cuda() for _ in range(5)]
+    # (a) the enqueued merge equals the synchronous one on the same (one-block) receive buffer
+    ix.flat_knn_device(qsets[0].data_ptr(), nq, k, ex.idx.data_ptr(), ex.dist.data_ptr(), ex.cnt.data_ptr())
+    outs = [[torch.zeros((nq, k), dtype=torch.int64, device=dev), torch.zeros((nq, k), dtype=torch.float32, device=dev),
+             torch.zeros((nq,), dtype=torch.int64, device=dev)] for _ in range(2)]
+    args = (ex.send.data_ptr(), ex.block, ex.off_ids, ex.off_dists, ex.off_counts, 1, nq, k)
+    ix.merge_topk_gathered(*args, *[t.data_ptr() for t in outs[0]])
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ix.merge_topk_gathered_async(*args, *[t.data_ptr() for t in outs[1]], stream=st.cuda_stream)
+    st.synchronize()
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    # (b) rotating buffers: every step's results stay intact while the next step runs
+    class OneRank(ShardExchange):  # the exchange of a single "rank" without a process group: the gathered buffer IS the send block
+        def exchange_merge(self, gpu_index, group=None):
+            b = self._bufs[self._cur]
+            b["recv"].copy_(b["send"])
+            stream = torch.cuda.current_stream()
+            gpu_index.merge_topk_gathered_async(b["recv"].data_ptr(), self.block, self.off_ids, self.off_dists, self.off_counts, 1,
+                                                self.nq, self.k, b["m_idx"].data_ptr(), b["m_dist"].data_ptr(), b["m_cnt"].data_ptr(),
+                                                stream=stream.cuda_stream)
+            if b["event"] is None:
+                b["event"] = torch.cuda.Event()
+            b["event"].record(stream)
+            return b["m_idx"], b["m_dist"], b["m_cnt"]
+    px = OneRank(nq, k, dev, 1, force=True)
+    got = []
+    for dq in qsets:
+        bi, bd, bc = px.begin_step()
+        ix.flat_knn_device(dq.data_ptr(), nq, k, bi.data_ptr(), bd.data_ptr(), bc.data_ptr())
+        mi, md, mc = px.exchange_merge(ix)
+        got.append((mi, md, mc))
+        if len(got) >= 2:  # the previous step's results are complete by now (its buffers are reused only at the NEXT begin_step)
+            px._bufs[(px._cur + 1) % 2]["event"].synchronize()
+            pi, pd, _ = got[-2]
+            ref_i, ref_d = ix.flat_knn(qsets[len(got) - 2].cpu().numpy(), k)[:2]
+            assert np.array_equal(pi.cpu().numpy(), ref_i.astype(np.int64)) and np.array_equal(pd.cpu().numpy(), ref_d)
+    px.wait()
+    ref_i, ref_d = ix.flat_knn(qsets[-1].cpu().numpy(), k)[:2]
+    assert np.array_equal(got[-1][0].cpu().numpy(), ref_i.astype(np.int64)) and np.array_equal(got[-1][1].cpu().numpy(), ref_d)
