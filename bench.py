@@ -44,7 +44,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-MFMA_SUSTAINED = None  # (TFLOP/s, GHz) of vdb_mfma_probe in this run
 
 
 def gist_like_gpu(torch, n, dim, seed, device, chunk=131072):
@@ -139,11 +138,6 @@ def flat_roofline(ix, rows, dim, nq):
         tf = passes * rows * ((dim + 63) // 64 * 64) * 128 * 2 / avg_s / 1e12
         extra["matrix_pipe"] = {"achieved_TFLOPs": round(tf, 1), "nominal_peak_TFLOPs": 2500.0, "frac_of_nominal": round(tf / 2500.0, 4),
                                 "instruction": "v_mfma_f32_16x16x32_f16"}
-        if MFMA_SUSTAINED:
-            extra["matrix_pipe"].update({"sustained_peak_TFLOPs": MFMA_SUSTAINED[0], "clock_GHz_at_sustained_peak": MFMA_SUSTAINED[1],
-                                         "frac_of_sustained": round(tf / MFMA_SUSTAINED[0], 4),
-                                         "note": "sustained peak = vdb_mfma_probe in this run: the same instruction back to back on every SIMD, "
-                                                 "4 waves per SIMD; the chip lowers its clock under that load"})
     else:
         extra["frac_of"] = "SURVEY 8(d) algorithmic bytes (the kernel streams 4 B/element)"
     return hbm_roofline(kernel, p, extra)
@@ -229,11 +223,6 @@ def main():
         from lab_1806_vec_db_amd.index import stream_probe
 
         attainable = round(stream_probe(local_rank, 3_840_000_000, 5), 1)  # before the corpus exists: 3.84 GB of its own
-        global MFMA_SUSTAINED
-        from lab_1806_vec_db_amd.index import mfma_probe
-
-        # the matrix pipe's rate under sustained load on this box (the chip is power-limited well below the nominal 2.5 PFLOP/s)
-        MFMA_SUSTAINED = tuple(round(v, 2) for v in mfma_probe(local_rank, 4, 200_000))
 
     # identical corpus on every rank (same seed), each keeps its row block
     gen = gist_like_gpu if args.data == "gistlike" else gist_lowrank_gpu
@@ -440,6 +429,16 @@ def main():
         del host_base
         legs.update(legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable))
         out["legs"] = legs
+    mp = (out.get("roofline") or {}).get("matrix_pipe")
+    if mp is not None and world == 1:
+        # the matrix pipe's rate under sustained load on this box (the chip is power-limited well below the nominal 2.5 PFLOP/s);
+        # measured AFTER every timed region: half a second of nothing but MFMAs is not what a timed step should start behind
+        from lab_1806_vec_db_amd.index import mfma_probe
+
+        tfl, ghz = (round(v, 2) for v in mfma_probe(local_rank, 4, 200_000))
+        mp.update({"sustained_peak_TFLOPs": tfl, "clock_GHz_at_sustained_peak": ghz, "frac_of_sustained": round(mp["achieved_TFLOPs"] / tfl, 4),
+                   "note": "sustained peak = vdb_mfma_probe at the end of this run: the same instruction back to back on every SIMD, "
+                           "4 waves per SIMD; the chip lowers its clock under that load"})
     print(json.dumps(out))
     if world > 1 or force_x:
         dist.destroy_process_group()
