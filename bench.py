@@ -340,21 +340,26 @@ def main():
         # pq_adc: code bytes of one scan = rows x ceil(m*n_bits/8), one scan serves the queries whose LUTs sit side by side
         # in LDS; hnsw: n_dist x (dim*4 + 4) + n_expanded x max_m0*4 counted by the kernel
         kernel = {"pq_flat": "pq_adc", "hnsw": "hnsw", "hnsw_pq": "hnsw", "ivf": "ivf_rerank"}[wl]
-        if wl == "ivf" and ix.prof_get("ivf_half")["launches"]:
-            kernel = "ivf_half"  # the scan's certified pre-pass over the fp16 image is the dominant kernel when it runs
+        if wl == "ivf":  # the scan's certified pre-pass (8-bit tier, fp16 tier) holds the dominant kernel when it runs
+            kernel = next((kn for kn in ("ivf_q8", "ivf_half") if ix.prof_get(kn)["launches"]), kernel)
         roofline = hbm_roofline(kernel, ix.prof_get(kernel))
         if wl == "ivf" and roofline:
-            offers, kept = ix.get_stat("ivf_last_offers"), ix.get_stat("ivf_last_kept")
-            roofline["units_per_launch"] = ("offers x (dim*2 + 4) bytes of the fp16 image (k_ivf_half_bounds); the exact stage then fetches dim*4 "
-                                            "bytes for the offers the pre-pass kept" if kernel == "ivf_half" else "offers x (dim*4 + 4) bytes (k_rerank_t)")
+            offers, kept, kept8 = ix.get_stat("ivf_last_offers"), ix.get_stat("ivf_last_kept"), ix.get_stat("ivf_last_kept_q8")
+            roofline["units_per_launch"] = {"ivf_q8": "offers x (dim + 12) bytes of the 8-bit image (k_ivf_q8_bounds); the fp16 tier reads dim*2 bytes for "
+                                                      "the offers it passes on, the exact stage dim*4 for what is left",
+                                            "ivf_half": "offers x (dim*2 + 4) bytes of the fp16 image (k_ivf_half_bounds); the exact stage then fetches "
+                                                        "dim*4 bytes for the offers the pre-pass kept",
+                                            "ivf_rerank": "offers x (dim*4 + 4) bytes (k_rerank_t)"}[kernel]
             roofline["offers_per_query"] = round(offers / max(q1 - q0, 1), 1)
+            if kernel == "ivf_q8":
+                roofline["kept_by_8bit_tier_per_query"] = round(kept8 / max(q1 - q0, 1), 1)
             roofline["kept_for_exact_stage_per_query"] = round(kept / max(q1 - q0, 1), 1)
-            if kernel == "ivf_half":
-                ex = ix.prof_get("ivf_rerank")
-                roofline["exact_stage"] = {"kernel": "ivf_rerank", "avg_launch_ms": round(ex["ms"] / max(ex["launches"], 1), 4),
-                                           "bytes_per_launch": ex["bytes"] / max(ex["launches"], 1)}
+            later = {"ivf_q8": ("ivf_half", "ivf_rerank"), "ivf_half": ("ivf_rerank",)}.get(kernel, ())
+            if later:
+                roofline["later_stages"] = [{"kernel": kn, "avg_launch_ms": round(ix.prof_get(kn)["ms"] / max(ix.prof_get(kn)["launches"], 1), 4),
+                                             "bytes_per_launch": ix.prof_get(kn)["bytes"] / max(ix.prof_get(kn)["launches"], 1)} for kn in later]
             alg = offers * (dim * 4 + 4)  # SURVEY 8(d)-style figure: every offered row as f32
-            tot_ms = sum(ix.prof_get(kn)["ms"] for kn in ("ivf_half", "ivf_rerank")) / max(ix.prof_get("ivf_rerank")["launches"], 1)
+            tot_ms = sum(ix.prof_get(kn)["ms"] for kn in ("ivf_q8", "ivf_half", "ivf_rerank")) / max(ix.prof_get("ivf_rerank")["launches"], 1)
             roofline["f32_equivalent_GBps"] = round(alg / (tot_ms * 1e-3) / 1e9, 1) if tot_ms > 0 else None
     if roofline and attainable:
         roofline["attainable_peak_GBps"] = attainable

@@ -129,6 +129,8 @@ int vdb_flat_set_mode(vdb_index *idx, int mode);
  *                      queries, where the walk is bound by bytes rather than by latency), 0 off, 2 always
  *   "ivf_half"         the same pre-pass for the IVF probe-list scan (offers that cannot be among the k nearest are dropped before the
  *                      f32 rows are fetched; same results): 1 auto (default), 0 off
+ *   "ivf_q8"           an 8-bit tier in front of it for long probe lists (1 B/element image with a scale and a measured error per row,
+ *                      exact integer dot products): 1 auto (default), 0 off
  *   "hnsw_build_gpu"   candidate phase of batched HNSW builds (vdb_hnsw_build with batch >= 256): 0 auto = the level-0 searches of a
  *                      batch and the distances between its members run on the GPU (same graph as the all-host builder), 1 off
  *   "hnsw_pool_cap"    most live candidates the fast HNSW walk keeps in LDS (it uses min(this, ef + max_m0 + 64); maximum 2048) before a query is handed to
@@ -149,8 +151,8 @@ int vdb_flat_fallback_count(const vdb_index *idx, uint64_t *out);
  *                        pool of the fast walk overflowed),
  *   "hnsw_half_dropped"  of the last HNSW call's distance evaluations (vdb_hnsw_last_stats), the rows its certified
  *                        half-precision pre-pass ruled out without fetching the f32 row,
- *   "ivf_last_offers", "ivf_last_kept"  (while vdb_prof_enable is on) rows the last IVF call offered to its result sets and the
- *                        ones its certified half-precision pre-pass kept for the exact stage,
+ *   "ivf_last_offers", "ivf_last_kept_q8", "ivf_last_kept"  (while vdb_prof_enable is on) rows the last IVF call offered to its result
+ *                        sets, the ones the 8-bit tier passed on (0: tier not run) and the ones that reached the exact stage,
  *   "hbm_bytes_per_row"  resident HBM bytes per row over all per-row buffers (rows, norms, mirrors, PQ codes, level-0 links). */
 int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out);
 

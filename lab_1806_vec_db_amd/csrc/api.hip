@@ -373,6 +373,8 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         hnsw_set_half((int)value);
     else if (n == "ivf_half")
         ivf_set_half((int)value);
+    else if (n == "ivf_q8")
+        ivf_set_q8((int)value);
     else if (n == "hnsw_build_gpu")
         hnsw_set_build_gpu((int)value);
     else if (n == "hnsw_pool_cap")
@@ -436,6 +438,8 @@ int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out) {
         *out = idx->ix.hnsw.last_half_dropped.load();
     else if (n == "ivf_last_offers")
         *out = idx->ix.ivf.last_offers.load();
+    else if (n == "ivf_last_kept_q8")
+        *out = idx->ix.ivf.last_kept_q8.load();
     else if (n == "ivf_last_kept")
         *out = idx->ix.ivf.last_kept.load();
     else if (n == "hbm_bytes_per_row")

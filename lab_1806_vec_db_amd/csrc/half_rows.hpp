@@ -114,21 +114,20 @@ __device__ __forceinline__ float half_dots32(const uint16_t *__restrict__ rows_h
 }
 
 
-// approximate distance `a` of a row with cached |x|^2 = xs against a query with |q|^2 = qsq from S = half_dots32(..), and the
-// bound E (see the header comment); metric: MET_L2_CACHED, MET_L2_DIRECT or MET_COSINE
-__device__ __forceinline__ void half_approx(int metric, uint32_t dim, float S, float xs, float qsq, float dx_abs, float dx_rel, float &a,
-                                            float &E) {
+// approximate distance `a` of a row with cached |x|^2 = xs against a query with |q|^2 = qsq from an approximate dot product S
+// whose distance to the real x.q is at most `op` (the operand term: rounding of the image[s]), and the bound E (see the
+// header comment); metric: MET_L2_CACHED, MET_L2_DIRECT or MET_COSINE
+__device__ __forceinline__ void approx_from_dot(int metric, uint32_t dim, float S, float xs, float qsq, float op, float &a, float &E) {
     constexpr float u = 0x1p-24f;
     const float nx = sqrtf(xs) * 1.001f, nq = sqrtf(qsq) * 1.001f;  // (cached norms: strict folds, relative error gamma_d << 1e-3)
-    const float dxa = fminf(dx_abs, dx_rel * nx);
     if (metric == MET_COSINE) {
-        const float B = 1.002f * (2.0f * float(dim + 2) * u * nx * nq + dxa * nq);
+        const float B = 1.002f * (2.0f * float(dim + 2) * u * nx * nq + op);
         const float den = fmaxf(sqrtf(xs) * sqrtf(qsq), 1e-10f);
         const float t = S / den;
         a = 1.0f - t;
         E = 1.01f * (B / den + 2.0f * u * (fabsf(t) + fabsf(a) + B / den + 1.0f));
     } else if (metric == MET_L2_CACHED) {
-        const float B = 1.002f * (2.0f * float(dim + 2) * u * nx * nq + dxa * nq);
+        const float B = 1.002f * (2.0f * float(dim + 2) * u * nx * nq + op);
         const float s2 = xs + qsq;
         a = s2 - 2.0f * S;
         E = 1.01f * (2.0f * B + 2.0f * u * (fabsf(a) + 2.0f * B));
@@ -136,8 +135,14 @@ __device__ __forceinline__ void half_approx(int metric, uint32_t dim, float S, f
         const float s2 = xs + qsq;
         a = s2 - 2.0f * S;
         const float nn = nx + nq;
-        E = 1.01f * (2.5f * float(dim + 8) * u * nn * nn + 2.0f * dxa * nq);
+        E = 1.01f * (2.5f * float(dim + 8) * u * nn * nn + 2.0f * op);
     }
+}
+// fp16 image, f32 query: op = |dx||q| with the measured |dx| <= min(dx_abs, dx_rel |x|)
+__device__ __forceinline__ void half_approx(int metric, uint32_t dim, float S, float xs, float qsq, float dx_abs, float dx_rel, float &a,
+                                            float &E) {
+    const float nx = sqrtf(xs) * 1.001f, nq = sqrtf(qsq) * 1.001f;
+    approx_from_dot(metric, dim, S, xs, qsq, fminf(dx_abs, dx_rel * nx) * nq, a, E);
 }
 // true: the reference's distance of the row is certainly above `worst`
 __device__ __forceinline__ bool half_rules_out(int metric, uint32_t dim, float S, float xs, float qsq, float dx_abs, float dx_rel,
@@ -145,6 +150,85 @@ __device__ __forceinline__ bool half_rules_out(int metric, uint32_t dim, float S
     float a, E;
     half_approx(metric, dim, S, xs, qsq, dx_abs, dx_rel, a, E);
     return a - E > worst && E < INFINITY;  // (NaN compares false: such rows take the exact path)
+}
+
+
+// ---- 8-bit tier ----------------------------------------------------------------------------------------------------------
+// The IVF scan keeps a dozen of the thousands of rows it is offered, so most offers can be settled from an even smaller
+// image: rows_q8[r][i] = rint(x_i / s_r) in [-127, 127] with one scale s_r = max|x_i| / 127 per row and the MEASURED
+// |dx_r| = |x_r - s_r q8_r| beside it (k_rows_to_q8); the query is quantised the same way per call.  The dot product of
+// the two images is an exact integer (|sum| <= dim * 127^2 < 2^24 for dim <= 1040, exact as f32), so
+// |s_r s_q isum - x.q| <= |dx_r||q| + |x_r||dq| + |dx_r||dq| (Cauchy-Schwarz) + the two roundings of the scaling.
+// q8_dots32: the exact integer sums of up to 32 rows (one per lane 0..31 with fresh == true), 64-B pieces of a row per group of 8
+// lanes, HALF_ROWS_DEPTH + 3 pieces in flight.
+__device__ __forceinline__ int32_t q8_dots32(const int8_t *__restrict__ rows_q8, uint32_t dim, const int8_t *qlds8, uint32_t nb, bool fresh,
+                                             uint32_t lane) {
+    typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+    constexpr int D = HALF_ROWS_DEPTH + 3;
+    const uint32_t nlines = dim / 64, last = nlines - 1;
+    const uint64_t fm = __ballot(fresh);
+    const uint32_t nfresh = (uint32_t)__builtin_popcountll(fm);
+    const uint32_t rank = (uint32_t)__builtin_popcountll(fm & ((1ull << lane) - 1));
+    const uint32_t cnb = (uint32_t)__builtin_amdgcn_ds_permute(int((fresh ? rank : nfresh + (lane - rank)) * 4), int(nb));
+    const uint32_t gg = lane >> 3, jj = lane & 7;
+    const v2u *rp[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t src = 8 * k + gg;
+        const uint32_t nbk = __shfl(cnb, src < nfresh ? src : 0u);
+        rp[k] = reinterpret_cast<const v2u *>(rows_q8 + uint64_t(nbk) * dim) + jj;
+    }
+    v2u buf[D][4];
+    static_for<D>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const uint32_t Li = (uint32_t)i < last ? (uint32_t)i : last;
+#pragma unroll
+        for (int k = 0; k < 4; k++) buf[i][k] = rp[k][Li * 8];
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    int32_t acc[4] = {0, 0, 0, 0};
+    const v2u *q2 = reinterpret_cast<const v2u *>(qlds8) + jj;  // the 8 query columns of this lane's piece
+    for (uint32_t L0 = 0; L0 < nlines; L0 += D) {
+        static_for<D>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const uint32_t L = L0 + i;
+            const uint32_t Lc = L < last ? L : last, Ln = L + D < last ? L + D : last;
+            v2u cur[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) cur[k] = buf[i][k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) buf[i][k] = rp[k][Ln * 8];
+            __builtin_amdgcn_sched_barrier(0);
+            const v2u qq = q2[Lc * 8];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int32_t a = acc[k];
+                a = __builtin_amdgcn_sdot4((int)cur[k].x, (int)qq.x, a, false);
+                a = __builtin_amdgcn_sdot4((int)cur[k].y, (int)qq.y, a, false);
+                acc[k] = L < nlines ? a : acc[k];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        acc[k] += __shfl_xor(acc[k], 1);
+        acc[k] += __shfl_xor(acc[k], 2);
+        acc[k] += __shfl_xor(acc[k], 4);
+    }
+    const uint32_t src = 8 * (lane & 7), kr = (lane >> 3) & 3;
+    const int32_t s0 = __shfl(acc[0], src), s1 = __shfl(acc[1], src), s2 = __shfl(acc[2], src), s3 = __shfl(acc[3], src);
+    const int32_t sr = kr == 0 ? s0 : (kr == 1 ? s1 : (kr == 2 ? s2 : s3));
+    return __shfl(sr, rank);
+}
+// S and its operand term from the integer sum: row scale / error sx, dxr, query scale / error sq, dq
+__device__ __forceinline__ void q8_approx(int metric, uint32_t dim, int32_t isum, float xs, float qsq, float sx, float dxr, float sq, float dq,
+                                          float &a, float &E) {
+    constexpr float u = 0x1p-24f;
+    const float S = (sx * sq) * float(isum);
+    const float nx = sqrtf(xs) * 1.001f, nq = sqrtf(qsq) * 1.001f;
+    const float op = 1.001f * (dxr * nq + nx * dq + dxr * dq) + 4.0f * u * fabsf(S);
+    approx_from_dot(metric, dim, S, xs, qsq, op, a, E);
 }
 
 }  // namespace vdb

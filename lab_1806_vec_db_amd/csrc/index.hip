@@ -132,6 +132,7 @@ void Index::swap_remove(uint64_t i) {
     h_sq.resize(last);
     n = last;
     rows_h_n = 0;  // (rebuilt by the next walk that uses it)
+    rows_q8_n = 0;
     // xsq_max stays an upper bound (certification only needs a bound)
 }
 
@@ -156,6 +157,7 @@ uint64_t Index::hbm_bytes_per_row() const {
         if (half_valid) b += uint64_t(mfma_dim_pad((uint32_t)dim)) * sizeof(uint16_t);
     }
     if (rows_h_n) b += dim * sizeof(uint16_t);
+    if (rows_q8_n) b += dim + 2 * sizeof(float);
     if (pq.present) b += pq.enc_dim * (pq.codes_t_valid ? 2 : 1);
     if (hnsw.present) b += hnsw.max_m0 * sizeof(uint32_t) + sizeof(uint32_t);
     return b;
@@ -214,6 +216,21 @@ bool Index::ensure_rows_h(Workspace &ws) {
     VDB_SYNC(ws.stream);
     rows_h_n = n;
     rows_h_exp = half_exp;
+    return true;
+}
+
+bool Index::ensure_rows_q8(Workspace &ws) {
+    if (elem_u8 || dim % 64 != 0 || dim > 1024 || n == 0) return false;  // (dim * 127^2 < 2^24: the integer sums are exact as f32)
+    std::lock_guard<std::mutex> g(rows_q8_mu);
+    if (rows_q8_n == n) return true;
+    const uint64_t r0 = rows_q8_n > n ? 0 : rows_q8_n;
+    d_rows_q8.grow(n * dim + 16, r0 * dim, ws.stream);
+    d_q8_scale.grow((n + 64) * sizeof(float), r0 * sizeof(float), ws.stream);
+    d_q8_err.grow((n + 64) * sizeof(float), r0 * sizeof(float), ws.stream);
+    launch_rows_to_q8(d_rows.as<float>() + r0 * dim, n - r0, (uint32_t)dim, d_rows_q8.as<int8_t>() + r0 * dim, d_q8_scale.as<float>() + r0,
+                      d_q8_err.as<float>() + r0, ws.stream);
+    VDB_SYNC(ws.stream);
+    rows_q8_n = n;
     return true;
 }
 

@@ -137,6 +137,8 @@ struct IVFState {
     std::vector<uint32_t> offsets;         // k+1
     std::vector<uint32_t> sizes_desc;      // cluster sizes, descending (bounds the candidates of n probes)
     DevBuf d_offsets, d_members;           // u32 [k+1], u32 [n] (ascending id inside a cluster)
+    std::atomic<uint64_t> last_kept_q8{0};  // offers the 8-bit tier passed on to the fp16 tier (0: that tier did not run)
+    std::atomic<uint32_t> q8_overflows{0};
     std::atomic<uint64_t> last_offers{0}, last_kept{0};  // measurement on: offers of the last call / those its pre-pass kept
     std::atomic<uint32_t> half_overflows{0};  // calls whose half-precision pre-pass kept more offers than its lists hold (4: stop trying)
 };
@@ -199,6 +201,12 @@ struct Index {
     int rows_h_exp = 0;
     std::mutex rows_h_mu;
     bool ensure_rows_h(Workspace &ws);  // false: this index has no fp16 image (dim, element type, extreme norms)
+    // 8-bit image of the rows with one scale and one measured error per row (half_rows.hpp, "8-bit tier"): the first tier of
+    // the IVF scan's pre-pass; built on first use, extended after add, dropped by swap_remove
+    DevBuf d_rows_q8, d_q8_scale, d_q8_err;
+    uint64_t rows_q8_n = 0;
+    std::mutex rows_q8_mu;
+    bool ensure_rows_q8(Workspace &ws);
     std::vector<float> h_sq;  // host mirror of d_sq (4 B/row), kept in step by add_rows / swap_remove
     float xsq_max = 0.0f;
     float xsq_min_pos = 3.4e38f;  // smallest positive row |x|^2 seen (cosine certification: clamp check)

@@ -73,6 +73,7 @@ static void ivf_assign_rows(Index &ix, std::vector<uint64_t> &assign) {
 
 static void ivf_install(Index &ix, uint64_t k, const float *centroids, const uint64_t *assign) {
     ix.ivf.half_overflows = 0;
+    ix.ivf.q8_overflows = 0;
     VDB_REQUIRE(k >= 1, "The number of centroids should be greater than 0.");  // k_means.rs:45-48
     VDB_REQUIRE(ix.n < (1ull << 32), "ivf: too many rows");
     ivf_clear(ix);
@@ -223,6 +224,44 @@ __global__ __launch_bounds__(64) void k_ivf_half_bounds(const uint16_t *__restri
         }
     }
 }
+// the same bounds from the 8-bit image (half_rows.hpp, "8-bit tier"): a quarter of the bytes of the f32 rows; the wider bound lets
+// a few dozen offers per query through to the fp16 tier instead of a dozen
+__global__ __launch_bounds__(64) void k_ivf_q8_bounds(const int8_t *__restrict__ rows_q8, const float *__restrict__ row_scale,
+                                                      const float *__restrict__ row_err, uint32_t dim, int metric,
+                                                      const int8_t *__restrict__ Q8, const float *__restrict__ q_scale,
+                                                      const float *__restrict__ q_err, const float *__restrict__ xsq,
+                                                      const float *__restrict__ qsq, const uint64_t *__restrict__ cand, uint32_t ld,
+                                                      float *__restrict__ lo, float *__restrict__ hi) {
+    extern __shared__ __attribute__((aligned(16))) int8_t ivf_q8[];  // [dim]
+    const uint32_t q = blockIdx.y, lane = threadIdx.x;
+    for (uint32_t i = lane; i < dim / 4; i += 64)
+        reinterpret_cast<uint32_t *>(ivf_q8)[i] = reinterpret_cast<const uint32_t *>(Q8 + uint64_t(q) * dim)[i];
+    __syncthreads();
+    const float qs = qsq[q], sq = q_scale[q], dq = q_err[q];
+#pragma unroll 1
+    for (uint32_t h = 0; h < 2; h++) {
+        const uint32_t j = blockIdx.x * 64 + h * 32 + (lane & 31);
+        const bool mine = lane < 32 && j < ld;
+        const uint64_t c = mine ? cand[uint64_t(q) * ld + j] : PAIR_NONE;
+        const bool live = c != PAIR_NONE;
+        const uint32_t nb = live ? uint32_t(c) : 0u;
+        float l = INFINITY, u = INFINITY;
+        if (__ballot(live) != 0) {  // wave-uniform
+            const int32_t isum = q8_dots32(rows_q8, dim, ivf_q8, nb, live, lane);
+            float a, E;
+            q8_approx(metric, dim, isum, xsq[nb], qs, row_scale[nb], row_err[nb], sq, dq, a, E);
+            if (live) {
+                const bool fin = E < INFINITY && a - a == 0.0f;
+                l = fin ? a - E : -INFINITY;
+                u = fin ? a + E : INFINITY;
+            }
+        }
+        if (mine) {
+            lo[uint64_t(q) * ld + j] = l;
+            hi[uint64_t(q) * ld + j] = u;
+        }
+    }
+}
 // out[q][0..ld2) = the offers of query q with lo <= T[q], in offer order, PAIR_NONE padded; flags[q] = 1 when they do not fit
 __global__ __launch_bounds__(256) void k_ivf_keep(const uint64_t *__restrict__ cand, uint32_t ld, const float *__restrict__ lo,
                                                   const float *__restrict__ T, uint64_t *__restrict__ out, uint32_t ld2,
@@ -255,9 +294,11 @@ __global__ __launch_bounds__(256) void k_ivf_keep(const uint64_t *__restrict__ c
 }
 static int g_ivf_half = 1;  // 1 auto, 0 off
 void ivf_set_half(int v) { g_ivf_half = v; }
+static int g_ivf_q8 = 1;  // the 8-bit tier in front of the fp16 tier: 1 auto, 0 off
+void ivf_set_q8(int v) { g_ivf_q8 = v; }
 
 void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t n_probes,
-                    uint64_t *d_idx, float *d_dist, uint64_t *d_cnt, bool use_half) {
+                    uint64_t *d_idx, float *d_dist, uint64_t *d_cnt, bool use_half, bool use_q8) {
     hipStream_t s = ws.stream;
     IVFState &iv = ix.ivf;
     if (nq == 0) return;
@@ -273,7 +314,7 @@ void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uin
         const uint64_t qs = std::max<uint64_t>(1, (size_t(2) << 30) / (std::max<uint64_t>(b, 64) * 16));
         if (nq > qs) {
             for (uint64_t q0 = 0; q0 < nq; q0 += qs)
-                ivf_knn_device(ix, ws, d_q + q0 * ix.dim, std::min(qs, nq - q0), k, n_probes, d_idx + q0 * k, d_dist + q0 * k, d_cnt + q0, use_half);
+                ivf_knn_device(ix, ws, d_q + q0 * ix.dim, std::min(qs, nq - q0), k, n_probes, d_idx + q0 * k, d_dist + q0 * k, d_cnt + q0, use_half, use_q8);
             return;
         }
     }
@@ -307,7 +348,7 @@ void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uin
     ws.keys_b.reserve(nq * ld * sizeof(uint64_t));
     ws.misc.reserve(64);
     unsigned long long *d_ncand = ws.misc.as<unsigned long long>();
-    VDB_HIP(hipMemsetAsync(d_ncand, 0, 2 * sizeof(unsigned long long), s));  // [0] offers, [1] offers kept by the pre-pass
+    VDB_HIP(hipMemsetAsync(d_ncand, 0, 3 * sizeof(unsigned long long), s));  // [0] offers, [1] kept for the exact stage, [2] kept by the 8-bit tier
     hipLaunchKernelGGL(k_ivf_candidates, dim3((unsigned)nq), dim3(256), 0, s, d_probes, capp, (uint32_t)np,
                        iv.d_offsets.as<uint32_t>(), iv.d_members.as<uint32_t>(), ld, ws.keys_a.as<uint64_t>(), d_ncand);
     // (2b) the certified half-precision pre-pass: only the offers that may be among the k nearest go on
@@ -319,6 +360,7 @@ void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uin
                       ix.ensure_rows_h(ws);
     double scan_bytes_per_row = double(ix.dim) * sizeof(float) + sizeof(float);
     uint8_t *flags = nullptr;
+    bool q8 = false;
     if (half) {
         const int metric = ix.dist == 0 ? MET_L2_DIRECT : MET_COSINE;
         ws.dense.reserve(2 * nq * ld * sizeof(float));
@@ -326,15 +368,38 @@ void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uin
         ws.lists.reserve(2 * nq * ld2 * sizeof(uint64_t));
         float *d_lo = ws.dense.as<float>(), *d_hi = d_lo + nq * ld, *d_T = ws.qaux.as<float>();
         uint64_t *kept = ws.lists.as<uint64_t>();
-        flags = static_cast<uint8_t *>(ws.pinned(nq));
-        std::memset(flags, 0, nq);
+        flags = static_cast<uint8_t *>(ws.pinned(2 * nq));
+        std::memset(flags, 0, 2 * nq);
+        // first tier, when the lists are long enough to pay for it: bounds from the 8-bit image (1 B/element) keep at most ldA
+        // offers per query for the fp16 tier
+        uint32_t ldh = ld;  // length of the lists the fp16 tier reads
+        const uint32_t ldA = (uint32_t)((std::min<uint64_t>(ld, std::max<uint64_t>(std::max<uint64_t>(1024, 64ull * ksel), ld / 8)) + 63) & ~63ull);
+        if (use_q8 && g_ivf_q8 && iv.q8_overflows < 4 && ld >= 4 * ldA && ix.ensure_rows_q8(ws)) {
+            ws.keys_c.reserve(nq * ldA * sizeof(uint64_t));
+            ws.qfrag.reserve(nq * (ix.dim + 2 * sizeof(float)) + 256);  // the queries' 8-bit images, scales and errors
+            int8_t *d_q8 = ws.qfrag.as<int8_t>();
+            float *d_qsc = reinterpret_cast<float *>(d_q8 + ((nq * ix.dim + 15) & ~uint64_t(15))), *d_qer = d_qsc + nq;
+            launch_rows_to_q8(d_q, nq, (uint32_t)ix.dim, d_q8, d_qsc, d_qer, s);
+            ix.prof_begin(ws, "ivf_q8", 0.0);
+            hipLaunchKernelGGL(k_ivf_q8_bounds, dim3(ld / 64, (unsigned)nq), dim3(64), ix.dim, s, ix.d_rows_q8.as<int8_t>(),
+                               ix.d_q8_scale.as<float>(), ix.d_q8_err.as<float>(), (uint32_t)ix.dim, metric, d_q8, d_qsc, d_qer,
+                               ix.d_sq.as<float>(), ws.qsq.as<float>(), cand_keys, ld, d_lo, d_hi);
+            ix.prof_end(ws);
+            launch_select_tau(d_hi, ld, ld, (uint32_t)nq, (uint32_t)nq, ksel, d_T, s);
+            uint8_t *flagsA = flags + nq;
+            hipLaunchKernelGGL(k_ivf_keep, dim3((unsigned)nq), dim3(256), 0, s, cand_keys, ld, d_lo, d_T, ws.keys_c.as<uint64_t>(), ldA, flagsA,
+                               d_ncand + 2);
+            cand_keys = ws.keys_c.as<uint64_t>();
+            ldh = ldA;
+            q8 = true;
+        }
         ix.prof_begin(ws, "ivf_half", 0.0);
-        hipLaunchKernelGGL(k_ivf_half_bounds, dim3(ld / 64, (unsigned)nq), dim3(64), ix.dim * sizeof(float), s, ix.d_rows_h.as<uint16_t>(),
+        hipLaunchKernelGGL(k_ivf_half_bounds, dim3(ldh / 64, (unsigned)nq), dim3(64), ix.dim * sizeof(float), s, ix.d_rows_h.as<uint16_t>(),
                            (uint32_t)ix.dim, 1.0f / ix.half_sx(), ix.half_dx_abs, ix.half_dx_rel, metric, d_q, ix.d_sq.as<float>(),
-                           ws.qsq.as<float>(), cand_keys, ld, d_lo, d_hi);
+                           ws.qsq.as<float>(), cand_keys, ldh, d_lo, d_hi);
         ix.prof_end(ws);
-        launch_select_tau(d_hi, ld, ld, (uint32_t)nq, (uint32_t)nq, ksel, d_T, s);
-        hipLaunchKernelGGL(k_ivf_keep, dim3((unsigned)nq), dim3(256), 0, s, cand_keys, ld, d_lo, d_T, kept, ld2, flags, d_ncand + 1);
+        launch_select_tau(d_hi, ldh, ldh, (uint32_t)nq, (uint32_t)nq, ksel, d_T, s);
+        hipLaunchKernelGGL(k_ivf_keep, dim3((unsigned)nq), dim3(256), 0, s, cand_keys, ldh, d_lo, d_T, kept, ld2, flags, d_ncand + 1);
         cand_keys = kept;
         exact_keys = kept + nq * ld2;
         ldx = ld2;
@@ -351,18 +416,30 @@ void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uin
     pq_resort_finalize(ix, ws, exact_keys, ldx, ldx, nq, ksel, k, ix.id_offset, d_idx, d_dist, d_cnt);
     if (half) {  // a query whose kept offers did not fit: the whole call again with the plain scan (rare; the index stops trying after four)
         VDB_SYNC(s);
-        bool over = false;
+        bool over = false, overA = false;
         for (uint64_t q = 0; q < nq; q++) over |= flags[q] != 0;
-        if (over) {
-            iv.half_overflows++;
-            ivf_knn_device(ix, ws, d_q, nq, k, n_probes, d_idx, d_dist, d_cnt, false);
+        for (uint64_t q = 0; q8 && q < nq; q++) overA |= flags[nq + q] != 0;
+        if (overA) iv.q8_overflows++;
+        if (over || overA) {  // (the 8-bit tier's lists overflowed: again with the fp16 tier alone; the fp16 tier's: the plain scan)
+            if (over) iv.half_overflows++;
+            ivf_knn_device(ix, ws, d_q, nq, k, n_probes, d_idx, d_dist, d_cnt, !over, false);
             return;
         }
     }
     if (!ws.pending.empty()) {  // measurement on: the scan's algorithmic bytes = scanned rows x (dim*4 + 4), known only now
-        unsigned long long total[2] = {0, 0};
+        unsigned long long total[3] = {0, 0, 0};
         VDB_HIP(hipMemcpyAsync(total, d_ncand, sizeof(total), hipMemcpyDeviceToHost, s));
         VDB_SYNC(s);
+        if (q8 && ws.pending.size() >= 3) {  // 8-bit rows + scale, error, norm for every offer; fp16 rows for what that tier kept
+            ws.pending[ws.pending.size() - 3].bytes += double(total[0]) * (double(ix.dim) + 3 * sizeof(float));
+            ws.pending[ws.pending.size() - 2].bytes += double(total[2]) * (double(ix.dim) * sizeof(uint16_t) + sizeof(float));
+            ws.pending.back().bytes += double(total[1]) * scan_bytes_per_row;
+            iv.last_offers = total[0];
+            iv.last_kept = total[1];
+            iv.last_kept_q8 = total[2];
+            return;
+        }
+        iv.last_kept_q8 = 0;
         // (with the pre-pass the two records split the bytes asked for: fp16 rows + norms for every offer, f32 rows for the kept
         // ones; SURVEY 8(d)'s figure stays offers x (dim*4 + 4))
         if (half && ws.pending.size() >= 2) {

@@ -76,6 +76,53 @@ void launch_rows_to_half(const float *X, uint64_t count, float sx, uint16_t *H, 
                        reinterpret_cast<uint4 *>(H));
 }
 
+// ---- 8-bit image (half_rows.hpp, "8-bit tier"): one wave per row -- scale = max|x_i| / 127 (1 for an all-zero row),
+// q_i = rint(x_i / scale) clamped to [-127, 127], err = |x - scale q| as measured (f32 sums, inflated by 1.001).  A row with a
+// non-finite element gets err = +inf: its bound is infinite and the caller keeps it for the exact stage.  dim % 4 == 0.
+__global__ __launch_bounds__(256) void k_rows_to_q8(const float *__restrict__ X, uint64_t n, uint32_t dim, int8_t *__restrict__ Q8,
+                                                    float *__restrict__ scale, float *__restrict__ err) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t row = uint64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float4 *x4 = reinterpret_cast<const float4 *>(X + row * dim);
+    float mx = 0.0f;
+    bool bad = false;
+    for (uint32_t j = lane; j < dim / 4; j += 64) {
+        const float4 v = x4[j];
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        bad |= !(v.x - v.x == 0.0f) || !(v.y - v.y == 0.0f) || !(v.z - v.z == 0.0f) || !(v.w - v.w == 0.0f);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    bad = __ballot(bad) != 0;
+    const float sc = (mx > 0.0f && !bad) ? mx / 127.0f : 1.0f;
+    const float inv = 1.0f / sc;
+    float e2 = 0.0f;
+    char4 *q4 = reinterpret_cast<char4 *>(Q8 + row * dim);
+    for (uint32_t j = lane; j < dim / 4; j += 64) {
+        const float4 v = bad ? make_float4(0.f, 0.f, 0.f, 0.f) : x4[j];
+        float q[4] = {rintf(v.x * inv), rintf(v.y * inv), rintf(v.z * inv), rintf(v.w * inv)};
+        const float xv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            q[e] = fminf(fmaxf(q[e], -127.0f), 127.0f);
+            const float d = xv[e] - q[e] * sc;
+            e2 += d * d;
+        }
+        q4[j] = make_char4((signed char)q[0], (signed char)q[1], (signed char)q[2], (signed char)q[3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e2 += __shfl_xor(e2, o);
+    if (lane == 0) {
+        scale[row] = sc;
+        err[row] = bad ? INFINITY : sqrtf(e2) * 1.001f;
+    }
+}
+void launch_rows_to_q8(const float *X, uint64_t n, uint32_t dim, int8_t *Q8, float *scale, float *err, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_rows_to_q8, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, X, n, dim, Q8, scale, err);
+}
+
 // |v - fp16(v * scale) / scale|^2 summed over a vector by one wave (all differences are exact in f32: v~ is v rounded
 // to 11 bits, or a subnormal / zero whose distance to v is representable)
 __device__ __forceinline__ float wave_round_err2(const float *v, uint32_t dim, float scale, float inv_scale, uint32_t lane) {

@@ -175,6 +175,7 @@ void launch_tile_rows_h(const float *X, uint64_t n, uint32_t dim, uint64_t tile0
 void launch_row_split_err(const float *X, const float *xsq, uint64_t row0, uint64_t row1, uint32_t dim, float sx,
                           uint32_t *out2 /* [2] float bits: max |dx|^2, max |dx|^2/|x|^2 (atomicMax) */, hipStream_t s);
 void launch_rows_to_half(const float *X, uint64_t count, float sx, uint16_t *H, hipStream_t s);
+void launch_rows_to_q8(const float *X, uint64_t n, uint32_t dim, int8_t *Q8, float *scale, float *err, hipStream_t s);
 void launch_query_prep_h(const float *Q, uint32_t nq, uint32_t nq_pad, uint32_t dim, float sx, float *qsq /* out: |q|^2, strict order */,
                          float *qscale, float *qmul, float *qerr, uint32_t *hits /* zeroed */,
                          void *qfrag /* non-null: also write the query image of launch_pack_queries_h(.., NH = 8, ..) */, hipStream_t s);

@@ -44,8 +44,9 @@ void ivf_build(Index &ix, uint64_t k_clusters, uint64_t train_n, uint64_t max_it
 void ivf_clear(Index &ix);
 void ivf_export(Index &ix, float *centroids, uint64_t *assign);
 void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t n_probes,
-                    uint64_t *d_idx, float *d_dist, uint64_t *d_cnt, bool use_half = true);
+                    uint64_t *d_idx, float *d_dist, uint64_t *d_cnt, bool use_half = true, bool use_q8 = true);
 void ivf_set_half(int v);
+void ivf_set_q8(int v);
 
 // ---- HNSW (index_algorithm/hnsw_index.rs) ----
 void hnsw_build(Index &ix, uint64_t M, uint64_t ef_construction, uint64_t seed, uint64_t batch, int nthreads);

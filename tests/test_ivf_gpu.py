@@ -101,7 +101,7 @@ def test_ivf_half_prepass_keeps_results(mods, data, dist, kind):
     answer, ties at the cut included (duplicated rows), on the corpora that stress the bound."""
     vdb, O = mods
     rng = np.random.default_rng(321)
-    n, dim, nq = 9000, 128, 24
+    n, dim, nq = 24000, 128, 24  # 30 clusters of ~800 rows: 9 and 30 probes give lists long enough for the 8-bit tier
     if data == "gist":
         base, qs = gist_like(n, dim=dim, seed=5), gist_like(nq, dim=dim, seed=6)
     elif data == "cancel":
@@ -121,14 +121,20 @@ def test_ivf_half_prepass_keeps_results(mods, data, dist, kind):
     ix.ivf_build(30, train_n=2000, max_iter=5, seed=3)
     ex = ix.ivf_export()
     iv = O.IVF(base, ex["centroids"], kind, assign=ex["assign"])
-    for k, npb in ((10, 4), (1, 2), (40, 9)):
+    for k, npb in ((10, 4), (1, 2), (40, 9), (3, 30)):
         ix.set_param("ivf_half", 0)
         try:
             i0, d0, c0 = ix.ivf_knn(qs, k, npb)
         finally:
             ix.set_param("ivf_half", 1)
-        i1, d1, c1 = ix.ivf_knn(qs, k, npb)
+        ix.set_param("ivf_q8", 0)  # fp16 tier alone
+        try:
+            i2, d2, c2 = ix.ivf_knn(qs, k, npb)
+        finally:
+            ix.set_param("ivf_q8", 1)
+        i1, d1, c1 = ix.ivf_knn(qs, k, npb)  # 8-bit tier (lists of at least 4 x max(1024, 64 k) offers) + fp16 tier
         assert np.array_equal(i0, i1) and np.array_equal(d0, d1) and np.array_equal(c0, c1), (k, npb)
+        assert np.array_equal(i0, i2) and np.array_equal(d0, d2) and np.array_equal(c0, c2), (k, npb)
         for q in range(nq):
             oi, od = iv.knn(qs[q], k, npb)
             c = int(c1[q])

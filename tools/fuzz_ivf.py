@@ -17,7 +17,7 @@ while time.time() < t_end:
     n = int(rng.integers(3000, 40000 if dim < 960 else 12000))
     nq = int(rng.choice([1, 9, 70, 300]))
     k = int(rng.choice([1, 5, 10, 40, 90]))
-    kc = int(rng.integers(4, 80))
+    kc = int(rng.integers(2, 80))
     npb = int(rng.choice([1, 2, 4, 9, 30]))
     dist = str(rng.choice(["l2sqr", "cosine"]))
     kind = 0 if dist == "l2sqr" else 1
@@ -40,12 +40,12 @@ while time.time() < t_end:
     ix.ivf_build(kc, train_n=min(n, 1500), max_iter=4, seed=it)
     ex = ix.ivf_export()
     iv = O.IVF(base, ex["centroids"], kind, assign=ex["assign"])
-    half = int(rng.choice([0, 1, 1]))
-    ix.set_param("ivf_half", half)
+    half = int(rng.choice([0, 1, 1])); q8 = int(rng.choice([0, 1, 1]))
+    ix.set_param("ivf_half", half); ix.set_param("ivf_q8", q8)
     try:
         idx, d, cnt = ix.ivf_knn(qs, k, npb)
     finally:
-        ix.set_param("ivf_half", 1)
+        ix.set_param("ivf_half", 1); ix.set_param("ivf_q8", 1)
     ok = True
     for q in range(nq):
         oi, od = iv.knn(qs[q], k, npb)
@@ -55,7 +55,7 @@ while time.time() < t_end:
             break
     if not ok:
         bad += 1
-        print(f"MISMATCH it={it} dim={dim} n={n} nq={nq} k={k} kc={kc} probes={npb} dist={dist} style={style} half={half} q={q}", flush=True)
+        print(f"MISMATCH it={it} dim={dim} n={n} nq={nq} k={k} kc={kc} probes={npb} dist={dist} style={style} half={half} q8={q8} q={q}", flush=True)
     ix.close()
     if it % 10 == 0:
         print(f"{it} configurations, {bad} mismatches", flush=True)

@@ -13,12 +13,12 @@ gt, _, _ = ix.flat_knn(qs, 10)
 t = time.time(); ix.ivf_build(kc, train_n=10000, max_iter=10, seed=42); print(f"ivf_build n={n} k={kc}: {time.time()-t:.1f} s", flush=True)
 for npb in (4, 16):
     ref = None
-    for half in (0, 1):  # the certified half-precision pre-pass of the scan off / on
-        ix.set_param('ivf_half', half)
+    for half, q8 in ((0, 0), (1, 0), (1, 1)):  # plain scan / fp16 tier / 8-bit tier + fp16 tier
+        ix.set_param('ivf_half', half); ix.set_param('ivf_q8', q8)
         for it in range(3):
             t = time.time(); idx, d, c = ix.ivf_knn(qs, 10, npb); dt = time.time() - t
         rec = np.mean([len(set(idx[q].tolist()) & set(gt[q].tolist())) / 10 for q in range(1000)])
         same = True if ref is None else bool((ref[0] == idx).all() and (ref[1] == d).all())
         ref = (idx.copy(), d.copy())
-        print(f"IVF n_probes={npb} ivf_half={half}: {dt*1e3:.1f} ms -> {1000/dt:.0f} QPS recall@10={rec:.4f} same={same}", flush=True)
-ix.set_param('ivf_half', 1)
+        print(f"IVF n_probes={npb} ivf_half={half} ivf_q8={q8}: {dt*1e3:.1f} ms -> {1000/dt:.0f} QPS recall@10={rec:.4f} same={same}", flush=True)
+ix.set_param('ivf_half', 1); ix.set_param('ivf_q8', 1)
