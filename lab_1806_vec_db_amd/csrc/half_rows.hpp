@@ -159,52 +159,62 @@ __device__ __forceinline__ bool half_rules_out(int metric, uint32_t dim, float S
 // |dx_r| = |x_r - s_r q8_r| beside it (k_rows_to_q8); the query is quantised the same way per call.  The dot product of
 // the two images is an exact integer (|sum| <= dim * 127^2 < 2^24 for dim <= 1040, exact as f32), so
 // |s_r s_q isum - x.q| <= |dx_r||q| + |x_r||dq| + |dx_r||dq| (Cauchy-Schwarz) + the two roundings of the scaling.
-// q8_dots32: the exact integer sums of up to 32 rows (one per lane 0..31 with fresh == true), 64-B pieces of a row per group of 8
-// lanes, HALF_ROWS_DEPTH + 3 pieces in flight.
+// q8_dots32: the exact integer sums of up to 32 rows (one per lane 0..31 with fresh == true), whole 128-B lines of a row per group
+// of 8 lanes, HALF_ROWS_DEPTH lines in flight.
 __device__ __forceinline__ int32_t q8_dots32(const int8_t *__restrict__ rows_q8, uint32_t dim, const int8_t *qlds8, uint32_t nb, bool fresh,
                                              uint32_t lane) {
-    typedef uint32_t v2u __attribute__((ext_vector_type(2)));
-    constexpr int D = HALF_ROWS_DEPTH + 3;
-    const uint32_t nlines = dim / 64, last = nlines - 1;
+    // 16-B pieces, 8 per 128-B line of a row; a row of dim bytes has dim/16 pieces, the last line may be half empty (dim % 128 ==
+    // 64): lanes past the row's end re-read its last piece against query bytes that are zero (the caller pads the query image in
+    // LDS with zeros up to a multiple of 128)
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    constexpr int D = HALF_ROWS_DEPTH;
+    const uint32_t npieces = dim / 16, nlines = (dim + 127) / 128, last = nlines - 1;
     const uint64_t fm = __ballot(fresh);
     const uint32_t nfresh = (uint32_t)__builtin_popcountll(fm);
     const uint32_t rank = (uint32_t)__builtin_popcountll(fm & ((1ull << lane) - 1));
     const uint32_t cnb = (uint32_t)__builtin_amdgcn_ds_permute(int((fresh ? rank : nfresh + (lane - rank)) * 4), int(nb));
     const uint32_t gg = lane >> 3, jj = lane & 7;
-    const v2u *rp[4];
+    const v4u *rp[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t src = 8 * k + gg;
         const uint32_t nbk = __shfl(cnb, src < nfresh ? src : 0u);
-        rp[k] = reinterpret_cast<const v2u *>(rows_q8 + uint64_t(nbk) * dim) + jj;
+        rp[k] = reinterpret_cast<const v4u *>(rows_q8 + uint64_t(nbk) * dim);
     }
-    v2u buf[D][4];
+    auto piece = [&](uint32_t L) -> uint32_t {  // this lane's piece of line L, clamped into the row
+        const uint32_t p = L * 8 + jj;
+        return p < npieces ? p : npieces - 1;
+    };
+    v4u buf[D][4];
     static_for<D>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        const uint32_t Li = (uint32_t)i < last ? (uint32_t)i : last;
+        const uint32_t pi = piece((uint32_t)i < last ? (uint32_t)i : last);
 #pragma unroll
-        for (int k = 0; k < 4; k++) buf[i][k] = rp[k][Li * 8];
+        for (int k = 0; k < 4; k++) buf[i][k] = rp[k][pi];
         __builtin_amdgcn_sched_barrier(0);
     });
     int32_t acc[4] = {0, 0, 0, 0};
-    const v2u *q2 = reinterpret_cast<const v2u *>(qlds8) + jj;  // the 8 query columns of this lane's piece
+    const v4u *q4 = reinterpret_cast<const v4u *>(qlds8) + jj;  // the 16 query columns of this lane's piece (zero past dim)
     for (uint32_t L0 = 0; L0 < nlines; L0 += D) {
         static_for<D>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const uint32_t L = L0 + i;
             const uint32_t Lc = L < last ? L : last, Ln = L + D < last ? L + D : last;
-            v2u cur[4];
+            v4u cur[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) cur[k] = buf[i][k];
+            const uint32_t pn = piece(Ln);
 #pragma unroll
-            for (int k = 0; k < 4; k++) buf[i][k] = rp[k][Ln * 8];
+            for (int k = 0; k < 4; k++) buf[i][k] = rp[k][pn];
             __builtin_amdgcn_sched_barrier(0);
-            const v2u qq = q2[Lc * 8];
+            const v4u qq = q4[Lc * 8];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 int32_t a = acc[k];
                 a = __builtin_amdgcn_sdot4((int)cur[k].x, (int)qq.x, a, false);
                 a = __builtin_amdgcn_sdot4((int)cur[k].y, (int)qq.y, a, false);
+                a = __builtin_amdgcn_sdot4((int)cur[k].z, (int)qq.z, a, false);
+                a = __builtin_amdgcn_sdot4((int)cur[k].w, (int)qq.w, a, false);
                 acc[k] = L < nlines ? a : acc[k];
             }
             __builtin_amdgcn_sched_barrier(0);

@@ -232,10 +232,10 @@ __global__ __launch_bounds__(64) void k_ivf_q8_bounds(const int8_t *__restrict__
                                                       const float *__restrict__ q_err, const float *__restrict__ xsq,
                                                       const float *__restrict__ qsq, const uint64_t *__restrict__ cand, uint32_t ld,
                                                       float *__restrict__ lo, float *__restrict__ hi) {
-    extern __shared__ __attribute__((aligned(16))) int8_t ivf_q8[];  // [dim]
+    extern __shared__ __attribute__((aligned(16))) int8_t ivf_q8[];  // [dim rounded up to 128], zero past dim
     const uint32_t q = blockIdx.y, lane = threadIdx.x;
-    for (uint32_t i = lane; i < dim / 4; i += 64)
-        reinterpret_cast<uint32_t *>(ivf_q8)[i] = reinterpret_cast<const uint32_t *>(Q8 + uint64_t(q) * dim)[i];
+    for (uint32_t i = lane; i < ((dim + 127) & ~127u) / 4; i += 64)
+        reinterpret_cast<uint32_t *>(ivf_q8)[i] = i < dim / 4 ? reinterpret_cast<const uint32_t *>(Q8 + uint64_t(q) * dim)[i] : 0u;
     __syncthreads();
     const float qs = qsq[q], sq = q_scale[q], dq = q_err[q];
 #pragma unroll 1
@@ -381,7 +381,7 @@ void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uin
             float *d_qsc = reinterpret_cast<float *>(d_q8 + ((nq * ix.dim + 15) & ~uint64_t(15))), *d_qer = d_qsc + nq;
             launch_rows_to_q8(d_q, nq, (uint32_t)ix.dim, d_q8, d_qsc, d_qer, s);
             ix.prof_begin(ws, "ivf_q8", 0.0);
-            hipLaunchKernelGGL(k_ivf_q8_bounds, dim3(ld / 64, (unsigned)nq), dim3(64), ix.dim, s, ix.d_rows_q8.as<int8_t>(),
+            hipLaunchKernelGGL(k_ivf_q8_bounds, dim3(ld / 64, (unsigned)nq), dim3(64), (ix.dim + 127) & ~uint64_t(127), s, ix.d_rows_q8.as<int8_t>(),
                                ix.d_q8_scale.as<float>(), ix.d_q8_err.as<float>(), (uint32_t)ix.dim, metric, d_q8, d_qsc, d_qer,
                                ix.d_sq.as<float>(), ws.qsq.as<float>(), cand_keys, ld, d_lo, d_hi);
             ix.prof_end(ws);
