@@ -130,7 +130,7 @@ int vdb_flat_set_mode(vdb_index *idx, int mode);
  *   "ivf_half"         the same pre-pass for the IVF probe-list scan (offers that cannot be among the k nearest are dropped before the
  *                      f32 rows are fetched; same results): 1 auto (default), 0 off
  *   "ivf_q8"           an 8-bit tier in front of it for long probe lists (1 B/element image with a scale and a measured error per row,
- *                      exact integer dot products): 1 auto (default), 0 off
+ *                      exact integer dot products; cluster-major for calls of 256 .. 16 384 (query, probe) pairs): 1 auto (default), 0 off, 2 query-major only
  *   "hnsw_build_gpu"   candidate phase of batched HNSW builds (vdb_hnsw_build with batch >= 256): 0 auto = the level-0 searches of a
  *                      batch and the distances between its members run on the GPU (same graph as the all-host builder), 1 off
  *   "hnsw_pool_cap"    most live candidates the fast HNSW walk keeps in LDS (it uses min(this, ef + max_m0 + 64); maximum 2048) before a query is handed to

@@ -13,7 +13,7 @@ gt, _, _ = ix.flat_knn(qs, 10)
 t = time.time(); ix.ivf_build(kc, train_n=10000, max_iter=10, seed=42); print(f"ivf_build n={n} k={kc}: {time.time()-t:.1f} s", flush=True)
 for npb in (4, 16):
     ref = None
-    for half, q8 in ((0, 0), (1, 0), (1, 1)):  # plain scan / fp16 tier / 8-bit tier + fp16 tier
+    for half, q8 in ((0, 0), (1, 0), (1, 2), (1, 1)):  # plain scan / fp16 tier / + 8-bit tier query-major / cluster-major
         ix.set_param('ivf_half', half); ix.set_param('ivf_q8', q8)
         for it in range(3):
             t = time.time(); idx, d, c = ix.ivf_knn(qs, 10, npb); dt = time.time() - t
