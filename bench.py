@@ -345,8 +345,14 @@ def main():
         roofline = hbm_roofline(kernel, ix.prof_get(kernel))
         if wl == "ivf" and roofline:
             offers, kept, kept8 = ix.get_stat("ivf_last_offers"), ix.get_stat("ivf_last_kept"), ix.get_stat("ivf_last_kept_q8")
-            roofline["units_per_launch"] = {"ivf_q8": "offers x (dim + 12) bytes of the 8-bit image (k_ivf_q8_bounds); the fp16 tier reads dim*2 bytes for "
-                                                      "the offers it passes on, the exact stage dim*4 for what is left",
+            fetched = ix.get_stat("ivf_last_rows_fetched_q8")
+            if kernel == "ivf_q8" and fetched:
+                roofline["rows_fetched_per_step"] = fetched
+                roofline["visits_per_fetched_row"] = round(offers / fetched, 2)
+            roofline["units_per_launch"] = {"ivf_q8": ("rows of the visited clusters x (dim + 12) bytes of the 8-bit image, each read ONCE per step (cluster-major "
+                                                       "k_ivf_q8_bounds_cm scores a row against every query that visits its cluster from registers) + 8 B of "
+                                                       "bounds per offer" if fetched else "offers x (dim + 12) bytes of the 8-bit image (k_ivf_q8_bounds)") +
+                                                      "; the fp16 tier reads dim*2 bytes for the offers it passes on, the exact stage dim*4 for what is left",
                                             "ivf_half": "offers x (dim*2 + 4) bytes of the fp16 image (k_ivf_half_bounds); the exact stage then fetches "
                                                         "dim*4 bytes for the offers the pre-pass kept",
                                             "ivf_rerank": "offers x (dim*4 + 4) bytes (k_rerank_t)"}[kernel]

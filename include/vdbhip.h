@@ -152,7 +152,8 @@ int vdb_flat_fallback_count(const vdb_index *idx, uint64_t *out);
  *   "hnsw_half_dropped"  of the last HNSW call's distance evaluations (vdb_hnsw_last_stats), the rows its certified
  *                        half-precision pre-pass ruled out without fetching the f32 row,
  *   "ivf_last_offers", "ivf_last_kept_q8", "ivf_last_kept"  (while vdb_prof_enable is on) rows the last IVF call offered to its result
- *                        sets, the ones the 8-bit tier passed on (0: tier not run) and the ones that reached the exact stage,
+ *                        sets, the ones the 8-bit tier passed on (0: tier not run) and the ones that reached the exact stage; "ivf_last_rows_fetched_q8":
+ *                        rows the cluster-major 8-bit tier read, once each (0: query-major),
  *   "hbm_bytes_per_row"  resident HBM bytes per row over all per-row buffers (rows, norms, mirrors, PQ codes, level-0 links). */
 int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out);
 

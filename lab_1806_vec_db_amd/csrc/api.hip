@@ -438,6 +438,8 @@ int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out) {
         *out = idx->ix.hnsw.last_half_dropped.load();
     else if (n == "ivf_last_offers")
         *out = idx->ix.ivf.last_offers.load();
+    else if (n == "ivf_last_rows_fetched_q8")
+        *out = idx->ix.ivf.last_rows_fetched_q8.load();
     else if (n == "ivf_last_kept_q8")
         *out = idx->ix.ivf.last_kept_q8.load();
     else if (n == "ivf_last_kept")

@@ -137,6 +137,7 @@ struct IVFState {
     std::vector<uint32_t> offsets;         // k+1
     std::vector<uint32_t> sizes_desc;      // cluster sizes, descending (bounds the candidates of n probes)
     DevBuf d_offsets, d_members;           // u32 [k+1], u32 [n] (ascending id inside a cluster)
+    std::atomic<uint64_t> last_rows_fetched_q8{0};  // cluster-major 8-bit tier: rows read (once each); 0: query-major or tier not run
     std::atomic<uint64_t> last_kept_q8{0};  // offers the 8-bit tier passed on to the fp16 tier (0: that tier did not run)
     std::atomic<uint32_t> q8_overflows{0};
     std::atomic<uint64_t> last_offers{0}, last_kept{0};  // measurement on: offers of the last call / those its pre-pass kept

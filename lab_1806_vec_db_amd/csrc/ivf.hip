@@ -266,8 +266,8 @@ __global__ __launch_bounds__(64) void k_ivf_q8_bounds(const int8_t *__restrict__
 // A batch of queries visits every cluster several times (1000 queries x 4 probes over 1000 clusters: 7.8 visits per row on
 // average, popular clusters more), and query-major the visits of one cluster are far apart in time: every visit fetches the
 // cluster's rows from HBM again.  Cluster-major they are adjacent: the (query, probe) pairs of the call are sorted by cluster
-// (k_ivf_pairs + one LDS sort), and a wavefront takes 64 rows of a cluster and scores them against EVERY query that probes
-// the cluster, one after the other -- the first pass brings the rows in, the others find them in L2.  The bounds land at
+// (k_ivf_pairs + one LDS sort), and a wavefront takes 32 rows of a cluster and scores them against EVERY query that probes
+// the cluster, one after the other, from registers.  The bounds land at
 // the same [query][offer position] the query-major kernel writes (pos = offer position of the probe's first row).
 __global__ __launch_bounds__(256) void k_ivf_pairs(const uint64_t *__restrict__ probe_keys, uint32_t ldp, uint32_t n_probes, uint32_t nq,
                                                    const uint32_t *__restrict__ offsets, uint64_t *__restrict__ pairs /* [nq*n_probes] */,
@@ -320,6 +320,10 @@ __global__ __launch_bounds__(1024) void k_ivf_sort_pairs(uint64_t *__restrict__ 
         atomicAdd(&count[c], 1u);
     }
 }
+// A wavefront owns 32 rows of a cluster and KEEPS them in registers for all visits: lane 8g + j holds the pieces j, j + 8, ... of
+// rows 8k + g (k = 0..3): 4 x ceil(dim/128) x 16 B = 128 registers at dim <= 1024.  Per visiting query: the query's 8-bit
+// image goes to LDS (1 KB), every lane multiplies its pieces (v_dot4_i32_i8), the 8 partial sums of a row are added
+// across the lanes of its group, and lanes 8g + k (k < 4) turn the sum of row 8k + g into its bounds.  The rows are fetched once.
 __global__ __launch_bounds__(64) void k_ivf_q8_bounds_cm(const int8_t *__restrict__ rows_q8, const float *__restrict__ row_scale,
                                                          const float *__restrict__ row_err, uint32_t dim, int metric,
                                                          const int8_t *__restrict__ Q8, const float *__restrict__ q_scale,
@@ -329,45 +333,67 @@ __global__ __launch_bounds__(64) void k_ivf_q8_bounds_cm(const int8_t *__restric
                                                          const uint32_t *__restrict__ pos, const uint32_t *__restrict__ first,
                                                          const uint32_t *__restrict__ count, uint32_t n_probes, uint32_t ld,
                                                          float *__restrict__ lo, float *__restrict__ hi) {
-    extern __shared__ __attribute__((aligned(16))) int8_t ivf_q8[];  // [dim rounded up to 128], zero past dim
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) int8_t ivf_q8[];  // [1024]: the query image, zero past dim
     const uint32_t c = blockIdx.y, lane = threadIdx.x;
     const uint32_t nv = count[c];  // visits of this cluster in the call
-    const uint32_t b = offsets[c], size = offsets[c + 1] - b, r0 = blockIdx.x * 64;
+    const uint32_t b = offsets[c], size = offsets[c + 1] - b, r0 = blockIdx.x * 32;
     if (nv == 0 || r0 >= size) return;  // block-uniform
     const uint32_t f = first[c];
-    // the wave's 64 rows as two halves of 32 (q8_dots32 scores one row per lane 0..31)
-    uint32_t nb[2];
-    bool live[2];
-    float xs_[2], sx_[2], dx_[2];
+    const uint32_t gg = lane >> 3, jj = lane & 7, npieces = dim / 16, nlines = (dim + 127) / 128;
+    v4u rows[4][8];
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const uint32_t j = r0 + h * 32 + (lane & 31);
-        live[h] = lane < 32 && j < size;
-        nb[h] = live[h] ? members[b + j] : 0u;
-        xs_[h] = xsq[nb[h]];
-        sx_[h] = row_scale[nb[h]];
-        dx_[h] = row_err[nb[h]];
+    for (int k = 0; k < 4; k++) {
+        const uint32_t j = r0 + 8 * k + gg;
+        const uint32_t nbk = j < size ? members[b + j] : members[b + r0];  // (rows past the cluster's end: a copy of its first row here, never written out)
+        const v4u *rp = reinterpret_cast<const v4u *>(rows_q8 + uint64_t(nbk) * dim);
+        static_for<8>([&](auto ic) {
+            constexpr int L = decltype(ic)::value;
+            const uint32_t pth = L * 8 + jj;
+            rows[k][L] = rp[pth < npieces ? pth : npieces - 1];  // (past the row's end: any piece, it meets zero query bytes)
+        });
     }
+    // epilogue lanes: lane 8g + k, k < 4, finishes row 8k + g
+    const uint32_t jm = r0 + 8 * jj + gg;
+    const bool fin_lane = jj < 4 && jm < size;
+    const uint32_t nbm = fin_lane ? members[b + jm] : 0u;
+    const float xs_m = xsq[nbm], sx_m = row_scale[nbm], dx_m = row_err[nbm];
     for (uint32_t t = 0; t < nv; t++) {
         const uint32_t e = uint32_t(pairs[f + t]);  // q * n_probes + p
         const uint32_t q = e / n_probes, at = pos[e];
         __syncthreads();
-        for (uint32_t i = lane; i < ((dim + 127) & ~127u) / 4; i += 64)
-            reinterpret_cast<uint32_t *>(ivf_q8)[i] = i < dim / 4 ? reinterpret_cast<const uint32_t *>(Q8 + uint64_t(q) * dim)[i] : 0u;
+        reinterpret_cast<v4u *>(ivf_q8)[lane] = lane < npieces ? reinterpret_cast<const v4u *>(Q8 + uint64_t(q) * dim)[lane] : (v4u){0u, 0u, 0u, 0u};
         __syncthreads();
-        const float qs = qsq[q], sq = q_scale[q], dq = q_err[q];
+        int32_t acc[4] = {0, 0, 0, 0};
+        static_for<8>([&](auto ic) {
+            constexpr int L = decltype(ic)::value;
+            if ((uint32_t)L < nlines) {  // uniform
+                const v4u qq = reinterpret_cast<const v4u *>(ivf_q8)[L * 8 + jj];
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            if (__ballot(live[h]) == 0) continue;  // wave-uniform
-            const int32_t isum = q8_dots32(rows_q8, dim, ivf_q8, nb[h], live[h], lane);
-            float a, E;
-            q8_approx(metric, dim, isum, xs_[h], qs, sx_[h], dx_[h], sq, dq, a, E);
-            if (live[h]) {
-                const bool fin = E < INFINITY && a - a == 0.0f;
-                const uint64_t o = uint64_t(q) * ld + at + r0 + h * 32 + lane;
-                lo[o] = fin ? a - E : -INFINITY;
-                hi[o] = fin ? a + E : INFINITY;
+                for (int k = 0; k < 4; k++) {
+                    int32_t a = acc[k];
+                    a = __builtin_amdgcn_sdot4((int)rows[k][L].x, (int)qq.x, a, false);
+                    a = __builtin_amdgcn_sdot4((int)rows[k][L].y, (int)qq.y, a, false);
+                    a = __builtin_amdgcn_sdot4((int)rows[k][L].z, (int)qq.z, a, false);
+                    a = __builtin_amdgcn_sdot4((int)rows[k][L].w, (int)qq.w, a, false);
+                    acc[k] = a;
+                }
             }
+        });
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            acc[k] += __shfl_xor(acc[k], 1);
+            acc[k] += __shfl_xor(acc[k], 2);
+            acc[k] += __shfl_xor(acc[k], 4);
+        }
+        const int32_t isum = jj == 0 ? acc[0] : (jj == 1 ? acc[1] : (jj == 2 ? acc[2] : acc[3]));
+        if (fin_lane) {
+            float a, E;
+            q8_approx(metric, dim, isum, xs_m, qsq[q], sx_m, dx_m, q_scale[q], q_err[q], a, E);
+            const bool fin = E < INFINITY && a - a == 0.0f;
+            const uint64_t o = uint64_t(q) * ld + at + jm;
+            lo[o] = fin ? a - E : -INFINITY;
+            hi[o] = fin ? a + E : INFINITY;
         }
     }
 }
@@ -457,7 +483,7 @@ void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uin
     ws.keys_b.reserve(nq * ld * sizeof(uint64_t));
     ws.misc.reserve(64 + nq * np * (sizeof(uint64_t) + sizeof(uint32_t)) + 2 * (iv.k + 1) * sizeof(uint32_t) + 64);  // counters | cluster-major pair tables
     unsigned long long *d_ncand = ws.misc.as<unsigned long long>();
-    VDB_HIP(hipMemsetAsync(d_ncand, 0, 3 * sizeof(unsigned long long), s));  // [0] offers, [1] kept for the exact stage, [2] kept by the 8-bit tier
+    VDB_HIP(hipMemsetAsync(d_ncand, 0, 4 * sizeof(unsigned long long), s));  // [0] offers, [1] kept for the exact stage, [2] kept by the 8-bit tier, [3] rows the cluster-major tier fetched
     hipLaunchKernelGGL(k_ivf_candidates, dim3((unsigned)nq), dim3(256), 0, s, d_probes, capp, (uint32_t)np,
                        iv.d_offsets.as<uint32_t>(), iv.d_members.as<uint32_t>(), ld, ws.keys_a.as<uint64_t>(), d_ncand);
     // (2b) the certified half-precision pre-pass: only the offers that may be among the k nearest go on
@@ -469,7 +495,7 @@ void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uin
                       ix.ensure_rows_h(ws);
     double scan_bytes_per_row = double(ix.dim) * sizeof(float) + sizeof(float);
     uint8_t *flags = nullptr;
-    bool q8 = false;
+    bool q8 = false, cluster_major = false;
     if (half) {
         const int metric = ix.dist == 0 ? MET_L2_DIRECT : MET_COSINE;
         ws.dense.reserve(2 * nq * ld * sizeof(float));
@@ -490,7 +516,7 @@ void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uin
             float *d_qsc = reinterpret_cast<float *>(d_q8 + ((nq * ix.dim + 15) & ~uint64_t(15))), *d_qer = d_qsc + nq;
             launch_rows_to_q8(d_q, nq, (uint32_t)ix.dim, d_q8, d_qsc, d_qer, s);
             const uint64_t npairs = nq * np;
-            const bool cluster_major = g_ivf_q8 != 2 && npairs >= 256 && npairs <= 16384 && np <= 65535 && iv.k <= 65535;
+            cluster_major = g_ivf_q8 != 2 && npairs >= 256 && npairs <= 16384 && np <= 65535 && iv.k <= 65535;
             if (cluster_major) {
                 // (query, probe) pairs by cluster; empty offer slots are never written below: +inf = not an offer
                 uint64_t *d_pairs = reinterpret_cast<uint64_t *>(ws.misc.as<uint8_t>() + 64);
@@ -512,9 +538,8 @@ void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uin
             if (cluster_major) {
                 uint64_t *d_pairs = reinterpret_cast<uint64_t *>(ws.misc.as<uint8_t>() + 64);
                 uint32_t *d_pos = reinterpret_cast<uint32_t *>(d_pairs + npairs), *d_first = d_pos + npairs, *d_count = d_first + iv.k + 1;
-                const unsigned chunks = (unsigned)((iv.sizes_desc.empty() ? 0u : iv.sizes_desc[0]) + 63) / 64;
-                hipLaunchKernelGGL(k_ivf_q8_bounds_cm, dim3(std::max(chunks, 1u), (unsigned)iv.k), dim3(64),
-                                   (ix.dim + 127) & ~uint64_t(127), s, ix.d_rows_q8.as<int8_t>(), ix.d_q8_scale.as<float>(),
+                const unsigned chunks = (unsigned)((iv.sizes_desc.empty() ? 0u : iv.sizes_desc[0]) + 31) / 32;
+                hipLaunchKernelGGL(k_ivf_q8_bounds_cm, dim3(std::max(chunks, 1u), (unsigned)iv.k), dim3(64), 1024, s, ix.d_rows_q8.as<int8_t>(), ix.d_q8_scale.as<float>(),
                                    ix.d_q8_err.as<float>(), (uint32_t)ix.dim, metric, d_q8, d_qsc, d_qer, ix.d_sq.as<float>(), ws.qsq.as<float>(),
                                    iv.d_offsets.as<uint32_t>(), iv.d_members.as<uint32_t>(), d_pairs, d_pos, d_first, d_count, (uint32_t)np, ld, d_lo, d_hi);
             } else {
@@ -565,11 +590,24 @@ void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uin
         }
     }
     if (!ws.pending.empty()) {  // measurement on: the scan's algorithmic bytes = scanned rows x (dim*4 + 4), known only now
-        unsigned long long total[3] = {0, 0, 0};
+        unsigned long long total[4] = {0, 0, 0, 0};
         VDB_HIP(hipMemcpyAsync(total, d_ncand, sizeof(total), hipMemcpyDeviceToHost, s));
         VDB_SYNC(s);
-        if (q8 && ws.pending.size() >= 3) {  // 8-bit rows + scale, error, norm for every offer; fp16 rows for what that tier kept
-            ws.pending[ws.pending.size() - 3].bytes += double(total[0]) * (double(ix.dim) + 3 * sizeof(float));
+        if (q8 && cluster_major) {  // rows the cluster-major tier read = the sizes of the clusters with at least one visit (a same-address
+            // atomic per block inside the kernel costs more than the kernel: the visit counts are read back instead)
+            const uint64_t npairs = nq * np;
+            const uint32_t *d_count = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint64_t *>(ws.misc.as<uint8_t>() + 64) + npairs) + npairs + iv.k + 1;
+            std::vector<uint32_t> cnt(iv.k);
+            VDB_HIP(hipMemcpyAsync(cnt.data(), d_count, iv.k * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            VDB_SYNC(s);
+            for (uint64_t c = 0; c < iv.k; c++)
+                if (cnt[c]) total[3] += iv.offsets[c + 1] - iv.offsets[c];
+        }
+        iv.last_rows_fetched_q8 = total[3];
+        if (q8 && ws.pending.size() >= 3) {  // 8-bit rows + scale, error, norm: for every offer (query-major) or once per row of a
+            // visited cluster (cluster-major) + the bounds written per offer; fp16 rows for what that tier kept
+            ws.pending[ws.pending.size() - 3].bytes += total[3] ? double(total[3]) * (double(ix.dim) + 3 * sizeof(float)) + double(total[0]) * 2 * sizeof(float)
+                                                                  : double(total[0]) * (double(ix.dim) + 3 * sizeof(float));
             ws.pending[ws.pending.size() - 2].bytes += double(total[2]) * (double(ix.dim) * sizeof(uint16_t) + sizeof(float));
             ws.pending.back().bytes += double(total[1]) * scan_bytes_per_row;
             iv.last_offers = total[0];
