@@ -25,6 +25,7 @@ At N=1 (default flags) the same run also reports, under "legs", every other item
   config1_gist_1000  BASELINE config 1: the reference's own data/gist_1000.bin x data/gist_test.bin, Flat, L2Sqr, k=10,
                      GPU beside the CPU oracle serial and on all cores (protocol of examples/bench.rs:403-433)
   pq_flat            PQ-Flat ADC (4-bit, m=320, ef=100) on a 1M low-rank gist-like corpus
+  ivf                IVF (sqrt(N) = 1000 clusters, 4 probes) on the same corpus: the probe-list scan as a certified 8-bit -> fp16 -> exact cascade
   hnsw               HNSW (M=16, efc=200, ef=128) on the first --hnsw-rows rows of that corpus (default: all 1M)
   hnsw_pq            the same graph walked with ADC distances + cached-form re-sort (HNSWIndex::knn_pq)
 each with its own roofline / cpu_baseline / parity, plus `attainable_peak_GBps` from a streaming-read probe in this run.
@@ -607,7 +608,9 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable
     def run(ix, wl, rows, ef, fn, extra_cfg, nq=nq, queries=queries, outs=(o_idx, o_dist, o_cnt), t_idx=t_idx):
         o_idx, o_dist, o_cnt = outs
         el, _ = timed(ix, fn, args.steps, max(1, min(args.warmup, 2)))
-        kernel = {"pq_flat": "pq_adc", "hnsw": "hnsw", "hnsw_pq": "hnsw"}[wl]
+        kernel = {"pq_flat": "pq_adc", "hnsw": "hnsw", "hnsw_pq": "hnsw", "ivf": "ivf_rerank"}[wl]
+        if wl == "ivf":  # the scan's certified cascade holds the dominant kernel when it runs
+            kernel = next((kn for kn in ("ivf_q8", "ivf_half") if ix.prof_get(kn)["launches"]), kernel)
         leg = {"value": round(nq * args.steps / el, 1), "unit": "queries/s", "steps": args.steps,
                "ms_per_step": round(el / args.steps * 1e3, 3), "data": "synthetic (low-rank gist-like)",
                "config": dict({"rows": rows, "dim": dim, "queries_per_step": nq, "k": k, "dist": "L2Sqr", "ef": ef}, **extra_cfg),
@@ -632,6 +635,19 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable
                 leg["hnsw_work_per_query"]["ruled_out_by_half_precision_pre_pass"] = round(dropped / nq, 1)
             leg["roofline"]["units_per_launch"] = ("n_half x dim*2 + (n_dist - ruled_out) x dim*4 + n_dist x 4 + n_expanded x max_m0*4 bytes, counted by the kernel" if wl == "hnsw" else
                                                    "n_dist x 160-B code rows + n_expanded x max_m0*4 bytes (ADC walk: latency-bound by construction), counted by the kernel")
+        elif wl == "ivf":
+            r = leg["roofline"]
+            offers, kept, kept8, fetched = (ix.get_stat(n_) for n_ in ("ivf_last_offers", "ivf_last_kept", "ivf_last_kept_q8", "ivf_last_rows_fetched_q8"))
+            leg["ivf_work_per_query"] = {"offers": round(offers / nq, 1), "kept_by_8bit_tier": round(kept8 / nq, 1), "exact_stage": round(kept / nq, 1)}
+            if fetched:
+                r["rows_fetched_per_step"] = fetched
+                r["visits_per_fetched_row"] = round(offers / fetched, 2)
+            r["units_per_launch"] = ("rows of the visited clusters x (dim + 12) B of the 8-bit image, each read once per step by the cluster-major tier "
+                                     "(k_ivf_q8_bounds_cm) + 8 B of bounds per offer; then dim*2 B per offer the tier keeps (fp16 tier) and dim*4 B per "
+                                     "offer that reaches the exact stage" if fetched else "bytes of the dominant tier, counted by the library")
+            alg = offers * (dim * 4 + 4)  # SURVEY 8(d)-style figure: every offered row as f32
+            tot_ms = sum(ix.prof_get(kn)["ms"] for kn in ("ivf_q8", "ivf_half", "ivf_rerank")) / max(ix.prof_get("ivf_rerank")["launches"], 1)
+            r["f32_equivalent_GBps"] = round(alg / (tot_ms * 1e-3) / 1e9, 1) if tot_ms > 0 else None
         else:
             r = leg["roofline"]
             r["units_per_launch"] = ("rows x ceil(m*n_bits/8) code bytes per scan; one scan (k_pq_adc16) serves the 8 queries whose "
@@ -670,6 +686,20 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable
     legs["pq_flat"] = run(ix, "pq_flat", n, 100,
                           lambda: ix.knn_pq_device(queries.data_ptr(), nq, k, 100, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr()),
                           {"workload": "pq_flat_knn_gist1m", "n_bits": 4, "m": dim // 3, "train_and_encode_s": round(pq_build_s, 1)})
+    ix.close()
+    del ix
+    torch.cuda.empty_cache()
+
+    # -- IVF (IVFIndex::from_vec_set, ivf_index.rs:66-118: sqrt(N) clusters, k-means on 10000 sampled rows, 10
+    #    iterations; knn with the default 4 probes)
+    ix = vdb.GpuIndex(dim, "l2sqr", device=local_rank)
+    ix.add_device(base.data_ptr(), n)
+    t_b = time.perf_counter()
+    ix.ivf_build(int(round(n ** 0.5)), train_n=10000, max_iter=10, tol=1e-6, seed=42)
+    ivf_build_s = time.perf_counter() - t_b
+    legs["ivf"] = run(ix, "ivf", n, 4,
+                      lambda: ix.ivf_knn_device(queries.data_ptr(), nq, k, 4, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr()),
+                      {"workload": "ivf_knn_gistlike_1000000", "clusters": int(round(n ** 0.5)), "n_probes": 4, "build_s": round(ivf_build_s, 1)})
     ix.close()
     del ix
     torch.cuda.empty_cache()
