@@ -87,6 +87,24 @@ def gist_lowrank_gpu(torch, n, dim, seed, device, latent=32, chunk=131072):
     return out
 
 
+def load_rows_file(torch, path, dim, r0, r1, device, chunk=131072, cycle=False):
+    """rows [r0, r1) of a raw row-major f32 file without header (src/bin/convert_fvecs.rs:29-31 writes exactly this), streamed
+    through a memory map; cycle=True repeats the file's rows when it holds fewer than r1"""
+    mm = np.memmap(path, dtype=np.float32, mode="r")
+    total = mm.shape[0] // dim
+    if total * dim != mm.shape[0] or total == 0:
+        raise SystemExit(f"bench.py: {path}: size is not a positive multiple of dim*4 = {dim * 4} bytes")
+    if r1 > total and not cycle:
+        raise SystemExit(f"bench.py: {path} holds {total} rows of dim {dim}, {r1} requested")
+    out = torch.empty((r1 - r0, dim), dtype=torch.float32, device=device)
+    for a in range(r0, r1, chunk):
+        b = min(r1, a + chunk)
+        ids = np.arange(a, b) % total
+        blk = mm.reshape(total, dim)[ids] if (cycle and b > total) else mm[a * dim:b * dim].reshape(b - a, dim)
+        out[a - r0:b - r0] = torch.from_numpy(np.ascontiguousarray(blk)).to(device)
+    return out
+
+
 def hbm_roofline(kernel, p, extra=None):
     """roofline object of one library kernel from its HIP-event record (vdb_prof_get): bytes and ms are sums over the
     launches of the timed region; `traffic` (PMC HBM bytes) cannot be collected inside a bench run and stays null --
@@ -147,7 +165,7 @@ def flat_roofline(ix, rows, dim, nq):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=0, help="corpus rows (default: 1,000,000 = Gist1M)")
     ap.add_argument("--dim", type=int, default=960)
@@ -176,9 +194,31 @@ def main():
     ap.add_argument("--hnsw-queries", type=int, default=8192,
                     help="queries per step of the hnsw / hnsw_pq legs: a walk is one wavefront and the chip keeps 2048 of them "
                          "resident, so the rate is flat from ~4096 queries per call on (a 1000-query call is reported beside it)")
+    ap.add_argument("--base-file", type=str, default="",
+                    help="raw row-major f32 corpus, no header (the output of src/bin/convert_fvecs.rs:29-31, e.g. a real gist_base "
+                         "converted from .fvecs): used instead of the synthetic rows when given; rows = file size / (dim * 4) unless --rows")
+    ap.add_argument("--query-file", type=str, default="", help="raw row-major f32 queries (same layout); the first --nq rows are used")
     ap.add_argument("--hnsw-batch", type=int, default=1024,
                     help="points per builder batch (the reference uses 4 x rayon threads); >= 256 puts the candidate phase on the GPU")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves -- as a CHILD process, before
+    # anything in this process touches the GPU (no exec of a GPU-initialised process), relay rank 0's JSON line (the child
+    # shares stdout) and exit with the child's code.  Under a launcher (WORLD_SIZE set) the flag must agree with it.
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')} ranks")
 
     import torch
     import torch.distributed as dist
@@ -211,9 +251,16 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     wl = args.workload
-    default_size = args.rows <= 0 and args.dim == 960 and args.nq == 1000
+    if bool(args.base_file) != bool(args.query_file):
+        raise SystemExit("bench.py: --base-file and --query-file go together")
+    from_file = bool(args.base_file)
+    if from_file and args.rows <= 0:
+        args.rows = os.path.getsize(args.base_file) // (args.dim * 4)
+    default_size = args.rows in (0, 1_000_000) and args.dim == 960 and args.nq == 1000
     if args.rows <= 0:
         args.rows = 1_000_000
+    data_name = (f"file: {os.path.basename(args.base_file)} x {os.path.basename(args.query_file)} (raw row-major f32, convert_fvecs.rs layout)"
+                 if from_file else ("synthetic" if args.data == "gistlike" else "synthetic (low-rank gist-like)"))
     legs_on = world == 1 and wl == "flat" and (args.legs == "all" or (args.legs == "auto" and default_size))
     ef = args.ef or {"pq_flat": 100, "hnsw": 128, "hnsw_pq": 128, "ivf": 4}.get(wl, 0)
     n, dim, nq, k = args.rows, args.dim, args.nq, args.k
@@ -227,8 +274,12 @@ def main():
 
     # identical corpus on every rank (same seed), each keeps its row block
     gen = gist_like_gpu if args.data == "gistlike" else gist_lowrank_gpu
-    base = gen(torch, n, dim, 1806, device)
-    queries = gen(torch, nq, dim, 1807, device)
+    if from_file:
+        base = load_rows_file(torch, args.base_file, dim, 0, n, device)
+        queries = load_rows_file(torch, args.query_file, dim, 0, nq, device)
+    else:
+        base = gen(torch, n, dim, 1806, device)
+        queries = gen(torch, nq, dim, 1807, device)
     r0, r1 = shard_bounds(n, world, rank) if wl in ("flat", "pq_flat") else (0, n)  # HNSW / IVF: full replica per GPU
     shard = base[r0:r1].contiguous()
     torch.cuda.synchronize()
@@ -322,14 +373,31 @@ def main():
         index.prof_reset()
         fence()
         t0 = time.perf_counter()
+        marks = [t0]
         for _ in range(steps):
             r = fn()
+            marks.append(time.perf_counter())
         fence()
         el = time.perf_counter() - t0
         index.prof_enable(False)
+        marks[-1] = t0 + el  # the closing fence belongs to the last step
+        step_times.clear()
+        step_times.extend((b - a) * 1e3 for a, b in zip(marks[:-1], marks[1:]))
         return el, r
 
+    step_times = []  # ms per step of the LAST timed() region (host clock between consecutive step returns)
+
+    def step_stats():
+        st = sorted(step_times)
+        if not st:
+            return None
+        return {"min": round(st[0], 4), "median": round(st[len(st) // 2], 4), "max": round(st[-1], 4),
+                "how": "host clock between consecutive step returns inside the one timed region (a Flat / PQ / HNSW step at N=1 ends in the "
+                       "library's own stream synchronisation; with N>1 the exchange of step i overlaps step i+1, so single steps are "
+                       "enqueue-to-enqueue and only the total is fenced)"}
+
     elapsed, res = timed(ix, step, args.steps, args.warmup)
+    head_steps = step_stats()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -390,9 +458,12 @@ def main():
     out = {
         "metric": f"queries/sec at recall@10, Gist1M d=960 ({names[0]}, {dname}, k=10)",
         "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic" if args.data == "gistlike" else "synthetic (low-rank gist-like)",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "step_ms": head_steps, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None,
+        # the arithmetic type of everything that leaves the library (strict-order f32 folds); the Flat filter in front of it ranks
+        # its shortlist from a scaled fp16 mirror and every answer is certified against the f32 rows
+        "dtype": "f32 (certified fp16 filter pass)" if (roofline or {}).get("kernel") == "flat_half" else "f32",
+        "data": data_name,
         "config": {"workload": names[1], "rows": n, "dim": dim, "queries_per_step": nq, "k": k, "dist": dname,
                    "parallelism": par if world > 1 else "single GPU"},
         "roofline": roofline, "recall_at_10": None,
@@ -431,7 +502,17 @@ def main():
     if legs_on:
         legs = {}
         outs = (o_idx, o_dist, o_cnt)
-        legs["flat_f32_operands"] = leg_flat_f32(ix, timed, queries, nq, k, outs, args, n, dim, res, attainable)
+        bytes_per_row = {"flat": out.get("hbm_bytes_per_row")}
+        legs["flat_f32_operands"] = f32 = leg_flat_f32(ix, timed, step_stats, queries, nq, k, outs, args, n, dim, res, attainable)
+        # SURVEY 8(d)'s own figure -- N*d*4 bytes per corpus pass -- where the driver's record keeps it: the same 1000-query step
+        # with the fp16 pass off, i.e. the split-bf16 kernel streaming 4 B/element (the ">= 70 % of HBM roofline" target)
+        fr = f32["roofline"] or {}
+        out["roofline"]["f32_operand_leg"] = {"qps": f32["value"], "ms_per_step": f32["ms_per_step"], "kernel": fr.get("kernel"),
+                                              "avg_launch_ms": fr.get("avg_launch_ms"), "bytes_per_launch": fr.get("bytes_per_launch"),
+                                              "achieved": fr.get("achieved"), "frac": fr.get("frac"), "unit": "GB/s",
+                                              "bytes_def": "SURVEY 8(d): corpus passes x N x d x 4 B, which this kernel really streams",
+                                              "results_equal_headline": f32["results_equal_headline"]}
+        bytes_per_row["flat_with_redo_tier"] = f32["hbm_bytes_per_row"]
         for b in (32, 1):
             legs[f"flat_B{b}"] = leg_flat_small(ix, timed, queries, b, k, outs, args, n, dim, res, attainable)
         ix.close()
@@ -439,7 +520,12 @@ def main():
         torch.cuda.empty_cache()
         legs["config1_gist_1000"] = leg_config1(vdb, O, torch, device, local_rank, threads, k)
         del host_base
-        legs.update(legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable))
+        legs.update(legs_ann(vdb, O, torch, device, local_rank, timed, step_stats, args, threads, attainable, from_file))
+        for nm in ("pq_flat", "ivf", "hnsw", "hnsw_pq"):
+            bytes_per_row[nm] = legs[nm].get("hbm_bytes_per_row")
+        out["hbm_bytes_per_row"] = dict(bytes_per_row, note="resident HBM bytes per 960-d row by index kind: f32 rows + norms + the mirrors / images / codes / "
+                                        "links that kind keeps (flat = f32 rows + fragment-ordered fp16 mirror; the redo tier's split-bf16 mirror, the "
+                                        "row-major fp16 image of the walks / IVF scan and IVF's 8-bit image are built on first use)")
         out["legs"] = legs
     mp = (out.get("roofline") or {}).get("matrix_pipe")
     if mp is not None and world == 1:
@@ -517,7 +603,7 @@ def with_attainable(roofline, attainable):
     return roofline
 
 
-def leg_flat_f32(ix, timed, queries, nq, k, outs, args, n, dim, ref, attainable):
+def leg_flat_f32(ix, timed, step_stats, queries, nq, k, outs, args, n, dim, ref, attainable):
     """the headline step with the fp16 first pass off: every corpus pass streams the 4-B/element split-bf16 mirror, i.e.
     SURVEY 8(d)'s N*d*4 algorithmic bytes; results must equal the headline's bit for bit"""
     ref_idx, ref_dist = ref[0].clone(), ref[1].clone()
@@ -528,8 +614,9 @@ def leg_flat_f32(ix, timed, queries, nq, k, outs, args, n, dim, ref, attainable)
     same = bool((outs[0] == ref_idx).all().item()) and bool((outs[1] == ref_dist).all().item())
     ix.set_param("flat_half", args.half)
     return {"value": round(nq * args.steps / el, 1), "unit": "queries/s", "steps": args.steps,
-            "ms_per_step": round(el / args.steps * 1e3, 3), "queries_per_step": nq, "queries_per_corpus_pass": 128,
-            "roofline": r, "results_equal_headline": same, "fallback_queries_total": ix.flat_fallback_count()}
+            "ms_per_step": round(el / args.steps * 1e3, 3), "step_ms": step_stats(), "queries_per_step": nq, "queries_per_corpus_pass": 128,
+            "roofline": r, "results_equal_headline": same, "fallback_queries_total": ix.flat_fallback_count(),
+            "hbm_bytes_per_row": ix.get_stat("hbm_bytes_per_row")}
 
 
 def leg_flat_small(ix, timed, queries, b, k, outs, args, n, dim, ref, attainable):
@@ -591,13 +678,20 @@ def leg_config1(vdb, O, torch, device, local_rank, threads, k):
     return leg
 
 
-def legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable):
+def legs_ann(vdb, O, torch, device, local_rank, timed, step_stats, args, threads, attainable, from_file=False):
     """BASELINE configs 3 and 4 on ONE low-rank gist-like corpus (recall on per-dimension-Gaussian rows is uninformative:
-    0.2 for HNSW, 0.5 for PQ): PQ-Flat ADC on 1M rows, HNSW on the first --hnsw-rows of them."""
+    0.2 for HNSW, 0.5 for PQ): PQ-Flat ADC on 1M rows, HNSW on the first --hnsw-rows of them.  With
+    --base-file / --query-file the file's rows are used instead (real Gist1M when present)."""
     n, dim, nq, k = 1_000_000, 960, 1000, 10
     legs = {}
-    base = gist_lowrank_gpu(torch, n, dim, 1806, device)
-    queries = gist_lowrank_gpu(torch, nq, dim, 1807, device)
+    if from_file:
+        base = load_rows_file(torch, args.base_file, dim, 0, n, device)
+        queries = load_rows_file(torch, args.query_file, dim, 0, nq, device)
+        data_name = f"file: {os.path.basename(args.base_file)} x {os.path.basename(args.query_file)}"
+    else:
+        base = gist_lowrank_gpu(torch, n, dim, 1806, device)
+        queries = gist_lowrank_gpu(torch, nq, dim, 1807, device)
+        data_name = "synthetic (low-rank gist-like)"
     o_idx = torch.zeros((nq, k), dtype=torch.int64, device=device)
     o_dist = torch.zeros((nq, k), dtype=torch.float32, device=device)
     o_cnt = torch.zeros((nq,), dtype=torch.int64, device=device)
@@ -612,7 +706,8 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable
         if wl == "ivf":  # the scan's certified cascade holds the dominant kernel when it runs
             kernel = next((kn for kn in ("ivf_q8", "ivf_half") if ix.prof_get(kn)["launches"]), kernel)
         leg = {"value": round(nq * args.steps / el, 1), "unit": "queries/s", "steps": args.steps,
-               "ms_per_step": round(el / args.steps * 1e3, 3), "data": "synthetic (low-rank gist-like)",
+               "ms_per_step": round(el / args.steps * 1e3, 3), "step_ms": step_stats(), "data": data_name,
+               "hbm_bytes_per_row": ix.get_stat("hbm_bytes_per_row"),
                "config": dict({"rows": rows, "dim": dim, "queries_per_step": nq, "k": k, "dist": "L2Sqr", "ef": ef}, **extra_cfg),
                "roofline": with_attainable(hbm_roofline(kernel, ix.prof_get(kernel)), attainable)}
         if wl in ("hnsw", "hnsw_pq"):
@@ -666,11 +761,35 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable
             del hb
         return leg
 
-    def small_call(ix, fn1000):
-        """the same search as ONE 1000-query call (the size of the other legs' steps): bounded by the longest walk, not a rate"""
-        el, _ = timed(ix, fn1000, args.steps, 1)
-        return {"queries_per_step": 1000, "value": round(1000 * args.steps / el, 1), "unit": "queries/s",
-                "ms_per_step": round(el / args.steps * 1e3, 3)}
+    def small_call(ix, fn, nq_call=1000):
+        """the same search as ONE call of nq_call queries (1000 = the size of the other legs' steps; 1 = the reference's own
+        per-call shape, db.search): bounded by the longest walk / the fixed launches of a call, not a rate"""
+        steps = args.steps if nq_call >= 100 else max(args.steps, 50)
+        el, _ = timed(ix, fn, steps, 2)
+        return {"queries_per_step": nq_call, "value": round(nq_call * steps / el, 1), "unit": "queries/s",
+                "ms_per_step": round(el / steps * 1e3, 4), "step_ms": step_stats()}
+
+    lat_ns = None
+    if attainable is not None:
+        from lab_1806_vec_db_amd.index import latency_probe
+
+        lat_ns = round(latency_probe(local_rank, 1 << 30, 20000), 1)
+
+    def latency_floor(leg, one_call, round_trips, what):
+        """A graph walk is a CHAIN: per expansion the popped node's link row, the visited words of its neighbours and the first
+        lines of their rows are three dependent HBM accesses (hnsw_index.rs:258-291 cannot start one before the previous
+        returned).  A call of <= 2048 queries is one round of resident walks, so its time is the longest chain, not bytes:
+        floor = expansions per query x dependent round trips x the measured latency of one dependent HBM load."""
+        if lat_ns is None:
+            return
+        ne = leg["hnsw_work_per_query"]["n_expanded"]
+        floor_ms = ne * round_trips * lat_ns * 1e-6
+        leg["roofline"]["latency_floor"] = {
+            "dependent_load_ns": lat_ns, "round_trips_per_expansion": round_trips, "what": what, "expansions_per_query": ne,
+            "floor_ms_per_call": round(floor_ms, 4), "one_call_of_1000_ms": one_call["ms_per_step"],
+            "frac": round(floor_ms / one_call["ms_per_step"], 4),
+            "note": "vdb_latency_probe in this run (pointer chase over a 1-GiB buffer); the mean walk, so calls bounded by their longest "
+                    "walk sit further above it; the HBM-bytes fraction beside it is the yardstick of the large calls only"}
 
     # -- PQ-Flat: config/bench_pq_hnsw.toml:16-23 (n_bits 4, m = dim/3, k_means_size 10000, max_iter 20, tol 1e-6), ef = 100
     ix = vdb.GpuIndex(dim, "l2sqr", device=local_rank)
@@ -686,6 +805,8 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable
     legs["pq_flat"] = run(ix, "pq_flat", n, 100,
                           lambda: ix.knn_pq_device(queries.data_ptr(), nq, k, 100, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr()),
                           {"workload": "pq_flat_knn_gist1m", "n_bits": 4, "m": dim // 3, "train_and_encode_s": round(pq_build_s, 1)})
+    legs["pq_flat"]["one_call_of_1"] = small_call(
+        ix, lambda: ix.knn_pq_device(queries.data_ptr(), 1, k, 100, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr()), 1)
     ix.close()
     del ix
     torch.cuda.empty_cache()
@@ -712,7 +833,8 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable
     ix.hnsw_build(M=16, ef_construction=200, seed=42, batch=args.hnsw_batch, nthreads=threads)
     hb_s = time.perf_counter() - t_b
     hq = max(1000, args.hnsw_queries)
-    queries_h = gist_lowrank_gpu(torch, hq, dim, 1807, device)
+    # (a query file shorter than the step is repeated cyclically: the rate of a step does not depend on the queries being distinct)
+    queries_h = load_rows_file(torch, args.query_file, dim, 0, hq, device, cycle=True) if from_file else gist_lowrank_gpu(torch, hq, dim, 1807, device)
     h_idx = torch.zeros((hq, k), dtype=torch.int64, device=device)
     h_dist = torch.zeros((hq, k), dtype=torch.float32, device=device)
     h_cnt = torch.zeros((hq,), dtype=torch.int64, device=device)
@@ -727,6 +849,9 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable
                        **hkw)
     legs["hnsw"]["one_call_of_1000"] = small_call(
         ix, lambda: ix.hnsw_knn_device(queries_h.data_ptr(), 1000, k, 128, h_idx.data_ptr(), h_dist.data_ptr(), h_cnt.data_ptr()))
+    legs["hnsw"]["one_call_of_1"] = small_call(
+        ix, lambda: ix.hnsw_knn_device(queries_h.data_ptr(), 1, k, 128, h_idx.data_ptr(), h_dist.data_ptr(), h_cnt.data_ptr()), 1)
+    latency_floor(legs["hnsw"], legs["hnsw"]["one_call_of_1000"], 3, "link row -> visited words -> first row lines")
     # -- HNSW + PQ (hnsw_index.rs:672-697; config/bench_pq_hnsw.toml: the reference's fastest published point): the same graph,
     #    the PQ leg's centroids, codes encoded on the GPU; ADC walk + cached-form re-sort
     ix.pq_attach(4, dim // 3, cent, None)
@@ -736,6 +861,9 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, args, threads, attainable
                           {"workload": f"hnsw_pq_knn_gistlike_{hr}", "M": 16, "ef_construction": 200, "n_bits": 4, "m": dim // 3}, **hkw)
     legs["hnsw_pq"]["one_call_of_1000"] = small_call(
         ix, lambda: ix.hnsw_knn_device(queries_h.data_ptr(), 1000, k, 128, h_idx.data_ptr(), h_dist.data_ptr(), h_cnt.data_ptr(), use_pq=True))
+    legs["hnsw_pq"]["one_call_of_1"] = small_call(
+        ix, lambda: ix.hnsw_knn_device(queries_h.data_ptr(), 1, k, 128, h_idx.data_ptr(), h_dist.data_ptr(), h_cnt.data_ptr(), use_pq=True), 1)
+    latency_floor(legs["hnsw_pq"], legs["hnsw_pq"]["one_call_of_1000"], 3, "link row -> visited words -> code rows")
     ix.close()
     return legs
 

@@ -307,6 +307,35 @@ int vdb_sharded_flat_knn(vdb_sharded *sh, const float *queries, uint64_t nq, uin
 int vdb_sharded_pq_attach(vdb_sharded *sh, uint64_t n_bits, uint64_t m, const float *centroids);
 int vdb_sharded_knn_pq(vdb_sharded *sh, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef,
                        uint64_t *out_idx, float *out_dist, uint64_t *out_count);
+/* REPLICA layout ("HNSW: replicas only"): every GPU of the context keeps ALL rows (ids are global as they are);
+ * a search splits the QUERIES instead -- rank r of S answers the block [r * ceil(nq/S), min(nq, (r+1) * ceil(nq/S)))
+ * (vdb_replica_query_block) and ONE fixed-size all-gather concatenates the blocks on every rank; no merge.  All of
+ * DynamicIndex's searches (dynamic_index.rs:68-93) run in this layout: vdb_sharded_flat_knn and vdb_sharded_knn_pq accept it
+ * as well as the row layout (any k), the HNSW searches below exist only here (a graph's edges cross any row partition).
+ * vdb_sharded_layout: 0 = no rows yet, 1 = row blocks (vdb_sharded_set_rows), 2 = replicas. */
+int vdb_sharded_set_rows_replica(vdb_sharded *sh, const float *rows, uint64_t n_total);
+int vdb_sharded_layout(const vdb_sharded *sh, int *out);
+int vdb_replica_query_block(uint64_t nq, uint64_t world, uint64_t rank, uint64_t *q0, uint64_t *q1);
+/* HNSWIndex over the replicas: built once per process on its first GPU (hnsw_index.rs:391-457 through vdb_hnsw_build's host
+ * builder; deterministic for a given seed / batch / thread count, so the processes of a multi-process job hold equal graphs)
+ * or attached from arrays (vdb_hnsw_attach's layout), then mirrored to the process's other GPUs. */
+int vdb_sharded_hnsw_build(vdb_sharded *sh, uint64_t M, uint64_t ef_construction, uint64_t seed, uint64_t batch, int nthreads);
+int vdb_sharded_hnsw_attach(vdb_sharded *sh, uint64_t M, uint64_t ef_construction, const uint32_t *level0, const uint64_t *len0,
+                            const uint64_t *vec_level, const uint32_t *upper, const uint64_t *upper_len, int has_enter,
+                            uint64_t enter_point, uint64_t enter_level);
+/* HNSWIndex::knn_with_ef (hnsw_index.rs:619-634; ef = 0 -> the graph's default) / knn_pq (:672-697) with the queries split
+ * over the replicas -- equal to the single-GPU answer row by row. */
+int vdb_sharded_hnsw_knn(vdb_sharded *sh, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef, uint64_t *out_idx,
+                         float *out_dist, uint64_t *out_count);
+int vdb_sharded_hnsw_knn_pq(vdb_sharded *sh, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef, uint64_t *out_idx,
+                            float *out_dist, uint64_t *out_count);
+/* Failed sharded calls.  vdb_sharded_set_rows[_replica] is all-or-nothing: when one GPU fails (out of memory, say) every
+ * shard is rolled back to an empty index and the call may be repeated.  A SEARCH that fails on one rank of a multi-PROCESS
+ * context (vdb_ctx_create_rank, world > 1) may leave the other ranks inside the all-gather; the object is then "poisoned"
+ * (vdb_sharded_poisoned -> 1) and refuses further searches with VDB_ERR_STATE-style errors: destroy it on every rank.
+ * Exercised on hardware with ONE rank only (the test boxes have one GPU): the N > 1 paths -- ncclCommInitAll, grouped
+ * all-gathers over several local GPUs, cross-process ordering -- are correct by construction, not by test. */
+int vdb_sharded_poisoned(const vdb_sharded *sh, int *out);
 
 /* ---- measurement hooks -------------------------------------------------------------------
  * When enabled, the dominant kernels are bracketed by HIP events on their own stream and the
@@ -319,6 +348,10 @@ int vdb_stream_probe(int device_id, uint64_t bytes, int iters, double *out_gbps)
  * by `waves_per_simd` waves on every SIMD, `iters` x 8 independent tiles per wave; dense TFLOP/s of the launch and the shader
  * clock (GHz) the chip held meanwhile.  Measurement hook. */
 int vdb_mfma_probe(int device_id, int waves_per_simd, int iters, double *out_tflops, double *out_clock_ghz);
+/* latency of one DEPENDENT HBM access on this box: a single lane follows a random cycle over the 128-B lines of a `bytes`-sized
+ * buffer (larger than L2 and the Infinity Cache) for `hops` loads; nanoseconds per load.  The floor of the graph walks
+ * (hnsw_index.rs:258-291 is a chain of dependent accesses per expansion) is quoted on it.  Measurement hook. */
+int vdb_latency_probe(int device_id, uint64_t bytes, uint32_t hops, double *out_ns_per_load);
 int vdb_prof_reset(vdb_index *idx);
 int vdb_prof_get(vdb_index *idx, const char *kernel, double *total_ms, uint64_t *launches, double *bytes);
 

@@ -97,8 +97,17 @@ SIGNATURES = {
     "vdb_sharded_flat_knn": [vp, f32p, u64, u64, u64, u64p, f32p, u64p],
     "vdb_sharded_pq_attach": [vp, u64, u64, f32p],
     "vdb_sharded_knn_pq": [vp, f32p, u64, u64, u64, u64, u64p, f32p, u64p],
+    "vdb_sharded_set_rows_replica": [vp, f32p, u64],
+    "vdb_sharded_layout": [vp, intp],
+    "vdb_replica_query_block": [u64, u64, u64, u64p, u64p],
+    "vdb_sharded_hnsw_build": [vp, u64, u64, u64, u64, C.c_int],
+    "vdb_sharded_hnsw_attach": [vp, u64, u64, u32p, u64p, u64p, u32p, u64p, C.c_int, u64, u64],
+    "vdb_sharded_hnsw_knn": [vp, f32p, u64, u64, u64, u64, u64p, f32p, u64p],
+    "vdb_sharded_hnsw_knn_pq": [vp, f32p, u64, u64, u64, u64, u64p, f32p, u64p],
+    "vdb_sharded_poisoned": [vp, intp],
     "vdb_stream_probe": [C.c_int, u64, C.c_int, f64p],
     "vdb_mfma_probe": [C.c_int, C.c_int, C.c_int, f64p, f64p],
+    "vdb_latency_probe": [C.c_int, C.c_uint64, C.c_uint32, f64p],
     "vdb_prof_enable": [vp, C.c_int],
     "vdb_prof_reset": [vp],
     "vdb_prof_get": [vp, C.c_char_p, f64p, u64p, f64p],

@@ -911,6 +911,13 @@ int vdb_mfma_probe(int device_id, int waves_per_simd, int iters, double *out_tfl
     mfma_probe(device_id, waves_per_simd, iters, out_tflops, out_clock_ghz);
     VDB_API_END
 }
+int vdb_latency_probe(int device_id, uint64_t bytes, uint32_t hops, double *out_ns_per_load) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(out_ns_per_load, "null out");
+    require_gpu();
+    *out_ns_per_load = latency_probe(device_id, bytes, hops);
+    VDB_API_END
+}
 int vdb_prof_enable(vdb_index *idx, int on) {
     VDB_API_BEGIN
     VDB_REQUIRE(idx, "null index");

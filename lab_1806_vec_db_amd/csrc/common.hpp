@@ -4,8 +4,11 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
+#include <set>
 #include <stdexcept>
 #include <string>
+#include <utility>
 
 namespace vdb {
 
@@ -35,6 +38,20 @@ struct Error : std::runtime_error {
     do {                                                \
         if (!(cond)) throw ::vdb::Error(1, (msg));      \
     } while (0)
+
+// Opt a kernel in to more dynamic LDS than the default limit, once per (kernel, device).  Read-side entry points are
+// re-entrant and vdb_ctx drives one host thread per GPU, so the "done" set is guarded and keyed by the current device (a
+// plain `static bool` raced between threads and only ever covered the device that happened to launch first).
+inline void func_max_lds(const void *fn, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    VDB_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> g(mu);
+    if (done.count({fn, dev})) return;
+    VDB_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({fn, dev});
+}
 
 // ---- total order of CandidatePair (candidate_pair.rs:36-41) as one u64 ---------------------
 // OrderedFloat<f32>: NaN greatest, all NaN equal, -0 == +0.  Canonicalise, then the usual

@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <thread>
 
 #include "ctx.hpp"
@@ -128,11 +129,17 @@ void for_each_shard(size_t n, F fn) {
 
 }  // namespace
 
+enum { LAYOUT_UNSET = 0, LAYOUT_ROWS = 1, LAYOUT_REPLICA = 2 };
+
 struct vdb_sharded {
     vdb_ctx *ctx = nullptr;
     uint64_t dim = 0;
     int dist = 0;
     uint64_t n_total = 0;
+    int layout = LAYOUT_UNSET;  // ROWS: contiguous row blocks (Flat, PQ-Flat); REPLICA: every GPU holds all rows, queries are split
+    // a collective call that failed on one rank of a multi-PROCESS job leaves its peers inside the all-gather: the object
+    // cannot know whether they got out, so every later search is refused (vdbhip.h, "failed sharded calls")
+    bool poisoned = false;
     std::vector<std::unique_ptr<Shard>> shards;
     ~vdb_sharded() {
         for (size_t i = 0; i < shards.size(); i++) {
@@ -155,6 +162,19 @@ struct vdb_sharded {
 
 namespace {
 
+bool multi_process(const vdb_sharded &sh) { return (size_t)sh.ctx->world > sh.shards.size(); }
+// body of a sharded search: refuses a poisoned object; an error inside poisons it when other processes take part
+#define VDB_SHARDED_SEARCH_BEGIN(sh)                                                                                           \
+    VDB_REQUIRE(!(sh)->poisoned, "this sharded index is poisoned: an earlier collective call failed on this rank while other " \
+                                 "processes were inside the exchange; destroy it on every rank and build a new one");          \
+    try {
+#define VDB_SHARDED_SEARCH_END(sh)             \
+    }                                          \
+    catch (...) {                              \
+        if (multi_process(*(sh))) (sh)->poisoned = true; \
+        throw;                                 \
+    }
+
 // one all-gather (or two, for the PQ key rows) over the communicator: every local GPU contributes `bytes` from send[i]
 // and receives world * bytes into recv[i], ordered on the shard's stream; without a communicator (world == 1) the
 // receive buffer IS the send buffer
@@ -171,6 +191,76 @@ void all_gather(vdb_sharded &sh, const std::vector<std::pair<const void *, void 
         }
     }
     VDB_NCCL(r.GroupEnd());
+}
+
+// ---- REPLICA layout: every GPU holds all rows, rank r answers the contiguous query block [r * per, min(nq, (r+1) * per)) with
+// per = ceil(nq / S) (shard.replica_query_slice), ONE fixed-size all-gather of [per*k ids | per*k distances | pad | per counts]
+// concatenates the blocks on every rank.  No merge: the blocks are disjoint rows of the answer.  HNSW searches exist only in
+// this layout (a graph's edges cross any row partition); Flat and PQ-Flat accept it too -- when the corpus fits one
+// GPU a replica reads the same bytes per step as a row shard and runs the per-query stages on 1/S of the queries.
+using LocalSearch = std::function<void(Index &, Workspace &, const float *d_q, uint64_t nq, uint64_t *d_idx, float *d_dist, uint64_t *d_cnt)>;
+
+// query block of rank r
+inline void replica_block(uint64_t nq, uint64_t S, uint64_t r, uint64_t &q0, uint64_t &q1) {
+    const uint64_t per = (nq + S - 1) / S;
+    q0 = std::min(nq, r * per);
+    q1 = std::min(nq, (r + 1) * per);
+}
+
+void replica_search(vdb_sharded &sh, const float *queries, uint64_t nq, uint64_t k, uint64_t *out_idx, float *out_dist,
+                    uint64_t *out_count, const LocalSearch &local) {
+    const uint64_t S = (uint64_t)sh.ctx->world, dim = sh.dim;
+    if (k == 0) {
+        if (out_count) std::memset(out_count, 0, nq * 8);
+        return;
+    }
+    constexpr uint64_t CHUNK = 65536;  // queries per exchange (bounds the staging buffers)
+    std::vector<char> host;
+    for (uint64_t c0 = 0; c0 < nq; c0 += CHUNK) {
+        const uint64_t nb = std::min(CHUNK, nq - c0), per = (nb + S - 1) / S;
+        const uint64_t off_d = per * k * 8, off_c = (per * k * 12 + 7) / 8 * 8, block = off_c + per * 8;
+        for_each_shard(sh.shards.size(), [&](size_t i) {
+            Shard &s = *sh.shards[i];
+            Index &ix = s.handle->ix;
+            ix.use_device();
+            uint64_t q0, q1;
+            replica_block(nb, S, (uint64_t)sh.ctx->ranks[i], q0, q1);
+            s.q.reserve(std::max<uint64_t>(per, 1) * dim * sizeof(float));
+            s.send.reserve(block);
+            if (!sh.ctx->comms.empty()) s.recv.reserve(S * block);
+            VDB_HIP(hipMemsetAsync(s.send.p, 0, block, s.stream));
+            if (q1 > q0)
+                VDB_HIP(hipMemcpyAsync(s.q.p, queries + (c0 + q0) * dim, (q1 - q0) * dim * sizeof(float), hipMemcpyHostToDevice, s.stream));
+            VDB_SYNC(s.stream);
+            if (q1 > q0) {
+                WsLease ws(ix);
+                char *b = s.send.as<char>();
+                local(ix, *ws, s.q.as<float>(), q1 - q0, reinterpret_cast<uint64_t *>(b), reinterpret_cast<float *>(b + off_d),
+                      reinterpret_cast<uint64_t *>(b + off_c));
+                VDB_SYNC(ws->stream);
+                ix.prof_collect(*ws);
+            }
+        });
+        std::vector<std::pair<const void *, void *>> bufs;
+        for (auto &s : sh.shards) bufs.push_back({s->send.p, s->recv.p});
+        all_gather(sh, bufs, 1, block);
+        Shard &s0 = *sh.shards[0];
+        s0.handle->ix.use_device();
+        VDB_SYNC(s0.stream);  // the collective
+        const bool comm = !sh.ctx->comms.empty();
+        const uint64_t ns = comm ? S : 1;
+        host.resize(ns * block);
+        VDB_HIP(hipMemcpy(host.data(), comm ? s0.recv.p : s0.send.p, ns * block, hipMemcpyDeviceToHost));
+        for (uint64_t r = 0; r < ns; r++) {
+            uint64_t q0, q1;
+            replica_block(nb, S, comm ? r : (uint64_t)sh.ctx->ranks[0], q0, q1);
+            if (q1 == q0) continue;
+            const char *b = host.data() + r * block;
+            std::memcpy(out_idx + (c0 + q0) * k, b, (q1 - q0) * k * 8);
+            std::memcpy(out_dist + (c0 + q0) * k, b + off_d, (q1 - q0) * k * 4);
+            if (out_count) std::memcpy(out_count + c0 + q0, b + off_c, (q1 - q0) * 8);
+        }
+    }
 }
 
 void ctx_validate_devices(const int *device_ids, int n_dev) {
@@ -280,23 +370,54 @@ int vdb_sharded_destroy(vdb_sharded *sh) {
     VDB_API_END
 }
 
-// every process passes the SAME corpus view; each local GPU keeps its contiguous block
+// every process passes the SAME corpus view.  ROWS layout: each local GPU keeps its contiguous block;
+// REPLICA layout: each keeps all rows (HNSW does not shard: "replicas only", queries are split instead).
+// A failure on any shard (an allocation on one GPU, say) rolls EVERY shard back to an empty index, so that a retry cannot
+// append a block twice on the GPUs that had succeeded.
+static void sharded_set_rows(vdb_sharded *sh, const float *rows, uint64_t n_total, int layout) {
+    VDB_REQUIRE(sh && (rows || n_total == 0), "null argument");
+    VDB_REQUIRE(sh->layout == LAYOUT_UNSET, "the corpus of a sharded index is set once (a different partition would move rows between GPUs)");
+    const uint64_t S = (uint64_t)sh->ctx->world, per = (n_total + S - 1) / S;
+    try {
+        for_each_shard(sh->shards.size(), [&](size_t i) {
+            Shard &s = *sh->shards[i];
+            const uint64_t r = (uint64_t)sh->ctx->ranks[i];
+            s.r0 = layout == LAYOUT_ROWS ? std::min(n_total, r * per) : 0;
+            s.r1 = layout == LAYOUT_ROWS ? std::min(n_total, (r + 1) * per) : n_total;
+            Index &ix = s.handle->ix;
+            ix.use_device();
+            if (s.r1 > s.r0) ix.add_rows(rows + s.r0 * sh->dim, s.r1 - s.r0, false);
+            ix.id_offset = s.r0;
+        });
+    } catch (...) {
+        for (size_t i = 0; i < sh->shards.size(); i++) {
+            (void)hipSetDevice(sh->ctx->devices[i]);
+            try {
+                sh->shards[i]->handle.reset(new vdb_index(sh->ctx->devices[i], sh->dim, sh->dist));
+            } catch (...) {
+                sh->poisoned = true;  // not even an empty index could be created on that GPU
+            }
+            sh->shards[i]->r0 = sh->shards[i]->r1 = 0;
+        }
+        throw;
+    }
+    sh->n_total = n_total;
+    sh->layout = layout;
+}
 int vdb_sharded_set_rows(vdb_sharded *sh, const float *rows, uint64_t n_total) {
     VDB_API_BEGIN
-    VDB_REQUIRE(sh && (rows || n_total == 0), "null argument");
-    VDB_REQUIRE(sh->n_total == 0, "the corpus of a sharded index is set once (a different partition would move rows between GPUs)");
-    const uint64_t S = (uint64_t)sh->ctx->world, per = (n_total + S - 1) / S;
-    for_each_shard(sh->shards.size(), [&](size_t i) {
-        Shard &s = *sh->shards[i];
-        const uint64_t r = (uint64_t)sh->ctx->ranks[i];
-        s.r0 = std::min(n_total, r * per);
-        s.r1 = std::min(n_total, (r + 1) * per);
-        Index &ix = s.handle->ix;
-        ix.use_device();
-        if (s.r1 > s.r0) ix.add_rows(rows + s.r0 * sh->dim, s.r1 - s.r0, false);
-        ix.id_offset = s.r0;
-    });
-    sh->n_total = n_total;
+    sharded_set_rows(sh, rows, n_total, LAYOUT_ROWS);
+    VDB_API_END
+}
+int vdb_sharded_set_rows_replica(vdb_sharded *sh, const float *rows, uint64_t n_total) {
+    VDB_API_BEGIN
+    sharded_set_rows(sh, rows, n_total, LAYOUT_REPLICA);
+    VDB_API_END
+}
+int vdb_sharded_layout(const vdb_sharded *sh, int *out) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(sh && out, "null argument");
+    *out = sh->layout;
     VDB_API_END
 }
 
@@ -323,6 +444,15 @@ int vdb_sharded_flat_knn(vdb_sharded *sh, const float *queries, uint64_t nq, uin
     VDB_REQUIRE(sh, "null index");
     VDB_REQUIRE(dim == sh->dim, "query dimension mismatch");
     VDB_REQUIRE(nq == 0 || (queries && out_idx && out_dist), "null argument");
+    VDB_REQUIRE(sh->layout != LAYOUT_UNSET || nq == 0, "the sharded index holds no rows (vdb_sharded_set_rows / _set_rows_replica)");
+    VDB_SHARDED_SEARCH_BEGIN(sh)
+    if (sh->layout == LAYOUT_REPLICA) {
+        replica_search(*sh, queries, nq, k, out_idx, out_dist, out_count,
+                       [&](Index &ix, Workspace &ws, const float *d_q, uint64_t n, uint64_t *di, float *dd, uint64_t *dc) {
+                           ix.flat_knn_device(ws, d_q, n, k, di, dd, dc);
+                       });
+        return VDB_OK;
+    }
     VDB_REQUIRE(k <= 1024, "sharded knn: k must be <= 1024 (the merge of the gathered lists)");
     const uint64_t S = (uint64_t)sh->ctx->world;
     constexpr uint64_t CHUNK = 8192;
@@ -367,6 +497,7 @@ int vdb_sharded_flat_knn(vdb_sharded *sh, const float *queries, uint64_t nq, uin
             std::memset(out_count + q0, 0, nb * 8);
         }
     }
+    VDB_SHARDED_SEARCH_END(sh)
     VDB_API_END
 }
 
@@ -394,6 +525,14 @@ int vdb_sharded_knn_pq(vdb_sharded *sh, const float *queries, uint64_t nq, uint6
     const uint64_t S = (uint64_t)sh->ctx->world, efg = std::max(ef, k);
     if (k == 0) {
         if (out_count) std::memset(out_count, 0, nq * 8);
+        return VDB_OK;
+    }
+    VDB_SHARDED_SEARCH_BEGIN(sh)
+    if (sh->layout == LAYOUT_REPLICA) {
+        replica_search(*sh, queries, nq, k, out_idx, out_dist, out_count,
+                       [&](Index &ix, Workspace &ws, const float *d_q, uint64_t n, uint64_t *di, float *dd, uint64_t *dc) {
+                           flat_knn_pq_device(ix, ws, d_q, n, k, ef, di, dd, dc);
+                       });
         return VDB_OK;
     }
     const uint64_t CHUNK = std::max<uint64_t>(1, std::min<uint64_t>(8192, (size_t(256) << 20) / (efg * 16 * S)));
@@ -442,6 +581,81 @@ int vdb_sharded_knn_pq(vdb_sharded *sh, const float *queries, uint64_t nq, uint6
         VDB_HIP(hipMemcpy(out_dist + q0 * k, s0.o_dist.p, nb * k * 4, hipMemcpyDeviceToHost));
         if (out_count) VDB_HIP(hipMemcpy(out_count + q0, s0.o_cnt.p, nb * 8, hipMemcpyDeviceToHost));
     }
+    VDB_SHARDED_SEARCH_END(sh)
+    VDB_API_END
+}
+
+// ---- HNSW behind the context: replicas, the third search DynamicIndex dispatches (dynamic_index.rs:68-93) --------
+// The graph is built ONCE per process on the first local GPU (the host builder is deterministic for a given seed, batch size
+// and thread count, so the processes of a multi-process job build equal graphs) and attached to the other local replicas.
+int vdb_sharded_hnsw_build(vdb_sharded *sh, uint64_t M, uint64_t ef_construction, uint64_t seed, uint64_t batch, int nthreads) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(sh, "null index");
+    VDB_REQUIRE(sh->layout == LAYOUT_REPLICA, "HNSW does not shard by rows (edges cross any partition): use vdb_sharded_set_rows_replica");
+    Index &ix0 = sh->shards[0]->handle->ix;
+    ix0.use_device();
+    hnsw_build(ix0, M, ef_construction, seed, batch, nthreads);
+    const HNSWState &h = ix0.hnsw;
+    for (size_t i = 1; i < sh->shards.size(); i++) {
+        Index &ix = sh->shards[i]->handle->ix;
+        ix.use_device();
+        hnsw_attach(ix, h.m, h.ef_construction, h.level0.data(), h.len0.data(), h.vec_level.data(), h.upper.data(), h.upper_len.data(),
+                    h.has_enter ? 1 : 0, h.enter_point, h.enter_level);
+    }
+    VDB_API_END
+}
+int vdb_sharded_hnsw_attach(vdb_sharded *sh, uint64_t M, uint64_t ef_construction, const uint32_t *level0, const uint64_t *len0,
+                            const uint64_t *vec_level, const uint32_t *upper, const uint64_t *upper_len, int has_enter,
+                            uint64_t enter_point, uint64_t enter_level) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(sh, "null index");
+    VDB_REQUIRE(sh->layout == LAYOUT_REPLICA, "HNSW does not shard by rows (edges cross any partition): use vdb_sharded_set_rows_replica");
+    for (size_t i = 0; i < sh->shards.size(); i++) {
+        Index &ix = sh->shards[i]->handle->ix;
+        ix.use_device();
+        hnsw_attach(ix, M, ef_construction, level0, len0, vec_level, upper, upper_len, has_enter, enter_point, enter_level);
+    }
+    VDB_API_END
+}
+static int sharded_hnsw_search(vdb_sharded *sh, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef, bool use_pq,
+                               uint64_t *out_idx, float *out_dist, uint64_t *out_count) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(sh, "null index");
+    VDB_REQUIRE(dim == sh->dim, "query dimension mismatch");
+    VDB_REQUIRE(nq == 0 || (queries && out_idx && out_dist), "null argument");
+    VDB_REQUIRE(sh->layout == LAYOUT_REPLICA, "HNSW does not shard by rows (edges cross any partition): use vdb_sharded_set_rows_replica");
+    for (auto &s : sh->shards) {
+        VDB_REQUIRE(s->handle->ix.hnsw.present, "knn_with_ef needs an HNSW graph (vdb_sharded_hnsw_build / _attach)");
+        VDB_REQUIRE(!use_pq || s->handle->ix.pq.present, "knn_pq needs a PQ table (vdb_sharded_pq_attach)");
+    }
+    if (ef == 0 && !use_pq) ef = sh->shards[0]->handle->ix.hnsw.default_ef;
+    VDB_SHARDED_SEARCH_BEGIN(sh)
+    replica_search(*sh, queries, nq, k, out_idx, out_dist, out_count,
+                   [&](Index &ix, Workspace &ws, const float *d_q, uint64_t n, uint64_t *di, float *dd, uint64_t *dc) {
+                       hnsw_knn_device(ix, ws, d_q, n, k, ef, use_pq, di, dd, dc);
+                   });
+    VDB_SHARDED_SEARCH_END(sh)
+    VDB_API_END
+}
+int vdb_sharded_hnsw_knn(vdb_sharded *sh, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef, uint64_t *out_idx,
+                         float *out_dist, uint64_t *out_count) {
+    return sharded_hnsw_search(sh, queries, nq, dim, k, ef, false, out_idx, out_dist, out_count);
+}
+int vdb_sharded_hnsw_knn_pq(vdb_sharded *sh, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef, uint64_t *out_idx,
+                            float *out_dist, uint64_t *out_count) {
+    return sharded_hnsw_search(sh, queries, nq, dim, k, ef, true, out_idx, out_dist, out_count);
+}
+// partition arithmetic of the REPLICA layout, exported for the host's tests: the query block of `rank` among `world`
+int vdb_replica_query_block(uint64_t nq, uint64_t world, uint64_t rank, uint64_t *q0, uint64_t *q1) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(q0 && q1 && world >= 1 && rank < world, "bad argument");
+    replica_block(nq, world, rank, *q0, *q1);
+    VDB_API_END
+}
+int vdb_sharded_poisoned(const vdb_sharded *sh, int *out) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(sh && out, "null argument");
+    *out = sh->poisoned ? 1 : 0;
     VDB_API_END
 }
 

@@ -1513,12 +1513,7 @@ template <int R, bool ADC>
 static void hnsw_launch(const HnswDev &g, const float *d_q, const float *qsq, const float *lut, uint32_t lut_in_lds,
                         uint32_t ef, uint32_t *vis, uint64_t vwords, uint64_t *out, unsigned long long *stats,
                         uint32_t *err, uint32_t nq, size_t lds, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hnsw_search<R, ADC>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
+    func_max_lds(reinterpret_cast<const void *>(&k_hnsw_search<R, ADC>), int(160 * 1024));
     hipLaunchKernelGGL((k_hnsw_search<R, ADC>), dim3(nq), dim3(64), lds, s, g, d_q, qsq, lut, lut_in_lds, ef, vis,
                        vwords, out, stats, err);
 }
@@ -1884,14 +1879,8 @@ void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, ui
         if (use_pq) b_exact.reserve(QBB * res_ld * 8);
         b_tmp.reserve(tb);
         b_ql.reserve(QBB * 4);
-        static bool attr = false;
-        if (!attr) {
-            VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hnsw_search_big<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-            VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hnsw_search_big<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-            attr = true;
-        }
+        func_max_lds(reinterpret_cast<const void *>(&k_hnsw_search_big<true>), int(64 * 1024));
+        func_max_lds(reinterpret_cast<const void *>(&k_hnsw_search_big<false>), int(64 * 1024));
         for (size_t c0 = 0; c0 < redo.size(); c0 += QBB) {
             const uint32_t nb = (uint32_t)std::min<size_t>(QBB, redo.size() - c0);
             VDB_HIP(hipMemcpyAsync(b_ql.p, redo.data() + c0, nb * 4, hipMemcpyHostToDevice, s));

@@ -179,7 +179,7 @@ struct Index {
     // LAZILY by the first search that needs it (the redo tier of the fp16 pass, calls without an fp16 mirror,
     // flat_half = 1): an index whose queries all certify on the fp16 pass never pays its N*d*4 bytes of HBM.
     DevBuf d_tiled;
-    bool tiled_built = false;       // d_tiled covers rows [0, n); kept in step by add_rows / swap_remove once built
+    std::atomic<bool> tiled_built{false};  // d_tiled covers rows [0, n); kept in step by add_rows / swap_remove once built
     std::mutex tiled_mu;            // read-side calls are re-entrant: one of them builds, the others wait
     void ensure_tiled(Workspace &ws);
     uint64_t hbm_bytes_per_row() const;  // resident bytes per row over all per-row buffers (rows, norms, mirrors, codes, links)

@@ -525,12 +525,7 @@ void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uin
                 VDB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_lo), 0x7f800000, 2 * nq * ld, s));
                 hipLaunchKernelGGL(k_ivf_pairs, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, d_probes, capp, (uint32_t)np, (uint32_t)nq,
                                    iv.d_offsets.as<uint32_t>(), d_pairs, d_pos);
-                static bool attr = false;
-                if (!attr) {
-                    VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ivf_sort_pairs), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                16384 * sizeof(uint64_t)));
-                    attr = true;
-                }
+                func_max_lds(reinterpret_cast<const void *>(&k_ivf_sort_pairs), int(16384 * sizeof(uint64_t)));
                 hipLaunchKernelGGL(k_ivf_sort_pairs, dim3(1), dim3(1024), (npairs <= 8192 ? 8192 : 16384) * sizeof(uint64_t), s, d_pairs,
                                    (uint32_t)npairs, d_first, d_count);
             }

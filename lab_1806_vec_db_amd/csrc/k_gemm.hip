@@ -530,12 +530,7 @@ static void flat_gemm_launch1(const GemmArgs &a0, int num_cu, hipStream_t s) {
     }
     if (grid == 0 || a.ngroups == 0) return;
     const size_t lds = size_t(2) * KC * GEMM_NH * 128 * sizeof(uint4) + size_t(GEMM_WGBUF) * 12 + (4 + 4 * GEMM_BQ + 8 * 64) * 4 + size_t(8) * GEMM_STAGE * 24 + 16;
-    static bool attr_done = false;
-    if (!attr_done) {
-        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_gemm<TW, KC, MODE, PREC>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    func_max_lds(reinterpret_cast<const void *>(&k_flat_gemm<TW, KC, MODE, PREC>), int(160 * 1024));
     hipLaunchKernelGGL((k_flat_gemm<TW, KC, MODE, PREC>), dim3(grid, MODE == GEMM_SAMPLE ? a.ngroups : 1), dim3(512), lds, s, a);
     VDB_HIP(hipGetLastError());
 }

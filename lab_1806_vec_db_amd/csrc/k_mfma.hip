@@ -461,12 +461,7 @@ static void flat_mfma_launch(const MfmaArgs &a, int num_cu, hipStream_t s) {
     VDB_REQUIRE(q_bytes + fixed + 64 * 12 <= 160 * 1024, "flat mfma: Q image does not fit LDS");
     uint32_t wgbuf = (uint32_t)std::min<size_t>(MFMA_WGBUF, ((160 * 1024 - q_bytes - fixed) / 12) & ~size_t(63));
     size_t lds = q_bytes + size_t(wgbuf) * 12 + fixed;
-    static bool attr_done = false;
-    if (!attr_done) {
-        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_mfma<PD, MODE, NH>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    func_max_lds(reinterpret_cast<const void *>(&k_flat_mfma<PD, MODE, NH>), int(160 * 1024));
     constexpr uint32_t NW = 8;
     uint32_t n_visit = (a.n_items + a.item_step - 1) / a.item_step;
     uint32_t grid = (uint32_t)num_cu;

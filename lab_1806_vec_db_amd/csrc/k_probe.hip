@@ -7,6 +7,8 @@
 // The best of the two is reported; the buffer is larger than the 256-MB Infinity Cache and read non-temporally is not
 // needed: every pass touches `bytes` of distinct lines.
 #include <algorithm>
+#include <numeric>
+#include <vector>
 
 #include "common.hpp"
 
@@ -169,6 +171,71 @@ void mfma_probe(int device, int waves_per_simd, int iters, double *tflops, doubl
     (void)hipStreamDestroy(s);
     (void)hipFree(out);
     (void)hipFree(cyc);
+}
+
+// ---- latency of ONE dependent HBM access on this box ------------------------------------------------------------------------
+// The graph walks (k_hnsw_search) are chains of dependent accesses -- pop -> link row -> visited words -> first row lines -- so
+// their floor is a latency, not a bandwidth.  One lane follows a random cyclic permutation (Sattolo) over 128-B lines of a buffer
+// larger than every cache: nanoseconds per hop = the round trip of a dependent global load that misses L2 and the Infinity
+// Cache.  Measurement hook only.
+__global__ __launch_bounds__(64) void k_probe_chase(const uint64_t *__restrict__ buf, uint32_t hops, uint64_t *out) {
+    if (threadIdx.x != 0) return;
+    uint64_t i = 0;
+    for (uint32_t h = 0; h < hops; h++) i = buf[i * 16];  // 16 x 8 B = one 128-B line per node
+    out[0] = i;
+}
+double latency_probe(int device, uint64_t bytes, uint32_t hops) {
+    VDB_HIP(hipSetDevice(device));
+    VDB_REQUIRE(bytes >= (1ull << 20) && bytes <= (16ull << 30), "latency probe: bytes must be in 1 MiB .. 16 GiB");
+    VDB_REQUIRE(hops >= 16 && hops <= (1u << 24), "latency probe: hops must be in 16..2^24");
+    const uint64_t lines = bytes / 128;
+    std::vector<uint32_t> perm(lines);
+    std::iota(perm.begin(), perm.end(), 0u);
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    auto next = [&]() {
+        st += 0x9E3779B97F4A7C15ull;
+        uint64_t z = st;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    for (uint64_t i = lines - 1; i > 0; i--) std::swap(perm[i], perm[next() % i]);  // Sattolo: one cycle through every line
+    std::vector<uint64_t> host(lines * 16, 0);
+    for (uint64_t i = 0; i < lines; i++) host[i * 16] = perm[i];
+    void *buf = nullptr, *out = nullptr;
+    hipStream_t s = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    double ns = 0.0;
+    try {
+        VDB_HIP(hipMalloc(&buf, lines * 128));
+        VDB_HIP(hipMalloc(&out, 64));
+        VDB_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        VDB_HIP(hipEventCreate(&a));
+        VDB_HIP(hipEventCreate(&b));
+        VDB_HIP(hipMemcpy(buf, host.data(), lines * 128, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_probe_chase, dim3(1), dim3(64), 0, s, static_cast<const uint64_t *>(buf), 64u, static_cast<uint64_t *>(out));
+        VDB_HIP(hipEventRecord(a, s));
+        hipLaunchKernelGGL(k_probe_chase, dim3(1), dim3(64), 0, s, static_cast<const uint64_t *>(buf), hops, static_cast<uint64_t *>(out));
+        VDB_HIP(hipEventRecord(b, s));
+        VDB_HIP(hipEventSynchronize(b));
+        VDB_HIP(hipGetLastError());
+        float ms = 0;
+        VDB_HIP(hipEventElapsedTime(&ms, a, b));
+        ns = double(ms) * 1e6 / double(hops);
+    } catch (...) {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+        if (s) (void)hipStreamDestroy(s);
+        if (buf) (void)hipFree(buf);
+        if (out) (void)hipFree(out);
+        throw;
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    (void)hipStreamDestroy(s);
+    (void)hipFree(buf);
+    (void)hipFree(out);
+    return ns;
 }
 
 }  // namespace vdb

@@ -297,12 +297,7 @@ void launch_select_tau(const float *keys, uint64_t ld, uint32_t n, uint32_t nq, 
     }
     VDB_REQUIRE(n <= SELECT_MAX_N, "select_tau: sample too long");
     size_t lds = (size_t(n) + 2048 + 258) * sizeof(uint32_t);
-    static bool attr_done = false;
-    if (!attr_done) {
-        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select_tau),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-        attr_done = true;
-    }
+    func_max_lds(reinterpret_cast<const void *>(&k_select_tau), int(144 * 1024));
     hipLaunchKernelGGL(k_select_tau, dim3(nq), dim3(256), lds, s, keys, ld, n, kth, nq_real, tau);
     VDB_HIP(hipGetLastError());
 }

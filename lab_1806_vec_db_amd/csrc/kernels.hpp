@@ -114,6 +114,7 @@ void launch_rerank_u8(const uint8_t *X, uint32_t dim, const float *Q, uint32_t n
 // attainable HBM read bandwidth in GB/s: pure streaming read of `bytes`, `iters` timed passes, best of two patterns
 double stream_probe(int device, uint64_t bytes, int iters);
 void mfma_probe(int device, int waves_per_simd, int iters, double *tflops, double *clock_ghz);
+double latency_probe(int device, uint64_t bytes, uint32_t hops);  // ns per dependent HBM load (pointer chase over 128-B lines)
 
 // ---- k_sort.hip (k > 1024) -----------------------------------------------------------------
 size_t sort_pairs_temp_bytes(uint64_t n);

@@ -1220,12 +1220,7 @@ void pq_build(Index &ix, uint64_t n_bits, uint64_t m, uint64_t train_n, uint64_t
 
 template <int NW, bool COS>
 static void adc16_launch_nw(const Adc16Args &a, dim3 grid, size_t lds, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pq_adc16<NW, COS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
-        attr = true;
-    }
+    func_max_lds(reinterpret_cast<const void *>(&k_pq_adc16<NW, COS>), int(160 * 1024));
     hipLaunchKernelGGL((k_pq_adc16<NW, COS>), grid, dim3(1024), lds, s, a);
 }
 template <bool COS>
@@ -1260,12 +1255,7 @@ static void adc_launch_m(Index &ix, Workspace &ws, AdcArgs a) {
     if (grid == 0 || a.nq_total == 0) return;
     dim3 g(grid, (a.nq_total + BQ - 1) / BQ);
     if (in_lds) {
-        static bool attr = false;
-        if (!attr) {
-            VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pq_adc<BQ, NBITS, true, MODE>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr = true;
-        }
+        func_max_lds(reinterpret_cast<const void *>(&k_pq_adc<BQ, NBITS, true, MODE>), int(160 * 1024));
         hipLaunchKernelGGL((k_pq_adc<BQ, NBITS, true, MODE>), g, dim3(nt), lds, ws.stream, a);
     } else {
         hipLaunchKernelGGL((k_pq_adc<BQ, NBITS, false, MODE>), g, dim3(nt), lds, ws.stream, a);

@@ -71,7 +71,8 @@ class GpuIndex:
     # -- lifetime ---------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            self._lib.vdb_index_destroy(self._h)
+            if not getattr(self, "_borrowed", False):  # (ShardedIndex.local_index: the sharded index owns the handle)
+                self._lib.vdb_index_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -456,6 +457,13 @@ def mfma_probe(device: int = 0, waves_per_simd: int = 2, iters: int = 200_000):
     t, c = C.c_double(), C.c_double()
     L.check(L.load().vdb_mfma_probe(int(device), int(waves_per_simd), int(iters), C.byref(t), C.byref(c)))
     return float(t.value), float(c.value)
+
+
+def latency_probe(device: int = 0, nbytes: int = 1 << 30, hops: int = 20000) -> float:
+    """Nanoseconds per DEPENDENT HBM load on this box (one lane chasing a random cycle over 128-B lines of an nbytes buffer)."""
+    v = C.c_double()
+    L.check(L.load().vdb_latency_probe(int(device), int(nbytes), int(hops), C.byref(v)))
+    return float(v.value)
 
 
 def merge_topk(dists: np.ndarray, ids: np.ndarray, counts: np.ndarray, k: int):

@@ -69,6 +69,35 @@ class ShardedIndex:
             raise L.VdbError(f"dimension mismatch: index dim {self.dim}, got shape {r.shape}")
         L.check(self._lib.vdb_sharded_set_rows(self._h, _ptr(r, L.f32p), r.shape[0]))
 
+    def set_rows_replica(self, rows):
+        """REPLICA layout: every GPU keeps all rows, searches split the queries (the only layout HNSW runs in)"""
+        r = _f32(rows)
+        if r.ndim != 2 or r.shape[1] != self.dim:
+            raise L.VdbError(f"dimension mismatch: index dim {self.dim}, got shape {r.shape}")
+        L.check(self._lib.vdb_sharded_set_rows_replica(self._h, _ptr(r, L.f32p), r.shape[0]))
+
+    @property
+    def layout(self) -> str:
+        v = C.c_int()
+        L.check(self._lib.vdb_sharded_layout(self._h, C.byref(v)))
+        return {0: "unset", 1: "rows", 2: "replica"}[v.value]
+
+    @property
+    def poisoned(self) -> bool:
+        v = C.c_int()
+        L.check(self._lib.vdb_sharded_poisoned(self._h, C.byref(v)))
+        return bool(v.value)
+
+    def local_index(self, i: int = 0):
+        """borrowed GpuIndex view of this process's i-th shard / replica (exports, statistics); do not close it"""
+        from .index import GpuIndex
+
+        h = L.vp()
+        L.check(self._lib.vdb_sharded_local(self._h, int(i), C.byref(h)))
+        g = GpuIndex.__new__(GpuIndex)
+        g._lib, g._h, g.device, g._borrowed = self._lib, h, -1, True
+        return g
+
     def local_stat(self, i: int, name: str) -> int:
         h = L.vp()
         L.check(self._lib.vdb_sharded_local(self._h, int(i), C.byref(h)))
@@ -99,3 +128,31 @@ class ShardedIndex:
 
     def knn_pq(self, queries, k: int, ef: int):
         return self._search(self._lib.vdb_sharded_knn_pq, queries, k, ef)
+
+    # -- HNSW over the replicas (vdb_sharded_hnsw_*) ---------------------------------------------------------------------------
+    def hnsw_build(self, M: int = 16, ef_construction: int = 200, seed: int = 42, batch: int = 1, nthreads: int = 0):
+        L.check(self._lib.vdb_sharded_hnsw_build(self._h, int(M), int(ef_construction), int(seed), int(batch), int(nthreads)))
+
+    def hnsw_attach(self, M: int, ef_construction: int, graph: dict):
+        """graph = GpuIndex.hnsw_export() (level0, len0, vec_level, upper, upper_len, has_enter, enter_point, enter_level)"""
+        l0 = np.ascontiguousarray(graph["level0"], dtype=np.uint32)
+        n0 = np.ascontiguousarray(graph["len0"], dtype=np.uint64)
+        vl = np.ascontiguousarray(graph["vec_level"], dtype=np.uint64)
+        up = np.ascontiguousarray(graph["upper"], dtype=np.uint32)
+        ul = np.ascontiguousarray(graph["upper_len"], dtype=np.uint64)
+        L.check(self._lib.vdb_sharded_hnsw_attach(self._h, int(M), int(ef_construction), _ptr(l0, L.u32p), _ptr(n0, L.u64p), _ptr(vl, L.u64p),
+                                                  _ptr(up, L.u32p), _ptr(ul, L.u64p), int(bool(graph["has_enter"])), int(graph["enter_point"]),
+                                                  int(graph["enter_level"])))
+
+    def knn_with_ef(self, queries, k: int, ef: int = 0):
+        return self._search(self._lib.vdb_sharded_hnsw_knn, queries, k, ef)
+
+    def hnsw_knn_pq(self, queries, k: int, ef: int):
+        return self._search(self._lib.vdb_sharded_hnsw_knn_pq, queries, k, ef)
+
+
+def replica_query_block(nq: int, world: int, rank: int) -> tuple[int, int]:
+    """the library's partition arithmetic of the REPLICA layout (vdb_replica_query_block); equals shard.replica_query_slice"""
+    a, b = C.c_uint64(), C.c_uint64()
+    L.check(L.load().vdb_replica_query_block(int(nq), int(world), int(rank), C.byref(a), C.byref(b)))
+    return int(a.value), int(b.value)

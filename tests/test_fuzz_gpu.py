@@ -112,3 +112,54 @@ def test_pq_ivf_hnsw_random_configuration(mods, seed):
             c = int(cnt[q])
             assert c == len(oi)
             _check(idx[q, :c], d[q, :c], oi, od)
+
+
+def test_flat_soak_configuration_87_of_round_2(mods):
+    """Configuration #87 of tools/fuzz_flat.py seed 77 -- the one in flight when round 2's soak of an (uncommitted, since
+    deleted) small-call cascade ended in a GPU memory-access fault (gpurun_out/fuzz_fs.log:88).  The
+    generator state in front of it was recovered on the CPU (tools/replay_fuzz_flat.py -> tests/golden/...state.json), so
+    these are the very rows and the very query: dim 192, 19 051 standard-normal rows, ONE query, k = 1, Cosine, one-part
+    batch_add.  Runs it through every Flat tier choice of the shipped tree, and through the IVF scan, whose 8-bit / fp16
+    tier kernels and Index::ensure_rows_q8 the deleted cascade had reused."""
+    import json
+    import os
+    vdb, O = mods
+    st = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fuzz_flat_seed77_cfg87_state.json")))
+    rng = np.random.default_rng(0)
+    rng.bit_generator.state = st["state"]
+    dim = int(rng.choice([64, 96, 100, 128, 192, 256, 320, 384, 512, 768, 960, 1000, 1024, 1536]))
+    n = int(rng.integers(17000, 60000))
+    nq = int(rng.choice([1, 3, 17, 64, 65, 100, 128, 129, 200, 257]))
+    k = int(rng.choice([1, 2, 5, 10, 16, 17, 33, 64, 70]))
+    dist = str(rng.choice(["l2sqr", "cosine"]))
+    style = int(rng.integers(0, 4))
+    assert (dim, n, nq, k, dist, style) == (192, 19051, 1, 1, "cosine", 0)
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    oi, od, oc = O.flat_knn_batch(base, qs, k, 1, nthreads=8)
+    ix = vdb.GpuIndex(dim, dist)
+    ix.batch_add(base)
+    for mode, half, tail in ((0, 0, 0), (0, 1, 0), (0, 2, 1), (2, 0, 1), (2, 1, 1), (1, 0, 0)):
+        ix.set_flat_mode(mode)
+        ix.set_param("flat_half", half)
+        ix.set_param("flat_tail", tail)
+        idx, d, cnt = ix.flat_knn(qs, k)
+        assert cnt.tolist() == oc.tolist() == [1], (mode, half, tail)
+        _check(idx[0, :1], d[0, :1], oi[0][:1], od[0][:1])
+    ix.set_flat_mode(0)
+    ix.set_param("flat_half", 0)
+    ix.set_param("flat_tail", 0)
+    # the IVF scan over the same rows: few clusters and all of them probed -> probe lists of the whole table, the shape the
+    # cascade gave the shared tier kernels (8-bit tier forced query-major = 2, cluster-major = 1, off = 0)
+    ix.ivf_build(3, train_n=2000, max_iter=3, seed=1)
+    ex = ix.ivf_export()
+    iv = O.IVF(base, ex["centroids"], 1, assign=ex["assign"])
+    want_i, want_d = iv.knn(qs[0], k, 3)
+    try:
+        for q8 in (2, 1, 0):
+            ix.set_param("ivf_q8", q8)
+            idx, d, cnt = ix.ivf_knn(qs, k, 3)
+            assert int(cnt[0]) == len(want_i)
+            _check(idx[0, :1], d[0, :1], want_i, want_d)
+    finally:
+        ix.set_param("ivf_q8", 1)
