@@ -609,7 +609,7 @@ def leg_flat_f32(ix, timed, step_stats, queries, nq, k, outs, args, n, dim, ref,
     ref_idx, ref_dist = ref[0].clone(), ref[1].clone()
     ix.set_param("flat_half", 1)
     fn = lambda: ix.flat_knn_device(queries.data_ptr(), nq, k, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr())  # noqa: E731
-    el, _ = timed(ix, fn, args.steps, max(1, min(args.warmup, 2)))
+    el, _ = timed(ix, fn, args.steps, max(1, args.warmup))
     r = with_attainable(flat_roofline(ix, n, dim, nq), attainable)
     same = bool((outs[0] == ref_idx).all().item()) and bool((outs[1] == ref_dist).all().item())
     ix.set_param("flat_half", args.half)
@@ -701,7 +701,7 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, step_stats, args, threads
 
     def run(ix, wl, rows, ef, fn, extra_cfg, nq=nq, queries=queries, outs=(o_idx, o_dist, o_cnt), t_idx=t_idx):
         o_idx, o_dist, o_cnt = outs
-        el, _ = timed(ix, fn, args.steps, max(1, min(args.warmup, 2)))
+        el, _ = timed(ix, fn, args.steps, max(1, args.warmup))
         kernel = {"pq_flat": "pq_adc", "hnsw": "hnsw", "hnsw_pq": "hnsw", "ivf": "ivf_rerank"}[wl]
         if wl == "ivf":  # the scan's certified cascade holds the dominant kernel when it runs
             kernel = next((kn for kn in ("ivf_q8", "ivf_half") if ix.prof_get(kn)["launches"]), kernel)

@@ -295,6 +295,34 @@ int vdb_flat_knn(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim
     VDB_API_BEGIN
     VDB_REQUIRE(idx, "null index");
     check_query_args(idx->ix, queries, nq, dim, out_idx, out_dist);
+    Index &ix = idx->ix;
+    if (nq > 0 && k > 0 && ix.flat_small_applies(nq, k)) {
+        // The db.search() shape (pyo3/mod.rs:199-214): a few queries, a small table.  One launch, and no copy engine on either
+        // side of it: the queries go through ONE block of pinned host memory (read by the kernel over PCIe when only a
+        // handful of workgroups want them, else one async copy), the kernel writes ids / distances / counts straight back
+        // into that block, and the stream synchronisation that ends the call is the only wait.
+        ix.use_device();
+        WsLease ws(ix);
+        const size_t qb = nq * dim * sizeof(float), ib = nq * k * sizeof(uint64_t), db = nq * k * sizeof(float);
+        const size_t off_i = (qb + 15) & ~size_t(15), off_d = off_i + ib, off_c = (off_d + db + 7) & ~size_t(7);
+        char *h = static_cast<char *>(ws->pinned(off_c + nq * sizeof(uint64_t)));
+        std::memcpy(h, queries, qb);
+        const float *q = reinterpret_cast<const float *>(h);
+        const uint64_t n_wg = (ix.n + flat_small_rows_per_wg(ix.n, ix.num_cu) - 1) / flat_small_rows_per_wg(ix.n, ix.num_cu);
+        if (n_wg * nq > 64) {  // many readers: stage the queries in HBM once
+            ws->q.reserve(qb);
+            VDB_HIP(hipMemcpyAsync(ws->q.p, h, qb, hipMemcpyHostToDevice, ws->stream));
+            q = ws->q.as<float>();
+        }
+        ix.flat_small_device(*ws, q, nq, k, reinterpret_cast<uint64_t *>(h + off_i), reinterpret_cast<float *>(h + off_d),
+                             reinterpret_cast<uint64_t *>(h + off_c));
+        VDB_SYNC(ws->stream);
+        ix.prof_collect(*ws);
+        std::memcpy(out_idx, h + off_i, ib);
+        std::memcpy(out_dist, h + off_d, db);
+        if (out_count) std::memcpy(out_count, h + off_c, nq * sizeof(uint64_t));
+        return VDB_OK;
+    }
     host_search(idx->ix, queries, nq, k, 0, out_idx, out_dist, out_count, flat_dev);
     VDB_API_END
 }
@@ -401,6 +429,10 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         idx->ix.flat_gemm_debug = (int)value;
     else if (n == "flat_tail")  // exact stage of the Flat pipeline: 0 fused launch when the shortlist fits 64 rows, 1 separate kernels
         idx->ix.flat_tail_mode = (int)value;
+    else if (n == "flat_small")  // one-launch search of small tables (k_small.hip): 0 auto, 1 off, 2 whenever the shape allows
+        idx->ix.flat_small_mode = (int)value;
+    else if (n == "flat_small_max_rows")
+        idx->ix.flat_small_max_rows = (uint64_t)value;
     else if (n == "flat_half")  // fp16 first pass of large query batches: 0 auto, 1 off, 2 on regardless of the redo rate
         idx->ix.flat_half_mode = (int)value;
     else if (n == "flat_half_kmul") {  // its shortlist: max(64, kmul * k) rows per query

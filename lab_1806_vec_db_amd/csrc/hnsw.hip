@@ -1388,28 +1388,25 @@ void hnsw_clear(Index &ix) {
 // launchers, below)
 struct BuildDev;
 static std::shared_ptr<BuildDev> hnsw_build_gpu_assist(Index &ix, Builder::GpuAssist &ga, const std::vector<uint64_t> &levels);
-static int g_hnsw_build_gpu = 0;  // 0 auto (batches of >= 256 points, ef_construction <= 1024), 1 off
+static std::atomic<int> g_hnsw_build_gpu{0};  // 0 auto (batches of >= 256 points, ef_construction <= 1024), 1 off
 void hnsw_set_build_gpu(int v) { g_hnsw_build_gpu = v; }
 
-void hnsw_build(Index &ix, uint64_t M, uint64_t ef_construction, uint64_t seed, uint64_t batch, int nthreads) {
-    VDB_REQUIRE(!ix.elem_u8, "PQ / HNSW / IVF are built over f32 tables (DynamicIndex, dynamic_index.rs:11-14): a VecSet<u8> index serves Flat search");
+// the builder proper, on host arrays only (no GPU call unless `prepare_gpu` installs the assist): what hnsw_build runs,
+// and what the thread-sanitizer build of tests/cpp/tsan_host.cpp drives with 16 threads
+static void hnsw_build_host(HNSWState &h, const float *rows, const float *sq, uint64_t n, uint64_t dim, int dist, uint64_t M,
+                     uint64_t ef_construction, uint64_t seed, uint64_t batch, int nthreads,
+                     const std::function<std::shared_ptr<void>(Builder &, Builder::GpuAssist &, const std::vector<uint64_t> &)> &prepare_gpu) {
     VDB_REQUIRE(M >= 2, "M must be >= 2");
-    HNSWState &h = ix.hnsw;
     h.present = false;
     reset_graph(h);
     hnsw_config(h, M, ef_construction);
     h.rng_state = seed;
-    const float *rows = ix.host_rows();
-    Builder b(h, rows, ix.h_sq.data(), ix.dim, ix.dist);
-    uint64_t n = ix.n;
+    Builder b(h, rows, sq, dim, dist);
     std::vector<uint64_t> levels(n);
     for (uint64_t i = 0; i < n; i++) levels[i] = rand_level(h.rng_state, h.inv_log_m);
     Builder::GpuAssist ga;
-    std::shared_ptr<BuildDev> bdev;
-    if (g_hnsw_build_gpu != 1 && batch >= ga.min_batch && h.ef_construction <= 1024 && n >= 4 * ga.min_batch) {
-        bdev = hnsw_build_gpu_assist(ix, ga, levels);
-        b.gpu = &ga;
-    }
+    std::shared_ptr<void> bdev;
+    if (prepare_gpu) bdev = prepare_gpu(b, ga, levels);
     Scratch s;
     uint64_t cur = 0;
     while (cur < n) {
@@ -1427,6 +1424,26 @@ void hnsw_build(Index &ix, uint64_t M, uint64_t ef_construction, uint64_t seed, 
                      (unsigned long long)n, b.t_search, nthreads, b.t_gpu, b.t_connect, b.t_sync);
     h.present = true;
     h.dev_dirty = true;
+}
+// entry point of the host-only sanitizer build: the all-host builder over caller-owned arrays, graph out through `h`
+void hnsw_build_host_only(HNSWState &h, const float *rows, const float *sq, uint64_t n, uint64_t dim, int dist, uint64_t M,
+                          uint64_t ef_construction, uint64_t seed, uint64_t batch, int nthreads) {
+    hnsw_build_host(h, rows, sq, n, dim, dist, M, ef_construction, seed, batch, nthreads, nullptr);
+}
+
+void hnsw_build(Index &ix, uint64_t M, uint64_t ef_construction, uint64_t seed, uint64_t batch, int nthreads) {
+    VDB_REQUIRE(!ix.elem_u8, "PQ / HNSW / IVF are built over f32 tables (DynamicIndex, dynamic_index.rs:11-14): a VecSet<u8> index serves Flat search");
+    VDB_REQUIRE(M >= 2, "M must be >= 2");
+    const float *rows = ix.host_rows();
+    hnsw_build_host(ix.hnsw, rows, ix.h_sq.data(), ix.n, ix.dim, ix.dist, M, ef_construction, seed, batch, nthreads,
+                    [&](Builder &b, Builder::GpuAssist &ga, const std::vector<uint64_t> &levels) -> std::shared_ptr<void> {
+                        if (g_hnsw_build_gpu != 1 && batch >= ga.min_batch && ix.hnsw.ef_construction <= 1024 && ix.n >= 4 * ga.min_batch) {
+                            std::shared_ptr<BuildDev> bdev = hnsw_build_gpu_assist(ix, ga, levels);
+                            b.gpu = &ga;
+                            return bdev;
+                        }
+                        return nullptr;
+                    });
 }
 
 void hnsw_attach(Index &ix, uint64_t M, uint64_t ef_construction, const uint32_t *level0, const uint64_t *len0,
@@ -1518,11 +1535,11 @@ static void hnsw_launch(const HnswDev &g, const float *d_q, const float *qsq, co
                        vwords, out, stats, err);
 }
 
-static int g_hnsw_dma = 1;
+static std::atomic<int> g_hnsw_dma{1};
 void hnsw_set_dma(int v) { g_hnsw_dma = v; }
-static int g_hnsw_half = 1;  // certified half-precision pre-pass of the exact walk: 1 auto (calls of >= 768 queries), 0 off, 2 always
+static std::atomic<int> g_hnsw_half{1};  // certified half-precision pre-pass of the exact walk: 1 auto (calls of >= 768 queries), 0 off, 2 always
 void hnsw_set_half(int v) { g_hnsw_half = v; }
-static uint32_t g_hnsw_pool_cap = HNSW_POOL;
+static std::atomic<uint32_t> g_hnsw_pool_cap{HNSW_POOL};
 void hnsw_set_pool_cap(int v) { g_hnsw_pool_cap = v < 1 ? 1u : (v > (int)HNSW_POOL ? HNSW_POOL : (uint32_t)v); }
 // Candidate pool entries of a walk.  Every expansion starts by dropping the pairs at or above the worst result, which
 // leaves pairs that are also in the result list (< ef of them) or tie its worst distance with a smaller index; until the

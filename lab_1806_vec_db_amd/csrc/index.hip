@@ -8,6 +8,7 @@
 namespace vdb {
 
 Index::Index(int dev, uint64_t d, int ds, bool u8) : device(dev), dim(d), dist(ds), elem_u8(u8) {
+#ifndef VDB_HOST_SANITIZER_BUILD  // (the thread-sanitizer binary of tests/cpp/tsan_host.cpp has no device: host-side state only)
     use_device();
     hipDeviceProp_t prop;
     VDB_HIP(hipGetDeviceProperties(&prop, dev));
@@ -15,6 +16,7 @@ Index::Index(int dev, uint64_t d, int ds, bool u8) : device(dev), dim(d), dist(d
     std::string arch = prop.gcnArchName;
     if (arch.rfind("gfx950", 0) != 0)
         throw Error(4, "libvdbhip is built for gfx950 (MI355X) only; device reports " + arch);
+#endif
 }
 
 std::unique_ptr<Workspace> Index::acquire_ws() {
@@ -367,6 +369,40 @@ void Index::flat_sorted_device(Workspace &ws, const float *d_q, uint64_t nq, uin
     }
 }
 
+// ---- Flat: small table, few queries -> one launch (k_small.hip) ------------------------------------------------------------
+bool Index::flat_small_applies(uint64_t nq, uint64_t k) const {
+    if (flat_small_mode == 1 || elem_u8 || n == 0 || !flat_small_supported(n, (uint32_t)dim, nq, k)) return false;
+    if (flat_small_mode == 2) return true;
+    return flat_mode == 0 && n <= flat_small_max_rows && nq < 32;
+}
+void Index::flat_small_device(Workspace &ws, const float *q, uint64_t nq, uint64_t k, uint64_t *o_idx, float *o_dist, uint64_t *o_cnt) {
+    hipStream_t s = ws.stream;
+    const uint32_t ksel = (uint32_t)std::min<uint64_t>(k, n);
+    ws.small_part.reserve(flat_small_part_keys(n, nq, ksel, num_cu) * sizeof(uint64_t));
+    if (ws.small_cnt.cap < 64 * sizeof(uint32_t)) {
+        ws.small_cnt.reserve(64 * sizeof(uint32_t));
+        VDB_HIP(hipMemsetAsync(ws.small_cnt.p, 0, 64 * sizeof(uint32_t), s));  // the kernel leaves them zero
+    }
+    FlatSmallArgs a{};
+    a.X = d_rows.as<float>();
+    a.n = n;
+    a.dim = (uint32_t)dim;
+    a.Q = q;
+    a.metric = dist == 0 ? MET_L2_DIRECT : MET_COSINE;
+    a.xsq = d_sq.as<float>();
+    a.part = ws.small_part.as<uint64_t>();
+    a.counter = ws.small_cnt.as<uint32_t>();
+    a.ksel = ksel;
+    a.kstride = (uint32_t)k;
+    a.id_offset = id_offset;
+    a.out_idx = o_idx;
+    a.out_dist = o_dist;
+    a.out_count = o_cnt;
+    prof_begin(ws, "flat_small", double(nq) * double(n) * dim * sizeof(float));
+    launch_flat_small(a, (uint32_t)nq, num_cu, s);
+    prof_end(ws);
+}
+
 // ---- Flat: full pipeline ---------------------------------------------------------------------------
 void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t *d_idx,
                             float *d_dist, uint64_t *d_cnt, bool allow_half, uint32_t kprime_min) {
@@ -374,6 +410,10 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     if (nq == 0) return;
     if (k == 0 || n == 0) {  // ResultSet::new(0) rejects everything; empty VecSet -> empty result
         VDB_HIP(hipMemsetAsync(d_cnt, 0, nq * sizeof(uint64_t), s));
+        return;
+    }
+    if (flat_small_applies(nq, k)) {
+        flat_small_device(ws, d_q, nq, k, d_idx, d_dist, d_cnt);
         return;
     }
     const uint64_t ksel64 = std::min<uint64_t>(k, n);

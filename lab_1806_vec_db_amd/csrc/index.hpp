@@ -64,6 +64,7 @@ struct ProfEntry {
 struct Workspace {
     hipStream_t stream = nullptr;
     DevBuf q, qsq, qfrag, qfrag_g, qaux, dense, lists, keys_a, keys_b, keys_c, flags, out_idx, out_dist, out_cnt, lut, misc;
+    DevBuf small_part, small_cnt;  // k_flat_small: per-workgroup key lists, arrival counters (zero between launches)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     struct Pending {
         std::string name;
@@ -86,7 +87,11 @@ struct Workspace {
         }
         return h_pinned;
     }
-    Workspace() { VDB_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); }
+    Workspace() {
+#ifndef VDB_HOST_SANITIZER_BUILD  // (tests/cpp/tsan_host.cpp drives the pool and the host builders with no device present)
+        VDB_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+#endif
+    }
     ~Workspace() {
         if (h_pinned) (void)hipHostFree(h_pinned);
         for (auto &e : ev_pool) {
@@ -219,6 +224,11 @@ struct Index {
     int flat_gemm_mode = 0;   // 0 auto (more than 64 queries per call), 1 off, 2 forced (k_gemm.hip)
     int flat_gemm_debug = 0;
     int flat_tail_mode = 0;  // 0 auto (fused exact stage when k' <= 64), 1 separate kernels
+    int flat_small_mode = 0;          // one-launch search of small tables (k_small.hip): 0 auto, 1 off, 2 whenever the shape allows
+    uint64_t flat_small_max_rows = 16384;  // auto: tables up to this many rows (where the MFMA shortlist takes over), calls of < 32 queries
+    bool flat_small_applies(uint64_t nq, uint64_t k) const;
+    // q / outputs: device memory or device-visible pinned host memory
+    void flat_small_device(Workspace &ws, const float *q, uint64_t nq, uint64_t k, uint64_t *o_idx, float *o_dist, uint64_t *o_cnt);
     std::atomic<uint64_t> fallback_count{0};
     PQState pq;
     HNSWState hnsw;
@@ -231,7 +241,11 @@ struct Index {
     std::map<std::string, ProfEntry> prof;
 
     Index(int dev, uint64_t d, int ds, bool u8 = false);
-    void use_device() const { VDB_HIP(hipSetDevice(device)); }
+    void use_device() const {
+#ifndef VDB_HOST_SANITIZER_BUILD
+        VDB_HIP(hipSetDevice(device));
+#endif
+    }
     std::unique_ptr<Workspace> acquire_ws();
     void release_ws(std::unique_ptr<Workspace> ws);
     const float *host_rows() const;  // materialise the host mirror if needed

@@ -13,6 +13,7 @@
 //    order, (3) k_rerank computes their exact distances, (4) k_pq_resort replays ResultSet::add over that order
 //    (the same replay FlatIndex::knn_pq uses).
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <numeric>
 
@@ -427,9 +428,9 @@ __global__ __launch_bounds__(256) void k_ivf_keep(const uint64_t *__restrict__ c
     if (tid == 0 && base > ld2) flags[q] = 1;
     if (tid == 0) atomicAdd(n_kept_total, (unsigned long long)(base < ld2 ? base : ld2));  // rows the exact stage fetches
 }
-static int g_ivf_half = 1;  // 1 auto, 0 off
+static std::atomic<int> g_ivf_half{1};  // 1 auto, 0 off
 void ivf_set_half(int v) { g_ivf_half = v; }
-static int g_ivf_q8 = 1;  // the 8-bit tier in front of the fp16 tier: 1 auto, 0 off
+static std::atomic<int> g_ivf_q8{1};  // the 8-bit tier in front of the fp16 tier: 1 auto, 0 off
 void ivf_set_q8(int v) { g_ivf_q8 = v; }
 
 void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t n_probes,

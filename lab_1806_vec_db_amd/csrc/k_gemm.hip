@@ -21,6 +21,7 @@
 // HBM traffic: one corpus pass (N x d x 4 B) per 128 queries.  The keys are approximate ranking keys exactly as in
 // k_flat_mfma; exactness comes from k_rerank + k_certify downstream (index.hip).
 #include <type_traits>
+#include <atomic>
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -36,15 +37,15 @@ constexpr uint32_t GEMM_NH = 8;             // 16-query halves per group
 constexpr uint32_t GEMM_BQ = 16 * GEMM_NH;  // 128 queries per pass
 constexpr uint32_t GEMM_WGBUF = 3072;       // LDS hit buffer entries per workgroup and group
 constexpr uint32_t GEMM_STAGE = 64;         // per wave and unit: lanes whose (tile, half) key quartet passed the threshold
-static int g_gemm_tw = 3;
+static std::atomic<int> g_gemm_tw{3};
 void gemm_set_tw(int v) { g_gemm_tw = v == 2 ? 2 : 3; }
-static int g_gemm_nt = 0;  // 0 auto (by mirror size), 1 never, 2 always
+static std::atomic<int> g_gemm_nt{0};  // 0 auto (by mirror size), 1 never, 2 always
 void gemm_set_nt(int v) { g_gemm_nt = v; }
-static int g_gemm_zigzag = 0;  // 0 auto, 1 never, 2 always
+static std::atomic<int> g_gemm_zigzag{0};  // 0 auto, 1 never, 2 always
 void gemm_set_zigzag(int v) { g_gemm_zigzag = v; }
-static uint64_t g_gemm_block_rows = 0;  // 0 auto; n: scan in blocks of n rows (rounded to whole workgroup steps), one launch each
+static std::atomic<uint64_t> g_gemm_block_rows{0};  // 0 auto; n: scan in blocks of n rows (rounded to whole workgroup steps), one launch each
 void gemm_set_block_rows(uint64_t v) { g_gemm_block_rows = v; }
-static int g_gemm_stagger = 0;  // measured: no effect (the epilogue cost is per CU, not a chip-wide HBM gap), kept as a switch
+static std::atomic<int> g_gemm_stagger{0};  // measured: no effect (the epilogue cost is per CU, not a chip-wide HBM gap), kept as a switch
 void gemm_set_stagger(int v) { g_gemm_stagger = v; }
 uint32_t gemm_group() { return GEMM_BQ; }
 

@@ -29,6 +29,7 @@
 // every B fragment is one lane-linear, conflict-free ds_read_b128.  X never touches LDS: it is read
 // once, by exactly one wave, straight into VGPRs through a register ring (GEMV regime).
 #include <algorithm>
+#include <atomic>
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -51,9 +52,9 @@ bool mfma_supported(uint32_t dim) { return mfma_batch(dim) != 0; }
 constexpr int MFMA_RT = 2;              // 16-row tiles per wave item
 constexpr uint32_t MFMA_WGBUF = 3072;   // per-workgroup LDS hit buffer entries (MODE_FILTER): 36 KB beside the 120 KB Q image
 uint64_t mfma_row_pad() { return 64; }  // rows of padding the kernel may touch past n (xsq reads)
-static int g_mfma_variant = 0;
+static std::atomic<int> g_mfma_variant{0};
 void mfma_set_variant(int v) { g_mfma_variant = v; }
-static uint32_t g_mfma_share = 2;  // query batches per HBM pass (XCD-shared passes, see k_flat_mfma)
+static std::atomic<uint32_t> g_mfma_share{2};  // query batches per HBM pass (XCD-shared passes, see k_flat_mfma)
 void mfma_set_share(int v) { g_mfma_share = v < 1 ? 1 : (v > 8 ? 8 : (uint32_t)v); }
 uint32_t mfma_share() { return g_mfma_share; }
 size_t mfma_sync_words(uint32_t nbatch, int num_cu) { return size_t(num_cu) * (nbatch + 1) * (1 + 8); }
@@ -521,7 +522,7 @@ uint32_t mfma_num_items(uint64_t n) { return (uint32_t)((n + 16 * MFMA_RT - 1) /
 //    selection work for the same expected hit count (target = max(1024, 4 k')).  The k'-hit guarantee becomes a probability: hits / step is
 //    Gamma(r)-distributed, P[hits < k'] = P[Gamma(r) < k'/step] (r = 8, k'/step = 0.5: 6e-8), so it is CHECKED: a
 //    query with fewer than k' hits is redone like any other uncertified query.
-static int g_sample_thin = 1;
+static std::atomic<int> g_sample_thin{1};
 void mfma_set_sample_thin(int v) { g_sample_thin = v; }
 void mfma_sample_plan(uint64_t n, uint32_t kprime, uint32_t *step_out, uint32_t *rank_out) {
     const uint32_t items = mfma_num_items(n), target = std::max<uint32_t>(1024, 4 * kprime);

@@ -65,6 +65,27 @@ struct FlatTailArgs {
 };
 bool flat_tail64_supported(uint32_t dim, uint32_t kprime, uint32_t ksel);
 void launch_flat_tail64(const FlatTailArgs &a, uint32_t nq, hipStream_t s);
+// k_small.hip: FlatIndex::knn of a few queries over a small table in ONE launch (the db.search() shape): coalesced rows ->
+// products -> strict fold per lane -> in-kernel (distance, index) top-k -> outputs.  dim % 4 == 0, k <= 64, nq <= 64.
+struct FlatSmallArgs {
+    const float *X;        // row-major rows
+    uint64_t n;
+    uint32_t dim;
+    const float *Q;        // [nq][dim]; device memory or device-visible pinned host memory
+    int metric;            // MET_L2_DIRECT or MET_COSINE
+    const float *xsq;      // row norms (Cosine)
+    uint64_t *part;        // flat_small_part_keys() pair keys of scratch
+    uint32_t *counter;     // [nq] arrival counters, zero on entry, zero again on exit
+    uint32_t ksel, kstride;
+    uint64_t id_offset;
+    uint64_t *out_idx;     // device memory or device-visible pinned host memory
+    float *out_dist;
+    uint64_t *out_count;
+};
+bool flat_small_supported(uint64_t n, uint32_t dim, uint64_t nq, uint64_t k);
+uint32_t flat_small_rows_per_wg(uint64_t n, int num_cu);
+size_t flat_small_part_keys(uint64_t n, uint64_t nq, uint32_t ksel, int num_cu);
+void launch_flat_small(const FlatSmallArgs &a, uint32_t nq, int num_cu, hipStream_t s);
 void launch_certify(const uint64_t *exact_sorted, uint32_t lde, const uint64_t *approx_sorted, uint32_t lda,
                     uint32_t nq, uint32_t k, uint32_t kprime, uint64_t n_rows, const float *qsq, float xsq_max,
                     float xsq_min_pos, int cosine, uint32_t dim, uint8_t *flags, hipStream_t s);

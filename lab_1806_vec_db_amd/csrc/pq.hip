@@ -8,6 +8,7 @@
 // group order (pq_table.rs:254-292).  One thread owns one code row and adds in that order, so the sums
 // equal the reference's bit for bit; the LUT entries themselves are strict-order folds.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <thread>
@@ -80,9 +81,9 @@ struct AdcArgs {
     uint32_t nq_total;        // queries of the whole launch; blockIdx.y selects the sub-batch of BQ queries
     int fast;                 // batched-lookup inner loop (tuning switch, vdb_set_param "pq_adc_fast")
 };
-static int g_adc_fast = 1;
+static std::atomic<int> g_adc_fast{1};
 void pq_set_adc_fast(int v) { g_adc_fast = v; }
-static int g_adc16 = 0;  // quantised first pass of the threshold-filter scan: 0 auto (4-bit, L2Sqr, 16-B code words), 1 off
+static std::atomic<int> g_adc16{0};  // quantised first pass of the threshold-filter scan: 0 auto (4-bit, L2Sqr, 16-B code words), 1 off
 void pq_set_adc16(int v) { g_adc16 = v; }
 constexpr uint32_t ADC_WGBUF = 2048;  // LDS hit buffer entries per workgroup (MODE 1)
 
