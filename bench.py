@@ -194,6 +194,12 @@ def main():
     ap.add_argument("--hnsw-queries", type=int, default=8192,
                     help="queries per step of the hnsw / hnsw_pq legs: a walk is one wavefront and the chip keeps 2048 of them "
                          "resident, so the rate is flat from ~4096 queries per call on (a 1000-query call is reported beside it)")
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="flat: query batches (steps) in flight: with 2, step i+1 is enqueued (vdb_flat_knn_device_begin) before the host "
+                         "looks at step i's certification flags (_end), so the corpus passes of consecutive steps run back to back and "
+                         "the exact stage of one step overlaps the query preparation of the next; 1 = every step is one synchronous call; "
+                         "0 = auto: 2 on one GPU, 3 on row shards (where the per-step fixed cost is a larger share; on one GPU 2 and 3 "
+                         "measure the same rate)")
     ap.add_argument("--base-file", type=str, default="",
                     help="raw row-major f32 corpus, no header (the output of src/bin/convert_fvecs.rs:29-31, e.g. a real gist_base "
                          "converted from .fvecs): used instead of the synthetic rows when given; rows = file size / (dim * 4) unless --rows")
@@ -319,7 +325,8 @@ def main():
     torch.cuda.empty_cache()
 
     # the local results live in the send block of the per-step exchange (typed views, no packing)
-    ex = ShardExchange(nq, k, device, world if backend == "nccl" else 1, force=force_x)
+    depth = (max(1, min(args.pipeline, 4)) if args.pipeline > 0 else (2 if world == 1 else 3)) if wl == "flat" else 1
+    ex = ShardExchange(nq, k, device, world if backend == "nccl" else 1, force=force_x, min_depth=depth + 1 if depth > 1 else 1)
     o_idx, o_dist, o_cnt = ex.idx, ex.dist, ex.cnt
 
     host_xchg = backend != "nccl" and world > 1
@@ -329,11 +336,35 @@ def main():
         s_ex = torch.zeros((nq, efk), dtype=torch.int64, device=device)
     q0, q1 = replica_query_slice(nq, world, rank)
 
+    inflight = []  # flat, depth > 1: (pending handle, buffer slot, views) of the steps begun and not yet ended
+    last = [None]
+
+    def flat_finish_one():
+        h, slot, (b_idx, b_dist, b_cnt) = inflight.pop(0)
+        ix.flat_knn_device_end(h)  # the step's local answer is complete (certified or redone) when this returns
+        if host_xchg:
+            last[0] = allgather_merge(b_idx.cpu(), b_dist.cpu(), b_cnt.cpu(), k)
+        else:
+            last[0] = ex.exchange_merge(ix, slot=slot)  # enqueued on torch's stream: runs under the steps already begun
+        return last[0]
+
+    def drain():
+        while inflight:
+            flat_finish_one()
+        return last[0]
+
     def step():
         if wl == "flat":
-            # the step's send block (two rotate: the all-gather + merge of step i run on torch's stream under the search of step
-            # i+1, which the library issues on its own stream; everything is complete at the fence that ends the timed region)
+            # the step's send block (the sets rotate: the all-gather + merge of step i run on torch's stream under the search of
+            # step i+1, which the library issues on its own stream; everything is complete at the fence that ends the timed region)
             b_idx, b_dist, b_cnt = ex.begin_step()
+            if depth > 1:
+                h = ix.flat_knn_device_begin(queries.data_ptr(), nq, k, b_idx.data_ptr(), b_dist.data_ptr(), b_cnt.data_ptr(),
+                                             stream=torch.cuda.current_stream().cuda_stream)
+                inflight.append((h, ex.slot, (b_idx, b_dist, b_cnt)))
+                if len(inflight) >= depth:
+                    flat_finish_one()
+                return last[0]
             ix.flat_knn_device(queries.data_ptr(), nq, k, b_idx.data_ptr(), b_dist.data_ptr(), b_cnt.data_ptr())
             if host_xchg:
                 return allgather_merge(b_idx.cpu(), b_dist.cpu(), b_cnt.cpu(), k)
@@ -364,11 +395,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed(index, fn, steps, warmup):
-        """W untimed + EXACTLY `steps` timed calls of fn between fences; the library's HIP-event records cover the timed calls"""
+    def timed(index, fn, steps, warmup, drain=None):
+        """W untimed + EXACTLY `steps` timed calls of fn between fences; the library's HIP-event records cover the timed calls.
+        drain (pipelined steps): completes the steps still in flight -- before the opening fence, so that the timed region starts
+        with an empty pipeline, and before the closing one, so that all `steps` steps are answered inside it"""
         r = None
         for _ in range(warmup):
             r = fn()
+        if drain is not None:
+            r = drain() or r
         index.prof_enable(True)
         index.prof_reset()
         fence()
@@ -377,6 +412,8 @@ def main():
         for _ in range(steps):
             r = fn()
             marks.append(time.perf_counter())
+        if drain is not None:
+            r = drain() or r
         fence()
         el = time.perf_counter() - t0
         index.prof_enable(False)
@@ -396,7 +433,7 @@ def main():
                        "library's own stream synchronisation; with N>1 the exchange of step i overlaps step i+1, so single steps are "
                        "enqueue-to-enqueue and only the total is fenced)"}
 
-    elapsed, res = timed(ix, step, args.steps, args.warmup)
+    elapsed, res = timed(ix, step, args.steps, args.warmup, drain if depth > 1 else None)
     head_steps = step_stats()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
@@ -405,6 +442,17 @@ def main():
 
     if wl == "flat":
         roofline = flat_roofline(ix, r1 - r0, dim, nq)
+        if roofline and depth > 1:
+            roofline["overlap_note"] = (f"{depth} steps in flight: the HIP-event duration of a corpus pass includes the CUs it waited for while the "
+                                        "neighbouring steps' exact stage / query preparation ran beside it (passes themselves take turns)")
+            if world == 1:
+                # the same kernel with nothing beside it: a short region of synchronous calls right after the timed one
+                el1, _ = timed(ix, lambda: ix.flat_knn_device(queries.data_ptr(), nq, k, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr()),
+                               min(args.steps, 10), 2)
+                r1s = flat_roofline(ix, r1 - r0, dim, nq) or {}
+                roofline["one_step_in_flight"] = {"qps": round(nq * min(args.steps, 10) / el1, 1), "ms_per_step": round(el1 / min(args.steps, 10) * 1e3, 3),
+                                                  "avg_launch_ms": r1s.get("avg_launch_ms"), "achieved": r1s.get("achieved"), "frac": r1s.get("frac"),
+                                                  "unit": "GB/s"}
     else:
         # pq_adc: code bytes of one scan = rows x ceil(m*n_bits/8), one scan serves the queries whose LUTs sit side by side
         # in LDS; hnsw: n_dist x (dim*4 + 4) + n_expanded x max_m0*4 counted by the kernel
@@ -465,7 +513,7 @@ def main():
         "dtype": "f32 (certified fp16 filter pass)" if (roofline or {}).get("kernel") == "flat_half" else "f32",
         "data": data_name,
         "config": {"workload": names[1], "rows": n, "dim": dim, "queries_per_step": nq, "k": k, "dist": dname,
-                   "parallelism": par if world > 1 else "single GPU"},
+                   "parallelism": par if world > 1 else "single GPU", "steps_in_flight": depth},
         "roofline": roofline, "recall_at_10": None,
     }
     if wl == "flat":

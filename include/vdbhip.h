@@ -98,6 +98,16 @@ int vdb_flat_knn(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim
  * synchronises `stream` once at the end (certification read-back). */
 int vdb_flat_knn_device(vdb_index *idx, const void *d_queries, uint64_t nq, uint64_t dim, uint64_t k,
                         void *d_out_idx, void *d_out_dist, void *d_out_count, void *stream);
+/* The same call in two halves, for hosts that keep several independent query batches in flight (bench.rs:410-418 loops over
+ * queries; a serving host loops over batches): _begin enqueues the whole search on one of the index's streams, ordered behind
+ * `stream` by an event (no host wait), and returns a pending-call handle; _end waits for it, redoes uncertified queries and
+ * frees the handle (also when it reports an error).  With begin(i+1) issued before end(i) the corpus passes of consecutive
+ * batches run back to back and the exact stage of one batch overlaps the query preparation of the next.  Every begun call must
+ * be ended before the index is destroyed or written to; outputs and query buffers of a pending call must stay untouched. */
+typedef struct vdb_pending vdb_pending;
+int vdb_flat_knn_device_begin(vdb_index *idx, const void *d_queries, uint64_t nq, uint64_t dim, uint64_t k, void *d_out_idx,
+                              void *d_out_dist, void *d_out_count, void *stream, vdb_pending **out);
+int vdb_flat_knn_device_end(vdb_pending *pending);
 /* the approximate keys the Flat shortlist pass compares with its threshold, for EVERY row, from the same kernel in its dense
  * mode (test / measurement entry point behind the certification-bound tests): out_keys [nq][len];
  * L2Sqr: key = |x|^2 - 2 S~, approximate distance = key + |q|^2;  Cosine: key = -S~ / |x|, approximate distance = 1 + key / |q|.

@@ -41,6 +41,8 @@ SIGNATURES = {
     "vdb_calc_dist": [C.c_int, f32p, f32p, u64, C.c_int, f32p],
     "vdb_flat_knn": [vp, f32p, u64, u64, u64, u64p, f32p, u64p],
     "vdb_flat_knn_device": [vp, vp, u64, u64, u64, vp, vp, vp, vp],
+    "vdb_flat_knn_device_begin": [vp, vp, u64, u64, u64, vp, vp, vp, vp, C.POINTER(vp)],
+    "vdb_flat_knn_device_end": [vp],
     "vdb_flat_shortlist_keys": [vp, f32p, u64, u64, C.c_int, f32p, f32p, f32p, f32p],
     "vdb_flat_set_mode": [vp, C.c_int],
     "vdb_flat_fallback_count": [vp, u64p],

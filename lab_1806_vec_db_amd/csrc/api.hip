@@ -363,6 +363,68 @@ int vdb_flat_knn_device(vdb_index *idx, const void *d_queries, uint64_t nq, uint
     VDB_API_END
 }
 
+// ---- a Flat call in two halves: software pipelining of independent query batches ----------------------------------------------
+// vdb_flat_knn_device returns when the batch is answered: the host reads the certification flags (one byte per query) to
+// decide whether anything must be redone.  Between that read and the first kernel of the next call the GPU idles, and the
+// per-query stages at both ends of a call (query preparation, threshold sample and selection in front of the corpus pass;
+// the exact stage behind it) cannot overlap each other.  begin() enqueues the whole pipeline on a workspace stream -- ordered
+// behind the caller's stream through an event, not a host wait -- and returns; end() waits, reads the flags, redoes what was
+// not certified.  Two batches in flight (begin(i+1) before end(i)) keep the corpus passes back to back and let the exact
+// stage of batch i run beside the front stages of batch i+1.  Results are the synchronous call's, bit for bit.
+struct vdb_pending {
+    vdb_index *idx = nullptr;
+    std::unique_ptr<Workspace> ws;
+    FlatPending p;
+};
+
+int vdb_flat_knn_device_begin(vdb_index *idx, const void *d_queries, uint64_t nq, uint64_t dim, uint64_t k, void *d_out_idx,
+                              void *d_out_dist, void *d_out_count, void *stream, vdb_pending **out) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx && out, "null argument");
+    Index &ix = idx->ix;
+    check_query_args(ix, d_queries, nq, dim, d_out_idx, d_out_dist);
+    VDB_REQUIRE(nq == 0 || d_out_count, "null out_count");
+    VDB_REQUIRE(nq <= 32768, "at most 32768 queries per device call");
+    ix.use_device();
+    std::unique_ptr<vdb_pending> pd(new vdb_pending);
+    pd->idx = idx;
+    pd->ws = ix.acquire_ws();
+    try {
+        Workspace &ws = *pd->ws;
+        if (!ws.order_ev) VDB_HIP(hipEventCreateWithFlags(&ws.order_ev, hipEventDisableTiming));
+        VDB_HIP(hipEventRecord(ws.order_ev, static_cast<hipStream_t>(stream)));  // whatever produced the queries / last read the outputs
+        VDB_HIP(hipStreamWaitEvent(ws.stream, ws.order_ev, 0));
+        ix.flat_knn_enqueue(ws, static_cast<const float *>(d_queries), nq, k, static_cast<uint64_t *>(d_out_idx),
+                            static_cast<float *>(d_out_dist), static_cast<uint64_t *>(d_out_count), true, 0, pd->p);
+    } catch (...) {
+        (void)hipStreamSynchronize(pd->ws->stream);
+        ix.release_ws(std::move(pd->ws));
+        throw;
+    }
+    *out = pd.release();
+    VDB_API_END
+}
+
+// completes the call begun with `pending` and releases it (also on error); the outputs are valid when this returns
+int vdb_flat_knn_device_end(vdb_pending *pending) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(pending, "null pending call");
+    std::unique_ptr<vdb_pending> pd(pending);
+    Index &ix = pd->idx->ix;
+    ix.use_device();
+    try {
+        ix.flat_knn_finish(*pd->ws, pd->p);
+        VDB_SYNC(pd->ws->stream);
+        ix.prof_collect(*pd->ws);
+    } catch (...) {
+        (void)hipStreamSynchronize(pd->ws->stream);
+        ix.release_ws(std::move(pd->ws));
+        throw;
+    }
+    ix.release_ws(std::move(pd->ws));
+    VDB_API_END
+}
+
 int vdb_flat_shortlist_keys(vdb_index *idx, const float *queries, uint64_t nq, uint64_t dim, int tier, float *out_keys,
                             float *out_qsq, float *out_qerr, float *out_dx4) {
     VDB_API_BEGIN

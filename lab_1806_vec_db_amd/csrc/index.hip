@@ -406,7 +406,18 @@ void Index::flat_small_device(Workspace &ws, const float *q, uint64_t nq, uint64
 // ---- Flat: full pipeline ---------------------------------------------------------------------------
 void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t *d_idx,
                             float *d_dist, uint64_t *d_cnt, bool allow_half, uint32_t kprime_min) {
+    FlatPending p;
+    flat_knn_enqueue(ws, d_q, nq, k, d_idx, d_dist, d_cnt, allow_half, kprime_min, p);
+    flat_knn_finish(ws, p);
+}
+
+// Everything of a Flat call up to (not including) the host's look at the certification flags.  p.active on return: the MFMA
+// pipeline is enqueued on ws.stream and flat_knn_finish must follow (same workspace); otherwise the call took one of the
+// synchronous-by-nature paths (small table, exact scan, k > 1024) and is enqueued in full -- nothing left but the stream sync.
+void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t *d_idx, float *d_dist,
+                             uint64_t *d_cnt, bool allow_half, uint32_t kprime_min, FlatPending &p) {
     hipStream_t s = ws.stream;
+    p = FlatPending{};
     if (nq == 0) return;
     if (k == 0 || n == 0) {  // ResultSet::new(0) rejects everything; empty VecSet -> empty result
         VDB_HIP(hipMemsetAsync(d_cnt, 0, nq * sizeof(uint64_t), s));
@@ -525,6 +536,13 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
     // algorithmic bytes: one corpus pass (N*d*4) serves 32*share queries (bytes/query = N*d*4 / B)
     // (the fp16 pass streams N*d*2 bytes per 128 queries: its own counter, so that GB/s are the bytes really read)
     const uint64_t hbm_passes = gemm ? ngroups : (nbatch + mfma_share() - 1) / mfma_share();
+    // Calls in flight on other workspaces (re-entrant readers, vdb_flat_knn_device_begin): their corpus passes take turns.
+    // Each pass wants every CU (one persistent workgroup per CU); two of them resident at once only wait for each other's
+    // workgroups, and their HIP-event durations would measure that wait.  The small kernels around the passes still overlap.
+    {
+        std::lock_guard<std::mutex> g(pass_mu);
+        if (pass_ev_valid) VDB_HIP(hipStreamWaitEvent(s, pass_ev, 0));
+    }
     prof_begin(ws, half ? "flat_half" : "flat_mfma", double(hbm_passes) * double(n) * dim * (half ? sizeof(uint16_t) : sizeof(float)));
     if (gemm)
         launch_flat_gemm_filter(xt, n, (uint32_t)dim, ws.qfrag_g.as<float>(), d_qmul, (uint32_t)ngroups,
@@ -533,6 +551,12 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
         launch_flat_mfma_filter(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>(), (uint32_t)nbatch,
                                 d_sq.as<float>(), cosine, d_tau, d_cand, d_hits, CAND_CAP, d_sync, num_cu, s);
     prof_end(ws);
+    {
+        std::lock_guard<std::mutex> g(pass_mu);
+        if (!pass_ev) VDB_HIP(hipEventCreateWithFlags(&pass_ev, hipEventDisableTiming));
+        VDB_HIP(hipEventRecord(pass_ev, s));
+        pass_ev_valid = true;
+    }
     SplitErr se;
     if (half) {
         se.qerr = d_qerr;
@@ -573,6 +597,30 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
                            n, ws.qsq.as<float>(), xsq_max, xsq_min_pos, cosine, (uint32_t)dim, se, d_hits, CAND_CAP, id_offset,
                            static_cast<uint8_t *>(ws.pinned(nq)), d_idx, d_dist, d_cnt, s);
     }
+    p.active = true;
+    p.half = half;
+    p.kprime = kprime;
+    p.ksel = ksel;
+    p.nq = nq;
+    p.k = k;
+    p.d_q = d_q;
+    p.d_idx = d_idx;
+    p.d_dist = d_dist;
+    p.d_cnt = d_cnt;
+}
+
+// the host's half of a Flat call: wait for the stream, read the certification flags, redo what was not certified
+void Index::flat_knn_finish(Workspace &ws, FlatPending &p) {
+    hipStream_t s = ws.stream;
+    if (!p.active) return;
+    p.active = false;
+    const bool half = p.half;
+    const uint32_t kprime = p.kprime, ksel = p.ksel;
+    const uint64_t nq = p.nq, k = p.k;
+    const float *d_q = p.d_q;
+    uint64_t *d_idx = p.d_idx;
+    float *d_dist = p.d_dist;
+    uint64_t *d_cnt = p.d_cnt;
     // the flags go straight to pinned host memory (device-visible): no copy kernel between the last kernel and the sync
     const uint8_t *flags = static_cast<const uint8_t *>(ws.pinned(nq));
     VDB_SYNC(s);

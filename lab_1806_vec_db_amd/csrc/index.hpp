@@ -77,6 +77,7 @@ struct Workspace {
     // through the runtime's own staging buffer and costs an extra hop before the stream sync returns
     void *h_pinned = nullptr;
     size_t h_pinned_cap = 0;
+    hipEvent_t order_ev = nullptr;  // orders this workspace's stream behind a caller's stream without a host wait (vdb_*_begin)
     void *pinned(size_t bytes) {
         if (bytes > h_pinned_cap) {
             if (h_pinned) (void)hipHostFree(h_pinned);
@@ -94,6 +95,7 @@ struct Workspace {
     }
     ~Workspace() {
         if (h_pinned) (void)hipHostFree(h_pinned);
+        if (order_ev) (void)hipEventDestroy(order_ev);
         for (auto &e : ev_pool) {
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);
@@ -130,6 +132,18 @@ struct HNSWState {
     std::atomic<uint64_t> last_n_dist{0}, last_n_expanded{0};
     std::atomic<uint64_t> last_half_dropped{0};  // of last_n_dist: rows the certified half-precision pre-pass ruled out (last call)
     std::atomic<uint64_t> heap_walk_queries{0};  // queries answered by k_hnsw_search_big (ef > 1024 or LDS pool overflow)
+};
+
+// a Flat call between its two halves (Index::flat_knn_enqueue / flat_knn_finish)
+struct FlatPending {
+    bool active = false;  // the MFMA pipeline is on the stream, its certification flags are still to be read
+    bool half = false;
+    uint32_t kprime = 0, ksel = 0;
+    uint64_t nq = 0, k = 0;
+    const float *d_q = nullptr;
+    uint64_t *d_idx = nullptr;
+    float *d_dist = nullptr;
+    uint64_t *d_cnt = nullptr;
 };
 
 struct Index;
@@ -236,11 +250,18 @@ struct Index {
 
     std::mutex ws_mu;
     std::vector<std::unique_ptr<Workspace>> ws_free;
+    // end of the most recent Flat corpus pass enqueued on any of this index's streams (flat_knn_enqueue orders passes by it)
+    std::mutex pass_mu;
+    hipEvent_t pass_ev = nullptr;
+    bool pass_ev_valid = false;
     bool prof_on = false;
     std::mutex prof_mu;
     std::map<std::string, ProfEntry> prof;
 
     Index(int dev, uint64_t d, int ds, bool u8 = false);
+    ~Index() {
+        if (pass_ev) (void)hipEventDestroy(pass_ev);
+    }
     void use_device() const {
 #ifndef VDB_HOST_SANITIZER_BUILD
         VDB_HIP(hipSetDevice(device));
@@ -261,6 +282,9 @@ struct Index {
     // search entry points; d_* are device pointers, results [nq][k]
     void flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t *d_idx, float *d_dist,
                          uint64_t *d_cnt, bool allow_half = true, uint32_t kprime_min = 0);
+    void flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t *d_idx, float *d_dist, uint64_t *d_cnt,
+                          bool allow_half, uint32_t kprime_min, FlatPending &p);
+    void flat_knn_finish(Workspace &ws, FlatPending &p);
     void flat_sorted_device(Workspace &ws, const float *d_q, uint64_t nq, uint64_t ksel, uint64_t k, uint64_t *d_idx,
                             float *d_dist, uint64_t *d_cnt);
     void scan_rows(uint64_t nrows, uint32_t d, const float *Q, uint32_t nq, int metric, const float *xsq, const float *qsq, float *out,

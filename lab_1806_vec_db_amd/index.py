@@ -201,6 +201,19 @@ class GpuIndex:
         L.check(self._lib.vdb_flat_knn_device(self._h, L.vp(q_ptr), int(nq), self.dim, int(k), L.vp(out_idx_ptr),
                                               L.vp(out_dist_ptr), L.vp(out_cnt_ptr), L.vp(stream)))
 
+    def flat_knn_device_begin(self, q_ptr: int, nq: int, k: int, out_idx_ptr: int, out_dist_ptr: int, out_cnt_ptr: int,
+                              stream: int = 0):
+        """first half of flat_knn_device (vdb_flat_knn_device_begin): enqueues the search behind `stream` and returns a pending
+        handle for flat_knn_device_end; keep two batches in flight to pipeline independent query batches"""
+        h = L.vp()
+        L.check(self._lib.vdb_flat_knn_device_begin(self._h, L.vp(q_ptr), int(nq), self.dim, int(k), L.vp(out_idx_ptr),
+                                                    L.vp(out_dist_ptr), L.vp(out_cnt_ptr), L.vp(stream), C.byref(h)))
+        return h
+
+    def flat_knn_device_end(self, pending):
+        """second half: waits for the call, redoes uncertified queries, frees the handle; outputs valid on return"""
+        L.check(self._lib.vdb_flat_knn_device_end(pending))
+
     def knn_pq_device(self, q_ptr: int, nq: int, k: int, ef: int, out_idx_ptr: int, out_dist_ptr: int,
                       out_cnt_ptr: int, stream: int = 0):
         L.check(self._lib.vdb_flat_knn_pq_device(self._h, L.vp(q_ptr), int(nq), self.dim, int(k), int(ef),

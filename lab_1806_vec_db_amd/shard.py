@@ -146,9 +146,10 @@ class ShardExchange:
     has passed its exchange (the caller's fence, or `wait()`).
     """
 
-    def __init__(self, nq: int, k: int, device, world: int, force: bool = False):
+    def __init__(self, nq: int, k: int, device, world: int, force: bool = False, min_depth: int = 1):
         """force: run the collective and the gathered merge even for one rank (a 1-rank RCCL all-gather: the only way to
-        execute this path's nccl calls on a one-GPU box)"""
+        execute this path's nccl calls on a one-GPU box); min_depth: buffer sets to rotate at least (a host that keeps two
+        searches in flight -- vdb_flat_knn_device_begin / _end -- needs three: one being exchanged, two being written)"""
         import torch
 
         self.nq, self.k, self.world = nq, k, world
@@ -158,7 +159,7 @@ class ShardExchange:
         self.off_counts = (nq * k * 12 + 7) // 8 * 8
         self.block = self.off_counts + nq * 8
         self.active = world > 1 or force
-        self.depth = 2 if self.active else 1
+        self.depth = max(2 if self.active else 1, int(min_depth))
         self._bufs = []
         for _ in range(self.depth):
             send = torch.zeros(self.block, dtype=torch.uint8, device=device)
@@ -189,15 +190,21 @@ class ShardExchange:
             self._set_views()
         return self.idx, self.dist, self.cnt
 
-    def exchange_merge(self, gpu_index, group=None):
-        """After the local search has filled idx / dist / cnt: the merged (idx, dist, cnt), the same on every rank.  For k <= 64
-        they are valid once torch's current stream has passed this point (see the class comment)."""
+    @property
+    def slot(self) -> int:
+        """the buffer set begin_step() handed out last (pass it to exchange_merge when later steps have begun since)"""
+        return self._cur
+
+    def exchange_merge(self, gpu_index, group=None, slot=None):
+        """After the local search has filled idx / dist / cnt (of buffer set `slot`, default: the current one): the merged
+        (idx, dist, cnt), the same on every rank.  For k <= 64 they are valid once torch's current stream has passed this point
+        (see the class comment)."""
+        b = self._bufs[self._cur if slot is None else slot]
         if not self.active:
-            return self.idx, self.dist, self.cnt
+            return b["idx"], b["dist"], b["cnt"]
         import torch
         import torch.distributed as dist
 
-        b = self._bufs[self._cur]
         dist.all_gather_into_tensor(b["recv"], b["send"], group=group)
         stream = torch.cuda.current_stream()
         args = (b["recv"].data_ptr(), self.block, self.off_ids, self.off_dists, self.off_counts, self.world, self.nq, self.k,

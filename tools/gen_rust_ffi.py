@@ -11,7 +11,7 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-OPAQUE = {"vdb_index": "VdbIndex", "vdb_ctx": "VdbCtx", "vdb_sharded": "VdbSharded"}
+OPAQUE = {"vdb_index": "VdbIndex", "vdb_ctx": "VdbCtx", "vdb_sharded": "VdbSharded", "vdb_pending": "VdbPending"}
 SCALAR = {"int": "c_int", "uint64_t": "u64", "int64_t": "i64", "uint32_t": "u32", "uint8_t": "u8", "float": "f32",
           "double": "f64", "char": "c_char", "void": "c_void", "size_t": "usize"}
 
