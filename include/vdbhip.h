@@ -146,7 +146,12 @@ int vdb_flat_set_mode(vdb_index *idx, int mode);
  *   "hnsw_pool_cap"    most live candidates the fast HNSW walk keeps in LDS (it uses min(this, ef + max_m0 + 64); maximum 2048) before a query is handed to
  *                      the heap walk; tests lower it to exercise that hand-over
  *   "pq_adc16"         quantised first pass of the threshold-filter ADC scan (16-bit tables, 8 queries per pass; exact f32
- *                      sums for its candidates): 0 auto (4-bit codes, whole 16-B code words; L2Sqr 8 and Cosine 7 queries per pass), 1 off */
+ *                      sums for its candidates): 0 auto (4-bit codes, whole 16-B code words; L2Sqr 8 and Cosine 7 queries per pass), 1 off
+ *   "pq_sample16"      the threshold sample of that scan on the quantised tables as well (L2Sqr): 0 auto (on), 1 off (exact f32 sample).
+ *                      The threshold only decides how many rows the scan keeps; the count is checked and short lists are redone
+ *   "flat_small"       FlatIndex::knn of a few queries over a small table in ONE launch (the db.search() shape; dim % 4 == 0, k <= 64):
+ *                      0 auto (tables of at most "flat_small_max_rows" = 16 384 rows, calls of fewer than 32 queries, flat mode 0),
+ *                      1 off, 2 whenever the shape allows (up to 64 queries) */
 int vdb_set_param(vdb_index *idx, const char *name, int64_t value);
 /* number of queries whose MFMA shortlist failed certification and were redone by the exact scan */
 int vdb_flat_fallback_count(const vdb_index *idx, uint64_t *out);
@@ -154,6 +159,7 @@ int vdb_flat_fallback_count(const vdb_index *idx, uint64_t *out);
  *   "flat_fallback"      = vdb_flat_fallback_count,
  *   "flat_half_queries"  queries that went through the fp16 first pass,
  *   "flat_half_redo"     of those, the ones it could not certify (redone with the split-bf16 pass),
+ *   "pq_adc16_queries"   queries whose ADC scan ran on the quantised 16-bit tables (k_pq_adc16) since the table was attached,
  *   "flat_half_valid"    1 when the index holds the fp16 mirror,
  *   "flat_bf16_mirror"   1 once the split-bf16 mirror (4 B/element) has been built -- lazily, by the first search that
  *                        needs it (redo tier, flat_half = 1, calls without an fp16 mirror),
@@ -354,6 +360,10 @@ int vdb_prof_enable(vdb_index *idx, int on);
 /* attainable HBM read bandwidth of this box: a pure streaming read of `bytes` (> the 256-MB Infinity Cache)
  * repeated `iters` times, best of two access patterns, in GB/s (1e9 B/s).  Allocates and frees its own buffer. */
 int vdb_stream_probe(int device_id, uint64_t bytes, int iters, double *out_gbps);
+/* the same bytes read the way the Flat filter would have to read them if its fp16 operand were the ROW-MAJOR image the graph
+ * walks gather from (one fp16 copy of the rows instead of two): MFMA A-fragment loads, 16 rows x 64 B per instruction, rows of
+ * row_bytes (a multiple of 128, e.g. 1920 = a 960-d fp16 row).  The A/B behind DESIGN's "two fp16 images" note.  Measurement hook. */
+int vdb_stream_probe_rows(int device_id, uint64_t bytes, int iters, uint32_t row_bytes, double *out_gbps);
 /* matrix-pipe rate of this box under sustained load: v_mfma_f32_16x16x32_f16 (the Flat filter's instruction) issued back to back
  * by `waves_per_simd` waves on every SIMD, `iters` x 8 independent tiles per wave; dense TFLOP/s of the launch and the shader
  * clock (GHz) the chip held meanwhile.  Measurement hook. */

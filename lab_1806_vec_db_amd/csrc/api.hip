@@ -471,6 +471,8 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         hnsw_set_pool_cap((int)value);
     else if (n == "pq_adc_fast")
         pq_set_adc_fast((int)value);
+    else if (n == "pq_sample16")
+        pq_set_adc16_sample((int)value);
     else if (n == "pq_adc16")
         pq_set_adc16((int)value);
     else if (n == "flat_sample_thin")
@@ -538,6 +540,8 @@ int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out) {
         *out = idx->ix.ivf.last_kept_q8.load();
     else if (n == "ivf_last_kept")
         *out = idx->ix.ivf.last_kept.load();
+    else if (n == "pq_adc16_queries")
+        *out = idx->ix.pq.adc16_queries.load();
     else if (n == "hbm_bytes_per_row")
         *out = idx->ix.hbm_bytes_per_row();
     else
@@ -996,6 +1000,13 @@ int vdb_stream_probe(int device_id, uint64_t bytes, int iters, double *out_gbps)
     VDB_REQUIRE(out_gbps, "null out");
     require_gpu();
     *out_gbps = stream_probe(device_id, bytes, iters);
+    VDB_API_END
+}
+int vdb_stream_probe_rows(int device_id, uint64_t bytes, int iters, uint32_t row_bytes, double *out_gbps) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(out_gbps, "null out");
+    require_gpu();
+    *out_gbps = stream_probe_pattern(device_id, bytes, iters, 1, row_bytes);
     VDB_API_END
 }
 int vdb_mfma_probe(int device_id, int waves_per_simd, int iters, double *out_tflops, double *out_clock_ghz) {

@@ -114,6 +114,7 @@ struct PQState {
     DevBuf d_centroids, d_cent_cache, d_codes, d_gstart;
     DevBuf d_codes_t;                // word-major mirror of d_codes for the quantised ADC scan (pq.hip: k_pq_tile_codes)
     bool codes_t_valid = false;
+    std::atomic<uint64_t> adc16_queries{0};  // queries whose ADC scan ran on the quantised tables (k_pq_adc16)
 };
 
 struct HNSWState {

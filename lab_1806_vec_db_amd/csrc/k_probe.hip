@@ -14,6 +14,8 @@
 
 namespace vdb {
 
+double stream_probe_pattern(int device, uint64_t bytes, int iters, int pattern_sel, uint32_t row_bytes);
+
 template <int INFLIGHT>
 __global__ __launch_bounds__(512) void k_probe_chunks(const float4 *__restrict__ src, uint64_t n_kb, uint32_t chunk_kb,
                                                       float *out) {
@@ -49,9 +51,43 @@ __global__ __launch_bounds__(256) void k_probe_linear(const float4 *__restrict__
     if (acc == 12345.678f) out[0] = acc;
 }
 
+// The Flat filter's operand loads if its fp16 mirror were the ROW-MAJOR image the HNSW / IVF gathers use (one fp16 copy instead
+// of two): a wave owns 48 rows (three 16-row tiles) of row_bytes each and walks them in 64-B k-blocks; one A-fragment load of
+// v_mfma_f32_16x16x32_f16 is then lane l -> row (l & 15), bytes 16 (l >> 4) of the k-block: 16 half lines 1 920 B apart per
+// instruction instead of one contiguous KB.  INFLIGHT k-block pairs (= whole lines) per tile in flight.
+template <int INFLIGHT>
+__global__ __launch_bounds__(512) void k_probe_rowfrag(const float4 *__restrict__ src, uint64_t n_rows, uint32_t row_f4, float *out) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint64_t stride = uint64_t(gridDim.x) * nw, n_units = n_rows / 48;
+    float acc = 0.f;
+    for (uint64_t u = blockIdx.x * nw + wave; u < n_units; u += stride) {
+        const float4 *p0 = src + (u * 48 + (lane & 15)) * row_f4 + (lane >> 4);
+        for (uint32_t kb = 0; kb + 2 * INFLIGHT <= row_f4 / 4; kb += 2 * INFLIGHT) {  // a 64-B k-block = 4 pieces of 16 B
+            float4 v[INFLIGHT][3][2];
+#pragma unroll
+            for (int j = 0; j < INFLIGHT; j++)
+#pragma unroll
+                for (int t = 0; t < 3; t++)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) v[j][t][h] = p0[uint64_t(t) * 16 * row_f4 + (kb + 2 * j + h) * 4];
+#pragma unroll
+            for (int j = 0; j < INFLIGHT; j++)
+#pragma unroll
+                for (int t = 0; t < 3; t++)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) acc += v[j][t][h].x + v[j][t][h].y + v[j][t][h].z + v[j][t][h].w;
+        }
+    }
+    if (acc == 12345.678f) out[0] = acc;
+}
+
+// pattern 0: best of chunks / linear (the attainable streaming rate); pattern 1: k_probe_rowfrag over rows of row_bytes
 // returns GB/s (1e9 bytes per second) of the better pattern; bytes is rounded down to whole 120-KB chunks
-double stream_probe(int device, uint64_t bytes, int iters) {
+double stream_probe(int device, uint64_t bytes, int iters) { return stream_probe_pattern(device, bytes, iters, 0, 0); }
+double stream_probe_pattern(int device, uint64_t bytes, int iters, int pattern_sel, uint32_t row_bytes) {
     VDB_HIP(hipSetDevice(device));
+    VDB_REQUIRE(pattern_sel == 0 || (pattern_sel == 1 && row_bytes >= 512 && row_bytes % 128 == 0 && row_bytes <= 65536),
+                "stream probe: pattern 0, or 1 with rows of a multiple of 128 bytes (>= 512)");
     VDB_REQUIRE(bytes >= (64ull << 20) && bytes <= (64ull << 30), "stream probe: bytes must be in 64 MiB .. 64 GiB");
     VDB_REQUIRE(iters >= 1 && iters <= 1000, "stream probe: iters must be in 1..1000");
     const uint64_t n_kb = bytes / (120 * 1024) * 120;
@@ -66,9 +102,12 @@ double stream_probe(int device, uint64_t bytes, int iters) {
         VDB_HIP(hipEventCreate(&a));
         VDB_HIP(hipEventCreate(&b));
         VDB_HIP(hipMemsetAsync(src, 1, n_kb * 1024, s));
-        for (int pattern = 0; pattern < 2; pattern++) {
+        for (int pattern = pattern_sel ? 2 : 0; pattern < (pattern_sel ? 3 : 2); pattern++) {
             auto launch = [&]() {
-                if (pattern == 0)
+                if (pattern == 2)
+                    hipLaunchKernelGGL(k_probe_rowfrag<4>, dim3(256), dim3(512), 0, s, static_cast<const float4 *>(src), n_kb * 1024 / row_bytes,
+                                       row_bytes / 16, static_cast<float *>(out));
+                else if (pattern == 0)
                     hipLaunchKernelGGL(k_probe_chunks<10>, dim3(256), dim3(512), 0, s, static_cast<const float4 *>(src), n_kb,
                                        120u, static_cast<float *>(out));
                 else
@@ -84,7 +123,8 @@ double stream_probe(int device, uint64_t bytes, int iters) {
             VDB_HIP(hipGetLastError());
             float ms = 0;
             VDB_HIP(hipEventElapsedTime(&ms, a, b));
-            best = std::max(best, double(n_kb) * 1024.0 * iters / (double(ms) * 1e-3) / 1e9);
+            const double moved = pattern == 2 ? double(n_kb * 1024 / row_bytes / 48 * 48) * double(row_bytes / 512 * 512) : double(n_kb) * 1024.0;
+            best = std::max(best, moved * iters / (double(ms) * 1e-3) / 1e9);
         }
     } catch (...) {
         if (a) (void)hipEventDestroy(a);

@@ -134,6 +134,7 @@ void launch_rerank_u8(const uint8_t *X, uint32_t dim, const float *Q, uint32_t n
 // ---- k_probe.hip ---------------------------------------------------------------------------
 // attainable HBM read bandwidth in GB/s: pure streaming read of `bytes`, `iters` timed passes, best of two patterns
 double stream_probe(int device, uint64_t bytes, int iters);
+double stream_probe_pattern(int device, uint64_t bytes, int iters, int pattern, uint32_t row_bytes);  // 1: MFMA-fragment loads from row-major rows
 void mfma_probe(int device, int waves_per_simd, int iters, double *tflops, double *clock_ghz);
 double latency_probe(int device, uint64_t bytes, uint32_t hops);  // ns per dependent HBM load (pointer chase over 128-B lines)
 

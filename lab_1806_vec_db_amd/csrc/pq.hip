@@ -83,6 +83,8 @@ struct AdcArgs {
 };
 static std::atomic<int> g_adc_fast{1};
 void pq_set_adc_fast(int v) { g_adc_fast = v; }
+static std::atomic<int> g_adc16_sample{0};  // threshold sample on the quantised tables (L2Sqr): 0 auto (on with the quantised scan), 1 off (f32 sample)
+void pq_set_adc16_sample(int v) { g_adc16_sample = v; }
 static std::atomic<int> g_adc16{0};  // quantised first pass of the threshold-filter scan: 0 auto (4-bit, L2Sqr, 16-B code words), 1 off
 void pq_set_adc16(int v) { g_adc16 = v; }
 constexpr uint32_t ADC_WGBUF = 2048;  // LDS hit buffer entries per workgroup (MODE 1)
@@ -335,14 +337,30 @@ __global__ __launch_bounds__(1024) void k_pq_adc(AdcArgs a) {
 // 128-B lines, and the 1024 rows of a workgroup iteration (160 KB) do not fit the L1, so every line came from L2 up to 8
 // times.  The scan therefore reads a word-major mirror of the codes: tile of 64 rows x word w x lane -> one wave load
 // = 1 KB contiguous, every line fetched once.  Built once per table (the codes are immutable until the next build).
-__global__ __launch_bounds__(256) void k_pq_tile_codes(const uint4 *__restrict__ codes, uint64_t n, uint32_t nwords,
+// Code rows that are not whole 16-B words (odd m, m not a multiple of 32: the DB's default m = ceil(dim / 3) gives 171 groups at
+// dim 512, 342 at dim 1024) are padded with zero bytes up to the next word: the padded nibbles select entries of groups beyond
+// m, whose tables are all zero in the quantised image (k_pq_quant16), so they add nothing to any sum.
+__global__ __launch_bounds__(256) void k_pq_tile_codes(const uint8_t *__restrict__ codes, uint64_t n, uint32_t enc_dim, uint32_t nwords,
                                                        uint4 *__restrict__ tiled) {
     const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;  // output entry: ((tile * nwords) + w) * 64 + lane
     const uint64_t total = (n + 63) / 64 * 64 * nwords;
     if (i >= total) return;
     const uint64_t lane = i & 63, tw = i >> 6, tile = tw / nwords, w = tw - tile * nwords;
     const uint64_t row = tile * 64 + lane;
-    tiled[i] = row < n ? codes[row * nwords + w] : make_uint4(0, 0, 0, 0);
+    uint32_t v[4] = {0u, 0u, 0u, 0u};
+    if (row < n) {
+        const uint8_t *src = codes + row * enc_dim;
+        if ((enc_dim & 15u) == 0) {
+            const uint4 x = reinterpret_cast<const uint4 *>(src)[w];
+            v[0] = x.x, v[1] = x.y, v[2] = x.z, v[3] = x.w;
+        } else {
+            for (uint32_t b = 0; b < 16; b++) {
+                const uint32_t at = uint32_t(w) * 16 + b;
+                if (at < enc_dim) v[b >> 2] |= uint32_t(src[at]) << (8 * (b & 3));
+            }
+        }
+    }
+    tiled[i] = make_uint4(v[0], v[1], v[2], v[3]);
 }
 
 constexpr uint32_t ADC16_Q = 8;          // queries per workgroup pass
@@ -355,7 +373,8 @@ constexpr uint32_t ADC16_WGBUF = 2048;   // LDS hit buffer entries per workgroup
 // -- an UPPER bound of S --, slot 7 of every entry holds floor((cc - mnc_g) / DC): a lower bound of C, the same for all
 // queries (written by the block of the group's first query).  A row survives when S_ub >= 0 and
 // S_ub^2 >= rho^2 |q|^2 C_lb with rho = 1 - tau (less slack), see k_pq_adc16.
-__global__ __launch_bounds__(256) void k_pq_quant16(const float *__restrict__ lut, const float *__restrict__ cent_cache, uint32_t m,
+// m_pad = groups of the image (32 per 16-B code word); the entries of groups m .. m_pad - 1 are zero (padded code bytes).
+__global__ __launch_bounds__(256) void k_pq_quant16(const float *__restrict__ lut, const float *__restrict__ cent_cache, uint32_t m, uint32_t m_pad,
                                                     uint32_t nq, int cosine, uint16_t *__restrict__ img, double *__restrict__ qM,
                                                     double *__restrict__ qD, double *__restrict__ qMC, double *__restrict__ qDC,
                                                     uint32_t *__restrict__ qflag) {
@@ -404,7 +423,8 @@ __global__ __launch_bounds__(256) void k_pq_quant16(const float *__restrict__ lu
     reduce3(R, M, A);
     const bool flag = sbad != 0 || !(R < 1.0e300) || !(fabs(M) < 1.0e300);
     const double D = (!flag && R > 0.0) ? R / (cosine ? 64000.0 : 65000.0) : 1.0;
-    uint16_t *dst = img + uint64_t(q / NQ) * m * 16 * 8 + (q % NQ);
+    uint16_t *dst = img + uint64_t(q / NQ) * m_pad * 16 * 8 + (q % NQ);
+    for (uint32_t i = m * 16 + t; i < m_pad * 16; i += 256) dst[i * 8] = 0;
     for (uint32_t g = t; g < m; g += 256) {
         float mn = INFINITY;
 #pragma unroll
@@ -435,7 +455,8 @@ __global__ __launch_bounds__(256) void k_pq_quant16(const float *__restrict__ lu
         reduce3(RC, MC, Z);
         DC = RC > 0.0 && RC < 1.0e300 ? RC / 65000.0 : 1.0;
         if (q % NQ == 0) {
-            uint16_t *dc = img + uint64_t(q / NQ) * m * 16 * 8 + 7;
+            uint16_t *dc = img + uint64_t(q / NQ) * m_pad * 16 * 8 + 7;
+            for (uint32_t i = m * 16 + t; i < m_pad * 16; i += 256) dc[i * 8] = 0;
             for (uint32_t g = t; g < m; g += 256) {
                 float mn = INFINITY;
 #pragma unroll
@@ -462,7 +483,7 @@ __global__ __launch_bounds__(256) void k_pq_quant16(const float *__restrict__ lu
 struct Adc16Args {
     const uint4 *codes_t;    // word-major mirror of the code rows (k_pq_tile_codes)
     uint64_t n;
-    uint32_t enc_dim, m;
+    uint32_t enc_dim, m;     // m = groups of the IMAGE (32 per code word, >= the table's m); enc_dim = bytes of a code row
     const uint4 *img;        // [ceil(nq/8)][m*16] 16-B entries
     const double *qM, *qD;   // [nq]
     const double *qMC, *qDC; // [nq] Cosine: offset / step of the |centroid|^2 table (identical for all queries)
@@ -474,6 +495,10 @@ struct Adc16Args {
     uint64_t *cand;          // [nq][cap] row ids (upper word 0)
     uint32_t *cnt;           // [nq]
     uint32_t cap;
+    // SAMPLE mode (threshold sample on the quantised tables): every blk_step-th 1024-row block, dense sums out
+    uint32_t blk_step;       // >= 1
+    float *s16_out;          // [nq][ld_s] quantised sums of the sampled rows as floats (exact: <= 65000 + m), +inf past n
+    uint64_t ld_s;
 };
 
 // NW = 16-B code words per row (enc_dim / 16) as a compile-time constant: the row loop is fully unrolled, every
@@ -488,7 +513,12 @@ struct Adc16Args {
 #ifndef ADC16_ABANDON
 #define ADC16_ABANDON 0
 #endif
-template <int NW, bool COS>
+// SAMPLE = true (L2Sqr only): the same row sums over a strided block sample, written densely -- the threshold sample of the
+// scan at the scan's own rate (the f32 kernel needed 0.36 ms for 17 408 rows x 1000 queries, a quarter of this kernel's rate
+// per lookup).  The threshold only steers how many rows the scan keeps (the count is CHECKED afterwards and a short list is
+// redone densely), so it may come from quantised sums: tau = M + D (s* + m/2), s* = the r-th smallest sampled sum, m/2 = the
+// expected loss of the m floors.
+template <int NW, bool COS, bool SAMPLE = false>
 __global__ __launch_bounds__(1024) void k_pq_adc16(Adc16Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
     constexpr uint32_t NQ = COS ? 7 : 8;  // query slots of an entry (Cosine: slot 7 = the |centroid|^2 table)
@@ -510,7 +540,7 @@ __global__ __launch_bounds__(1024) void k_pq_adc16(Adc16Args a) {
         const uint4 *src = a.img + uint64_t(blockIdx.y) * m * 16;
         for (uint32_t i = tid; i < m * 16; i += 1024) tab[i] = src[i];
         if (tid < 1 + 2 * ADC16_Q) hit_n[tid] = 0;
-        if (!COS && tid < NQ) {
+        if (!COS && !SAMPLE && tid < NQ) {
             int32_t T = -1;
             const uint32_t q = q0 + tid;
             if (q < a.nq && a.qflag[q] == 0) {
@@ -577,18 +607,24 @@ __global__ __launch_bounds__(1024) void k_pq_adc16(Adc16Args a) {
         const int32_t t0 = T[2 * i] + 1, t1 = T[2 * i + 1] + 1;
         Tp[i] = uint32_t(t0 > 65535 ? 65535 : t0) | (uint32_t(t1 > 65535 ? 65535 : t1) << 16);
     }
-    const uint64_t r_begin = uint64_t(blockIdx.x) * a.rows_per_wg;
-    const uint64_t r_end = r_begin + a.rows_per_wg < a.n ? r_begin + a.rows_per_wg : a.n;
-    const uint32_t nwords = NW ? (uint32_t)NW : a.enc_dim / 16;
+    // scan: this workgroup's contiguous share of the rows; sample: sampled blocks blockIdx.x, + gridDim.x, ... (block j of the
+    // sample = rows [j * blk_step * 1024, + 1024))
+    const uint64_t n_sb = SAMPLE ? ((a.n + 1023) / 1024 + a.blk_step - 1) / a.blk_step : 0;
+    const uint64_t r_begin = SAMPLE ? uint64_t(blockIdx.x) * a.blk_step * 1024 : uint64_t(blockIdx.x) * a.rows_per_wg;
+    const uint64_t r_end = SAMPLE ? (blockIdx.x < n_sb ? (n_sb - 1) * a.blk_step * 1024 + 1 : 0)
+                                  : (r_begin + a.rows_per_wg < a.n ? r_begin + a.rows_per_wg : a.n);
+    const uint64_t r_inc = SAMPLE ? uint64_t(gridDim.x) * a.blk_step * 1024 : 1024;
+    const uint32_t nwords = NW ? (uint32_t)NW : a.m / 32;
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef __attribute__((address_space(3))) uint4 lds_u4;
 #endif
-    for (uint64_t rb = r_begin; rb < r_end; rb += 1024) {
+    for (uint64_t rb = r_begin; rb < r_end; rb += r_inc) {
         const uint64_t row = rb + tid;
-        const bool valid = row < r_end;
+        const bool valid = SAMPLE ? row < a.n : row < r_end;
         // word w of row (rb + tid): tile = row / 64 (uniform in the wave: rb is a multiple of 64), lane = row % 64; rows
         // past n inside the last tile are zero padding
-        const uint4 *cw = a.codes_t + (row >> 6) * nwords * 64 + (row & 63);
+        const uint64_t lrow = (SAMPLE && !valid) ? a.n - 1 : row;  // (the scan's blocks end inside the last, zero-padded tile; a sample block may not)
+        const uint4 *cw = a.codes_t + (lrow >> 6) * nwords * 64 + (lrow & 63);
         uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         // one 16-B code word = 32 groups.  Byte b of a 32-bit word: low nibble = group 8wi + 2b, high nibble the next one;
         // their byte offsets inside the group's 256-B block (code * 16) sit packed in the bytes of e4 / o4.
@@ -668,6 +704,13 @@ __global__ __launch_bounds__(1024) void k_pq_adc16(Adc16Args a) {
         }
         const int32_t s[8] = {int32_t(a0 & 0xffffu), int32_t(a0 >> 16), int32_t(a1 & 0xffffu), int32_t(a1 >> 16),
                               int32_t(a2 & 0xffffu), int32_t(a2 >> 16), int32_t(a3 & 0xffffu), int32_t(a3 >> 16)};
+        if (SAMPLE) {
+            const uint64_t col = rb / (uint64_t(a.blk_step) * 1024) * 1024 + tid;  // position in the sample
+#pragma unroll
+            for (int b = 0; b < (int)NQ; b++)
+                if (q0 + b < a.nq) a.s16_out[uint64_t(q0 + b) * a.ld_s + col] = valid ? float(s[b]) : INFINITY;
+            continue;
+        }
         float c_lb = 0.0f;
         if (COS) c_lb = fmaxf(cMs[7] + cDs[7] * float(s[7]), 0.0f);
 #pragma unroll
@@ -691,6 +734,7 @@ __global__ __launch_bounds__(1024) void k_pq_adc16(Adc16Args a) {
             }
         }
     }
+    if (SAMPLE) return;
     __syncthreads();
     uint32_t total = hit_n[0];
     if (total > ADC16_WGBUF) total = ADC16_WGBUF;
@@ -733,8 +777,21 @@ __global__ __launch_bounds__(256) void k_pq_adc_exact(const uint8_t *__restrict_
         const uint32_t row = uint32_t(cq[i]);
         const uint4 *cw = reinterpret_cast<const uint4 *>(codes + uint64_t(row) * enc_dim);
         float sum = 0.0f, cdp = 0.0f;
-        uint4 v = cw[0];
-        for (uint32_t w = 0; w < enc_dim / 16; w++) {
+        if ((enc_dim & 15u) != 0) {  // code rows that are not whole (16-B aligned) words: byte by byte, same group order
+            const uint8_t *cb = codes + uint64_t(row) * enc_dim;
+            for (uint32_t g = 0; g < m; g += 2) {
+                const uint32_t byte = cb[g >> 1];
+                const uint32_t a0 = g * 16 + (byte & 0xf), a1 = (g + 1) * 16 + (byte >> 4);
+                sum = sum + slut[a0];
+                if (COS) cdp = cdp + scc[a0];
+                if (g + 1 < m) {
+                    sum = sum + slut[a1];
+                    if (COS) cdp = cdp + scc[a1];
+                }
+            }
+        }
+        uint4 v = (enc_dim & 15u) == 0 ? cw[0] : make_uint4(0, 0, 0, 0);
+        for (uint32_t w = 0; w < ((enc_dim & 15u) == 0 ? enc_dim / 16 : 0u); w++) {
             const uint32_t words[4] = {v.x, v.y, v.z, v.w};
             if (w + 1 < enc_dim / 16) v = cw[w + 1];
 #pragma unroll
@@ -974,17 +1031,18 @@ static void pq_install(Index &ix, uint64_t n_bits, uint64_t m, const float *cent
     pq.d_codes.reserve(std::max<uint64_t>(ix.n, 1) * pq.enc_dim);
 }
 
-// word-major mirror of the codes for the quantised scan (4-bit tables with whole 16-B code words only)
+// word-major mirror of the codes for the quantised scan (4-bit tables; rows padded to whole 16-B code words)
 static void pq_tile_codes(Index &ix) {
     PQState &pq = ix.pq;
     pq.codes_t_valid = false;
-    if (pq.n_bits != 4 || (pq.enc_dim % 16) != 0 || pq.m != 2 * pq.enc_dim || ix.n == 0) return;
-    const uint32_t nwords = (uint32_t)(pq.enc_dim / 16);
+    if (pq.n_bits != 4 || ix.n == 0) return;
+    const uint32_t nwords = (uint32_t)((pq.enc_dim + 15) / 16);
+    if (size_t(nwords) * 32 * 256 > 150 * 1024) return;  // the 16-bit tables of 8 queries would not fit LDS: such tables never take the quantised scan
     const uint64_t total = (ix.n + 63) / 64 * 64 * nwords;
     pq.d_codes_t.reserve(total * sizeof(uint4));
     WsLease ws(ix);
-    hipLaunchKernelGGL(k_pq_tile_codes, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ws->stream, pq.d_codes.as<uint4>(), ix.n,
-                       nwords, pq.d_codes_t.as<uint4>());
+    hipLaunchKernelGGL(k_pq_tile_codes, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ws->stream, pq.d_codes.as<uint8_t>(), ix.n,
+                       (uint32_t)pq.enc_dim, nwords, pq.d_codes_t.as<uint4>());
     VDB_SYNC(ws->stream);
     pq.codes_t_valid = true;
 }
@@ -1224,10 +1282,37 @@ static void adc16_launch_nw(const Adc16Args &a, dim3 grid, size_t lds, hipStream
     func_max_lds(reinterpret_cast<const void *>(&k_pq_adc16<NW, COS>), int(160 * 1024));
     hipLaunchKernelGGL((k_pq_adc16<NW, COS>), grid, dim3(1024), lds, s, a);
 }
+template <int NW>
+static void adc16_sample_nw(const Adc16Args &a, dim3 grid, size_t lds, hipStream_t s) {
+    func_max_lds(reinterpret_cast<const void *>(&k_pq_adc16<NW, false, true>), int(160 * 1024));
+    hipLaunchKernelGGL((k_pq_adc16<NW, false, true>), grid, dim3(1024), lds, s, a);
+}
+static void adc16_sample_launch(const Adc16Args &a, uint32_t nwords, dim3 grid, size_t lds, hipStream_t s) {
+    switch (nwords) {
+        case 4: adc16_sample_nw<4>(a, grid, lds, s); break;
+        case 6: adc16_sample_nw<6>(a, grid, lds, s); break;
+        case 11: adc16_sample_nw<11>(a, grid, lds, s); break;
+        case 8: adc16_sample_nw<8>(a, grid, lds, s); break;
+        case 10: adc16_sample_nw<10>(a, grid, lds, s); break;
+        case 16: adc16_sample_nw<16>(a, grid, lds, s); break;
+        default: adc16_sample_nw<0>(a, grid, lds, s); break;
+    }
+}
+// tau[q] = M + D (s* + m/2) from the r-th smallest quantised sample sum s* (in tau[q] on entry); a flagged table (not
+// quantisable) gets +inf: its list overflows and the query takes the f32 scan, as without the sample
+__global__ void k_pq_tau_from16(float *__restrict__ tau, const double *__restrict__ qM, const double *__restrict__ qD,
+                                const uint32_t *__restrict__ qflag, uint32_t m, uint32_t nq) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const float s = tau[q];
+    tau[q] = (qflag[q] != 0 || !(s < 1.0e9f)) ? INFINITY : float(qM[q] + qD[q] * (double(s) + 0.5 * double(m)));
+}
 template <bool COS>
 static void adc16_launch_c(const Adc16Args &a, uint32_t nwords, dim3 grid, size_t lds, hipStream_t s) {
-    switch (nwords) {  // m = 32 * nwords groups: 128 / 256 / 320 (Gist1M, dim / 3) / 512
+    switch (nwords) {  // 32 * nwords groups: 128 / 171 -> 192 (dim 512 / 3) / 256 / 320 (Gist1M, dim / 3) / 342 -> 352 (dim 1024 / 3) / 512
         case 4: adc16_launch_nw<4, COS>(a, grid, lds, s); break;
+        case 6: adc16_launch_nw<6, COS>(a, grid, lds, s); break;
+        case 11: adc16_launch_nw<11, COS>(a, grid, lds, s); break;
         case 8: adc16_launch_nw<8, COS>(a, grid, lds, s); break;
         case 10: adc16_launch_nw<10, COS>(a, grid, lds, s); break;
         case 16: adc16_launch_nw<16, COS>(a, grid, lds, s); break;
@@ -1435,9 +1520,9 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
     // fused path: tau[q] from a strided row-block sample (exact f32 ADC values), then one filtered scan of all rows.
     // q16: the scan runs on the 16-bit quantised tables, 8 queries per pass (k_pq_adc16), and the exact f32 sums are
     // computed for its candidates only (k_pq_adc_exact); otherwise the f32 scan itself filters (k_pq_adc MODE 1).
-    const size_t lds16 = size_t(pq.m) * 256 + 128 + ADC16_WGBUF * 8 + (1 + 2 * ADC16_Q) * 4;
-    const bool q16 = g_adc16 != 1 && pq.codes_t_valid && pq.n_bits == 4 && (pq.enc_dim % 16) == 0 && pq.m == 2 * pq.enc_dim &&
-                     lds16 <= 150 * 1024 && nt == 1024 && (ix.dist == 0 ? BQ == 4 : true);
+    const uint32_t nw16 = (uint32_t)((pq.enc_dim + 15) / 16), m16 = 32 * nw16;  // code words per (padded) row, groups of the image
+    const size_t lds16 = size_t(m16) * 256 + 128 + ADC16_WGBUF * 8 + (1 + 2 * ADC16_Q) * 4;
+    const bool q16 = g_adc16 != 1 && pq.codes_t_valid && pq.n_bits == 4 && lds16 <= 150 * 1024 && nt == 1024 && (ix.dist == 0 ? BQ == 4 : true);
     const bool cos16 = q16 && ix.dist == 1;
     const uint32_t NQ16 = cos16 ? 7 : 8;  // queries per pass of the quantised scan (Cosine: slot 7 of an entry is the |centroid|^2 table)
     const uint64_t ld_s = (n_s + 63) & ~63ull;
@@ -1458,7 +1543,7 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
     uint32_t *d_qflag = nullptr;
     if (q16) {
         const uint64_t ngrp = (nq + NQ16 - 1) / NQ16;
-        ws.qfrag_g.reserve(ngrp * pq.m * 256);
+        ws.qfrag_g.reserve(ngrp * size_t(m16) * 256);
         ws.qaux.reserve(nq * (4 * sizeof(double) + sizeof(uint32_t)));
         d_qM = ws.qaux.as<double>();
         d_qD = d_qM + nq;
@@ -1467,11 +1552,28 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
         d_qflag = reinterpret_cast<uint32_t *>(d_qDC + nq);
         // slots of the last image group beyond nq keep whatever the buffer held: their thresholds never hit
         hipLaunchKernelGGL(k_pq_quant16, dim3((unsigned)nq), dim3(256), 0, s, ws.lut.as<float>(), pq.d_cent_cache.as<float>(),
-                           (uint32_t)pq.m, (uint32_t)nq, cos16 ? 1 : 0, ws.qfrag_g.as<uint16_t>(), d_qM, d_qD, d_qMC, d_qDC, d_qflag);
+                           (uint32_t)pq.m, m16, (uint32_t)nq, cos16 ? 1 : 0, ws.qfrag_g.as<uint16_t>(), d_qM, d_qD, d_qMC, d_qDC, d_qflag);
     }
     for (uint64_t g0 = 0; g0 < nq; g0 += GQ) {
         const uint64_t gn = std::min<uint64_t>(GQ, nq - g0);
-        {
+        const bool sample16 = q16 && !cos16 && g_adc16_sample != 1;
+        if (sample16) {  // the sample at the scan's rate, on the scan's tables: quantised sums, tau from their s_rank-th smallest
+            Adc16Args a{};
+            a.codes_t = pq.d_codes_t.as<uint4>();
+            a.n = n;
+            a.enc_dim = (uint32_t)pq.enc_dim;
+            a.m = m16;
+            a.img = reinterpret_cast<const uint4 *>(ws.qfrag_g.as<uint8_t>() + (g0 / NQ16) * size_t(m16) * 256);
+            a.nq = (uint32_t)gn;
+            a.blk_step = step;
+            a.s16_out = ws.dense.as<float>();
+            a.ld_s = ld_s;
+            const uint32_t ngrp = (uint32_t)((gn + NQ16 - 1) / NQ16);
+            const uint64_t n_sb = (nblk + step - 1) / step;
+            // one table image per workgroup: as few workgroups per query group as still fill the chip
+            const uint32_t gx = (uint32_t)std::min<uint64_t>(n_sb, std::max<uint64_t>(1, (uint64_t(ix.num_cu) + ngrp - 1) / ngrp));
+            adc16_sample_launch(a, nw16, dim3(gx, ngrp), lds16, s);
+        } else {
             AdcArgs a = base;
             a.nq_total = (uint32_t)gn;
             a.lut = ws.lut.as<float>() + g0 * lsz;
@@ -1488,14 +1590,17 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
             launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, cape, (uint32_t)gn, s_rank, ws.keys_a.as<uint64_t>() + g0 * cape, s);
             launch_extract_tau(ws.keys_a.as<uint64_t>() + g0 * cape, cape, (uint32_t)gn, s_rank, d_tau + g0, s);
         }
+        if (sample16)
+            hipLaunchKernelGGL(k_pq_tau_from16, dim3((unsigned)((gn + 255) / 256)), dim3(256), 0, s, d_tau + g0, d_qM + g0, d_qD + g0,
+                               d_qflag + g0, (uint32_t)pq.m, (uint32_t)gn);
         uint64_t *d_cand = ws.lists.as<uint64_t>();  // the sample lists are dead now
         if (q16) {
             Adc16Args a{};
             a.codes_t = pq.d_codes_t.as<uint4>();
             a.n = n;
             a.enc_dim = (uint32_t)pq.enc_dim;
-            a.m = (uint32_t)pq.m;
-            a.img = reinterpret_cast<const uint4 *>(ws.qfrag_g.as<uint8_t>() + (g0 / NQ16) * pq.m * 256);  // GQ % 56 == 0
+            a.m = m16;
+            a.img = reinterpret_cast<const uint4 *>(ws.qfrag_g.as<uint8_t>() + (g0 / NQ16) * size_t(m16) * 256);  // GQ % 56 == 0
             a.qM = d_qM + g0;
             a.qD = d_qD + g0;
             a.qMC = d_qMC + g0;
@@ -1511,7 +1616,8 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
             const uint32_t nwg = (uint32_t)((n + a.rows_per_wg - 1) / a.rows_per_wg);
             const uint32_t ngrp = (uint32_t)((gn + NQ16 - 1) / NQ16);
             ix.prof_begin(ws, "pq_adc", double(ngrp) * double(n) * pq.enc_dim);
-            adc16_launch(a, cos16, (uint32_t)(pq.enc_dim / 16), dim3(nwg, ngrp), lds16, s);
+            adc16_launch(a, cos16, nw16, dim3(nwg, ngrp), lds16, s);
+            pq.adc16_queries += gn;
             ix.prof_end(ws);
             if (cos16)
                 hipLaunchKernelGGL(k_pq_adc_exact<true>, dim3((unsigned)gn), dim3(256), 2 * lsz * sizeof(float), s, pq.d_codes.as<uint8_t>(),

@@ -11,7 +11,8 @@ void pq_attach(Index &ix, uint64_t n_bits, uint64_t m, const float *centroids, c
 void pq_build(Index &ix, uint64_t n_bits, uint64_t m, uint64_t train_n, uint64_t max_iter, float tol, uint64_t seed);
 void pq_clear(Index &ix);
 void pq_set_adc_fast(int v);
-void pq_set_adc16(int v);  // quantised first pass of the ADC scan: 0 auto, 1 off
+void pq_set_adc16(int v);
+void pq_set_adc16_sample(int v);  // threshold sample of the quantised scan on the quantised tables too: 0 auto, 1 off (f32 sample)  // quantised first pass of the ADC scan: 0 auto, 1 off
 void flat_knn_pq_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef,
                         uint64_t *d_idx, float *d_dist, uint64_t *d_cnt);
 

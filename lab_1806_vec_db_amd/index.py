@@ -465,6 +465,13 @@ def stream_probe(device: int = 0, nbytes: int = 3_840_000_000, iters: int = 5) -
     return float(v.value)
 
 
+def stream_probe_rows(device: int = 0, nbytes: int = 1_920_000_000, iters: int = 5, row_bytes: int = 1920) -> float:
+    """GB/s of MFMA A-fragment loads (16 rows x 64 B per instruction) from a row-major image of rows of row_bytes (multiple of 128; 1920 = a 960-d fp16 row)."""
+    v = C.c_double()
+    L.check(L.load().vdb_stream_probe_rows(int(device), int(nbytes), int(iters), int(row_bytes), C.byref(v)))
+    return float(v.value)
+
+
 def mfma_probe(device: int = 0, waves_per_simd: int = 2, iters: int = 200_000):
     """(dense fp16 TFLOP/s, shader clock in GHz) of back-to-back v_mfma_f32_16x16x32_f16 on every SIMD of this box."""
     t, c = C.c_double(), C.c_double()

@@ -126,3 +126,75 @@ def test_quantised_scan_fallbacks_on_degenerate_queries(mods, dist, kind):
     finally:
         ix.set_param("pq_adc16", 0)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_quantised_threshold_sample_keeps_results():
+    """The threshold sample of the quantised ADC scan on the quantised tables themselves (k_pq_adc16<.., SAMPLE>, tau = M + D (s* +
+    m/2)) against the exact f32 sample: the threshold only decides how many rows the scan keeps (the count is checked), so the
+    answers must be identical -- and equal the oracle's (pq_table.rs:239-301, flat_index.rs:84-104)."""
+    import lab_1806_vec_db_amd as vdb
+    from oracle import oracle as O
+    from conftest import gist_like
+
+    n, dim, m = 140000, 64, 32
+    rng = np.random.default_rng(8)
+    base = gist_like(n, dim=dim, seed=33)
+    base[70000:70020] = base[:20]  # ADC ties across the table
+    qs = gist_like(70, dim=dim, seed=34)
+    ix = vdb.GpuIndex(dim, "l2sqr")
+    ix.batch_add(base)
+    ix.pq_build(n_bits=4, m=m, train_n=3000, max_iter=4, seed=2)
+    pq = ix.pq_export()
+    opq = O.PQ.from_centroids(dim, m, 4, 0, pq["centroids"])
+    opq.set_codes(pq["codes"])
+    res = {}
+    try:
+        for v in (0, 1):
+            ix.set_param("pq_sample16", v)
+            for ef in (10, 100, 700):
+                res[(v, ef)] = ix.knn_pq(qs, 10, ef)
+    finally:
+        ix.set_param("pq_sample16", 0)
+    for ef in (10, 100, 700):
+        a, b = res[(0, ef)], res[(1, ef)]
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), ef
+        for q in (0, 33, 69):
+            oi, od = O.flat_knn_pq(base, opq, qs[q], 10, ef)
+            assert a[0][q, :len(oi)].tolist() == oi.tolist() and np.array_equal(a[1][q, :len(od)], od)
+    ix.close()
+
+
+@pytest.mark.parametrize("dist,kind", [("l2sqr", 0), ("cosine", 1)])
+@pytest.mark.parametrize("dim,m", [(64, 43), (192, 171), (344, 342), (96, 33)])
+def test_quantised_scan_with_padded_code_words(dim, m, dist, kind):
+    """Tables whose code rows are not whole 16-B words (odd m; the DB's default m = ceil(dim / 3): 171 at dim 512, 342 at dim
+    1024) on the quantised scan: rows padded with zero bytes, zero tables for the padded groups.  Same answers as the f32 scan
+    (pq_adc16 = 1) and as the oracle (pq_table.rs:239-301), and the quantised kernel really ran."""
+    import lab_1806_vec_db_amd as vdb
+    from oracle import oracle as O
+
+    n = 66000
+    rng = np.random.default_rng(dim + m)
+    base = (rng.standard_normal((n, dim)) * rng.uniform(0.2, 2.0, dim)).astype(np.float32)
+    base[40000:40010] = base[:10]
+    qs = (base[rng.integers(0, n, 12)] + 0.1 * rng.standard_normal((12, dim))).astype(np.float32)
+    ix = vdb.GpuIndex(dim, dist)
+    ix.batch_add(base)
+    ix.pq_build(n_bits=4, m=m, train_n=2000, max_iter=3, seed=1)
+    pq = ix.pq_export()
+    opq = O.PQ.from_centroids(dim, m, 4, kind, pq["centroids"])
+    opq.set_codes(pq["codes"])
+    a = ix.knn_pq(qs, 10, 100)
+    ran = ix.get_stat("pq_adc16_queries")
+    assert ran >= 12
+    ix.set_param("pq_adc16", 1)
+    try:
+        b = ix.knn_pq(qs, 10, 100)
+    finally:
+        ix.set_param("pq_adc16", 0)
+    assert ix.get_stat("pq_adc16_queries") == ran
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    for q in range(12):
+        oi, od = O.flat_knn_pq(base, opq, qs[q], 10, 100, kind)
+        assert a[0][q, :len(oi)].tolist() == oi.tolist() and np.array_equal(a[1][q, :len(od)], od)
+    ix.close()

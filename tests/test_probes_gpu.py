@@ -18,3 +18,18 @@ def test_stream_and_mfma_probes():
         stream_probe(0, 1 << 20, 1)      # smaller than the Infinity Cache: refused
     with pytest.raises(vdb.VdbError):
         mfma_probe(0, 0, 10)
+
+
+def test_latency_and_row_fragment_probes():
+    """vdb_latency_probe (the dependent-load latency the graph walks' floor is quoted on) and vdb_stream_probe_rows (MFMA
+    fragment loads from a row-major image: the A/B behind keeping two fp16 copies of the rows)."""
+    import lab_1806_vec_db_amd as vdb
+    from lab_1806_vec_db_amd.index import latency_probe, stream_probe_rows
+    ns = latency_probe(0, 512 << 20, 4000)
+    assert 100.0 < ns < 5000.0, ns       # an HBM round trip: a few hundred nanoseconds
+    gbps = stream_probe_rows(0, 512 << 20, 2, 1920)
+    assert 200.0 < gbps < 8000.0, gbps
+    with pytest.raises(vdb.VdbError):
+        latency_probe(0, 1 << 10, 100)
+    with pytest.raises(vdb.VdbError):
+        stream_probe_rows(0, 512 << 20, 2, 1000)  # rows must be whole 128-B lines

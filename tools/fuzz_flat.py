@@ -1,5 +1,5 @@
 """Randomised parity run of the Flat pipeline against the oracle (longer than tests/test_fuzz_gpu.py; not part of the suite).
-usage: python tools/fuzz_flat.py [seconds] [seed] [data style 0-3]"""
+usage: python tools/fuzz_flat.py [seconds] [seed] [data style 0-3 or -1 = random] [smallest table, default 17000 rows]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,17 +8,18 @@ from oracle import oracle as O
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1806)
+min_n = int(sys.argv[4]) if len(sys.argv) > 4 else 17000  # (below 16 384 rows calls of < 32 queries take the one-launch kernel)
 t_end = time.time() + budget
 it = bad = 0
 while time.time() < t_end:
     it += 1
     dim = int(rng.choice([64, 96, 100, 128, 192, 256, 320, 384, 512, 768, 960, 1000, 1024, 1536]))
-    n = int(rng.integers(17000, 60000))
+    n = int(rng.integers(min_n, 60000))
     nq = int(rng.choice([1, 3, 17, 64, 65, 100, 128, 129, 200, 257]))
     k = int(rng.choice([1, 2, 5, 10, 16, 17, 33, 64, 70]))
     dist = str(rng.choice(["l2sqr", "cosine"]))
     kind = 0 if dist == "l2sqr" else 1
-    style = int(sys.argv[3]) if len(sys.argv) > 3 else int(rng.integers(0, 4))
+    style = int(sys.argv[3]) if len(sys.argv) > 3 and int(sys.argv[3]) >= 0 else int(rng.integers(0, 4))
     if style == 0:
         base = rng.standard_normal((n, dim)).astype(np.float32)
         qs = rng.standard_normal((nq, dim)).astype(np.float32)
