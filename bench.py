@@ -817,26 +817,31 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, step_stats, args, threads
         return {"queries_per_step": nq_call, "value": round(nq_call * steps / el, 1), "unit": "queries/s",
                 "ms_per_step": round(el / steps * 1e3, 4), "step_ms": step_stats()}
 
-    lat_ns = None
+    lat_ns = add_ns = None
     if attainable is not None:
-        from lab_1806_vec_db_amd.index import latency_probe
+        from lab_1806_vec_db_amd.index import fold_probe, latency_probe
 
         lat_ns = round(latency_probe(local_rank, 1 << 30, 20000), 1)
+        add_ns = round(fold_probe(local_rank, 1 << 22), 3)
 
-    def latency_floor(leg, one_call, round_trips, what):
+    def latency_floor(leg, one_call, round_trips, what, chain_adds):
         """A graph walk is a CHAIN: per expansion the popped node's link row, the visited words of its neighbours and the first
         lines of their rows are three dependent HBM accesses (hnsw_index.rs:258-291 cannot start one before the previous
-        returned).  A call of <= 2048 queries is one round of resident walks, so its time is the longest chain, not bytes:
-        floor = expansions per query x dependent round trips x the measured latency of one dependent HBM load."""
+        returned), and a neighbour that may enter the result set is scored by the reference's strict left fold -- chain_adds
+        dependent f32 adds (dim for the exact walk, hnsw_index.rs:351-358; m table entries for the ADC walk, pq_table.rs:254-292)
+        which no lane count shortens.  A call of <= 2048 queries is one round of resident walks, so its time is the longest
+        chain, not bytes: floor = expansions per query x (round trips x dependent-load latency + chain_adds x dependent-add
+        latency), both latencies measured in this run."""
         if lat_ns is None:
             return
         ne = leg["hnsw_work_per_query"]["n_expanded"]
-        floor_ms = ne * round_trips * lat_ns * 1e-6
+        floor_ms = ne * (round_trips * lat_ns + chain_adds * add_ns) * 1e-6
         leg["roofline"]["latency_floor"] = {
             "dependent_load_ns": lat_ns, "round_trips_per_expansion": round_trips, "what": what, "expansions_per_query": ne,
+            "dependent_add_ns": add_ns, "fold_chain_adds_per_expansion": chain_adds,
             "floor_ms_per_call": round(floor_ms, 4), "one_call_of_1000_ms": one_call["ms_per_step"],
             "frac": round(floor_ms / one_call["ms_per_step"], 4),
-            "note": "vdb_latency_probe in this run (pointer chase over a 1-GiB buffer); the mean walk, so calls bounded by their longest "
+            "note": "vdb_latency_probe (pointer chase over a 1-GiB buffer) and vdb_fold_probe in this run; the mean walk, so calls bounded by their longest "
                     "walk sit further above it; the HBM-bytes fraction beside it is the yardstick of the large calls only"}
 
     # -- PQ-Flat: config/bench_pq_hnsw.toml:16-23 (n_bits 4, m = dim/3, k_means_size 10000, max_iter 20, tol 1e-6), ef = 100
@@ -899,7 +904,7 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, step_stats, args, threads
         ix, lambda: ix.hnsw_knn_device(queries_h.data_ptr(), 1000, k, 128, h_idx.data_ptr(), h_dist.data_ptr(), h_cnt.data_ptr()))
     legs["hnsw"]["one_call_of_1"] = small_call(
         ix, lambda: ix.hnsw_knn_device(queries_h.data_ptr(), 1, k, 128, h_idx.data_ptr(), h_dist.data_ptr(), h_cnt.data_ptr()), 1)
-    latency_floor(legs["hnsw"], legs["hnsw"]["one_call_of_1000"], 3, "link row -> visited words -> first row lines")
+    latency_floor(legs["hnsw"], legs["hnsw"]["one_call_of_1000"], 3, "link row -> visited words -> first row lines", dim)
     # -- HNSW + PQ (hnsw_index.rs:672-697; config/bench_pq_hnsw.toml: the reference's fastest published point): the same graph,
     #    the PQ leg's centroids, codes encoded on the GPU; ADC walk + cached-form re-sort
     ix.pq_attach(4, dim // 3, cent, None)
@@ -911,7 +916,7 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, step_stats, args, threads
         ix, lambda: ix.hnsw_knn_device(queries_h.data_ptr(), 1000, k, 128, h_idx.data_ptr(), h_dist.data_ptr(), h_cnt.data_ptr(), use_pq=True))
     legs["hnsw_pq"]["one_call_of_1"] = small_call(
         ix, lambda: ix.hnsw_knn_device(queries_h.data_ptr(), 1, k, 128, h_idx.data_ptr(), h_dist.data_ptr(), h_cnt.data_ptr(), use_pq=True), 1)
-    latency_floor(legs["hnsw_pq"], legs["hnsw_pq"]["one_call_of_1000"], 3, "link row -> visited words -> code rows")
+    latency_floor(legs["hnsw_pq"], legs["hnsw_pq"]["one_call_of_1000"], 3, "link row -> visited words -> code rows", dim // 3)
     ix.close()
     return legs
 

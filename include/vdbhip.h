@@ -372,6 +372,9 @@ int vdb_mfma_probe(int device_id, int waves_per_simd, int iters, double *out_tfl
  * buffer (larger than L2 and the Infinity Cache) for `hops` loads; nanoseconds per load.  The floor of the graph walks
  * (hnsw_index.rs:258-291 is a chain of dependent accesses per expansion) is quoted on it.  Measurement hook. */
 int vdb_latency_probe(int device_id, uint64_t bytes, uint32_t hops, double *out_ns_per_load);
+/* latency of one DEPENDENT f32 add: the reference's distances are strict left folds (distance/mod.rs:72-77), so a d-column row
+ * is a chain of d of them on whatever hardware; nanoseconds per add over a chain of `adds`.  Measurement hook. */
+int vdb_fold_probe(int device_id, uint32_t adds, double *out_ns_per_add);
 int vdb_prof_reset(vdb_index *idx);
 int vdb_prof_get(vdb_index *idx, const char *kernel, double *total_ms, uint64_t *launches, double *bytes);
 

@@ -1023,6 +1023,13 @@ int vdb_latency_probe(int device_id, uint64_t bytes, uint32_t hops, double *out_
     *out_ns_per_load = latency_probe(device_id, bytes, hops);
     VDB_API_END
 }
+int vdb_fold_probe(int device_id, uint32_t adds, double *out_ns_per_add) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(out_ns_per_add, "null out");
+    require_gpu();
+    *out_ns_per_add = fold_probe(device_id, adds);
+    VDB_API_END
+}
 int vdb_prof_enable(vdb_index *idx, int on) {
     VDB_API_BEGIN
     VDB_REQUIRE(idx, "null index");

@@ -278,4 +278,53 @@ double latency_probe(int device, uint64_t bytes, uint32_t hops) {
     return ns;
 }
 
+// ---- latency of ONE dependent f32 add: the other half of a walk's floor -------------------------------------------------------
+// The reference's distances are strict left folds (distance/mod.rs:72-77): a row of d columns is a chain of d dependent adds
+// whatever the lane count.  One wave, `adds` dependent v_add_f32 (the compiler cannot re-associate: -fno-fast-math): ns per add.
+__global__ __launch_bounds__(64) void k_probe_fold(uint32_t adds, float x, float *out) {
+    float acc = 0.0f;
+    for (uint32_t i = 0; i < adds; i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            acc = acc + x;
+            asm volatile("" : "+v"(acc));  // (keeps the eight adds eight instructions)
+        }
+    }
+    if (acc == 12345.678f) out[0] = acc;
+}
+double fold_probe(int device, uint32_t adds) {
+    VDB_HIP(hipSetDevice(device));
+    VDB_REQUIRE(adds >= 1024 && adds <= (1u << 28), "fold probe: adds must be in 1024..2^28");
+    void *out = nullptr;
+    hipStream_t s = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    double ns = 0.0;
+    try {
+        VDB_HIP(hipMalloc(&out, 64));
+        VDB_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        VDB_HIP(hipEventCreate(&a));
+        VDB_HIP(hipEventCreate(&b));
+        hipLaunchKernelGGL(k_probe_fold, dim3(1), dim3(64), 0, s, 1024u, 1.0f, static_cast<float *>(out));
+        VDB_HIP(hipEventRecord(a, s));
+        hipLaunchKernelGGL(k_probe_fold, dim3(1), dim3(64), 0, s, adds, 1.0f, static_cast<float *>(out));
+        VDB_HIP(hipEventRecord(b, s));
+        VDB_HIP(hipEventSynchronize(b));
+        VDB_HIP(hipGetLastError());
+        float ms = 0;
+        VDB_HIP(hipEventElapsedTime(&ms, a, b));
+        ns = double(ms) * 1e6 / double(adds);
+    } catch (...) {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+        if (s) (void)hipStreamDestroy(s);
+        if (out) (void)hipFree(out);
+        throw;
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    (void)hipStreamDestroy(s);
+    (void)hipFree(out);
+    return ns;
+}
+
 }  // namespace vdb

@@ -136,7 +136,8 @@ void launch_rerank_u8(const uint8_t *X, uint32_t dim, const float *Q, uint32_t n
 double stream_probe(int device, uint64_t bytes, int iters);
 double stream_probe_pattern(int device, uint64_t bytes, int iters, int pattern, uint32_t row_bytes);  // 1: MFMA-fragment loads from row-major rows
 void mfma_probe(int device, int waves_per_simd, int iters, double *tflops, double *clock_ghz);
-double latency_probe(int device, uint64_t bytes, uint32_t hops);  // ns per dependent HBM load (pointer chase over 128-B lines)
+double latency_probe(int device, uint64_t bytes, uint32_t hops);
+double fold_probe(int device, uint32_t adds);  // ns per dependent f32 add (the strict fold's chain)  // ns per dependent HBM load (pointer chase over 128-B lines)
 
 // ---- k_sort.hip (k > 1024) -----------------------------------------------------------------
 size_t sort_pairs_temp_bytes(uint64_t n);

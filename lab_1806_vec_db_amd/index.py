@@ -486,6 +486,13 @@ def latency_probe(device: int = 0, nbytes: int = 1 << 30, hops: int = 20000) -> 
     return float(v.value)
 
 
+def fold_probe(device: int = 0, adds: int = 1 << 22) -> float:
+    """Nanoseconds per DEPENDENT f32 add on this box (the chain a strict left fold is made of)."""
+    v = C.c_double()
+    L.check(L.load().vdb_fold_probe(int(device), int(adds), C.byref(v)))
+    return float(v.value)
+
+
 def merge_topk(dists: np.ndarray, ids: np.ndarray, counts: np.ndarray, k: int):
     """Merge per-shard sorted lists [S][nq][k] into the global top-k by (distance, index)."""
     d = _f32(dists)

@@ -24,9 +24,11 @@ def test_latency_and_row_fragment_probes():
     """vdb_latency_probe (the dependent-load latency the graph walks' floor is quoted on) and vdb_stream_probe_rows (MFMA
     fragment loads from a row-major image: the A/B behind keeping two fp16 copies of the rows)."""
     import lab_1806_vec_db_amd as vdb
-    from lab_1806_vec_db_amd.index import latency_probe, stream_probe_rows
+    from lab_1806_vec_db_amd.index import fold_probe, latency_probe, stream_probe_rows
     ns = latency_probe(0, 512 << 20, 4000)
     assert 100.0 < ns < 5000.0, ns       # an HBM round trip: a few hundred nanoseconds
+    na = fold_probe(0, 1 << 20)
+    assert 0.5 < na < 20.0, na           # a dependent v_add_f32: a handful of cycles
     gbps = stream_probe_rows(0, 512 << 20, 2, 1920)
     assert 200.0 < gbps < 8000.0, gbps
     with pytest.raises(vdb.VdbError):
