@@ -198,8 +198,9 @@ def main():
                     help="flat: query batches (steps) in flight: with 2, step i+1 is enqueued (vdb_flat_knn_device_begin) before the host "
                          "looks at step i's certification flags (_end), so the corpus passes of consecutive steps run back to back and "
                          "the exact stage of one step overlaps the query preparation of the next; 1 = every step is one synchronous call; "
-                         "0 = auto: 2 on one GPU, 3 on row shards (where the per-step fixed cost is a larger share; on one GPU 2 and 3 "
-                         "measure the same rate)")
+                         "0 = auto: 1 on one GPU (the pipelining is worth 0 - 2 % there and would blur the HIP-event duration of the corpus pass "
+                         "the roofline is quoted on), 3 on row shards, where the per-step fixed cost is the larger share of a step "
+                         "(one of 8 shards: 0.44 -> 0.375 ms per step)")
     ap.add_argument("--base-file", type=str, default="",
                     help="raw row-major f32 corpus, no header (the output of src/bin/convert_fvecs.rs:29-31, e.g. a real gist_base "
                          "converted from .fvecs): used instead of the synthetic rows when given; rows = file size / (dim * 4) unless --rows")
@@ -325,7 +326,7 @@ def main():
     torch.cuda.empty_cache()
 
     # the local results live in the send block of the per-step exchange (typed views, no packing)
-    depth = (max(1, min(args.pipeline, 4)) if args.pipeline > 0 else (2 if world == 1 else 3)) if wl == "flat" else 1
+    depth = (max(1, min(args.pipeline, 4)) if args.pipeline > 0 else (1 if world == 1 else 3)) if wl == "flat" else 1
     ex = ShardExchange(nq, k, device, world if backend == "nccl" else 1, force=force_x, min_depth=depth + 1 if depth > 1 else 1)
     o_idx, o_dist, o_cnt = ex.idx, ex.dist, ex.cnt
 
