@@ -459,8 +459,6 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         idx->ix.flat_gemm_mode = (int)value;
     else if (n == "hnsw_dma")
         hnsw_set_dma((int)value);
-    else if (n == "hnsw_latency")
-        hnsw_set_latency((int)value);
     else if (n == "hnsw_half")
         hnsw_set_half((int)value);
     else if (n == "ivf_half")

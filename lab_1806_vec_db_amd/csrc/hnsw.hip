@@ -63,12 +63,6 @@ struct HnswDev {
     const uint16_t *rows_h;  // row-major fp16 image of the rows (null: no pre-pass), values fp16(x / inv_sx)
     float inv_sx, dx_abs, dx_rel;  // its scale and measured rounding error (Index::half_dx_*)
     uint32_t pool_cap;  // live candidates the LDS pool may hold (<= HNSW_POOL; a test hook lowers it to reach the heap walk)
-    // latency mode (calls that are a fraction of one round of walks: the time is the dependent chain of one expansion, not bytes):
-    //   bit 0: the pre-pass scores every LISTED neighbour, not only the fresh ones -- its row loads then do not wait for the
-    //          visited test-and-set's return (one dependent round trip less; a few already-visited rows are scored for nothing);
-    //   bit 1: the link row and length of the SECOND-best candidate are fetched at pop time and used if it is popped next.
-    // Neither changes a value that is used: prefetches and discarded scores only.
-    uint32_t latency_mode;
 };
 
 constexpr uint32_t HNSW_POOL = 2048;  // most candidate pool entries per query (LDS)
@@ -566,7 +560,6 @@ __global__ __launch_bounds__(64, 2) void k_hnsw_search(HnswDev g, const float *_
 #else
 #define HNSW_TICK(acc, t_prev)
 #endif
-    uint32_t pf_node = 0xFFFFFFFFu, pf_nb0 = 0, pf_len = 0;  // latency mode bit 1: link row / length fetched ahead for this node
     while (pool_n > 0 && !overflow) {
 #ifdef HNSW_STAMP
         unsigned long long t_prev = wall_clock64();
@@ -613,28 +606,8 @@ __global__ __launch_bounds__(64, 2) void k_hnsw_search(HnswDev g, const float *_
         const uint32_t *lk = g.level0 + uint64_t(p) * g.max_m0;
         // the link row is fetched whole, in the same round trip as its length (every row has max_m0 slots): a load guarded
         // by `j < len` would wait for the length first -- one more dependent trip in a loop that is a chain of them
-        uint32_t nb0, len;
-        if ((g.latency_mode & 2u) && p == pf_node) {  // wave-uniform: the prefetch of the previous expansion was for this node
-            nb0 = pf_nb0;
-            len = pf_len;
-        } else {
-            nb0 = lane < g.max_m0 ? lk[lane] : 0u;
-            len = g.len0[p];
-        }
-        if (g.latency_mode & 2u) {
-            // the smallest pair left in the pool is popped next unless this expansion finds something smaller: start its link row now
-            uint64_t nx = PAIR_NONE;
-            for (uint32_t base = 0; base < pool_n; base += 64) {
-                const uint32_t i = base + lane;
-                const uint64_t v = i < pool_n ? pool[i] : PAIR_NONE;
-                nx = v < nx ? v : nx;
-            }
-            nx = wave_min_u64(nx);
-            pf_node = nx == PAIR_NONE ? 0xFFFFFFFFu : uint32_t(nx);
-            const uint32_t pn = nx == PAIR_NONE ? p : uint32_t(nx);
-            pf_nb0 = lane < g.max_m0 ? g.level0[uint64_t(pn) * g.max_m0 + lane] : 0u;
-            pf_len = g.len0[pn];
-        }
+        const uint32_t nb0 = lane < g.max_m0 ? lk[lane] : 0u;
+        const uint32_t len = g.len0[p];
         for (uint32_t base = 0; base < len && !overflow; base += 64) {
             uint32_t j = base + lane;
             uint32_t nb = 0;
@@ -655,13 +628,11 @@ __global__ __launch_bounds__(64, 2) void k_hnsw_search(HnswDev g, const float *_
                     } else {
                         bool need = fresh;
                         if (g.rows_h != nullptr && tau != PAIR_NONE) {  // (until the result list is full every row is admitted)
-                            // latency mode: score every listed neighbour -- `j < len` is known one round trip before `fresh` is
-                            const bool score = (g.latency_mode & 1u) ? j < len : fresh;
-                            const float S = half_dots32(g.rows_h, g.dim, g.inv_sx, fl, nb, score, lane);
+                            const float S = half_dots32(g.rows_h, g.dim, g.inv_sx, fl, nb, fresh, lane);
                             const float xs = g.xsq[nb];
                             need = fresh && !half_rules_out(g.cosine ? MET_COSINE : MET_L2_CACHED, g.dim, S, xs, qsq, g.dx_abs, g.dx_rel, f32_from_orderable(uint32_t(tau >> 32)));
                             n_drop += (uint32_t)__builtin_popcountll(__ballot(fresh && !need));
-                            n_half += (uint32_t)__builtin_popcountll(__ballot(score));
+                            n_half += (uint32_t)__builtin_popcountll(fm);
                             d = INFINITY;  // a dropped row fails check_candidate below, as its exact distance would
                         }
                         const uint32_t nneed = (uint32_t)__builtin_popcountll(__ballot(need));
@@ -1569,8 +1540,6 @@ void hnsw_set_dma(int v) { g_hnsw_dma = v; }
 static std::atomic<int> g_hnsw_half{1};  // certified half-precision pre-pass of the exact walk: 1 auto (calls of >= 768 queries), 0 off, 2 always
 void hnsw_set_half(int v) { g_hnsw_half = v; }
 static std::atomic<uint32_t> g_hnsw_pool_cap{HNSW_POOL};
-static std::atomic<int> g_hnsw_latency{0};  // latency mode of the walk (HnswDev::latency_mode): 0 auto (both bits for calls of <= 2048 queries), 1 off, 2 + bits = forced
-void hnsw_set_latency(int v) { g_hnsw_latency = v; }
 void hnsw_set_pool_cap(int v) { g_hnsw_pool_cap = v < 1 ? 1u : (v > (int)HNSW_POOL ? HNSW_POOL : (uint32_t)v); }
 // Candidate pool entries of a walk.  Every expansion starts by dropping the pairs at or above the worst result, which
 // leaves pairs that are also in the result list (< ef of them) or tie its worst distance with a smaller index; until the
@@ -1820,8 +1789,6 @@ void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, ui
         g.dx_rel = ix.half_dx_rel;
     }
     g.pool_cap = hnsw_pool_slots(efk, (uint32_t)h.max_m0);
-    // calls of at most one round of resident walks (2 048 waves on the chip) wait for one expansion's dependent chain
-    g.latency_mode = g_hnsw_latency == 0 ? (nq <= 2048 ? 3u : 0u) : (g_hnsw_latency == 1 ? 0u : (uint32_t(g_hnsw_latency) - 2u) & 3u);
     const size_t lds = hnsw_lds_bytes(g.pool_cap, lds_big, g.dma);
     g.rows = ix.d_rows.as<float>();
     g.xsq = ix.d_sq.as<float>();

@@ -57,7 +57,6 @@ void hnsw_attach(Index &ix, uint64_t M, uint64_t ef_construction, const uint32_t
 void hnsw_clear(Index &ix);
 void hnsw_set_dma(int v);
 void hnsw_set_half(int v);
-void hnsw_set_latency(int v);  // 0 auto, 1 off, 2 + bits forced (bit 0: pre-pass over all listed neighbours, bit 1: next candidate's links fetched ahead)
 void hnsw_set_build_gpu(int v);  // candidate phase of batched builds on the GPU: 0 auto (batch >= 256), 1 off
 void hnsw_set_pool_cap(int v);  // test hook: live candidates the fast walk's LDS pool holds before a query moves to the heap walk
 void hnsw_insert_rows(Index &ix, const float *rows, uint64_t n);
