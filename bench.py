@@ -122,6 +122,19 @@ def hbm_roofline(kernel, p, extra=None):
     return r
 
 
+def pmc_traffic(kernel, rows, dim, nq):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this very command (profiles/
+    r03_pmc_traffic.json: counters cannot be collected inside a timed run) -- only for the workload they were collected on"""
+    try:
+        e = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"))).get(kernel)
+    except (OSError, ValueError):
+        return None
+    if not e or e.get("workload") != {"rows": rows, "dim": dim, "queries_per_step": nq}:
+        return None
+    return {"traffic": e["hbm_side_bytes"], "traffic_source": "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate "
+                                                              "passes of `bench.py --legs none`, per launch; not collected in this run)"}
+
+
 def flat_kernel_of(ix):
     """dominant kernel of the Flat steps just timed: the fp16 first pass (k_flat_gemm<GEMM_F16>) when it ran, else the
     split-bf16 pass (k_flat_gemm<GEMM_BF16X3> / k_flat_mfma), else the exact scan"""
@@ -443,6 +456,8 @@ def main():
 
     if wl == "flat":
         roofline = flat_roofline(ix, r1 - r0, dim, nq)
+        if roofline and world == 1:
+            roofline.update(pmc_traffic(roofline["kernel"], r1 - r0, dim, nq) or {})
         if roofline and depth > 1:
             roofline["overlap_note"] = (f"{depth} steps in flight: the HIP-event duration of a corpus pass includes the CUs it waited for while the "
                                         "neighbouring steps' exact stage / query preparation ran beside it (passes themselves take turns)")
@@ -875,6 +890,18 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, step_stats, args, threads
     legs["ivf"] = run(ix, "ivf", n, 4,
                       lambda: ix.ivf_knn_device(queries.data_ptr(), nq, k, 4, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr()),
                       {"workload": "ivf_knn_gistlike_1000000", "clusters": int(round(n ** 0.5)), "n_probes": 4, "build_s": round(ivf_build_s, 1)})
+    # the reference's default is 4 probes (ivf_index.rs:108); recall there is low on any data, so the same index at 16 and 64 probes too
+    # (rate + recall@10 against the GPU Flat ground truth; parity against the oracle is the 4-probe line's)
+    ix.flat_knn_device(queries.data_ptr(), nq, k, t_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr())
+    gt = t_idx.cpu().numpy().astype(np.uint64)
+    legs["ivf"]["more_probes"] = []
+    for npb in (16, 64):
+        fn_p = lambda: ix.ivf_knn_device(queries.data_ptr(), nq, k, npb, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr())  # noqa: E731
+        el, _ = timed(ix, fn_p, args.steps, 2)
+        gi = o_idx.cpu().numpy().astype(np.uint64)
+        rec = float(np.mean([len(set(gt[q].tolist()) & set(gi[q].tolist())) / k for q in range(nq)]))
+        legs["ivf"]["more_probes"].append({"n_probes": npb, "value": round(nq * args.steps / el, 1), "unit": "queries/s",
+                                           "ms_per_step": round(el / args.steps * 1e3, 3), "recall_at_10": round(rec, 4)})
     ix.close()
     del ix
     torch.cuda.empty_cache()
