@@ -355,6 +355,60 @@ __device__ __forceinline__ float wave_rerank_fold(const float *__restrict__ X, u
     return acc;
 }
 
+// The same fold with the work of a row spread over the 8 lanes that fetch it (k_flat_tail64, round 3).  A wave takes 8 rows:
+// lane 8g + p fetches piece p (16 B) of every 32-column chunk of row g -- a whole 128-B line per row and instruction, DEPTH
+// chunks ahead -- and turns it into PRODUCTS itself: (x - q)^2 or x * q, each separately rounded exactly as distance/mod.rs:
+// 72-77 rounds them; which lane computes a product is immaterial.  The products of a chunk meet in a [8][9]-float4 LDS tile and
+// every lane of group g adds row g's 32 values in reference order (the 8 lanes compute the same sum; only one chain matters).
+// Against wave_rerank_fold -- 64 rows per wave, every lane subtracts, multiplies AND adds its own row: 96 dependent-issue VALU
+// operations per chunk -- a chunk costs 4 packed product operations + 32 adds, and the four waves of a workgroup take 8 rows each
+// instead of leaving 3 waves idle.  Columns past dim contribute +0.0 (exact: the running sum is never -0.0).
+template <int FOLD, int DEPTH>
+__device__ __forceinline__ float group_rerank_fold(const float *__restrict__ X, uint32_t dim, uint32_t idx, bool live, const float4 *qs4,
+                                                   float4 *tile /* this wave's [8][9] */, uint32_t lane) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const uint32_t d4 = dim / 4, g = lane >> 3, p = lane & 7;
+    const f4 *rp = reinterpret_cast<const f4 *>(X + uint64_t(idx) * dim) + p;
+    const f4 *q4 = reinterpret_cast<const f4 *>(qs4);
+    f4 *t4 = reinterpret_cast<f4 *>(tile);
+    const uint32_t nch = (d4 + 7) / 8;
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    f4 stg[DEPTH];
+#pragma unroll
+    for (int st = 0; st < DEPTH; st++) stg[st] = (uint32_t(st) < nch && uint32_t(st) * 8 + p < d4 && live) ? rp[st * 8] : zero;
+    float acc = 0.0f;
+    for (uint32_t ch0 = 0; ch0 < nch; ch0 += DEPTH) {
+#pragma unroll
+        for (int st = 0; st < DEPTH; st++) {
+            const uint32_t ch = ch0 + st;
+            if (ch >= nch) break;  // uniform
+            const bool inside = ch * 8 + p < d4;
+            f4 pr = zero;
+            if (inside) {
+                const f4 x = stg[st], w = q4[ch * 8 + p];
+                if (FOLD == FOLD_L2) {
+                    const f4 df = x - w;
+                    pr = df * df;
+                } else {
+                    pr = x * w;
+                }
+            }
+            t4[g * 9 + p] = pr;
+            const uint32_t nx = ch + DEPTH;
+            stg[st] = (nx < nch && nx * 8 + p < d4 && live) ? rp[nx * 8] : zero;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const f4 v = t4[g * 9 + j];
+                acc = acc + v.x;
+                acc = acc + v.y;
+                acc = acc + v.z;
+                acc = acc + v.w;
+            }
+        }
+    }
+    return acc;
+}
+
 // The same re-rank with coalesced row fetches (dim % 4 == 0): k_rerank lets every lane walk its own row 16 B at a time,
 // i.e. one load instruction touches 64 different 128-B lines and each line has to survive in the L1 across 8
 // instructions -- 35 us for 32 candidates x 1000 queries at dim 960, but 184 us for 64 (the lines of the waves
@@ -633,54 +687,72 @@ void launch_flat_finish(const uint64_t *exact_sorted, uint32_t lde, const uint64
 // ---------------------------------------------------------------------------------------------
 template <int FOLD>
 __global__ __launch_bounds__(256) void k_flat_tail64(FlatTailArgs a) {
-    extern __shared__ float4 ft_smem[];  // [dim/4] query, then [64 rows][9] float4 (8 used)
+    extern __shared__ float4 ft_smem[];  // [dim/4] query, then 4 waves x [8 rows][9] float4 product tiles
     __shared__ uint64_t sbest[4][64];
-    const uint32_t q = blockIdx.x, lane = threadIdx.x & 63;
+    __shared__ uint64_t skeys[64];       // exact pair keys of the shortlist, by shortlist position
+    __shared__ uint32_t s_flag;
+    const uint32_t q = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t d4 = a.dim / 4;
-    float4 *qs4 = ft_smem, *tile = ft_smem + d4;
+    float4 *qs4 = ft_smem, *tile = ft_smem + d4 + wave * 72;
     for (uint32_t i = threadIdx.x; i < d4; i += 256) qs4[i] = reinterpret_cast<const float4 *>(a.Q + uint64_t(q) * a.dim)[i];
     const uint32_t cnt_q = a.cnt[q];
     const uint32_t total = cnt_q <= a.cap ? cnt_q : 0;  // cnt > cap: slots are not all written, the query is redone
-    const uint64_t best = block_top64(a.cand + uint64_t(q) * a.cap, total, sbest);  // (its barrier also covers qs4)
-    if (threadIdx.x >= 64) return;
-    const uint64_t c = lane < a.kprime ? best : PAIR_NONE;
-    const bool live = c != PAIR_NONE;
-    const uint32_t idx = live ? uint32_t(c) : 0u;
+    const uint64_t best0 = block_top64(a.cand + uint64_t(q) * a.cap, total, sbest);  // (its barrier also covers qs4)
+    // the shortlist (ascending approximate pairs, valid in wave 0) for all four waves
+    if (wave == 0) sbest[0][lane] = lane < a.kprime ? best0 : PAIR_NONE;
+    if (threadIdx.x < 64) skeys[threadIdx.x] = PAIR_NONE;
+    __syncthreads();
     const uint32_t kk = a.ksel < a.kprime ? a.ksel : a.kprime;
-    auto exact_key = [&](float acc) -> uint64_t {
-        const float xs = (a.metric == MET_L2_DIRECT) ? 0.0f : a.xsq[idx];
-        const float qs = (a.metric == MET_L2_DIRECT) ? 0.0f : a.qsq[q];
-        return pair_key(epilogue(a.metric, acc, xs, qs), idx);
+    // exact pair keys of shortlist positions [j0, j0 + 32): wave w folds positions j0 + 8w .. + 7, one per group of 8 lanes
+    auto rerank32 = [&](uint32_t j0) {
+        const uint32_t j = j0 + wave * 8 + (lane >> 3);
+        const uint64_t c = sbest[0][j];
+        const bool live = c != PAIR_NONE;
+        const uint32_t idx = live ? uint32_t(c) : 0u;
+        const float acc = group_rerank_fold<FOLD, 8>(a.X, a.dim, idx, live, qs4, tile, lane);
+        if (live && (lane & 7) == 0) {
+            const float xs = (a.metric == MET_L2_DIRECT) ? 0.0f : a.xsq[idx];
+            const float qs = (a.metric == MET_L2_DIRECT) ? 0.0f : a.qsq[q];
+            skeys[j] = pair_key(epilogue(a.metric, acc, xs, qs), idx);
+        }
     };
     // Two stages when the shortlist is longer than 32 rows: the 32 best approximate candidates are re-ranked first and
     // certified against the 33rd-smallest approximate key (every row outside those 32 -- the other shortlisted rows
     // included -- has a key at least that large); only a query that fails this test pays for the other rows' gathers.
-    // The exact stage is bound by those gathers (64 rows x dim x 4 B per query), so most queries now cost half.
-    uint64_t r = PAIR_NONE, sorted;
+    // The exact stage is bound by those gathers (64 rows x dim x 4 B per query), so most queries cost half.
+    const bool two_stage = a.kprime > 32 && kk <= 32 && cnt_q <= a.cap;  // block-uniform
+    uint64_t sorted = PAIR_NONE;
     uint8_t flag = 1;
-    const bool two_stage = a.kprime > 32 && kk <= 32 && cnt_q <= a.cap;
+    rerank32(0);
+    if (!two_stage && a.kprime > 32) rerank32(32);
+    __syncthreads();
+    if (wave == 0) {
+        sorted = sort64(skeys[lane], lane);  // (distance, index) order, PAIR_NONE last
+        const uint32_t kp = two_stage ? 32u : a.kprime;
+        const uint64_t ek = __shfl(sorted, kk - 1), ak = sbest[0][kp - 1 + (two_stage ? 1 : 0)];  // two-stage: the smallest key OUTSIDE the first 32
+        uint8_t f = 1;
+        if (lane == 0) {
+            f = flat_certify_flag(ek, ak, q, kp, a.n_rows, a.qsq, a.xsq_max, a.xsq_min_pos, a.cosine, a.dim, a.se, cnt_q, a.cap);
+            s_flag = f;
+        }
+        flag = (uint8_t)__shfl((int)f, 0);
+    }
     if (two_stage) {
-        const bool l1 = live && lane < 32;
-        const float acc1 = wave_rerank_fold<FOLD, 2>(a.X, a.dim, idx, l1, qs4, tile, lane);
-        if (l1) r = exact_key(acc1);
-        sorted = sort64(r, lane);
-        const uint64_t ek1 = __shfl(sorted, kk - 1), ak1 = __shfl(best, 32);  // the smallest key outside the first 32
-        uint8_t f1 = 1;
-        if (lane == 0)
-            f1 = flat_certify_flag(ek1, ak1, q, 32, a.n_rows, a.qsq, a.xsq_max, a.xsq_min_pos, a.cosine, a.dim, a.se, cnt_q, a.cap);
-        flag = (uint8_t)__shfl((int)f1, 0);
+        __syncthreads();
+        if (s_flag) {  // block-uniform: the rest of the shortlist
+            rerank32(32);
+            __syncthreads();
+            if (wave == 0) {
+                sorted = sort64(skeys[lane], lane);
+                const uint64_t ek = __shfl(sorted, kk - 1), ak = sbest[0][a.kprime - 1];
+                uint8_t f = 1;
+                if (lane == 0)
+                    f = flat_certify_flag(ek, ak, q, a.kprime, a.n_rows, a.qsq, a.xsq_max, a.xsq_min_pos, a.cosine, a.dim, a.se, cnt_q, a.cap);
+                flag = (uint8_t)__shfl((int)f, 0);
+            }
+        }
     }
-    if (flag) {  // wave-uniform: the rest of the shortlist (all of it without the first stage)
-        const bool l2 = live && (!two_stage || lane >= 32);
-        const float acc2 = wave_rerank_fold<FOLD, 2>(a.X, a.dim, idx, l2, qs4, tile, lane);
-        if (l2) r = exact_key(acc2);
-        sorted = sort64(r, lane);  // (distance, index) order, PAIR_NONE last
-        const uint64_t ek = __shfl(sorted, kk - 1), ak = __shfl(best, a.kprime - 1);
-        uint8_t f2 = 1;
-        if (lane == 0)
-            f2 = flat_certify_flag(ek, ak, q, a.kprime, a.n_rows, a.qsq, a.xsq_max, a.xsq_min_pos, a.cosine, a.dim, a.se, cnt_q, a.cap);
-        flag = (uint8_t)__shfl((int)f2, 0);
-    }
+    if (wave != 0) return;
     const bool ok = lane < a.ksel && sorted != PAIR_NONE;
     if (lane < a.ksel) {
         a.out_idx[uint64_t(q) * a.kstride + lane] = ok ? uint64_t(uint32_t(sorted)) + a.id_offset : 0;
@@ -698,7 +770,7 @@ bool flat_tail64_supported(uint32_t dim, uint32_t kprime, uint32_t ksel) {
 void launch_flat_tail64(const FlatTailArgs &a, uint32_t nq, hipStream_t s) {
     if (nq == 0) return;
     VDB_REQUIRE(flat_tail64_supported(a.dim, a.kprime, a.ksel), "flat_tail64: unsupported shape");
-    const size_t lds = (size_t(a.dim / 4) + 64 * 9) * sizeof(float4);
+    const size_t lds = (size_t(a.dim / 4) + 4 * 72) * sizeof(float4);
     if (a.metric == MET_L2_DIRECT)
         hipLaunchKernelGGL((k_flat_tail64<FOLD_L2>), dim3(nq), dim3(256), lds, s, a);
     else
