@@ -1,4 +1,4 @@
-"""A/B probe of parameter COMBINATIONS inside one process: `probe_ab2.py "a=1,b=2;a=2,b=2" [rows] [nq]` alternates the
+"""A/B probe of parameter COMBINATIONS inside one process: `probe_flat_ab.py "a=1,b=2;a=2,b=2" [rows] [nq]` alternates the
 settings, times whole Flat steps + the filter kernel and checks that the results never change (tooling)."""
 import sys, time, numpy as np, torch
 sys.path.insert(0, '.')
