@@ -174,6 +174,24 @@ public:
     ShardedIndex(const ShardedIndex &) = delete;
     ShardedIndex &operator=(const ShardedIndex &) = delete;
     void set_rows(const float *rows, uint64_t n) { check(vdb_sharded_set_rows(h_, rows, n)); }
+    // REPLICA layout: every GPU keeps all rows and a search splits the queries -- the layout the HNSW searches need
+    // ("replicas only"); knn_batch / knn_pq_batch work in it as well
+    void set_rows_replica(const float *rows, uint64_t n) { check(vdb_sharded_set_rows_replica(h_, rows, n)); }
+    void build_hnsw(uint64_t ef_construction = 200, uint64_t M = 16, uint64_t seed = 42, uint64_t batch = 1, int nthreads = 0) {
+        check(vdb_sharded_hnsw_build(h_, M, ef_construction, seed, batch, nthreads));  // metadata_vec_table.rs:84-98
+    }
+    // IndexKNNWithEf::knn_with_ef / HNSWIndex::knn_pq over the replicas (dynamic_index.rs:76-93)
+    std::vector<std::vector<CandidatePair>> knn_with_ef_batch(const float *queries, uint64_t nq, uint64_t k, uint64_t ef) const {
+        return run(nq, k, [&](uint64_t *i, float *d, uint64_t *c) { return vdb_sharded_hnsw_knn(h_, queries, nq, dim_, k, ef, i, d, c); });
+    }
+    std::vector<std::vector<CandidatePair>> hnsw_knn_pq_batch(const float *queries, uint64_t nq, uint64_t k, uint64_t ef) const {
+        return run(nq, k, [&](uint64_t *i, float *d, uint64_t *c) { return vdb_sharded_hnsw_knn_pq(h_, queries, nq, dim_, k, ef, i, d, c); });
+    }
+    bool poisoned() const {
+        int v = 0;
+        check(vdb_sharded_poisoned(h_, &v));
+        return v != 0;
+    }
     uint64_t len() const {
         uint64_t n = 0;
         check(vdb_sharded_len(h_, &n));

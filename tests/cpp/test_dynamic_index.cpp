@@ -68,6 +68,21 @@ int main(int argc, char **argv) {
         const float q[4] = {0, 0, 1, 0};
         auto s1 = sh.knn_batch(q, 1, 2);
         EXPECT(s1.size() == 1 && s1[0].size() == 2 && s1[0][0].index == 2 && s1[0][0].distance == 0.0f);
+        // REPLICA layout: all three DynamicIndex searches behind the context (the HNSW ones only here)
+        ShardedIndex rp(4, DistanceAlgorithm::Cosine, {0});
+        rp.set_rows_replica(rows, 3);
+        rp.build_hnsw();
+        auto h1 = rp.knn_with_ef_batch(q, 1, 3, 3);
+        EXPECT(h1.size() == 1 && h1[0].size() == 3 && h1[0][0].index == 2 && h1[0][0].distance == 0.0f && !rp.poisoned());
+        auto f1 = rp.knn_batch(q, 1, 2);
+        EXPECT(f1[0].size() == 2 && f1[0][0].index == 2);
+        bool refused = false;
+        try {
+            sh.build_hnsw();  // a graph does not shard by rows
+        } catch (const Error &) {
+            refused = true;
+        }
+        EXPECT(refused);
     }
     std::printf("cpp host ok\n");
     return 0;

@@ -79,3 +79,34 @@ def test_sharded_other_workloads_equal_single(tmp_path, workload, rows, dim):
     assert np.array_equal(a["idx"], b["idx"])
     assert np.array_equal(a["dist"], b["dist"])
     assert np.array_equal(a["cnt"], b["cnt"])
+
+
+def test_pipelined_steps_with_the_rccl_exchange_and_self_launch(tmp_path):
+    """Three steps in flight (vdb_flat_knn_device_begin / _end, what bench.py keeps on row shards) together with the real
+    RCCL all-gather + gathered merge of a 1-rank group (VDB_FORCE_EXCHANGE=1): the results of the last step equal the plain
+    synchronous run's.  And `bench.py --gpus 2` WITHOUT a launcher starts its own two ranks (gloo rehearsal on the one GPU)."""
+    r0 = _run(1, str(tmp_path / "plain.npz"), 29641, ["--pipeline", "1"])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29642", VDB_FORCE_EXCHANGE="1")
+    env.pop("VDB_DIST_BACKEND", None)
+    args = ["--gpus", "1", "--steps", "5", "--warmup", "2", "--rows", "60000", "--nq", "96", "--cpu-queries", "0", "--pipeline", "3",
+            "--dump", str(tmp_path / "p3.npz")]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["steps_in_flight"] == 3 and r0["config"]["steps_in_flight"] == 1
+    a, b = np.load(tmp_path / "plain.npz"), np.load(tmp_path / "p3.npz")
+    assert np.array_equal(a["idx"], b["idx"]) and np.array_equal(a["dist"], b["dist"]) and np.array_equal(a["cnt"], b["cnt"])
+    # self-launch: no torch.distributed.run around it, WORLD_SIZE unset
+    env2 = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env2["VDB_DIST_BACKEND"] = "gloo"
+    args2 = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "60000", "--nq", "96", "--cpu-queries", "0", "--dump", str(tmp_path / "s2.npz")]
+    out2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args2, env=env2, capture_output=True, text=True, timeout=900)
+    assert out2.returncode == 0, out2.stderr[-2000:]
+    line2 = json.loads([l for l in out2.stdout.splitlines() if l.startswith("{")][-1])
+    assert line2["n_gpus"] == 2 and line2["config"]["steps_in_flight"] == 3
+    c = np.load(tmp_path / "s2.npz")
+    assert np.array_equal(a["idx"], c["idx"]) and np.array_equal(a["dist"], c["dist"]) and np.array_equal(a["cnt"], c["cnt"])
+    # a launcher that disagrees with --gpus is an error, not a silent one-rank run
+    env3 = dict(env2, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out3 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env3, capture_output=True, text=True, timeout=300)
+    assert out3.returncode != 0 and "WORLD_SIZE" in (out3.stderr + out3.stdout)
