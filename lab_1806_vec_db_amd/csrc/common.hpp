@@ -109,8 +109,13 @@ __device__ __forceinline__ uint64_t merge64(uint64_t a, uint64_t b, uint32_t lan
 // The 64 smallest of `total` keys at src, ascending across the lanes of wave 0 (other waves: unspecified).  Block of
 // 256 threads; a wave takes every fourth batch of 4 x 64 keys, sorts the four runs (interleaved, so that the shuffle
 // latencies overlap), merges them pairwise and into its running best-64; the four lists meet in LDS.  A batch without
-// a key below the wave's current 64th smallest is skipped.  Contains one __syncthreads().
-__device__ __forceinline__ uint64_t block_top64(const uint64_t *__restrict__ src, uint32_t total, uint64_t (*sbest)[64]) {
+// a key below the wave's current kth smallest is skipped (kth = 64: the full list; a caller that only needs the kth smallest
+// passes its k -- lanes >= kth of the result are then unspecified -- and skips more).  Contains one __syncthreads().
+// AGENT_LOADS: the keys were written by other workgroups of the SAME launch with agent-scope atomic stores; they are read with
+// agent-scope atomic loads (sc1: served from the coherence point, not from a possibly stale line of this XCD's L2), so that
+// the caller needs no acquire fence (which would invalidate the whole L2).
+template <bool AGENT_LOADS = false>
+__device__ __forceinline__ uint64_t block_top64(const uint64_t *__restrict__ src, uint32_t total, uint64_t (*sbest)[64], uint32_t kth = 64) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t batches = (total + 255) / 256;
     uint64_t best = PAIR_NONE;
@@ -119,9 +124,12 @@ __device__ __forceinline__ uint64_t block_top64(const uint64_t *__restrict__ src
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t i = (bt * 4 + u) * 64 + lane;
-            r[u] = i < total ? src[i] : PAIR_NONE;
+            if (AGENT_LOADS)
+                r[u] = i < total ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : PAIR_NONE;
+            else
+                r[u] = i < total ? src[i] : PAIR_NONE;
         }
-        const uint64_t tau = __shfl(best, 63);
+        const uint64_t tau = __shfl(best, kth - 1);
         uint64_t lo = r[0] < r[1] ? r[0] : r[1], lo2 = r[2] < r[3] ? r[2] : r[3];
         lo = lo < lo2 ? lo : lo2;
         if (__ballot(lo < tau) == 0) continue;  // wave-uniform

@@ -12,8 +12,9 @@
 //   * lane r of wave 0 is left with nothing but the reference's strict left fold over row r's products: 4 dependent adds per
 //     ds_read_b128, ~1.9 us for 960 columns -- the floor of a strict fold;
 //   * wave 0 sorts its (distance, index) pair keys across the lanes, writes the first min(k, R) of them (later ones cannot be among
-//     the k smallest), and the LAST workgroup to arrive (one counter per query) selects the k smallest of all lists and writes the
-//     ids, distances and count -- to device memory or straight into the caller's pinned host block.
+//     the k smallest; stored rank-major), and the LAST workgroup to arrive (one counter per query) selects the k smallest of all
+//     lists and writes the ids, distances and count -- to device memory or straight into the caller's pinned host block
+//     (the lists cross XCDs as agent-scope atomic stores / loads: no L2 write-back or invalidation);
 // Cosine: |q|^2 is the strict fold of q_j * q_j (distance/mod.rs:60-69 recomputes both norms per pair; the row norms are the
 // cached folds of d_sq), done once per workgroup by one lane of wave 3 over products all threads prepared.
 #include <algorithm>
@@ -109,24 +110,44 @@ __global__ __launch_bounds__(256) void k_flat_small(FlatSmallArgs a) {
         }
         uint32_t cols = dim - c * G::CW;
         if (cols > (uint32_t)G::CW) cols = G::CW;
+        // The fold is a chain of dependent adds (4.8 ns each); an LDS round trip in front of every four of them would triple it.
+        // 32 products are read ahead of the adds that consume them (two register sets); columns past `cols` hold +0.0 in the
+        // tile (store_chunk) and adding +0.0 is exact (the running sum is never -0.0), so the trip count is rounded up to 32.
         if (wave == 0 && lane < R) {
-            const float *trow = &tile[buf][lane * G::LDT];
-            for (uint32_t j = 0; j < cols; j += 4) {  // cols % 4 == 0 (dim % 4 == 0)
-                const f4 v = *reinterpret_cast<const f4 *>(trow + j);
-                acc = acc + v.x;
-                acc = acc + v.y;
-                acc = acc + v.z;
-                acc = acc + v.w;
+            const f4 *tr = reinterpret_cast<const f4 *>(&tile[buf][lane * G::LDT]);
+            const uint32_t nv = (cols + 31) / 32 * 8;  // 16-B pieces, in blocks of 8 (CW % 32 == 0: inside the row)
+            f4 cur[8], nxt[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) cur[u] = tr[u];
+            for (uint32_t j0 = 0; j0 < nv; j0 += 8) {
+                const uint32_t jn = j0 + 8 < nv ? j0 + 8 : j0;  // (the last block re-reads itself: no branch around the loads)
+#pragma unroll
+                for (int u = 0; u < 8; u++) nxt[u] = tr[jn + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    acc = acc + cur[u].x;
+                    acc = acc + cur[u].y;
+                    acc = acc + cur[u].z;
+                    acc = acc + cur[u].w;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) cur[u] = nxt[u];
             }
         }
         if (COS && tid == 192) {  // |q|^2 = strict fold of q_j * q_j (distance/mod.rs:72-74 over q, q), this chunk's share: as long as wave 0's fold
-            const float *qc = qq + c * G::CW;
-            for (uint32_t j = 0; j < cols; j += 4) {
-                const f4 v = *reinterpret_cast<const f4 *>(qc + j);
-                qacc = qacc + v.x;
-                qacc = qacc + v.y;
-                qacc = qacc + v.z;
-                qacc = qacc + v.w;
+            const f4 *qc = reinterpret_cast<const f4 *>(qq + c * G::CW);
+            const uint32_t nv = cols / 4;
+            for (uint32_t j0 = 0; j0 < nv; j0 += 8) {
+                f4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = j0 + u < nv ? qc[j0 + u] : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    qacc = qacc + v[u].x;
+                    qacc = qacc + v[u].y;
+                    qacc = qacc + v[u].z;
+                    qacc = qacc + v[u].w;
+                }
             }
             if (c + 1 == nchunk) s_qsq = qacc;
         }
@@ -154,14 +175,20 @@ __global__ __launch_bounds__(256) void k_flat_small(FlatSmallArgs a) {
             key = pair_key(d, (uint32_t)row);
         }
         key = sort64(key, lane);
-        if (lane < kw) part[uint64_t(wg) * kw + lane] = key;
-        __threadfence();  // the list is visible device-wide before the arrival is
+        // rank-major: the j-th smallest keys of all workgroups sit together, the heads first -- after the heads the merge's
+        // running k-th best is close to final and the batches of later ranks are skipped wholesale
+        // The lists travel between XCDs, whose L2s are not coherent with each other.  No fences: a release fence writes this
+        // XCD's L2 back and an acquire fence invalidates it -- in every workgroup, under the row stream of its neighbours
+        // (measured: 8 queries over 16 000 rows 206 us with __threadfence() on both sides, 122 us without any).  The keys go
+        // out as agent-scope atomic stores (written through to the coherence point), the arrival is counted once they are
+        // acknowledged (vmcnt), and the last workgroup reads them back with agent-scope atomic loads.
+        if (lane < kw) __hip_atomic_store(&part[uint64_t(lane) * nwg + wg], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) s_last = atomicAdd(&a.counter[qi], 1u) == nwg - 1 ? 1u : 0u;
     }
     __syncthreads();
     if (!s_last) return;  // block-uniform
-    __threadfence();      // acquire: the other workgroups' lists
-    const uint64_t best = block_top64(part, nwg * kw, sbest);
+    const uint64_t best = block_top64<true>(part, nwg * kw, sbest, a.ksel);
     if (wave != 0) return;
     const uint64_t cnt = a.n < a.ksel ? a.n : a.ksel;
     if (lane < a.kstride) {

@@ -28,3 +28,22 @@ for n in (1000, 16000):
     p = ix.prof_get('flat_small')
     print(f"rows {n}: python wrapper {t_py*1e6:.1f} us per call, bare C call {t_c*1e6:.1f} us, kernel (HIP events) {p['ms']/max(p['launches'],1)*1e3:.1f} us", flush=True)
     ix.close()
+
+# the same kernel with the query already in HBM (device-pointer entry): isolates what reading the query over PCIe costs
+import torch
+for n in (1000, 16000):
+    b = np.tile(base, (n // 1000, 1))
+    ix = vdb.GpuIndex(960, 'l2sqr'); ix.batch_add(b)
+    dq = torch.from_numpy(test[:8].copy()).cuda()
+    o_i = torch.zeros((8, 10), dtype=torch.int64, device='cuda'); o_d = torch.zeros((8, 10), dtype=torch.float32, device='cuda'); o_c = torch.zeros((8,), dtype=torch.int64, device='cuda')
+    torch.cuda.synchronize()
+    ix.prof_enable(True)
+    for nq in (1, 8):
+        for _ in range(20): ix.flat_knn_device(dq.data_ptr(), nq, 10, o_i.data_ptr(), o_d.data_ptr(), o_c.data_ptr())
+        ix.prof_reset()
+        t = time.perf_counter()
+        for _ in range(300): ix.flat_knn_device(dq.data_ptr(), nq, 10, o_i.data_ptr(), o_d.data_ptr(), o_c.data_ptr())
+        dt = (time.perf_counter() - t) / 300
+        p = ix.prof_get('flat_small')
+        print(f"rows {n}, {nq} queries in HBM: call {dt*1e6:.1f} us, kernel (HIP events) {p['ms']/max(p['launches'],1)*1e3:.1f} us", flush=True)
+    ix.close()
