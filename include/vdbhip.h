@@ -150,8 +150,9 @@ int vdb_flat_set_mode(vdb_index *idx, int mode);
  *   "pq_sample16"      the threshold sample of that scan on the quantised tables as well (L2Sqr): 0 auto (on), 1 off (exact f32 sample).
  *                      The threshold only decides how many rows the scan keeps; the count is checked and short lists are redone
  *   "flat_small"       FlatIndex::knn of a few queries over a small table in ONE launch (the db.search() shape; dim % 4 == 0, k <= 64):
- *                      0 auto (tables of at most "flat_small_max_rows" = 16 384 rows, calls of fewer than 32 queries, flat mode 0),
- *                      1 off, 2 whenever the shape allows (up to 64 queries) */
+ *                      0 auto (flat mode 0; tables of at most "flat_small_max_rows" = 16 384 rows: calls of fewer than 32 queries; larger
+ *                      tables: while rows x (0.9 queries - 0.3) < 75 000, i.e. one query up to ~125k rows, where the MFMA pipeline's
+ *                      fixed ~0.1 ms of dependent launches costs more than re-reading the rows per query), 1 off, 2 whenever the shape allows */
 int vdb_set_param(vdb_index *idx, const char *name, int64_t value);
 /* number of queries whose MFMA shortlist failed certification and were redone by the exact scan */
 int vdb_flat_fallback_count(const vdb_index *idx, uint64_t *out);

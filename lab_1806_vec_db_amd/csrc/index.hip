@@ -373,7 +373,13 @@ void Index::flat_sorted_device(Workspace &ws, const float *d_q, uint64_t nq, uin
 bool Index::flat_small_applies(uint64_t nq, uint64_t k) const {
     if (flat_small_mode == 1 || elem_u8 || n == 0 || !flat_small_supported(n, (uint32_t)dim, nq, k)) return false;
     if (flat_small_mode == 2) return true;
-    return flat_mode == 0 && n <= flat_small_max_rows && nq < 32;
+    if (flat_mode != 0) return false;
+    if (n <= flat_small_max_rows) return nq < 32;  // below the MFMA shortlist's domain the alternative is the five-launch scan
+    // Beyond it the one-launch kernel competes with the MFMA pipeline, whose cost is a fixed ~100 us of dependent launches plus
+    // ~0.3 us per 1000 rows, while this kernel re-reads the rows per query: ~25 us + ~0.9 us per 1000 (row, query) pairs
+    // (tools/probe_small_vs_mfma.py: one query wins up to ~125k rows of 960 columns, four queries up to ~23k).  Rows of other
+    // widths scale both sides alike.
+    return mfma_supported((uint32_t)dim) ? double(n) * (0.9 * double(nq) - 0.3) < 75000.0 : nq < 32 && n <= (1u << 17);
 }
 void Index::flat_small_device(Workspace &ws, const float *q, uint64_t nq, uint64_t k, uint64_t *o_idx, float *o_dist, uint64_t *o_cnt) {
     hipStream_t s = ws.stream;

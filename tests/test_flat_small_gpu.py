@@ -73,6 +73,17 @@ def test_small_equals_general_exact_path_and_auto_rule(mods):
     ix.flat_knn(qs[:4], 10)
     assert ix.prof_get("flat_small")["launches"] == 1
     ix.close()
+    # beyond 16 384 rows the kernel competes with the MFMA pipeline: one query on 40 000 rows takes it, six queries do not
+    big = np.round(np.abs(rng.normal(0.07, 0.045, (40000, 64))), 4).astype(np.float32)
+    jx = vdb.GpuIndex(64, "l2sqr")
+    jx.batch_add(big)
+    jx.prof_enable(True)
+    a = jx.flat_knn(big[:1] + np.float32(0.001), 10)
+    assert jx.prof_get("flat_small")["launches"] == 1
+    b6 = jx.flat_knn(big[:6] + np.float32(0.001), 10)
+    assert jx.prof_get("flat_small")["launches"] == 1 and jx.get_stat("flat_half_queries") + jx.prof_get("flat_mfma")["launches"] > 0
+    assert np.array_equal(a[0][0], b6[0][0]) and np.array_equal(a[1][0], b6[1][0])
+    jx.close()
 
 
 def test_small_nan_rows_and_swap_remove_and_offset(mods):

@@ -139,6 +139,10 @@ def test_flat_soak_configuration_87_of_round_2(mods):
     oi, od, oc = O.flat_knn_batch(base, qs, k, 1, nthreads=8)
     ix = vdb.GpuIndex(dim, dist)
     ix.batch_add(base)
+    idx, d, cnt = ix.flat_knn(qs, k)  # as a caller gets it today: one query on 19 051 rows takes the one-launch exact kernel
+    assert cnt.tolist() == [1]
+    _check(idx[0, :1], d[0, :1], oi[0][:1], od[0][:1])
+    ix.set_param("flat_small", 1)  # ... and through the MFMA tiers the soak of round 2 was about
     for mode, half, tail in ((0, 0, 0), (0, 1, 0), (0, 2, 1), (2, 0, 1), (2, 1, 1), (1, 0, 0)):
         ix.set_flat_mode(mode)
         ix.set_param("flat_half", half)
@@ -149,6 +153,7 @@ def test_flat_soak_configuration_87_of_round_2(mods):
     ix.set_flat_mode(0)
     ix.set_param("flat_half", 0)
     ix.set_param("flat_tail", 0)
+    ix.set_param("flat_small", 0)
     # the IVF scan over the same rows: few clusters and all of them probed -> probe lists of the whole table, the shape the
     # cascade gave the shared tier kernels (8-bit tier forced query-major = 2, cluster-major = 1, off = 0)
     ix.ivf_build(3, train_n=2000, max_iter=3, seed=1)
