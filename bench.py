@@ -712,6 +712,31 @@ def leg_config1(vdb, O, torch, device, local_rank, threads, k):
     t0 = time.perf_counter()
     per = [ix.flat_knn(test[q], k) for q in range(nq)]
     t_loop = time.perf_counter() - t0
+    # the same one-query calls from `threads` host threads at once -- what the CPU figure beside it is (one query per thread,
+    # bench.rs:414-416): read-side calls are re-entrant, every thread gets its own workspace and stream, the kernels overlap.
+    # Straight through the C ABI with per-thread result arrays (the Python wrapper's allocations would serialise on the GIL).
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+
+    from lab_1806_vec_db_amd import _lib as L
+
+    lib = L.load()
+    mt_i = np.zeros((nq, k), dtype=np.uint64)
+    mt_d = np.zeros((nq, k), dtype=np.float32)
+    mt_c = np.zeros(nq, dtype=np.uint64)
+
+    def worker(t):
+        for q in range(t, nq, threads):
+            rc = lib.vdb_flat_knn(ix._h, test[q].ctypes.data_as(L.f32p), 1, 960, k, mt_i[q].ctypes.data_as(L.u64p),
+                                  mt_d[q].ctypes.data_as(L.f32p), mt_c[q:].ctypes.data_as(L.u64p))
+            if rc != 0:
+                raise RuntimeError("vdb_flat_knn failed")
+
+    with ThreadPoolExecutor(threads) as pool:
+        list(pool.map(worker, range(threads)))  # warm-up: one workspace per thread
+        t0 = time.perf_counter()
+        list(pool.map(worker, range(threads)))
+        t_mt = time.perf_counter() - t0
     ix.flat_knn(test, k)
     t0 = time.perf_counter()
     gi, gd, gc = ix.flat_knn(test, k)
@@ -720,6 +745,8 @@ def leg_config1(vdb, O, torch, device, local_rank, threads, k):
            "dim": 960, "queries": nq, "k": k, "dist": "L2Sqr",
            "gpu_per_query_calls": {"ms_per_query": round(t_loop / nq * 1e3, 4), "value": round(nq / t_loop, 1), "unit": "queries/s",
                                    "note": "host pointers, one call per query (PCIe-inclusive), as bench.rs loops"},
+           "gpu_per_query_calls_threads": {"threads": threads, "value": round(nq / t_mt, 1), "unit": "queries/s",
+                                           "note": "one vdb_flat_knn call per query (host pointers) from this many host threads at once"},
            "gpu_one_call": {"ms_per_query": round(t_batch / nq * 1e3, 5), "value": round(nq / t_batch, 1), "unit": "queries/s",
                             "note": "host pointers, 1000 queries in one call (PCIe-inclusive)"}}
     if O is not None:
@@ -735,8 +762,8 @@ def leg_config1(vdb, O, torch, device, local_rank, threads, k):
                                "sample": "FlatIndex::knn, all 1000 queries, one query per thread",
                                "serial": {"value": round(nq / t_ser, 1), "ms_per_query": round(t_ser / nq * 1e3, 4), "cores": 1}}
         leg["parity"] = {"queries_checked": nq,
-                         "indices_identical": bool(np.array_equal(gi.astype(np.uint64), ci) and np.array_equal(loop_i, ci)),
-                         "distances_bit_exact": bool(np.array_equal(gd, cd) and np.array_equal(loop_d, cd))}
+                         "indices_identical": bool(np.array_equal(gi.astype(np.uint64), ci) and np.array_equal(loop_i, ci) and np.array_equal(mt_i, ci)),
+                         "distances_bit_exact": bool(np.array_equal(gd, cd) and np.array_equal(loop_d, cd) and np.array_equal(mt_d, cd))}
         leg["recall_at_10"] = float(np.mean([O.recall(ci[q], gi[q].astype(np.uint64)) for q in range(nq)]))
     ix.close()
     return leg
