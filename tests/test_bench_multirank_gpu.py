@@ -110,3 +110,20 @@ def test_pipelined_steps_with_the_rccl_exchange_and_self_launch(tmp_path):
     env3 = dict(env2, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     out3 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env3, capture_output=True, text=True, timeout=300)
     assert out3.returncode != 0 and "WORLD_SIZE" in (out3.stderr + out3.stdout)
+
+
+def test_bench_reads_raw_f32_files(tmp_path):
+    """--base-file / --query-file: raw row-major f32 without header, the layout src/bin/convert_fvecs.rs:29-31 writes -- here the
+    reference's own gist_1000.bin / gist_test.bin; rows come from the file size, `data` names the files, parity against the oracle."""
+    g = os.path.join(ROOT, "tests", "golden")
+    args = ["--base-file", os.path.join(g, "gist_1000.bin"), "--query-file", os.path.join(g, "gist_test.bin"), "--steps", "2", "--warmup", "1",
+            "--legs", "none", "--cpu-queries", "48", "--nq", "200", "--dump", str(tmp_path / "f.npz")]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["rows"] == 1000 and line["data"].startswith("file: gist_1000.bin x gist_test.bin")
+    assert line["parity"] == {"queries_checked": 48, "indices_identical": True, "distances_bit_exact": True}
+    d = np.load(tmp_path / "f.npz")
+    assert d["idx"][0].tolist()[:3] == [918, 467, 725]  # SURVEY 8c: query 0 of gist_test against gist_1000
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--base-file", os.path.join(g, "gist_1000.bin")], capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "go together" in (bad.stderr + bad.stdout)
