@@ -266,22 +266,45 @@ static void host_search(Index &ix, const float *queries, uint64_t nq, uint64_t k
     for (uint64_t q0 = 0; q0 < nq; q0 += CHUNK) {
         uint64_t nb = std::min<uint64_t>(CHUNK, nq - q0);
         uint64_t kk = std::max<uint64_t>(k, 1);
-        ws->q.reserve(nb * ix.dim * sizeof(float));
-        ws->out_idx.reserve(nb * kk * sizeof(uint64_t));
-        ws->out_dist.reserve(nb * kk * sizeof(float));
-        ws->out_cnt.reserve(nb * sizeof(uint64_t));
-        VDB_HIP(hipMemcpyAsync(ws->q.p, queries + q0 * ix.dim, nb * ix.dim * sizeof(float), hipMemcpyHostToDevice, s));
-        fn(ix, *ws, ws->q.as<float>(), nb, k, ef, ws->out_idx.as<uint64_t>(), ws->out_dist.as<float>(),
-           ws->out_cnt.as<uint64_t>());
-        if (k) {
-            VDB_HIP(hipMemcpyAsync(out_idx + q0 * k, ws->out_idx.p, nb * k * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-            VDB_HIP(hipMemcpyAsync(out_dist + q0 * k, ws->out_dist.p, nb * k * sizeof(float), hipMemcpyDeviceToHost, s));
+        // ONE device block for the three outputs [ids | distances | counts] and ONE pinned host block [queries | that block]:
+        // a call moves two async copies through page-locked memory instead of four pageable ones (each of which the runtime
+        // stages and waits for on its own) -- what a db.search()-shaped call of one query pays for besides its kernels
+        const size_t qb = nb * ix.dim * sizeof(float), ib = nb * kk * sizeof(uint64_t), db = nb * kk * sizeof(float), cb = nb * sizeof(uint64_t);
+        const size_t off_d = ib, off_c = (ib + db + 7) & ~size_t(7), ob = off_c + cb, q_pad = (qb + 15) & ~size_t(15);
+        const bool staged = q_pad + ob <= (size_t(8) << 20);
+        ws->q.reserve(qb);
+        ws->out_idx.reserve(ob);
+        char *d_out = ws->out_idx.as<char>();
+        char *h = staged ? static_cast<char *>(ws->pinned(q_pad + ob)) : nullptr;
+        if (staged) {
+            std::memcpy(h, queries + q0 * ix.dim, qb);
+            VDB_HIP(hipMemcpyAsync(ws->q.p, h, qb, hipMemcpyHostToDevice, s));
+        } else {
+            VDB_HIP(hipMemcpyAsync(ws->q.p, queries + q0 * ix.dim, qb, hipMemcpyHostToDevice, s));
         }
-        std::vector<uint64_t> cnt(nb);
-        VDB_HIP(hipMemcpyAsync(cnt.data(), ws->out_cnt.p, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-        VDB_SYNC(s);
+        fn(ix, *ws, ws->q.as<float>(), nb, k, ef, reinterpret_cast<uint64_t *>(d_out), reinterpret_cast<float *>(d_out + off_d),
+           reinterpret_cast<uint64_t *>(d_out + off_c));
+        // (fn may have used the pinned block for its own flags and has synchronised after reading them: the block is free again)
+        if (staged) {
+            h = static_cast<char *>(ws->pinned(q_pad + ob));
+            VDB_HIP(hipMemcpyAsync(h + q_pad, d_out, ob, hipMemcpyDeviceToHost, s));
+            VDB_SYNC(s);
+            if (k) {
+                std::memcpy(out_idx + q0 * k, h + q_pad, nb * k * sizeof(uint64_t));
+                std::memcpy(out_dist + q0 * k, h + q_pad + off_d, nb * k * sizeof(float));
+            }
+            if (out_count) std::memcpy(out_count + q0, h + q_pad + off_c, cb);
+        } else {
+            if (k) {
+                VDB_HIP(hipMemcpyAsync(out_idx + q0 * k, d_out, nb * k * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+                VDB_HIP(hipMemcpyAsync(out_dist + q0 * k, d_out + off_d, nb * k * sizeof(float), hipMemcpyDeviceToHost, s));
+            }
+            std::vector<uint64_t> cnt(nb);
+            VDB_HIP(hipMemcpyAsync(cnt.data(), d_out + off_c, cb, hipMemcpyDeviceToHost, s));
+            VDB_SYNC(s);
+            if (out_count) std::memcpy(out_count + q0, cnt.data(), cb);
+        }
         ix.prof_collect(*ws);
-        if (out_count) std::memcpy(out_count + q0, cnt.data(), nb * sizeof(uint64_t));
     }
 }
 
