@@ -447,10 +447,24 @@ void ivf_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uin
     {   // the candidate rows of a call are nq x (rows of the np largest clusters) pair keys, twice: bound them
         uint64_t b = 0;
         for (uint64_t j = 0; j < np; j++) b += iv.sizes_desc[j];
-        const uint64_t qs = std::max<uint64_t>(1, (size_t(2) << 30) / (std::max<uint64_t>(b, 64) * 16));
+        uint64_t qs = std::max<uint64_t>(1, (size_t(2) << 30) / (std::max<uint64_t>(b, 64) * 16));
+        // The cluster-major 8-bit tier sorts the (query, probe) pairs of a call in one workgroup's LDS: 16 384 pairs.  A call with
+        // more pairs used to take the query-major tier, which fetches a cluster once per visit (1000 queries x 64 probes: 61 GB
+        // per step instead of ~1 GB per sub-batch) -- sub-batches of 16 384 / np queries keep it cluster-major.
+        if (use_q8 && g_ivf_q8 == 1 && np <= 4096 && nq * np > 16384) qs = std::min<uint64_t>(qs, std::max<uint64_t>(1, 16384 / np));
         if (nq > qs) {
-            for (uint64_t q0 = 0; q0 < nq; q0 += qs)
+            uint64_t tot[4] = {0, 0, 0, 0};
+            for (uint64_t q0 = 0; q0 < nq; q0 += qs) {
                 ivf_knn_device(ix, ws, d_q + q0 * ix.dim, std::min(qs, nq - q0), k, n_probes, d_idx + q0 * k, d_dist + q0 * k, d_cnt + q0, use_half, use_q8);
+                tot[0] += iv.last_offers.load();
+                tot[1] += iv.last_kept.load();
+                tot[2] += iv.last_kept_q8.load();
+                tot[3] += iv.last_rows_fetched_q8.load();
+            }
+            iv.last_offers = tot[0];  // (the statistics of a call are those of all its sub-batches)
+            iv.last_kept = tot[1];
+            iv.last_kept_q8 = tot[2];
+            iv.last_rows_fetched_q8 = tot[3];
             return;
         }
     }
