@@ -903,6 +903,22 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, step_stats, args, threads
                           {"workload": "pq_flat_knn_gist1m", "n_bits": 4, "m": dim // 3, "train_and_encode_s": round(pq_build_s, 1)})
     legs["pq_flat"]["one_call_of_1"] = small_call(
         ix, lambda: ix.knn_pq_device(queries.data_ptr(), 1, k, 100, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr()), 1)
+    # the same table shape with 8-bit codes (n_bits = 8, pq_table.rs:142-145: 256 centroids per group, 320 B per code row): one query
+    # per pass on a one-byte table in LDS (k_pq_adc8), so the scan is bound by the code bytes -- 320 MB per query
+    tr8 = vdb.GpuIndex(dim, "l2sqr", device=local_rank)
+    tr8.add_device(base.data_ptr(), 20000)
+    tr8.pq_build(n_bits=8, m=dim // 3, train_n=0, max_iter=5, tol=1e-6, seed=42)
+    cent8 = tr8.pq_export()["centroids"]
+    tr8.close()
+    ix.pq_attach(8, dim // 3, cent8, None)
+    legs["pq_flat"]["n_bits_8"] = run(ix, "pq_flat", n, 100,
+                                      lambda: ix.knn_pq_device(queries.data_ptr(), nq, k, 100, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr()),
+                                      {"workload": "pq_flat_knn_gist1m_8bit", "n_bits": 8, "m": dim // 3})
+    r8 = legs["pq_flat"]["n_bits_8"]["roofline"]
+    if r8:
+        r8.pop("lds_gather", None)
+        r8["units_per_launch"] = ("queries x rows x m code bytes: one query per pass of k_pq_adc8 over the 320-MB code mirror (partly served by the "
+                                  "Infinity Cache from one pass to the next, so the rate can exceed what HBM alone delivers)")
     ix.close()
     del ix
     torch.cuda.empty_cache()

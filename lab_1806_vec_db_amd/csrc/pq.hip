@@ -825,6 +825,212 @@ __global__ __launch_bounds__(256) void k_pq_adc_exact(const uint8_t *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 8-bit codes (n_bits = 8, pq_table.rs:142-145: 256 centroids per group) on a quantised pass of their own (round 3).
+// A query's f32 table is m x 256 entries -- 327 KB at m = 320: no form of it that serves several queries fits LDS, and the
+// f32 scan reads it through L1 / L2 (0.37 ms per query per 1M rows).  One query's table at ONE BYTE per entry does fit
+// (m x 256 B = 80 KB):  lut8[g][c] = min(255, floor((lut[g][c] - mn_g) / D)),  D = sum_g range_g / (128 m).
+// The minimum with 255 only lowers an entry, so M + D * S8 <= sum_g lut[g][code_g] still holds (M = sum mn_g) and the
+// superset threshold of the 16-bit pass carries over:  S <= tau  ==>  S8 <= T8 := floor((tau (1 + 2 m 2^-24) - M (1 - 1e-12)) / D) + 2.
+// All lanes of a wave look up the SAME group at a time: its 256 one-byte entries are exactly one word per LDS bank, so a
+// wave's 64 lookups never conflict.  The scan is bound by the code bytes -- m bytes per row and query, one query per pass
+// -- i.e. by HBM: 320 MB per query at m = 320.  Candidates get their exact f32 sums in group order (k_pq_adc_exact8: the
+// query's f32 table read through L2) and the pairs above tau are dropped, as on the 16-bit pass.  L2Sqr only.
+__global__ __launch_bounds__(256) void k_pq_quant8(const float *__restrict__ lut, uint32_t m, uint32_t m_pad, uint32_t nq, uint8_t *__restrict__ img,
+                                                   double *__restrict__ qM, double *__restrict__ qD, uint32_t *__restrict__ qflag) {
+    const uint32_t q = blockIdx.x, t = threadIdx.x;
+    __shared__ double sR[256], sM[256];
+    __shared__ float smn[1024];  // group minima (m <= 1024: the table of a larger m does not fit LDS anyway)
+    __shared__ uint32_t sbad;
+    if (t == 0) sbad = 0;
+    __syncthreads();
+    const float *lq = lut + uint64_t(q) * m * 256;
+    double R = 0.0, M = 0.0;
+    bool bad = false;
+    // a wave per group, 4 entries per lane: coalesced reads, wave-level min / max
+    for (uint32_t g = t >> 6; g < m; g += 4) {
+        const float4 v = reinterpret_cast<const float4 *>(lq + g * 256)[t & 63];
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        float mn = INFINITY, mx = -INFINITY;
+        bool b = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (!(e[j] >= 0.0f) || e[j] > 3.0e38f) b = true;  // NaN, negative, inf: the query takes the f32 scan
+            mn = fminf(mn, e[j]);
+            mx = fmaxf(mx, e[j]);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            mn = fminf(mn, __shfl_xor(mn, off));
+            mx = fmaxf(mx, __shfl_xor(mx, off));
+        }
+        if (__ballot(b) != 0) bad = true;
+        if ((t & 63) == 0) {
+            smn[g] = mn;
+            R += double(mx) - double(mn);
+            M += double(mn);
+        }
+    }
+    if (bad) atomicOr(&sbad, 1u);
+    sR[t] = R;
+    sM[t] = M;
+    __syncthreads();
+    for (uint32_t st = 128; st > 0; st >>= 1) {
+        if (t < st) {
+            sR[t] += sR[t + st];
+            sM[t] += sM[t + st];
+        }
+        __syncthreads();
+    }
+    R = sR[0];
+    M = sM[0];
+    const bool flag = sbad != 0 || !(R < 1.0e300) || !(fabs(M) < 1.0e300);
+    const double D = (!flag && R > 0.0) ? R / (128.0 * double(m)) : 1.0;
+    uint8_t *dst = img + uint64_t(q) * m_pad * 256;
+    for (uint32_t i = m * 256 + t; i < m_pad * 256; i += 256) dst[i] = 0;  // groups of the padded code bytes
+    for (uint32_t i = t; i < m * 256; i += 256) {
+        const float mn = smn[i >> 8];
+        double x = flag ? 0.0 : floor((double(lq[i]) - double(mn)) / D);
+        x = x < 0.0 ? 0.0 : (x > 255.0 ? 255.0 : x);
+        dst[i] = (uint8_t)x;
+    }
+    if (t == 0) {
+        qM[q] = M;
+        qD[q] = D;
+        qflag[q] = flag ? 1u : 0u;
+    }
+}
+
+struct Adc8Args {
+    const uint4 *codes_t;   // word-major mirror of the (zero-padded) code rows
+    uint64_t n;
+    uint32_t nwords, m;     // 16-B code words per row; groups of the table (the image holds 16 * nwords of them)
+    const uint8_t *img;     // [nq][16 * nwords * 256]
+    const double *qM, *qD;
+    const uint32_t *qflag;
+    const float *tau;
+    uint32_t nq;
+    uint64_t rows_per_wg;   // multiple of 64
+    uint64_t *cand;         // [nq][cap] row ids
+    uint32_t *cnt;          // [nq]
+    uint32_t cap;
+    uint32_t blk_step;      // SAMPLE: every blk_step-th 1024-row block
+    float *s8_out;          // SAMPLE: [nq][ld_s] quantised sums as floats, +inf past n
+    uint64_t ld_s;
+};
+constexpr uint32_t ADC8_WGBUF = 4096;  // LDS hit buffer entries (one query per workgroup)
+
+template <bool SAMPLE>
+__global__ __launch_bounds__(1024) void k_pq_adc8(Adc8Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+    const uint32_t tid = threadIdx.x, q = blockIdx.y;
+    const uint32_t tab_bytes = a.nwords * 16 * 256;
+    uint8_t *tab = smem8;                                                  // [16 nwords][256]
+    uint32_t *hit_row = reinterpret_cast<uint32_t *>(smem8 + tab_bytes);   // [ADC8_WGBUF]
+    uint32_t *hit_n = hit_row + ADC8_WGBUF;                                // [0] entries, [1] threshold, [2] base of the flush
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.img + uint64_t(q) * tab_bytes);
+        uint4 *dst = reinterpret_cast<uint4 *>(tab);
+        for (uint32_t i = tid; i < tab_bytes / 16; i += 1024) dst[i] = src[i];
+        if (tid == 0) {
+            hit_n[0] = 0;
+            int32_t T = -1;
+            if (!SAMPLE && a.qflag[q] == 0) {
+                const double x = floor((double(a.tau[q]) * (1.0 + 2.0 * double(a.m) * 0x1p-24) - a.qM[q] * (1.0 - 1e-12)) / a.qD[q]) + 2.0;
+                // tau = +inf / NaN: everything passes -> the list overflows and the query takes the f32 scan
+                T = !(x < 2.0e9) ? 2000000000 : (x < 0.0 ? -1 : (int32_t)x);
+            }
+            hit_n[1] = (uint32_t)T;
+        }
+    }
+    __syncthreads();
+    const int32_t T = (int32_t)hit_n[1];
+    const uint64_t n_sb = SAMPLE ? ((a.n + 1023) / 1024 + a.blk_step - 1) / a.blk_step : 0;
+    const uint64_t r_begin = SAMPLE ? uint64_t(blockIdx.x) * a.blk_step * 1024 : uint64_t(blockIdx.x) * a.rows_per_wg;
+    const uint64_t r_end = SAMPLE ? (blockIdx.x < n_sb ? (n_sb - 1) * a.blk_step * 1024 + 1 : 0)
+                                  : (r_begin + a.rows_per_wg < a.n ? r_begin + a.rows_per_wg : a.n);
+    const uint64_t r_inc = SAMPLE ? uint64_t(gridDim.x) * a.blk_step * 1024 : 1024;
+    const uint32_t nwords = a.nwords;
+    for (uint64_t rb = r_begin; rb < r_end; rb += r_inc) {
+        const uint64_t row = rb + tid;
+        const bool valid = SAMPLE ? row < a.n : row < r_end;
+        const uint64_t lrow = (SAMPLE && !valid) ? a.n - 1 : row;
+        const uint4 *cw = a.codes_t + (lrow >> 6) * nwords * 64 + (lrow & 63);
+        uint32_t s0 = 0, s1 = 0;  // two running sums: the lookups of a word are independent, the adds need not be one chain
+        uint4 v = cw[0];
+        for (uint32_t w = 0; w < nwords; w++) {
+            const uint4 cur = v;
+            if (w + 1 < nwords) v = cw[(w + 1) * 64];  // next code word while this one is looked up
+            const uint8_t *tw = tab + w * 4096;       // 16 groups x 256 entries
+            const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+            for (int wi = 0; wi < 4; wi++) {
+                const uint32_t c = words[wi];
+                const uint32_t e0 = tw[(4 * wi + 0) * 256 + (c & 0xffu)], e1 = tw[(4 * wi + 1) * 256 + ((c >> 8) & 0xffu)];
+                const uint32_t e2 = tw[(4 * wi + 2) * 256 + ((c >> 16) & 0xffu)], e3 = tw[(4 * wi + 3) * 256 + (c >> 24)];
+                s0 += e0 + e2;
+                s1 += e1 + e3;
+            }
+        }
+        const uint32_t S8 = s0 + s1;
+        if (SAMPLE) {
+            const uint64_t col = rb / (uint64_t(a.blk_step) * 1024) * 1024 + tid;
+            a.s8_out[uint64_t(q) * a.ld_s + col] = valid ? float(S8) : INFINITY;
+            continue;
+        }
+        if (valid && (int32_t)S8 <= T) {
+            const uint32_t pos = atomicAdd(&hit_n[0], 1u);
+            if (pos < ADC8_WGBUF)
+                hit_row[pos] = uint32_t(row);
+            else
+                atomicAdd(&a.cnt[q], a.cap + 1);  // mark the query as overflowed (-> f32 scan)
+        }
+    }
+    if (SAMPLE) return;
+    __syncthreads();
+    uint32_t total = hit_n[0];
+    if (total > ADC8_WGBUF) total = ADC8_WGBUF;
+    if (tid == 0 && total > 0) hit_n[2] = atomicAdd(&a.cnt[q], total);
+    __syncthreads();
+    const uint32_t base = hit_n[2];
+    for (uint32_t i = tid; i < total; i += 1024) {
+        const uint32_t slot = base + i;
+        if (slot < a.cap) a.cand[uint64_t(q) * a.cap + slot] = hit_row[i];
+    }
+}
+
+// exact f32 ADC sums of the candidates of an 8-bit table, strict group order (pq_table.rs:254-292), the query's f32 table read
+// from global memory (327 KB at m = 320: L2-resident while its workgroup runs).  Row ids in, pair keys out (PAIR_NONE above tau).
+__global__ __launch_bounds__(256) void k_pq_adc_exact8(const uint8_t *__restrict__ codes, uint32_t enc_dim, uint32_t m, const float *__restrict__ lut,
+                                                       const float *__restrict__ tau, uint64_t *__restrict__ cand, const uint32_t *__restrict__ cnt,
+                                                       uint32_t cap, uint32_t *__restrict__ valid) {
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t total = cnt[q];
+    if (total > cap) return;  // overflowed list: the query is redone by the f32 scan
+    const float *lq = lut + uint64_t(q) * m * 256;
+    const float t = tau[q];
+    uint64_t *cq = cand + uint64_t(q) * cap;
+    uint32_t kept = 0;
+    for (uint32_t i = tid; i < total; i += 256) {
+        const uint32_t row = uint32_t(cq[i]);
+        const uint8_t *cb = codes + uint64_t(row) * enc_dim;
+        float sum = 0.0f;
+        uint32_t g = 0;
+        for (; g + 8 <= m; g += 8) {  // 8 table entries in flight, then 8 adds in group order
+            float e[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) e[j] = lq[(g + j) * 256 + cb[g + j]];
+#pragma unroll
+            for (int j = 0; j < 8; j++) sum = sum + e[j];
+        }
+        for (; g < m; g++) sum = sum + lq[g * 256 + cb[g]];
+        const bool keep = sum <= t;
+        cq[i] = keep ? pair_key(sum, row) : PAIR_NONE;
+        kept += keep ? 1u : 0u;
+    }
+    if (kept) atomicAdd(&valid[q], kept);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // ResultSet::pq_resort (candidate_pair.rs:102-108): replay `add` over the candidates in ADC order.
 // `add` admits a pair when the set is not full, or when its DISTANCE is strictly smaller than the worst
 // distance (candidate_pair.rs:61-74) -- not the lexicographic test -- so ties at the cut keep the
@@ -1031,13 +1237,14 @@ static void pq_install(Index &ix, uint64_t n_bits, uint64_t m, const float *cent
     pq.d_codes.reserve(std::max<uint64_t>(ix.n, 1) * pq.enc_dim);
 }
 
-// word-major mirror of the codes for the quantised scan (4-bit tables; rows padded to whole 16-B code words)
+// word-major mirror of the codes for the quantised scans (rows padded to whole 16-B code words)
 static void pq_tile_codes(Index &ix) {
     PQState &pq = ix.pq;
     pq.codes_t_valid = false;
-    if (pq.n_bits != 4 || ix.n == 0) return;
+    if ((pq.n_bits != 4 && pq.n_bits != 8) || ix.n == 0) return;
     const uint32_t nwords = (uint32_t)((pq.enc_dim + 15) / 16);
-    if (size_t(nwords) * 32 * 256 > 150 * 1024) return;  // the 16-bit tables of 8 queries would not fit LDS: such tables never take the quantised scan
+    // tables whose quantised image (4-bit: 16-bit entries of 8 queries; 8-bit: one-byte entries of one query) would not fit LDS never take the quantised scan
+    if (size_t(nwords) * (pq.n_bits == 4 ? 32 * 256 : 16 * 256) > 150 * 1024) return;
     const uint64_t total = (ix.n + 63) / 64 * 64 * nwords;
     pq.d_codes_t.reserve(total * sizeof(uint4));
     WsLease ws(ix);
@@ -1491,6 +1698,96 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
         launch_topk_dense(ws.dense.as<float>(), ld, n, (uint32_t)gn, efk, ws.lists.as<uint64_t>(), s);
         launch_topk_merge(ws.lists.as<uint64_t>(), nl, cape, (uint32_t)gn, efk, ws.keys_a.as<uint64_t>() + g0 * cape, s);
     };
+
+    // ---- 8-bit codes: one query per pass on a one-byte table in LDS (k_pq_adc8, see there) ------------------------------------
+    {
+        const uint32_t nw8 = (uint32_t)((pq.enc_dim + 15) / 16), m8 = 16 * nw8;
+        const size_t lds8 = size_t(m8) * 256 + ADC8_WGBUF * 4 + 16;
+        const bool q8 = g_adc16 != 1 && pq.codes_t_valid && pq.n_bits == 8 && ix.dist == 0 && pq.m <= 1024 && lds8 <= 150 * 1024 && n >= 65536;
+        const uint64_t nblk8 = (n + 1023) / 1024;
+        uint32_t step8 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, nblk8 / 16)), rank8 = efk;
+        {
+            const uint32_t r = efk / 8 < 8 ? 8 : efk / 8;
+            const uint64_t target = std::max<uint64_t>(1024, 4ull * efk);
+            const uint64_t st = std::min<uint64_t>(nblk8 / 16, target / r);
+            const double thr = r < 16 ? r / 8.0 : (r < 32 ? r / 4.0 : r / 3.0);
+            if (r < efk && st >= step8 && double(efk) <= thr * double(st) * 1.1) {
+                rank8 = r;
+                step8 = (uint32_t)st;
+            }
+        }
+        const uint64_t n_sb8 = (nblk8 + step8 - 1) / step8, n_s8 = n_sb8 * 1024;
+        if (q8 && n_s8 >= 2 * uint64_t(efk) && n_s8 >= 64ull * rank8) {
+            const uint64_t ld_s = (n_s8 + 63) & ~63ull;
+            const uint32_t nl_s = topk_num_lists(n_s8);
+            const uint32_t cap = (uint32_t)std::min<uint64_t>(65536, std::max<uint64_t>(4096, 4ull * rank8 * step8));
+            const uint64_t GQ = std::max<uint64_t>(64, std::min<uint64_t>(2048, (size_t(256) << 20) / (ld_s * sizeof(float))));
+            const uint64_t gq_max = std::min<uint64_t>(GQ, nq);
+            ws.dense.reserve(gq_max * ld_s * sizeof(float));
+            ws.lists.reserve(std::max<size_t>(gq_max * nl_s * cape, gq_max * size_t(cap)) * sizeof(uint64_t));
+            ws.misc.reserve(nq * (sizeof(float) + 2 * sizeof(uint32_t)));
+            float *d_tau = ws.misc.as<float>();
+            uint32_t *d_hits = reinterpret_cast<uint32_t *>(d_tau + nq), *d_valid = d_hits + nq;
+            VDB_HIP(hipMemsetAsync(d_hits, 0, 2 * nq * sizeof(uint32_t), s));
+            ws.qfrag_g.reserve(nq * size_t(m8) * 256);
+            ws.qaux.reserve(nq * (2 * sizeof(double) + sizeof(uint32_t)));
+            double *d_qM = ws.qaux.as<double>(), *d_qD = d_qM + nq;
+            uint32_t *d_qflag = reinterpret_cast<uint32_t *>(d_qD + nq);
+            hipLaunchKernelGGL(k_pq_quant8, dim3((unsigned)nq), dim3(256), 0, s, ws.lut.as<float>(), (uint32_t)pq.m, m8, (uint32_t)nq,
+                               ws.qfrag_g.as<uint8_t>(), d_qM, d_qD, d_qflag);
+            func_max_lds(reinterpret_cast<const void *>(&k_pq_adc8<false>), int(160 * 1024));
+            func_max_lds(reinterpret_cast<const void *>(&k_pq_adc8<true>), int(160 * 1024));
+            for (uint64_t g0 = 0; g0 < nq; g0 += GQ) {
+                const uint64_t gn = std::min<uint64_t>(GQ, nq - g0);
+                Adc8Args a{};
+                a.codes_t = pq.d_codes_t.as<uint4>();
+                a.n = n;
+                a.nwords = nw8;
+                a.m = (uint32_t)pq.m;
+                a.img = ws.qfrag_g.as<uint8_t>() + g0 * size_t(m8) * 256;
+                a.qM = d_qM + g0;
+                a.qD = d_qD + g0;
+                a.qflag = d_qflag + g0;
+                a.tau = d_tau + g0;
+                a.nq = (uint32_t)gn;
+                a.cand = ws.lists.as<uint64_t>();
+                a.cnt = d_hits + g0;
+                a.cap = cap;
+                a.blk_step = step8;
+                a.s8_out = ws.dense.as<float>();
+                a.ld_s = ld_s;
+                // every workgroup loads its query's 80-KB table: few workgroups per query, enough of them to fill the chip
+                const uint32_t gx = (uint32_t)std::min<uint64_t>(n_sb8, std::max<uint64_t>(1, (2ull * ix.num_cu + gn - 1) / gn));
+                hipLaunchKernelGGL(k_pq_adc8<true>, dim3(gx, (unsigned)gn), dim3(1024), lds8, s, a);
+                if (n_s8 <= select_tau_max_n()) {
+                    launch_select_tau(ws.dense.as<float>(), ld_s, (uint32_t)n_s8, (uint32_t)gn, (uint32_t)gn, rank8, d_tau + g0, s);
+                } else {
+                    launch_topk_dense(ws.dense.as<float>(), ld_s, n_s8, (uint32_t)gn, rank8, ws.lists.as<uint64_t>(), s);
+                    launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, cape, (uint32_t)gn, rank8, ws.keys_a.as<uint64_t>() + g0 * cape, s);
+                    launch_extract_tau(ws.keys_a.as<uint64_t>() + g0 * cape, cape, (uint32_t)gn, rank8, d_tau + g0, s);
+                }
+                hipLaunchKernelGGL(k_pq_tau_from16, dim3((unsigned)((gn + 255) / 256)), dim3(256), 0, s, d_tau + g0, d_qM + g0, d_qD + g0, d_qflag + g0,
+                                   (uint32_t)pq.m, (uint32_t)gn);
+                const uint32_t nwg = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ix.num_cu, (4ull * ix.num_cu + gn - 1) / gn));
+                a.rows_per_wg = ((n + nwg - 1) / nwg + 63) / 64 * 64;
+                const uint32_t nwg_eff = (uint32_t)((n + a.rows_per_wg - 1) / a.rows_per_wg);
+                ix.prof_begin(ws, "pq_adc", double(gn) * double(n) * pq.enc_dim);
+                hipLaunchKernelGGL(k_pq_adc8<false>, dim3(nwg_eff, (unsigned)gn), dim3(1024), lds8, s, a);
+                ix.prof_end(ws);
+                pq.adc16_queries += gn;
+                hipLaunchKernelGGL(k_pq_adc_exact8, dim3((unsigned)gn), dim3(256), 0, s, pq.d_codes.as<uint8_t>(), (uint32_t)pq.enc_dim, (uint32_t)pq.m,
+                                   ws.lut.as<float>() + g0 * lsz, d_tau + g0, ws.lists.as<uint64_t>(), d_hits + g0, cap, d_valid + g0);
+                launch_topk_merge_counted(ws.lists.as<uint64_t>(), cap, d_hits + g0, (uint32_t)gn, efk, ws.keys_a.as<uint64_t>() + g0 * cape, s);
+            }
+            uint32_t *hv = static_cast<uint32_t *>(ws.pinned(2 * nq * sizeof(uint32_t)));
+            VDB_HIP(hipMemcpyAsync(hv, d_hits, 2 * nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            VDB_SYNC(s);
+            const uint64_t need = std::min<uint64_t>(efk, n);
+            for (uint64_t q = 0; q < nq; q++)
+                if (hv[q] > cap || hv[nq + q] < need) dense_group(q, 1);  // overflowed / short / unquantisable: the f32 scan answers
+            return;
+        }
+    }
 
     const uint64_t nblk = (n + nt - 1) / nt;
     // Threshold sample: every step-th row block, tau = the s_rank-th smallest sampled ADC value.  s_rank = efk guarantees

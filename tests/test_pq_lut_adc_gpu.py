@@ -198,3 +198,42 @@ def test_quantised_scan_with_padded_code_words(dim, m, dist, kind):
         oi, od = O.flat_knn_pq(base, opq, qs[q], 10, 100, kind)
         assert a[0][q, :len(oi)].tolist() == oi.tolist() and np.array_equal(a[1][q, :len(od)], od)
     ix.close()
+
+
+@pytest.mark.parametrize("dim,m", [(64, 16), (80, 20), (96, 33), (128, 64)])
+def test_quantised_scan_of_8_bit_codes(dim, m):
+    """n_bits = 8 (256 centroids per group, pq_table.rs:142-145) on its own quantised pass: one query per pass, a one-byte table in
+    LDS, exact f32 sums for the candidates (k_pq_adc8 / k_pq_adc_exact8).  Same answers as the f32 scan (pq_adc16 = 1) and as
+    the oracle, whole and padded code words, ties, a degenerate query; Cosine tables keep the f32 scan."""
+    import lab_1806_vec_db_amd as vdb
+    from oracle import oracle as O
+
+    n = 70000
+    rng = np.random.default_rng(dim * 7 + m)
+    base = (rng.standard_normal((n, dim)) * rng.uniform(0.2, 2.0, dim)).astype(np.float32)
+    base[35000:35010] = base[:10]
+    qs = (base[rng.integers(0, n, 10)] + 0.1 * rng.standard_normal((10, dim))).astype(np.float32)
+    qs[3, 2] = np.nan  # unquantisable table -> the f32 scan answers that query
+    for dist, kind in (("l2sqr", 0), ("cosine", 1)):
+        ix = vdb.GpuIndex(dim, dist)
+        ix.batch_add(base)
+        ix.pq_build(n_bits=8, m=m, train_n=3000, max_iter=2, seed=1)
+        pq = ix.pq_export()
+        opq = O.PQ.from_centroids(dim, m, 8, kind, pq["centroids"])
+        opq.set_codes(pq["codes"])
+        for ef in (100, 700):
+            a = ix.knn_pq(qs, 10, ef)
+            ran = ix.get_stat("pq_adc16_queries")
+            assert (ran > 0) == (kind == 0)
+            ix.set_param("pq_adc16", 1)
+            try:
+                b = ix.knn_pq(qs, 10, ef)
+            finally:
+                ix.set_param("pq_adc16", 0)
+            assert ix.get_stat("pq_adc16_queries") == ran
+            assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a, b)), (dist, ef)
+            for q in range(10):
+                oi, od = O.flat_knn_pq(base, opq, qs[q], 10, ef, kind)
+                assert a[0][q, :len(oi)].tolist() == oi.tolist(), (dist, ef, q)
+                assert np.array_equal(a[1][q, :len(od)], od, equal_nan=True)
+        ix.close()
