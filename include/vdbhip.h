@@ -146,7 +146,8 @@ int vdb_flat_set_mode(vdb_index *idx, int mode);
  *   "hnsw_pool_cap"    most live candidates the fast HNSW walk keeps in LDS (it uses min(this, ef + max_m0 + 64); maximum 2048) before a query is handed to
  *                      the heap walk; tests lower it to exercise that hand-over
  *   "pq_adc16"         quantised first pass of the threshold-filter ADC scan (16-bit tables, 8 queries per pass; exact f32
- *                      sums for its candidates): 0 auto (4-bit codes, whole 16-B code words; L2Sqr 8 and Cosine 7 queries per pass), 1 off
+ *                      sums for its candidates): 0 auto (4-bit codes of any m: L2Sqr 8 and Cosine 7 queries per pass; 8-bit codes, L2Sqr: one
+ *                      query per pass on a one-byte table), 1 off
  *   "pq_sample16"      the threshold sample of that scan on the quantised tables as well (L2Sqr): 0 auto (on), 1 off (exact f32 sample).
  *                      The threshold only decides how many rows the scan keeps; the count is checked and short lists are redone
  *   "flat_small"       FlatIndex::knn of a few queries over a small table in ONE launch (the db.search() shape; dim % 4 == 0, k <= 64):
