@@ -623,7 +623,11 @@ __global__ __launch_bounds__(1024) void k_pq_adc16(Adc16Args a) {
         const bool valid = SAMPLE ? row < a.n : row < r_end;
         // word w of row (rb + tid): tile = row / 64 (uniform in the wave: rb is a multiple of 64), lane = row % 64; rows
         // past n inside the last tile are zero padding
-        const uint64_t lrow = (SAMPLE && !valid) ? a.n - 1 : row;  // (the scan's blocks end inside the last, zero-padded tile; a sample block may not)
+        // Lanes past the workgroup's share (a share is shorter than the 1024 lanes when the table has fewer than 1024 rows per
+        // CU) must not form addresses from their row number: the last workgroup's reach up to 1023 rows past the table, i.e.
+        // past the mirror -- found by tools/fuzz_pq.py as a memory-access fault on a 74 205-row table whose mirror ended on
+        // a page boundary (configuration #727, seed 4242; the over-read is as old as the kernel).  They re-read a valid row.
+        const uint64_t lrow = valid ? row : (SAMPLE ? a.n - 1 : r_end - 1);
         const uint4 *cw = a.codes_t + (lrow >> 6) * nwords * 64 + (lrow & 63);
         uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         // one 16-B code word = 32 groups.  Byte b of a 32-bit word: low nibble = group 8wi + 2b, high nibble the next one;
@@ -777,7 +781,9 @@ __global__ __launch_bounds__(256) void k_pq_adc_exact(const uint8_t *__restrict_
         const uint32_t row = uint32_t(cq[i]);
         const uint4 *cw = reinterpret_cast<const uint4 *>(codes + uint64_t(row) * enc_dim);
         float sum = 0.0f, cdp = 0.0f;
-        if ((enc_dim & 15u) != 0) {  // code rows that are not whole (16-B aligned) words: byte by byte, same group order
+        const bool words = (enc_dim & 15u) == 0 && m == 2 * enc_dim;  // whole 16-B words AND every nibble a real group
+        if (!words) {  // otherwise byte by byte, same group order (an odd m leaves the last high nibble without a table:
+            // tools/fuzz_pq.py, Cosine, m = 31 / 63 -- the word loop below would add whatever sits behind the query's table)
             const uint8_t *cb = codes + uint64_t(row) * enc_dim;
             for (uint32_t g = 0; g < m; g += 2) {
                 const uint32_t byte = cb[g >> 1];
@@ -790,8 +796,8 @@ __global__ __launch_bounds__(256) void k_pq_adc_exact(const uint8_t *__restrict_
                 }
             }
         }
-        uint4 v = (enc_dim & 15u) == 0 ? cw[0] : make_uint4(0, 0, 0, 0);
-        for (uint32_t w = 0; w < ((enc_dim & 15u) == 0 ? enc_dim / 16 : 0u); w++) {
+        uint4 v = words ? cw[0] : make_uint4(0, 0, 0, 0);
+        for (uint32_t w = 0; w < (words ? enc_dim / 16 : 0u); w++) {
             const uint32_t words[4] = {v.x, v.y, v.z, v.w};
             if (w + 1 < enc_dim / 16) v = cw[w + 1];
 #pragma unroll
@@ -953,7 +959,7 @@ __global__ __launch_bounds__(1024) void k_pq_adc8(Adc8Args a) {
     for (uint64_t rb = r_begin; rb < r_end; rb += r_inc) {
         const uint64_t row = rb + tid;
         const bool valid = SAMPLE ? row < a.n : row < r_end;
-        const uint64_t lrow = (SAMPLE && !valid) ? a.n - 1 : row;
+        const uint64_t lrow = valid ? row : (SAMPLE ? a.n - 1 : r_end - 1);  // (see k_pq_adc16: idle lanes re-read a valid row)
         const uint4 *cw = a.codes_t + (lrow >> 6) * nwords * 64 + (lrow & 63);
         uint32_t s0 = 0, s1 = 0;  // two running sums: the lookups of a word are independent, the adds need not be one chain
         uint4 v = cw[0];

@@ -165,11 +165,13 @@ def test_quantised_threshold_sample_keeps_results():
 
 
 @pytest.mark.parametrize("dist,kind", [("l2sqr", 0), ("cosine", 1)])
-@pytest.mark.parametrize("dim,m", [(64, 43), (192, 171), (344, 342), (96, 33)])
+@pytest.mark.parametrize("dim,m", [(64, 43), (192, 171), (344, 342), (96, 33), (100, 31), (128, 63)])
 def test_quantised_scan_with_padded_code_words(dim, m, dist, kind):
     """Tables whose code rows are not whole 16-B words (odd m; the DB's default m = ceil(dim / 3): 171 at dim 512, 342 at dim
     1024) on the quantised scan: rows padded with zero bytes, zero tables for the padded groups.  Same answers as the f32 scan
-    (pq_adc16 = 1) and as the oracle (pq_table.rs:239-301), and the quantised kernel really ran."""
+    (pq_adc16 = 1) and as the oracle (pq_table.rs:239-301), and the quantised kernel really ran.  m = 31 / 63: whole code words whose
+    last high nibble has no group (tools/fuzz_pq.py #127 / #349, seed 4242: the exact stage's word loop added what sits behind the
+    query's table -- the |centroid|^2 table under Cosine)."""
     import lab_1806_vec_db_amd as vdb
     from oracle import oracle as O
 
@@ -237,3 +239,36 @@ def test_quantised_scan_of_8_bit_codes(dim, m):
                 assert a[0][q, :len(oi)].tolist() == oi.tolist(), (dist, ef, q)
                 assert np.array_equal(a[1][q, :len(od)], od, equal_nan=True)
         ix.close()
+
+
+def test_quantised_scan_short_shares_configuration_727():
+    """tools/fuzz_pq.py seed 4242 #727 -- dim 32, 74 205 rows, 4-bit m = 9 (5-byte code rows), one query, k = 1, ef = 64, L2Sqr, f32
+    threshold sample: a memory-access fault.  With fewer than 1024 rows per CU a workgroup's share of the quantised scan is shorter
+    than its 1024 lanes, and the idle lanes of the LAST workgroup formed code-word addresses up to 1023 rows past the table -- past
+    the word-major mirror, which here ended on a page boundary (k_pq_adc16 since round 2; idle lanes now re-read a valid row).
+    The shape as a regression test (whether an over-read faults depends on what the allocator put behind the mirror)."""
+    import lab_1806_vec_db_amd as vdb
+    from oracle import oracle as O
+
+    n, dim, m = 74205, 32, 9
+    rng = np.random.default_rng(727)
+    base = np.round(np.abs(rng.normal(0.07, 0.045, (n, dim))), 4).astype(np.float32)
+    qs = (base[rng.integers(0, n, 3)] + 0.05 * rng.standard_normal((3, dim))).astype(np.float32)
+    ix = vdb.GpuIndex(dim, "l2sqr")
+    ix.batch_add(base)
+    ix.pq_build(n_bits=4, m=m, train_n=1500, max_iter=2, seed=727)
+    pq = ix.pq_export()
+    opq = O.PQ.from_centroids(dim, m, 4, 0, pq["centroids"])
+    opq.set_codes(pq["codes"])
+    try:
+        for s16 in (1, 0):
+            ix.set_param("pq_sample16", s16)
+            for nq in (1, 3):
+                idx, d, cnt = ix.knn_pq(qs[:nq], 1, 64)
+                for q in range(nq):
+                    oi, od = O.flat_knn_pq(base, opq, qs[q], 1, 64, 0)
+                    assert idx[q, :1].tolist() == oi.tolist() and np.array_equal(d[q, :1], od)
+    finally:
+        ix.set_param("pq_sample16", 0)
+    assert ix.get_stat("pq_adc16_queries") > 0
+    ix.close()
