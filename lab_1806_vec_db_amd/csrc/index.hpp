@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -15,24 +16,47 @@
 namespace vdb {
 
 // growable device buffer (amortised doubling, like Vec<T>: vec_set.rs:113-118)
+// VDB_EFENCE=1 (debugging aid, read once): every buffer is placed so that it ENDS where its allocation ends, and allocations are
+// whole 2-MiB granules -- a kernel that reads or writes more than the 256-B alignment slack past a buffer then leaves the
+// mapping and faults at once instead of silently touching whatever the allocator put there (how the over-read of
+// k_pq_adc16's idle lanes stayed unseen for a round).  Used for soaks of the test suite, never in production.
+inline bool devbuf_efence() {
+    static const bool on = [] {
+        const char *e = std::getenv("VDB_EFENCE");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    void *base = nullptr;  // what hipMalloc returned (== p unless VDB_EFENCE)
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
+        if (base) (void)hipFree(base);
+        p = base = nullptr;
         cap = 0;
+    }
+    static void alloc(size_t want, void **base_out, void **p_out) {
+        if (!devbuf_efence()) {
+            VDB_HIP(hipMalloc(base_out, want));
+            *p_out = *base_out;
+            return;
+        }
+        constexpr size_t G = size_t(2) << 20;
+        const size_t total = (want + G - 1) / G * G;
+        VDB_HIP(hipMalloc(base_out, total));
+        *p_out = static_cast<char *>(*base_out) + ((total - want) & ~size_t(255));
     }
     // contents are NOT preserved
     void reserve(size_t bytes) {
         if (bytes <= cap) return;
         release();
         size_t want = bytes < 256 ? 256 : bytes;
-        VDB_HIP(hipMalloc(&p, want));
+        alloc(want, &base, &p);
         cap = want;
     }
     // contents preserved up to `keep` bytes
@@ -40,13 +64,15 @@ struct DevBuf {
         if (bytes <= cap) return;
         size_t want = cap ? cap : 256;
         while (want < bytes) want *= 2;
-        void *np = nullptr;
-        VDB_HIP(hipMalloc(&np, want));
+        if (devbuf_efence()) want = bytes;  // (no slack capacity to hide an over-read in)
+        void *nb = nullptr, *np = nullptr;
+        alloc(want, &nb, &np);
         if (keep) {
             VDB_HIP(hipMemcpyAsync(np, p, keep, hipMemcpyDeviceToDevice, s));
             VDB_SYNC(s);
         }
-        if (p) (void)hipFree(p);
+        if (base) (void)hipFree(base);
+        base = nb;
         p = np;
         cap = want;
     }
