@@ -56,6 +56,25 @@ while time.time() < t_end:
     if not ok:
         bad += 1
         print(f"MISMATCH it={it} dim={dim} n={n} nq={nq} k={k} ef={ef} M={M} efc={efc} dist={dist} style={style} half={half} dma={dma} stats={st} oracle={(nd, ne)}", flush=True)
+    if rng.random() < 0.35:  # HNSWIndex::knn_pq on the same graph (hnsw_index.rs:672-697): ADC walk + cached-form re-sort
+        n_bits = int(rng.choice([4, 4, 8]))
+        m = int(rng.integers(1, min(dim, 48) + 1))
+        ix.pq_build(n_bits=n_bits, m=m, train_n=min(n, 1200 if n_bits == 4 else 3000), max_iter=2, seed=it)
+        pq = ix.pq_export()
+        opq = O.PQ.from_centroids(dim, m, n_bits, kind, pq["centroids"])
+        opq.set_codes(pq["codes"])
+        nqp = min(nq, 24)
+        idx, d, cnt = ix.knn_pq(qs[:nqp], k, ef)
+        okp = True
+        for q in range(nqp):
+            oi, od = oh.knn_pq(opq, qs[q], k, ef)
+            c = int(cnt[q])
+            if c != len(oi) or idx[q, :c].tolist() != oi.tolist() or not np.array_equal(d[q, :c], od, equal_nan=True):
+                okp = False
+                break
+        if not okp:
+            bad += 1
+            print(f"MISMATCH (knn_pq) it={it} dim={dim} n={n} nq={nqp} k={k} ef={ef} M={M} dist={dist} style={style} n_bits={n_bits} m={m}", flush=True)
     ix.close()
     if it % 10 == 0:
         print(f"{it} configurations, {bad} mismatches", flush=True)
