@@ -347,6 +347,11 @@ int vdb_sharded_hnsw_knn(vdb_sharded *sh, const float *queries, uint64_t nq, uin
                          float *out_dist, uint64_t *out_count);
 int vdb_sharded_hnsw_knn_pq(vdb_sharded *sh, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t ef, uint64_t *out_idx,
                             float *out_dist, uint64_t *out_count);
+/* IVFIndex over the replicas (ivf_index.rs:66-154): clusters built once per process (seeded, so equal in every process) and
+ * mirrored to its other GPUs; knn_with_ef(ef = n_probes; 0 -> the default 4) with the queries split. */
+int vdb_sharded_ivf_build(vdb_sharded *sh, uint64_t k_clusters, uint64_t train_n, uint64_t max_iter, float tol, uint64_t seed);
+int vdb_sharded_ivf_knn(vdb_sharded *sh, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t n_probes, uint64_t *out_idx,
+                        float *out_dist, uint64_t *out_count);
 /* Failed sharded calls.  vdb_sharded_set_rows[_replica] is all-or-nothing: when one GPU fails (out of memory, say) every
  * shard is rolled back to an empty index and the call may be repeated.  A SEARCH that fails on one rank of a multi-PROCESS
  * context (vdb_ctx_create_rank, world > 1) may leave the other ranks inside the all-gather; the object is then "poisoned"

@@ -107,6 +107,8 @@ SIGNATURES = {
     "vdb_sharded_hnsw_knn": [vp, f32p, u64, u64, u64, u64, u64p, f32p, u64p],
     "vdb_sharded_hnsw_knn_pq": [vp, f32p, u64, u64, u64, u64, u64p, f32p, u64p],
     "vdb_sharded_poisoned": [vp, intp],
+    "vdb_sharded_ivf_build": [vp, u64, u64, u64, C.c_float, u64],
+    "vdb_sharded_ivf_knn": [vp, f32p, u64, u64, u64, u64, u64p, f32p, u64p],
     "vdb_stream_probe": [C.c_int, u64, C.c_int, f64p],
     "vdb_stream_probe_rows": [C.c_int, u64, C.c_int, C.c_uint32, f64p],
     "vdb_mfma_probe": [C.c_int, C.c_int, C.c_int, f64p, f64p],

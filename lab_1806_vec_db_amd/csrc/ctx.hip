@@ -645,6 +645,44 @@ int vdb_sharded_hnsw_knn_pq(vdb_sharded *sh, const float *queries, uint64_t nq, 
                             float *out_dist, uint64_t *out_count) {
     return sharded_hnsw_search(sh, queries, nq, dim, k, ef, true, out_idx, out_dist, out_count);
 }
+// IVFIndex over the replicas (ivf_index.rs:34-154): clusters built once per process on its first GPU (seeded k-means: equal in
+// every process) and mirrored to the others; knn with the queries split
+int vdb_sharded_ivf_build(vdb_sharded *sh, uint64_t k_clusters, uint64_t train_n, uint64_t max_iter, float tol, uint64_t seed) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(sh, "null index");
+    VDB_REQUIRE(sh->layout == LAYOUT_REPLICA, "IVF behind the context runs on replicas: use vdb_sharded_set_rows_replica");
+    Index &ix0 = sh->shards[0]->handle->ix;
+    ix0.use_device();
+    ivf_build(ix0, k_clusters, train_n, max_iter, tol, seed);
+    if (sh->shards.size() > 1) {
+        std::vector<float> cent(ix0.ivf.k * ix0.dim);
+        std::vector<uint64_t> assign(ix0.n);
+        ivf_export(ix0, cent.data(), assign.data());
+        for (size_t i = 1; i < sh->shards.size(); i++) {
+            Index &ix = sh->shards[i]->handle->ix;
+            ix.use_device();
+            ivf_attach(ix, ix0.ivf.k, cent.data(), assign.data());
+        }
+    }
+    VDB_API_END
+}
+int vdb_sharded_ivf_knn(vdb_sharded *sh, const float *queries, uint64_t nq, uint64_t dim, uint64_t k, uint64_t n_probes, uint64_t *out_idx,
+                        float *out_dist, uint64_t *out_count) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(sh, "null index");
+    VDB_REQUIRE(dim == sh->dim, "query dimension mismatch");
+    VDB_REQUIRE(nq == 0 || (queries && out_idx && out_dist), "null argument");
+    VDB_REQUIRE(sh->layout == LAYOUT_REPLICA, "IVF behind the context runs on replicas: use vdb_sharded_set_rows_replica");
+    for (auto &s : sh->shards) VDB_REQUIRE(s->handle->ix.ivf.present, "no IVF index (vdb_sharded_ivf_build)");
+    if (n_probes == 0) n_probes = sh->shards[0]->handle->ix.ivf.default_n_probes;
+    VDB_SHARDED_SEARCH_BEGIN(sh)
+    replica_search(*sh, queries, nq, k, out_idx, out_dist, out_count,
+                   [&](Index &ix, Workspace &ws, const float *d_q, uint64_t n, uint64_t *di, float *dd, uint64_t *dc) {
+                       ivf_knn_device(ix, ws, d_q, n, k, n_probes, di, dd, dc);
+                   });
+    VDB_SHARDED_SEARCH_END(sh)
+    VDB_API_END
+}
 // partition arithmetic of the REPLICA layout, exported for the host's tests: the query block of `rank` among `world`
 int vdb_replica_query_block(uint64_t nq, uint64_t world, uint64_t rank, uint64_t *q0, uint64_t *q1) {
     VDB_API_BEGIN

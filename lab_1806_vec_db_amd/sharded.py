@@ -151,6 +151,14 @@ class ShardedIndex:
         return self._search(self._lib.vdb_sharded_hnsw_knn_pq, queries, k, ef)
 
 
+    # -- IVF over the replicas -------------------------------------------------------------------------------------------------
+    def ivf_build(self, k: int, train_n: int = 0, max_iter: int = 20, tol: float = 1e-6, seed: int = 42):
+        L.check(self._lib.vdb_sharded_ivf_build(self._h, int(k), int(train_n), int(max_iter), float(tol), int(seed)))
+
+    def ivf_knn(self, queries, k: int, n_probes: int = 0):
+        return self._search(self._lib.vdb_sharded_ivf_knn, queries, k, n_probes)
+
+
 def replica_query_block(nq: int, world: int, rank: int) -> tuple[int, int]:
     """the library's partition arithmetic of the REPLICA layout (vdb_replica_query_block); equals shard.replica_query_slice"""
     a, b = C.c_uint64(), C.c_uint64()

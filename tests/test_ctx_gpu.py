@@ -113,6 +113,11 @@ def test_replica_layout_all_three_searches(mode, monkeypatch):
     for q in range(9):
         oi, od = oh.knn_pq(opq, qs[q], 5, 40)
         assert gi[q, :len(oi)].tolist() == oi.tolist() and np.array_equal(gd[q, :len(od)], od)
+    # IVF over the replicas: same clusters, same answers as the plain index with the same seed
+    sh.ivf_build(9, train_n=500, max_iter=3, seed=4)
+    ref.ivf_build(9, train_n=500, max_iter=3, seed=4)
+    a, b = sh.ivf_knn(qs[:11], 10, 3), ref.ivf_knn(qs[:11], 10, 3)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
     # a second graph attached from arrays replaces the first
     sh.hnsw_attach(8, 60, g)
     gi2, _, _ = sh.knn_with_ef(qs[:5], 10, 50)
