@@ -454,7 +454,7 @@ int vdb_flat_shortlist_keys(vdb_index *idx, const float *queries, uint64_t nq, u
     VDB_REQUIRE(idx && queries && out_keys, "null argument");
     Index &ix = idx->ix;
     VDB_REQUIRE(dim == ix.dim, "query dimension mismatch");
-    VDB_REQUIRE(tier == 0 || tier == 1, "tier must be 0 (fp16 operands) or 1 (split-bf16 operands)");
+    VDB_REQUIRE(tier >= 0 && tier <= 2, "tier must be 0 (fp16 operands), 1 (split-bf16 operands) or 2 (8-bit operands, lower-bound keys)");
     ix.use_device();
     WsLease ws(ix);
     ws->q.reserve(nq * ix.dim * sizeof(float));
@@ -522,6 +522,18 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         idx->ix.flat_small_max_rows = (uint64_t)value;
     else if (n == "flat_half")  // fp16 first pass of large query batches: 0 auto, 1 off, 2 on regardless of the redo rate
         idx->ix.flat_half_mode = (int)value;
+    else if (n == "flat_i8")  // 8-bit first pass (L2Sqr): 0 auto, 1 off, 2 on regardless of the redo rate
+        idx->ix.flat_i8_mode = (int)value;
+    else if (n == "flat_i8_rows") {  // rows its exact stage may walk per query before giving up (multiple of 64)
+        VDB_REQUIRE(value >= 64 && value <= 1024 && value % 64 == 0, "flat_i8_rows must be a multiple of 64 in [64, 1024]");
+        idx->ix.flat_i8_kprime = (uint32_t)value;
+    }
+    else if (n == "flat_gemm8_nt")
+        gemm8_set_nt((int)value);
+    else if (n == "flat_gemm8_kc")
+        gemm8_set_kc((int)value);
+    else if (n == "flat_gemm8_burst")
+        gemm8_set_burst((int)value);
     else if (n == "flat_half_kmul") {  // its shortlist: max(64, kmul * k) rows per query
         VDB_REQUIRE(value >= 1 && value <= 64, "flat_half_kmul must be in [1, 64]");
         idx->ix.flat_half_kmul = (uint32_t)value;
@@ -549,6 +561,14 @@ int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out) {
         *out = idx->ix.half_redo.load();
     else if (n == "flat_half_valid")
         *out = idx->ix.half_valid ? 1 : 0;
+    else if (n == "flat_i8_queries")
+        *out = idx->ix.i8_queries.load();
+    else if (n == "flat_i8_redo")
+        *out = idx->ix.i8_redo.load();
+    else if (n == "flat_i8_valid")
+        *out = idx->ix.i8_valid.load() ? 1 : 0;
+    else if (n == "flat_i8_rows_walked")
+        *out = idx->ix.i8_rows_walked.load();
     else if (n == "flat_bf16_mirror")
         *out = idx->ix.tiled_built ? 1 : 0;
     else if (n == "hnsw_heap_walk_queries")

@@ -122,6 +122,17 @@ void Index::swap_remove(uint64_t i) {
                 if (half_valid) launch_tile_rows_h(v, last, (uint32_t)dim, ta, tb, half_sx(), d_tiled_h.p, s);
             });
     }
+    if (i8_valid) {  // (f32 rows only) the moved row's and the removed row's tiles, codes and constants
+        if (i8_n == n) {
+            for (uint64_t t : {i / 16, last / 16})
+                launch_tile_rows_i8(d_rows.as<float>(), last, (uint32_t)dim, t, t + 1, d_mu_i8.as<float>(), i8_l1, i8_l2, d_tiled_i8.p,
+                                    d_rowc_i8.as<float>(), s);
+            i8_n = last;
+        } else {
+            i8_valid = false;  // rows were added since the last search: rebuilt by the next one
+            i8_n = 0;
+        }
+    }
     VDB_SYNC(s);
     {
         std::lock_guard<std::mutex> g(host_mu);
@@ -158,6 +169,7 @@ uint64_t Index::hbm_bytes_per_row() const {
         if (tiled_built) b += uint64_t(mfma_dim_pad((uint32_t)dim)) * sizeof(float);
         if (half_valid) b += uint64_t(mfma_dim_pad((uint32_t)dim)) * sizeof(uint16_t);
     }
+    if (i8_valid) b += uint64_t(mfma_dim_pad((uint32_t)dim)) + 2 * sizeof(float);
     if (rows_h_n) b += dim * sizeof(uint16_t);
     if (rows_q8_n) b += dim + 2 * sizeof(float);
     if (pq.present) b += pq.enc_dim * (pq.codes_t_valid ? 2 : 1);
@@ -205,6 +217,59 @@ void Index::half_refresh(Workspace &ws, uint64_t n_old, uint64_t n_new) {
     half_dx_abs = std::max(half_dx_abs, std::sqrt(e2[0]) * 1.001f);  // the kernel's f32 sums: relative error << 1e-3
     half_dx_rel = std::max(half_dx_rel, std::sqrt(e2[1]) * 1.001f);
     half_valid = true;
+}
+
+// ---- centred 8-bit mirror (k_i8.hip) ---------------------------------------------------------------
+bool Index::i8_applicable(uint32_t ksel) const {
+    if (elem_u8 || dist != 0 || flat_i8_mode == 1 || (dim & 3) != 0 || !gemm8_supported((uint32_t)dim)) return false;
+    if (!flat_tail_lb_supported((uint32_t)dim, flat_i8_kprime, ksel) || n <= 64) return false;
+    if (!(xsq_max <= 0x1p80f)) return false;  // extreme data: the other tiers' own guards decide
+    const uint64_t iq = i8_queries.load(), ir = i8_redo.load();
+    return flat_i8_mode == 2 || iq < 1024 || ir * 8 <= iq;
+}
+void Index::ensure_i8(Workspace &ws) {
+    std::lock_guard<std::mutex> g(i8_mu);
+    if (i8_valid && i8_n == n) return;
+    hipStream_t s = ws.stream;
+    const uint32_t d = (uint32_t)dim;
+    const uint64_t tiles = ((n + 15) / 16 + 11) / 12 * 12;  // whole units of k_flat_gemm8
+    const uint64_t tile_bytes = 16 * size_t(mfma_dim_pad(d));
+    const bool rebuild = !i8_valid || i8_n > n || n >= 2 * i8_mu_rows;
+    uint64_t t0 = rebuild ? 0 : i8_n / 16;
+    d_tiled_i8.grow(tiles * tile_bytes, t0 * tile_bytes, s);
+    d_rowc_i8.grow(tiles * 16 * 2 * sizeof(float), t0 * 16 * 2 * sizeof(float), s);
+    if (rebuild) {
+        // mu = mean of a row sample; rho = typical |dx| / |x_c| of that sample -> l1 = rho, l2 = 1 / rho (k_i8.hip: any
+        // positive pair is valid, this one is tight for queries that look like rows)
+        d_mu_i8.reserve(size_t(d) * sizeof(float));
+        ws.dense.reserve(size_t(I8_MEAN_CHUNKS) * d * sizeof(float) + 2 * 16384 * sizeof(float));
+        launch_i8_col_mean(d_rows.as<float>(), n, d, ws.dense.as<float>(), d_mu_i8.as<float>(), s);
+        const uint64_t n_s = std::min<uint64_t>(n, 16384), stride = n / n_s, n_s16 = (n_s + 15) / 16 * 16;
+        float *d_stats = ws.dense.as<float>() + size_t(I8_MEAN_CHUNKS) * d;
+        launch_i8_row_stats(d_rows.as<float>(), n, d, d_mu_i8.as<float>(), n_s, stride, d_stats, s);
+        std::vector<float> st(2 * n_s16), mu(d);
+        VDB_HIP(hipMemcpyAsync(st.data(), d_stats, st.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+        VDB_HIP(hipMemcpyAsync(mu.data(), d_mu_i8.p, d * sizeof(float), hipMemcpyDeviceToHost, s));
+        VDB_SYNC(s);
+        double e2 = 0, xs = 0, m2 = 0;
+        for (uint64_t i = 0; i < n_s; i++)
+            if (std::isfinite(st[2 * i]) && std::isfinite(st[2 * i + 1])) {
+                e2 += st[2 * i];
+                xs += st[2 * i + 1];
+            }
+        for (float v : mu) m2 += double(v) * v;
+        float rho = xs > 0 ? (float)std::sqrt(e2 / xs) : 0.01f;
+        if (!(rho >= 1e-4f)) rho = 1e-4f;  // exactly representable rows: keep the split finite
+        if (rho > 0.5f) rho = 0.5f;
+        i8_l1 = rho;
+        i8_l2 = 1.0f / rho;
+        i8_mu_norm = (float)std::sqrt(m2) * 1.001f;
+        i8_mu_rows = n;
+    }
+    launch_tile_rows_i8(d_rows.as<float>(), n, d, t0, tiles, d_mu_i8.as<float>(), i8_l1, i8_l2, d_tiled_i8.p, d_rowc_i8.as<float>(), s);
+    VDB_SYNC(s);
+    i8_n = n;
+    i8_valid = true;
 }
 
 bool Index::ensure_rows_h(Workspace &ws) {
@@ -411,9 +476,9 @@ void Index::flat_small_device(Workspace &ws, const float *q, uint64_t nq, uint64
 
 // ---- Flat: full pipeline ---------------------------------------------------------------------------
 void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t *d_idx,
-                            float *d_dist, uint64_t *d_cnt, bool allow_half, uint32_t kprime_min) {
+                            float *d_dist, uint64_t *d_cnt, bool allow_half, uint32_t kprime_min, bool allow_i8) {
     FlatPending p;
-    flat_knn_enqueue(ws, d_q, nq, k, d_idx, d_dist, d_cnt, allow_half, kprime_min, p);
+    flat_knn_enqueue(ws, d_q, nq, k, d_idx, d_dist, d_cnt, allow_half, kprime_min, p, allow_i8);
     flat_knn_finish(ws, p);
 }
 
@@ -421,7 +486,7 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
 // pipeline is enqueued on ws.stream and flat_knn_finish must follow (same workspace); otherwise the call took one of the
 // synchronous-by-nature paths (small table, exact scan, k > 1024) and is enqueued in full -- nothing left but the stream sync.
 void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t *d_idx, float *d_dist,
-                             uint64_t *d_cnt, bool allow_half, uint32_t kprime_min, FlatPending &p) {
+                             uint64_t *d_cnt, bool allow_half, uint32_t kprime_min, FlatPending &p, bool allow_i8) {
     hipStream_t s = ws.stream;
     p = FlatPending{};
     if (nq == 0) return;
@@ -475,11 +540,19 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
     const uint64_t hq = half_queries.load(), hr = half_redo.load();
     const bool half_ok = allow_half && half_valid && flat_half_mode != 1 && kprime_h <= 1024 && n > kprime_h &&
                          (flat_half_mode == 2 || hq < 1024 || hr * 8 <= hq);
-    const bool gemm = flat_gemm_mode == 2 || (flat_gemm_mode == 0 && (nq > 64 || half_ok));
-    const bool half = half_ok && gemm;
+    // First pass on the centred 8-bit mirror (k_gemm8.hip, L2Sqr): half the bytes of the fp16 pass again; its keys are lower
+    // bounds of the distances, its exact stage walks the hit list until the k-th distance is below the next bound
+    // (k_flat_tail_lb).  What it cannot close in flat_i8_kprime rows goes through this function again (fp16 pass next).
+    const bool i8 = allow_i8 && allow_half && kprime_min == 0 && flat_gemm_mode != 1 && i8_applicable(ksel);
+    const bool gemm = i8 || flat_gemm_mode == 2 || (flat_gemm_mode == 0 && (nq > 64 || half_ok));
+    const bool half = !i8 && half_ok && gemm;
     if (half) kprime = kprime_h;
-    if (!half) ensure_tiled(ws);
-    if (!half) launch_row_sqnorm(d_q, nq, (uint32_t)dim, ws.qsq.as<float>(), s);  // (the fp16 pass: k_query_prep_h)
+    if (i8) {
+        kprime = flat_i8_kprime;
+        ensure_i8(ws);
+    }
+    if (!half && !i8) ensure_tiled(ws);
+    if (!half && !i8) launch_row_sqnorm(d_q, nq, (uint32_t)dim, ws.qsq.as<float>(), s);  // (the fp16 / 8-bit passes: k_query_prep_*)
     const uint32_t capp = topk_capacity(kprime);
     const uint32_t capk = topk_capacity(ksel);
     const uint64_t gq = gemm_group();
@@ -487,8 +560,10 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
     const uint64_t nq_pad = gemm ? ngroups * gq : (nq + bq - 1) / bq * bq;
     const uint64_t nbatch = nq_pad / bq;
     uint32_t s_step = 1, s_rank = kprime;  // threshold sample: every s_step-th item, tau = s_rank-th smallest sampled key
-    mfma_sample_plan(n, kprime, &s_step, &s_rank);
-    const uint64_t n_s = gemm ? gemm_sample_rows(n, s_step) : mfma_sample_rows(n, s_step);
+    // (8-bit pass: planned for 64 guaranteed hits, ~1000 expected -- its exact stage takes tau itself as the bound of everything
+    // outside the hit list, so a list shorter than flat_i8_kprime is no failure)
+    mfma_sample_plan(n, i8 ? 64u : kprime, &s_step, &s_rank);
+    const uint64_t n_s = i8 ? gemm8_sample_rows(n, s_step) : (gemm ? gemm_sample_rows(n, s_step) : mfma_sample_rows(n, s_step));
     const uint64_t ld_s = (n_s + 63) & ~63ull;
     const uint32_t nl_s = topk_num_lists(n_s);
     constexpr uint32_t CAND_CAP = 8192;
@@ -505,10 +580,16 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
     uint32_t *d_hits = reinterpret_cast<uint32_t *>(d_tau + nq_pad);
     if (!gemm) launch_mfma_pack_queries(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, ws.qfrag.as<float>(), s);
     const float *xt = half ? d_tiled_h.as<float>() : d_tiled.as<float>();
-    float *d_qscale = nullptr, *d_qmul = nullptr, *d_qerr = nullptr;
+    float *d_qscale = nullptr, *d_qmul = nullptr, *d_qerr = nullptr, *d_qoff = nullptr;
     if (gemm) {
         ws.qfrag_g.reserve(nq_pad * size_t(mfma_dim_pad((uint32_t)dim)) * sizeof(float));
-        if (half) {
+        if (i8) {
+            ws.qaux.reserve(3 * nq_pad * sizeof(float));
+            d_qscale = ws.qaux.as<float>();
+            d_qoff = d_qscale + nq_pad;
+            launch_query_prep_i8(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, d_mu_i8.as<float>(), i8_l1, i8_l2, ws.qsq.as<float>(),
+                                 d_qscale, d_qoff, d_hits, ws.qfrag_g.p, s);
+        } else if (half) {
             ws.qaux.reserve(3 * nq_pad * sizeof(float));
             d_qscale = ws.qaux.as<float>();
             d_qmul = d_qscale + nq_pad;
@@ -519,7 +600,10 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
             launch_mfma_pack_queries_nh(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, 8, ws.qfrag_g.as<float>(), s);
         }
     }
-    if (gemm)  // the sample through the 128-query kernel too: same arithmetic as the filter, 4x fewer re-reads of the sample
+    if (i8)
+        launch_flat_gemm8_sample(d_tiled_i8.p, n, (uint32_t)dim, ws.qfrag_g.p, d_qscale, (uint32_t)ngroups, d_rowc_i8.as<float>(), s_step,
+                                 ws.dense.as<float>(), ld_s, num_cu, s);
+    else if (gemm)  // the sample through the 128-query kernel too: same arithmetic as the filter, 4x fewer re-reads of the sample
         launch_flat_gemm_sample(xt, n, (uint32_t)dim, ws.qfrag_g.as<float>(), d_qmul, (uint32_t)ngroups,
                                 d_sq.as<float>(), cosine, s_step, ws.dense.as<float>(), ld_s, num_cu, s);
     else
@@ -538,7 +622,7 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
         VDB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_tau + nq), (int)0xFF800000u, nq_pad - nq, s));
     uint64_t *d_cand = ws.lists.as<uint64_t>();  // the sample lists are dead now
     uint32_t *d_sync = d_hits + nq_pad;
-    if (!half) VDB_HIP(hipMemsetAsync(d_hits, 0, (nq_pad + sync_words) * sizeof(uint32_t), s));  // (k_query_prep_h zeroes the counters)
+    if (!half && !i8) VDB_HIP(hipMemsetAsync(d_hits, 0, (nq_pad + sync_words) * sizeof(uint32_t), s));  // (k_query_prep_* zero the counters)
     // algorithmic bytes: one corpus pass (N*d*4) serves 32*share queries (bytes/query = N*d*4 / B)
     // (the fp16 pass streams N*d*2 bytes per 128 queries: its own counter, so that GB/s are the bytes really read)
     const uint64_t hbm_passes = gemm ? ngroups : (nbatch + mfma_share() - 1) / mfma_share();
@@ -549,8 +633,12 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
         std::lock_guard<std::mutex> g(pass_mu);
         if (pass_ev_valid) VDB_HIP(hipStreamWaitEvent(s, pass_ev, 0));
     }
-    prof_begin(ws, half ? "flat_half" : "flat_mfma", double(hbm_passes) * double(n) * dim * (half ? sizeof(uint16_t) : sizeof(float)));
-    if (gemm)
+    prof_begin(ws, i8 ? "flat_i8" : (half ? "flat_half" : "flat_mfma"),
+               double(hbm_passes) * double(n) * dim * (i8 ? 1 : (half ? sizeof(uint16_t) : sizeof(float))));
+    if (i8)
+        launch_flat_gemm8_filter(d_tiled_i8.p, n, (uint32_t)dim, ws.qfrag_g.p, d_qscale, (uint32_t)ngroups, d_rowc_i8.as<float>(), d_tau,
+                                 d_cand, d_hits, CAND_CAP, num_cu, s);
+    else if (gemm)
         launch_flat_gemm_filter(xt, n, (uint32_t)dim, ws.qfrag_g.as<float>(), d_qmul, (uint32_t)ngroups,
                                 d_sq.as<float>(), cosine, d_tau, d_cand, d_hits, CAND_CAP, flat_gemm_debug, num_cu, s);
     else
@@ -569,7 +657,11 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
         se.dx_abs = half_dx_abs;
         se.dx_rel = half_dx_rel;
     }
-    if (flat_tail_mode != 1 && !elem_u8 && flat_tail64_supported((uint32_t)dim, kprime, ksel)) {
+    if (i8) {
+        se.qoff = d_qoff;
+        se.mu_norm = i8_mu_norm;
+    }
+    if (i8 || (flat_tail_mode != 1 && !elem_u8 && flat_tail64_supported((uint32_t)dim, kprime, ksel))) {
         FlatTailArgs t{};
         t.cand = d_cand;
         t.cap = CAND_CAP;
@@ -593,7 +685,11 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
         t.out_idx = d_idx;
         t.out_dist = d_dist;
         t.out_count = d_cnt;
-        launch_flat_tail64(t, (uint32_t)nq, s);
+        t.tau = d_tau;
+        if (i8)
+            launch_flat_tail_lb(t, (uint32_t)nq, s);
+        else
+            launch_flat_tail64(t, (uint32_t)nq, s);
     } else {
         launch_topk_merge_counted(d_cand, CAND_CAP, d_hits, (uint32_t)nq, kprime, ws.keys_a.as<uint64_t>(), s);
         rerank_rows((uint32_t)dim, d_q, (uint32_t)nq, cosine ? MET_COSINE : MET_L2_DIRECT, d_sq.as<float>(),
@@ -605,6 +701,7 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
     }
     p.active = true;
     p.half = half;
+    p.i8 = i8;
     p.kprime = kprime;
     p.ksel = ksel;
     p.nq = nq;
@@ -620,7 +717,7 @@ void Index::flat_knn_finish(Workspace &ws, FlatPending &p) {
     hipStream_t s = ws.stream;
     if (!p.active) return;
     p.active = false;
-    const bool half = p.half;
+    const bool half = p.half, i8 = p.i8;
     const uint32_t kprime = p.kprime, ksel = p.ksel;
     const uint64_t nq = p.nq, k = p.k;
     const float *d_q = p.d_q;
@@ -639,8 +736,12 @@ void Index::flat_knn_finish(Workspace &ws, FlatPending &p) {
         half_queries += nq;
         half_redo += redo.size();
     }
+    if (i8) {
+        i8_queries += nq;
+        i8_redo += redo.size();
+    }
     if (redo.empty()) return;
-    if (!half) fallback_count += redo.size();
+    if (!half && !i8) fallback_count += redo.size();
     const uint64_t nr = redo.size();
     DevBuf rq, rqs, ri, rd, rc;  // small, rare: allocated on demand
     rq.reserve(nr * dim * sizeof(float));
@@ -654,7 +755,9 @@ void Index::flat_knn_finish(Workspace &ws, FlatPending &p) {
     }
     VDB_HIP(hipMemsetAsync(ri.p, 0, nr * k * sizeof(uint64_t), s));
     VDB_HIP(hipMemsetAsync(rd.p, 0, nr * k * sizeof(float), s));
-    if (half)
+    if (i8)  // next tier: the fp16 pass (or whatever this index has instead), with its own shortlist rules
+        flat_knn_device(ws, rq.as<float>(), nr, k, ri.as<uint64_t>(), rd.as<float>(), rc.as<uint64_t>(), true, 0, false);
+    else if (half)
         flat_knn_device(ws, rq.as<float>(), nr, k, ri.as<uint64_t>(), rd.as<float>(), rc.as<uint64_t>(), false, kprime);
     else
         flat_exact_device(ws, rq.as<float>(), rqs.as<float>(), nr, ksel, k, ri.as<uint64_t>(), rd.as<float>(), rc.as<uint64_t>());
@@ -677,11 +780,37 @@ void Index::flat_debug_keys(Workspace &ws, const float *d_q, uint64_t nq, int ti
     hipStream_t s = ws.stream;
     VDB_REQUIRE(nq >= 1 && nq <= 1024 && n >= 1, "debug keys: 1..1024 queries on a non-empty index");
     VDB_REQUIRE(mfma_supported((uint32_t)dim), "debug keys: the dimension has no MFMA shortlist path");
+    const int cosine = dist == 1 ? 1 : 0;
+    const uint64_t gq = gemm_group(), ngroups = (nq + gq - 1) / gq, nq_pad = ngroups * gq;
+    if (tier == 2) {  // 8-bit operands: keys are lower bounds, D >= key + qoff (h_qerr = qoff; h_dx = l1, l2, |mu|, 0)
+        VDB_REQUIRE(!elem_u8 && dist == 0 && (dim & 3) == 0 && gemm8_supported((uint32_t)dim), "debug keys: the index has no 8-bit pass");
+        ensure_i8(ws);
+        const uint64_t n_s8 = gemm8_sample_rows(n, 1), ld8 = (n_s8 + 63) & ~63ull;
+        ws.qsq.reserve(nq_pad * sizeof(float));
+        ws.qfrag_g.reserve(nq_pad * size_t(mfma_dim_pad((uint32_t)dim)));
+        ws.dense.reserve(nq_pad * ld8 * sizeof(float));
+        ws.qaux.reserve(2 * nq_pad * sizeof(float));
+        ws.misc.reserve(nq_pad * sizeof(uint32_t));
+        float *d_qs8 = ws.qaux.as<float>(), *d_qoff = d_qs8 + nq_pad;
+        launch_query_prep_i8(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, d_mu_i8.as<float>(), i8_l1, i8_l2, ws.qsq.as<float>(), d_qs8,
+                             d_qoff, ws.misc.as<uint32_t>(), ws.qfrag_g.p, s);
+        launch_flat_gemm8_sample(d_tiled_i8.p, n, (uint32_t)dim, ws.qfrag_g.p, d_qs8, (uint32_t)ngroups, d_rowc_i8.as<float>(), 1,
+                                 ws.dense.as<float>(), ld8, num_cu, s);
+        VDB_HIP(hipMemcpy2DAsync(h_keys, n * sizeof(float), ws.dense.p, ld8 * sizeof(float), n * sizeof(float), nq, hipMemcpyDeviceToHost, s));
+        if (h_qsq) VDB_HIP(hipMemcpyAsync(h_qsq, ws.qsq.p, nq * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (h_qerr) VDB_HIP(hipMemcpyAsync(h_qerr, d_qoff, nq * sizeof(float), hipMemcpyDeviceToHost, s));
+        VDB_SYNC(s);
+        if (h_dx) {
+            h_dx[0] = i8_l1;
+            h_dx[1] = i8_l2;
+            h_dx[2] = i8_mu_norm;
+            h_dx[3] = 0.0f;
+        }
+        return;
+    }
     const bool half = tier == 0;
     VDB_REQUIRE(!half || half_valid, "debug keys: the index holds no fp16 mirror");
     if (!half) ensure_tiled(ws);
-    const int cosine = dist == 1 ? 1 : 0;
-    const uint64_t gq = gemm_group(), ngroups = (nq + gq - 1) / gq, nq_pad = ngroups * gq;
     const uint64_t n_s = gemm_sample_rows(n, 1), ld = (n_s + 63) & ~63ull;
     ws.qsq.reserve(nq_pad * sizeof(float));
     ws.qfrag_g.reserve(nq_pad * size_t(mfma_dim_pad((uint32_t)dim)) * sizeof(float));

@@ -165,6 +165,7 @@ struct HNSWState {
 struct FlatPending {
     bool active = false;  // the MFMA pipeline is on the stream, its certification flags are still to be read
     bool half = false;
+    bool i8 = false;      // first pass on the 8-bit mirror (its uncertified queries go to the fp16 / split-bf16 tiers)
     uint32_t kprime = 0, ksel = 0;
     uint64_t nq = 0, k = 0;
     const float *d_q = nullptr;
@@ -240,6 +241,21 @@ struct Index {
     std::atomic<uint64_t> half_queries{0}, half_redo{0};  // queries through the fp16 pass / redone with split-bf16
     void half_refresh(Workspace &ws, uint64_t n_old, uint64_t n_new);  // after rows [n_old, n_new) changed
     float half_sx() const { return std::ldexp(1.0f, 13 - half_exp); }
+    // Centred 8-bit mirror for k_flat_gemm8 (k_gemm8.hip, k_i8.hip; L2Sqr over f32 rows): 1 B/element in fragment order +
+    // {C_r, M_r} per row.  Built by the first search that wants it (ensure_i8), extended after add_rows, kept in step by
+    // swap_remove; mu / lambda are re-chosen (and everything rewritten) when the table has doubled since they were measured.
+    DevBuf d_tiled_i8, d_rowc_i8, d_mu_i8;
+    std::atomic<bool> i8_valid{false};
+    uint64_t i8_n = 0;          // rows the mirror covers
+    uint64_t i8_mu_rows = 0;    // table size when mu / lambda were measured
+    float i8_l1 = 0.0f, i8_l2 = 0.0f, i8_mu_norm = 0.0f;
+    int flat_i8_mode = 0;       // 0 auto, 1 off, 2 on even after many uncertified queries
+    uint32_t flat_i8_kprime = 256;  // rows the exact stage may walk per query (64 per round)
+    std::atomic<uint64_t> i8_queries{0}, i8_redo{0};  // queries through the 8-bit pass / passed on to the next tier
+    std::atomic<uint64_t> i8_rows_walked{0};          // (measurement) not maintained in production
+    std::mutex i8_mu;
+    bool i8_applicable(uint32_t ksel) const;
+    void ensure_i8(Workspace &ws);
     // Row-major fp16 image of the rows, same scale and rounding as d_tiled_h (so half_dx_* bound its error as well): the
     // operand of the HNSW walk's certified pre-pass (hnsw.hip, hnsw_half_dots).  Built on the first walk that wants it,
     // extended when rows were added since, rebuilt when the scale changed.
@@ -308,9 +324,9 @@ struct Index {
 
     // search entry points; d_* are device pointers, results [nq][k]
     void flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t *d_idx, float *d_dist,
-                         uint64_t *d_cnt, bool allow_half = true, uint32_t kprime_min = 0);
+                         uint64_t *d_cnt, bool allow_half = true, uint32_t kprime_min = 0, bool allow_i8 = true);
     void flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t *d_idx, float *d_dist, uint64_t *d_cnt,
-                          bool allow_half, uint32_t kprime_min, FlatPending &p);
+                          bool allow_half, uint32_t kprime_min, FlatPending &p, bool allow_i8 = true);
     void flat_knn_finish(Workspace &ws, FlatPending &p);
     void flat_sorted_device(Workspace &ws, const float *d_q, uint64_t nq, uint64_t ksel, uint64_t k, uint64_t *d_idx,
                             float *d_dist, uint64_t *d_cnt);

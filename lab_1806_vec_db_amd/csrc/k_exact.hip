@@ -778,6 +778,140 @@ void launch_flat_tail64(const FlatTailArgs &a, uint32_t nq, hipStream_t s) {
     VDB_HIP(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------
+// The exact stage behind the 8-bit pass (k_gemm8.hip).  Its keys are not estimates but LOWER BOUNDS: D(r, q) >= key(r, q) +
+// O_q for every row (k_i8.hip), so nothing has to be known about the rows that were never looked at except the smallest key
+// among them.  The workgroup walks the query's hit list in key order, 64 keys per round (block_top64_above: the 64 smallest
+// keys above the previous round's last one), re-ranks them 32 / 31 at a time in the reference's order, keeps the k smallest
+// exact pairs, and stops as soon as
+//     D_k  <  (kappa + O_q) (1 - (d + 8) u) - 4 u (|x|max + |q| + 2 |mu|)^2
+// with kappa = the smallest key not yet evaluated (tau[q] once the list is exhausted: every row outside it has key > tau).
+// The first factor covers the strict fold of a row outside (e >= D (1 - gamma_{d+2})), the last term the two roundings of
+// the key's own evaluation.  Most queries stop after 32 .. 96 rows; one that is still open after max_rounds is flagged and
+// redone by the next tier.  L2Sqr only.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t block_top64_above(const uint64_t *__restrict__ src, uint32_t total, uint64_t (*sbest)[64], uint64_t above) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t batches = (total + 255) / 256;
+    uint64_t best = PAIR_NONE;
+    for (uint32_t bt = wave; bt < batches; bt += 4) {
+        uint64_t r[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = (bt * 4 + u) * 64 + lane;
+            const uint64_t v = i < total ? src[i] : PAIR_NONE;
+            r[u] = v > above ? v : PAIR_NONE;
+        }
+        const uint64_t tau = __shfl(best, 63);
+        uint64_t lo = r[0] < r[1] ? r[0] : r[1], lo2 = r[2] < r[3] ? r[2] : r[3];
+        lo = lo < lo2 ? lo : lo2;
+        if (__ballot(lo < tau) == 0) continue;  // wave-uniform
+#pragma unroll
+        for (uint32_t k = 2; k <= 64; k <<= 1)
+#pragma unroll
+            for (uint32_t j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+                for (int u = 0; u < 4; u++) r[u] = cmpx64(r[u], lane, j, (lane & k) == 0);
+        const uint64_t a = merge64(r[0], r[1], lane), b = merge64(r[2], r[3], lane);
+        best = merge64(best, merge64(a, b, lane), lane);
+    }
+    sbest[wave][lane] = best;
+    __syncthreads();
+    if (wave != 0) return PAIR_NONE;
+    const uint64_t a = merge64(sbest[0][lane], sbest[1][lane], lane), b = merge64(sbest[2][lane], sbest[3][lane], lane);
+    return merge64(a, b, lane);
+}
+__device__ __forceinline__ uint8_t flat_certify_lb(uint64_t ek, float kappa, uint32_t q, const FlatTailArgs &a) {
+    if (ek == PAIR_NONE) return 1;
+    const float dk = f32_from_orderable(uint32_t(ek >> 32));
+    const float qn = sqrtf(a.qsq[q]);
+    const float rx = fminf(sqrtf(a.xsq_max), (qn + sqrtf(fmaxf(dk, 0.0f))) * 1.001f);  // (flat_certify_flag: why)
+    const float nr = rx + qn + 2.0f * a.se.mu_norm;
+    float lower = kappa + a.se.qoff[q];
+    lower = lower - float(a.dim + 8) * 5.9604645e-8f * 1.01f * fabsf(lower) - 4.0f * 5.9604645e-8f * nr * nr;
+    return dk < lower ? 0 : 1;  // NaN anywhere -> not certified
+}
+template <int FOLD>
+__global__ __launch_bounds__(256) void k_flat_tail_lb(FlatTailArgs a) {
+    extern __shared__ float4 ftl_smem[];  // [dim/4] query, then 4 waves x [8 rows][9] float4 product tiles
+    __shared__ uint64_t sbest[4][64];
+    __shared__ uint64_t skeys[64];
+    __shared__ uint32_t s_flag;
+    const uint32_t q = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t d4 = a.dim / 4;
+    float4 *qs4 = ftl_smem, *tile = ftl_smem + d4 + wave * 72;
+    for (uint32_t i = threadIdx.x; i < d4; i += 256) qs4[i] = reinterpret_cast<const float4 *>(a.Q + uint64_t(q) * a.dim)[i];
+    const uint32_t cnt_q = a.cnt[q];
+    const uint32_t total = cnt_q <= a.cap ? cnt_q : 0;  // cnt > cap: slots are not all written, the query is redone
+    const uint32_t kk = a.ksel;                         // (<= 64)
+    const float tau_q = a.tau[q];
+    uint64_t run = PAIR_NONE;  // wave 0: the 64 smallest exact pairs so far, ascending across the lanes
+    uint64_t above = 0;        // every pair key is > 0 (the smallest orderable float is 0x007fffff)
+    uint8_t flag = 1;
+    const uint32_t rounds = cnt_q <= a.cap ? a.kprime / 64 : 0;
+    for (uint32_t rd = 0; rd < rounds; rd++) {
+        const uint64_t best = block_top64_above(a.cand + uint64_t(q) * a.cap, total, sbest, above);  // (its barrier also covers qs4)
+        __syncthreads();  // every wave is done with sbest[1..3]
+        if (wave == 0) sbest[0][lane] = best;
+        if (threadIdx.x < 64) skeys[threadIdx.x] = PAIR_NONE;
+        __syncthreads();
+        bool done = false;
+#pragma unroll 1
+        for (uint32_t stg = 0; stg < 2; stg++) {
+            const uint32_t j = stg * 32 + wave * 8 + (lane >> 3);  // position 63 is not evaluated: it opens the next round
+            const uint64_t c = sbest[0][j];
+            const bool live = c != PAIR_NONE && j < 63;
+            const uint32_t idx = live ? uint32_t(c) : 0u;
+            const float acc = group_rerank_fold<FOLD, 8>(a.X, a.dim, idx, live, qs4, tile, lane);
+            if (live && (lane & 7) == 0) skeys[j] = pair_key(epilogue(MET_L2_DIRECT, acc, 0.0f, 0.0f), idx);
+            __syncthreads();
+            if (wave == 0) {
+                const bool mine = lane >= stg * 32 && lane < stg * 32 + 32;
+                run = merge64(run, sort64(mine ? skeys[lane] : PAIR_NONE, lane), lane);
+                const uint64_t ek = __shfl(run, kk - 1), nxt = sbest[0][stg == 0 ? 32 : 63];
+                if (lane == 0) {
+                    const float kappa = nxt == PAIR_NONE ? tau_q : f32_from_orderable(uint32_t(nxt >> 32));
+                    s_flag = flat_certify_lb(ek, kappa, q, a) | (nxt == PAIR_NONE ? 2u : 0u);
+                }
+            }
+            __syncthreads();
+            const uint32_t f = s_flag;  // block-uniform
+            if ((f & 1u) == 0) {
+                flag = 0;
+                done = true;
+            } else if (f & 2u) {
+                done = true;  // the hit list is exhausted and the k-th distance is still above tau's bound
+            }
+            if (done) break;
+        }
+        if (done) break;
+        above = sbest[0][62];
+        __syncthreads();  // sbest[0] is rewritten by the next round
+    }
+    if (wave != 0) return;
+    const bool ok = lane < a.ksel && run != PAIR_NONE;
+    if (lane < a.ksel) {
+        a.out_idx[uint64_t(q) * a.kstride + lane] = ok ? uint64_t(uint32_t(run)) + a.id_offset : 0;
+        a.out_dist[uint64_t(q) * a.kstride + lane] = ok ? f32_from_orderable(uint32_t(run >> 32)) : 0.0f;
+    }
+    const uint32_t count = __builtin_popcountll(__ballot(ok));
+    if (lane == 0) {
+        if (a.out_count) a.out_count[q] = count;
+        a.flags[q] = flag;
+    }
+}
+bool flat_tail_lb_supported(uint32_t dim, uint32_t kprime, uint32_t ksel) {
+    return (dim & 3) == 0 && dim >= 64 && dim <= 8192 && kprime >= 64 && kprime % 64 == 0 && kprime <= 1024 && ksel >= 1 && ksel <= 64;
+}
+void launch_flat_tail_lb(const FlatTailArgs &a, uint32_t nq, hipStream_t s) {
+    if (nq == 0) return;
+    VDB_REQUIRE(flat_tail_lb_supported(a.dim, a.kprime, a.ksel) && a.metric == MET_L2_DIRECT && a.se.qoff && a.tau,
+                "flat_tail_lb: unsupported shape");
+    const size_t lds = (size_t(a.dim / 4) + 4 * 72) * sizeof(float4);
+    hipLaunchKernelGGL((k_flat_tail_lb<FOLD_L2>), dim3(nq), dim3(256), lds, s, a);
+    VDB_HIP(hipGetLastError());
+}
+
 void launch_certify(const uint64_t *exact_sorted, uint32_t lde, const uint64_t *approx_sorted, uint32_t lda,
                     uint32_t nq, uint32_t k, uint32_t kprime, uint64_t n_rows, const float *qsq, float xsq_max,
                     float xsq_min_pos, int cosine, uint32_t dim, uint8_t *flags, hipStream_t s) {

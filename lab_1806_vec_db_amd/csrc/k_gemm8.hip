@@ -1,0 +1,509 @@
+// k_gemm8.hip -- the Flat shortlist pass on 8-bit operands: 128 queries per HBM pass over a 1-B/element mirror.
+//
+// Same loop nest and data movement as k_flat_gemm (k_gemm.hip: a wave owns a unit of TW 16-row tiles with its TW x 8
+// accumulator tiles in registers, the X stream runs HBM -> register ring, the query group's B image is cut into K-chunks
+// double-buffered in LDS), with v_mfma_i32_16x16x64_i8 as the product: one 1-KB fragment per (tile, 64-column k-block),
+// half the bytes per row of the fp16 pass and the same number of matrix instructions per byte.
+//
+// What the keys are (k_i8.hip writes the operands and derives this): rows and queries are CENTRED on one vector mu of the
+// index (L2Sqr is translation invariant) and rounded to int8 with one scale per row / per query; the integer sums I(r,q)
+// are exact, and
+//     key(r, q) = C_r + M_r * (s_q * I(r, q))          M_r = -2 s_r
+// with C_r = |x_r - mu|^2 minus the row's share of the rounding error (Cauchy-Schwarz on the measured residuals, split
+// between row and query by the AM-GM inequality so that it stays a sum of a row term and a query term) is a LOWER BOUND of
+// D(r, q) - O_q for a per-query offset O_q -- not an estimate with an error bar.  A row whose key exceeds the threshold
+// cannot be closer than threshold + O_q; the exact stage (k_flat_tail_lb, k_exact.hip) walks the shortlist in key order
+// and stops as soon as the k-th exact distance is below the next key's bound.  Cosine uses the same kernel on unit rows.
+#include <atomic>
+#include <type_traits>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace vdb {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr uint32_t G8_NH = 8;            // 16-query halves per group
+constexpr uint32_t G8_BQ = 16 * G8_NH;   // 128 queries per pass (= gemm_group())
+constexpr uint32_t G8_WGBUF = 3072;      // LDS hit buffer entries per workgroup and group
+constexpr uint32_t G8_STAGE = 64;        // per wave and unit: lanes whose (tile, half) key quartet passed the threshold
+constexpr uint32_t G8_TW = 3;            // 16-row tiles per unit (the mirror is padded to whole units of 12 tiles: index.hip)
+
+struct Gemm8Args {
+    const uint4 *XT;      // [tile][kb64][lane] 16 int8: row 16*tile + (lane & 15), columns 64*kb + 16*(lane >> 4) + j
+    const uint4 *qfrag;   // [group][kb64][half][lane] 16 int8 of query 16*half + (lane & 15), same columns
+    const float *qscale;  // [ngroups*128] s_q
+    const float2 *rowc;   // [rows padded to whole units] {C_r, M_r}; rows >= n: {+inf, 0}
+    uint64_t n;
+    uint32_t KB, n_units, ngroups;
+    uint32_t unit_step;   // G8_SAMPLE: every unit_step-th unit is scored (n_units counts the sampled ones); else 1
+    float *out;           // G8_SAMPLE: dense keys out[q*ld + v*16*TW + row in unit] (+inf past n)
+    uint64_t ld;
+    const float *tau;     // [ngroups*128]
+    uint64_t *cand;       // [ngroups*128][cap]
+    uint32_t *cnt;        // [ngroups*128]
+    uint32_t cap;
+    uint32_t nt;          // non-temporal X loads (mirror beyond the Infinity Cache)
+};
+
+enum { G8_FILTER = 0, G8_SAMPLE = 1 };
+
+// BURST: the next Q chunk's KC staged pieces are all loaded at the top of the chunk and written at its bottom, so that the
+// wait for them leaves every refill of the chunk in flight (vmcnt is in order: waiting for a staging load that was issued
+// AFTER a ring refill forces that refill to have landed; with one piece per k-block the ring is effectively one k-block
+// deep -- 1.5 us of matrix work in the fp16 kernel, only half that here).  Costs 4 (KC - 1) registers.
+template <int KC, int MODE, bool XNT, bool BURST>
+__global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
+    constexpr int TW = G8_TW, NT = 512, NW = 8, NH = G8_NH, R = KC;
+    constexpr uint32_t CHUNK = KC * NH * 64;  // uint4 per Q chunk (KC k-blocks of 8 KB)
+    constexpr int QST = CHUNK / NT;           // staged uint4 per thread and chunk: one per k-block
+    static_assert(CHUNK % NT == 0 && QST == KC, "one staged uint4 per thread and k-block");
+    extern __shared__ __attribute__((aligned(16))) uint4 smem8[];  // [2][CHUNK] Q chunks, then the hit buffer
+    uint64_t *hit_key = reinterpret_cast<uint64_t *>(smem8 + 2 * CHUNK);
+    uint32_t *hit_q = reinterpret_cast<uint32_t *>(hit_key + G8_WGBUF);
+    uint32_t *hit_n = hit_q + G8_WGBUF;  // [0] entries, [1..128] per-query counts, [129..256] per-query bases
+    float *tau_s = reinterpret_cast<float *>(hit_n + 4 + 2 * G8_BQ);  // [128] thresholds of the current group
+    float *qs_s = tau_s + G8_BQ;                                      // [128] query scales
+    float *c_s = qs_s + G8_BQ;                                        // [8 waves][64] C_r of the wave's current unit
+    float *m_s = c_s + 8 * 64;                                        // [8 waves][64] M_r
+    float *stage_s = m_s + 8 * 64;  // [8 waves][G8_STAGE] float4 keys, then [8][G8_STAGE] first rows, then [8][G8_STAGE] queries
+
+    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nwaves = gridDim.x * NW, gw = blockIdx.x * NW + wave;
+    const uint32_t KB = a.KB, nchunk = KB / KC;
+    const uint64_t n = a.n;
+
+    // units are dealt exactly as in k_flat_gemm: round-robin full steps, the remainder to a window of workgroups that rotates
+    // with the query group
+    const uint32_t S0 = a.n_units / nwaves, rem = a.n_units - S0 * nwaves;
+    const uint32_t rem_wg = (rem + NW - 1) / NW;
+    const uint32_t rw = S0 == 0 ? 0u : rem_wg;
+    auto adv = [&](uint32_t slot) -> uint32_t { return slot >= rw ? slot - rw : slot + gridDim.x - rw; };
+    auto steps_of = [&](uint32_t slot) -> uint32_t {
+        if (rem == 0) return S0;
+        if (S0 == 0) return 1;
+        return S0 + (slot < rem_wg ? 1u : 0u);
+    };
+    auto unit_of = [&](uint32_t slot, uint32_t st) -> uint32_t {  // may be >= n_units (idle wave of the window's tail)
+        return st < S0 ? st * nwaves + gw : S0 * nwaves + slot * NW + wave;
+    };
+    auto unit_ptr = [&](uint32_t u) -> const char * {  // wave-uniform
+        if (u >= a.n_units) u = a.n_units - 1;  // idle waves re-read the last unit (L2 hits, results masked)
+        return reinterpret_cast<const char *>(a.XT) + uint64_t(u) * a.unit_step * TW * KB * 1024;
+    };
+    uint32_t slot_cur = blockIdx.x, slot_nxt = adv(slot_cur);
+    const char *cp_cur = unit_ptr(unit_of(slot_cur, 0)),
+               *cp_nxt = unit_ptr(1 < steps_of(slot_cur) ? unit_of(slot_cur, 1) : unit_of(slot_nxt, 0));
+    uint32_t voff[TW];
+#pragma unroll
+    for (int t = 0; t < TW; t++) voff[t] = lane * 16 + t * KB * 1024;
+    uint4 ring[R][TW];
+    auto fetch_at = [&](uint4(&dst)[TW], const char *base, uint32_t kb) {
+        const char *sb = base + kb * 1024;  // scalar
+#pragma unroll
+        for (int t = 0; t < TW; t++) {
+            if constexpr (XNT) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                dst[t] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(sb + voff[t])));
+            } else {
+                dst[t] = *reinterpret_cast<const uint4 *>(sb + voff[t]);
+            }
+        }
+    };
+    // (issue order pinned: the waits inside the loop are computed from the merge of this order and the steady state's; left
+    // to the scheduler the prologue goes tile-major and every chunk then starts by draining most of the ring)
+#pragma unroll
+    for (int p = 0; p < R; p++) {
+        fetch_at(ring[p], cp_cur, p);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    {
+        const uint4 *src = a.qfrag + (MODE == G8_SAMPLE ? uint64_t(blockIdx.y) * nchunk * CHUNK : 0);
+#pragma unroll
+        for (int j = 0; j < QST; j++) smem8[j * NT + threadIdx.x] = src[j * NT + threadIdx.x];
+    }
+    uint32_t buf = 0;
+    __syncthreads();
+
+    const uint32_t g_begin = MODE == G8_SAMPLE ? blockIdx.y : 0, g_end = MODE == G8_SAMPLE ? blockIdx.y + 1 : a.ngroups;
+    for (uint32_t grp = g_begin; grp < g_end; grp++) {
+        const uint4 *qgrp = a.qfrag + uint64_t(grp) * nchunk * CHUNK;
+        if (MODE == G8_FILTER && threadIdx.x < 1 + 2 * G8_BQ) hit_n[threadIdx.x] = 0;  // ordered before the first append by the chunk barriers
+        if (MODE == G8_FILTER && threadIdx.x < G8_BQ) tau_s[threadIdx.x] = a.tau[grp * G8_BQ + threadIdx.x];
+        if (threadIdx.x < G8_BQ) qs_s[threadIdx.x] = a.qscale[grp * G8_BQ + threadIdx.x];
+        const uint32_t steps = steps_of(slot_cur);
+        for (uint32_t st = 0; st < steps; st++) {
+            const uint32_t u_raw = unit_of(slot_cur, st);
+            const uint32_t u = u_raw < a.n_units ? u_raw : a.n_units - 1;
+            i32x4 acc[TW][NH];
+#pragma unroll
+            for (int t = 0; t < TW; t++)
+#pragma unroll
+                for (int h = 0; h < NH; h++) acc[t][h] = (i32x4){0, 0, 0, 0};
+            // row constants of this unit: one float2 per lane (lanes < 16 TW), staged global -> VGPR -> LDS with the Q chunk
+            const char *rc_base = reinterpret_cast<const char *>(a.rowc + uint64_t(__builtin_amdgcn_readfirstlane(u)) * a.unit_step * (16 * TW));
+            uint32_t rc_off = (lane < 16 * TW ? lane : 0) * 8;
+            asm volatile("" : "+v"(rc_off));  // per unit on purpose (see k_flat_gemm)
+            for (uint32_t c = 0; c < nchunk; c++) {
+                const uint4 *nxt = (c + 1 < nchunk ? qgrp + uint64_t(c + 1) * CHUNK
+                                    : (st + 1 < steps ? qgrp : (grp + 1 < a.ngroups ? qgrp + uint64_t(nchunk) * CHUNK : a.qfrag)));
+                const uint32_t tid16 = threadIdx.x * 16;
+                uint4 *qdst = smem8 + (buf ^ 1) * CHUNK + threadIdx.x;
+                const uint4 *qcur = smem8 + buf * CHUNK + lane;
+                const bool last_c = c + 1 == nchunk;
+                i32x4 q_n = __builtin_bit_cast(i32x4, qcur[0]);
+                float2 rc_stage = make_float2(0.0f, 0.0f);
+                // staged pieces as named scalars (a local array stays in scratch: k_flat_gemm); piece p lives in qs<p>
+                uint4 qs0, qs1, qs2, qs3, qs4;
+                auto stage_ref = [&](auto P) -> uint4 & {
+                    constexpr int p = decltype(P)::value;
+                    if constexpr (p == 0) return qs0;
+                    else if constexpr (p == 1) return qs1;
+                    else if constexpr (p == 2) return qs2;
+                    else if constexpr (p == 3) return qs3;
+                    else return qs4;
+                };
+                auto stage_load = [&](auto P) {
+                    constexpr int p = decltype(P)::value;
+                    stage_ref(P) = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(nxt + p * NT) + tid16);
+                };
+                auto kblock = [&](auto P) {
+                    constexpr int p = decltype(P)::value;
+                    if constexpr (!BURST) {
+                        stage_load(P);
+                        if (p == 0) rc_stage = *reinterpret_cast<const float2 *>(rc_base + rc_off);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // pin the issue order (k_flat_gemm: why)
+                    i32x4 xv[TW];
+#pragma unroll
+                    for (int t = 0; t < TW; t++) xv[t] = __builtin_bit_cast(i32x4, ring[p][t]);
+#pragma unroll
+                    for (int h = 0; h < NH; h++) {
+                        const i32x4 qv = q_n;
+                        if (!(p == KC - 1 && h == NH - 1)) {  // B fragments one step ahead of their MFMAs
+                            const int pn = h + 1 < NH ? p : p + 1, hn = h + 1 < NH ? h + 1 : 0;
+                            q_n = __builtin_bit_cast(i32x4, qcur[(pn * NH + hn) * 64]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int t = 0; t < TW; t++) acc[t][h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xv[t], qv, acc[t][h], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // slot p is free: refill it (before the staging writes, the chunk barrier and a possible epilogue)
+                    fetch_at(ring[p], last_c ? cp_nxt : cp_cur, last_c ? uint32_t(p) : (c + 1) * KC + p);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (!BURST) {
+                        qdst[p * NT] = stage_ref(P);
+                        if (p == 0) {
+                            c_s[wave * 64 + lane] = rc_stage.x;
+                            m_s[wave * 64 + lane] = rc_stage.y;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                using I0 = std::integral_constant<int, 0>;
+                using I1 = std::integral_constant<int, 1>;
+                using I2 = std::integral_constant<int, 2>;
+                using I3 = std::integral_constant<int, 3>;
+                using I4 = std::integral_constant<int, 4>;
+                if constexpr (BURST) {
+                    stage_load(I0{});
+                    stage_load(I1{});
+                    if constexpr (KC > 2) stage_load(I2{});
+                    if constexpr (KC > 3) stage_load(I3{});
+                    if constexpr (KC > 4) stage_load(I4{});
+                    rc_stage = *reinterpret_cast<const float2 *>(rc_base + rc_off);
+                }
+                kblock(I0{});
+                kblock(I1{});
+                if constexpr (KC > 2) kblock(I2{});
+                if constexpr (KC > 3) kblock(I3{});
+                if constexpr (KC > 4) kblock(I4{});
+                if constexpr (BURST) {
+                    qdst[0 * NT] = qs0;
+                    qdst[1 * NT] = qs1;
+                    if constexpr (KC > 2) qdst[2 * NT] = qs2;
+                    if constexpr (KC > 3) qdst[3 * NT] = qs3;
+                    if constexpr (KC > 4) qdst[4 * NT] = qs4;
+                    c_s[wave * 64 + lane] = rc_stage.x;
+                    m_s[wave * 64 + lane] = rc_stage.y;
+                }
+                __syncthreads();
+                buf ^= 1;
+            }
+            cp_cur = cp_nxt;
+            {
+                uint32_t un;
+                if (st + 2 < steps)
+                    un = unit_of(slot_cur, st + 2);
+                else if (st + 1 < steps)
+                    un = unit_of(slot_nxt, 0);
+                else
+                    un = 1 < steps_of(slot_nxt) ? unit_of(slot_nxt, 1) : unit_of(adv(slot_nxt), 0);
+                cp_nxt = unit_ptr(un);
+            }
+            // ---- epilogue: lane holds rows 4*g4..4*g4+3 of each tile for query r of each half ----
+            const uint64_t row0 = uint64_t(u_raw) * a.unit_step * (16 * TW);  // the unclamped unit: idle waves are past n
+            uint32_t stage_n = 0;                                             // wave-uniform
+            uint32_t lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(lane_e));  // lane constants recomputed here: carried across the main loop they are spilled
+            const uint32_t r = lane_e & 15, g4 = lane_e >> 4, lane = lane_e;  // (shadows the kernel-wide lane)
+            float4 *stage_k = reinterpret_cast<float4 *>(stage_s) + wave * G8_STAGE;
+            uint32_t *stage_r = reinterpret_cast<uint32_t *>(reinterpret_cast<float4 *>(stage_s) + 8 * G8_STAGE) + wave * G8_STAGE;
+            uint32_t *stage_q = stage_r + 8 * G8_STAGE;
+            float tau_n = MODE == G8_FILTER ? tau_s[r] : 0.0f, qs_n = qs_s[r];
+#pragma unroll
+            for (int t = 0; t < TW; t++) {
+                const float4 c4 = *reinterpret_cast<const float4 *>(&c_s[wave * 64 + t * 16 + 4 * g4]);
+                const float4 m4 = *reinterpret_cast<const float4 *>(&m_s[wave * 64 + t * 16 + 4 * g4]);
+                const f32x2 c01 = {c4.x, c4.y}, c23 = {c4.z, c4.w}, m01 = {m4.x, m4.y}, m23 = {m4.z, m4.w};
+                const uint32_t rb32 = uint32_t(row0) + t * 16 + 4 * g4;  // rows < 2^32
+                int h_from = -1;  // wave-uniform; >= 0: resume at this pair after a drain of the stage
+                for (;;) {
+                    int h_stop = NH;
+                    if (h_from >= 0) {
+                        if (MODE == G8_FILTER) tau_n = tau_s[h_from * 16 + r];
+                        qs_n = qs_s[h_from * 16 + r];
+                    }
+#pragma unroll
+                    for (int h = 0; h < NH; h++) {
+                        if (MODE == G8_FILTER && h < h_from) continue;
+                        const float tau_h = tau_n, sq = qs_n;
+                        {
+                            const int hn = (h + 1) % NH;  // the next pair's query (h = 0 again for the next tile)
+                            if (MODE == G8_FILTER) tau_n = tau_s[hn * 16 + r];
+                            qs_n = qs_s[hn * 16 + r];
+                        }
+                        // I is an exact integer (|I| <= 127^2 dim); the conversion is exact up to 2^24, one rounding beyond.
+                        // key = C + M * (s_q * I): two roundings, covered by the certification's rounding term
+                        const f32x2 sq2 = {sq, sq};
+                        f32x2 p01 = {float(acc[t][h][0]), float(acc[t][h][1])}, p23 = {float(acc[t][h][2]), float(acc[t][h][3])};
+                        p01 *= sq2;
+                        p23 *= sq2;
+                        const f32x2 k01 = __builtin_elementwise_fma(p01, m01, c01), k23 = __builtin_elementwise_fma(p23, m23, c23);
+                        if (MODE == G8_SAMPLE) {
+                            if (u_raw < a.n_units) {  // wave-uniform: waves past the last sampled unit write nothing
+                                float4 kv;
+                                kv.x = rb32 + 0 < n ? k01.x : INFINITY;
+                                kv.y = rb32 + 1 < n ? k01.y : INFINITY;
+                                kv.z = rb32 + 2 < n ? k23.x : INFINITY;
+                                kv.w = rb32 + 3 < n ? k23.y : INFINITY;
+                                const uint64_t col = uint64_t(u_raw) * (16 * TW) + t * 16 + 4 * g4;  // dense position in the sample
+                                *reinterpret_cast<float4 *>(a.out + (uint64_t(grp) * G8_BQ + h * 16 + r) * a.ld + col) = kv;
+                            }
+                            continue;
+                        }
+                        float kmin3, kmin;  // NaN keys never pass: v_min returns the other operand, the per-key tests are ordered
+                        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(kmin3) : "v"(k01.x), "v"(k01.y), "v"(k23.x));
+                        asm("v_min_f32 %0, %1, %2" : "=v"(kmin) : "v"(kmin3), "v"(k23.y));
+                        const bool pass = kmin <= tau_h;
+                        const uint64_t pm = __ballot(pass);
+                        if (pm) {
+                            const uint32_t np = __builtin_popcountll(pm);
+                            if (__builtin_amdgcn_readfirstlane(stage_n + np > G8_STAGE)) {  // wave-uniform
+                                h_stop = h;
+                                break;
+                            }
+                            if (pass) {
+                                const uint32_t slot = stage_n + __builtin_amdgcn_mbcnt_hi(uint32_t(pm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(pm), 0u));
+                                stage_k[slot] = make_float4(k01.x, k01.y, k23.x, k23.y);
+                                stage_r[slot] = rb32;
+                                stage_q[slot] = h * 16 + r;
+                            }
+                            stage_n += np;
+                        }
+                    }
+                    // drained once per unit (after the last tile) and whenever the stage fills up
+                    if (MODE == G8_FILTER && stage_n && (h_stop != NH || t == TW - 1)) {  // wave-uniform
+                        const uint32_t cnt = stage_n < G8_STAGE ? stage_n : G8_STAGE;
+                        for (uint32_t i = lane; i < cnt; i += 64) {
+                            const float4 kv = stage_k[i];
+                            const uint2 mt = make_uint2(stage_r[i], stage_q[i]);
+                            const float tq = tau_s[mt.y];
+                            const bool p0 = kv.x <= tq && mt.x + 0 < n, p1 = kv.y <= tq && mt.x + 1 < n;
+                            const bool p2 = kv.z <= tq && mt.x + 2 < n, p3 = kv.w <= tq && mt.x + 3 < n;
+                            const uint32_t mine = uint32_t(p0) + uint32_t(p1) + uint32_t(p2) + uint32_t(p3);
+                            if (mine) {
+                                uint32_t pos = atomicAdd(hit_n, mine);
+                                // every reserved slot below G8_WGBUF is written (the hand-off reads min(total, G8_WGBUF) slots)
+#define VDB_PARK8(P, KEY, E)                          \
+    if (P) {                                          \
+        if (pos < G8_WGBUF) {                         \
+            hit_key[pos] = pair_key(KEY, mt.x + E);   \
+            hit_q[pos] = mt.y;                        \
+        }                                             \
+        pos++;                                        \
+    }
+                                VDB_PARK8(p0, kv.x, 0)
+                                VDB_PARK8(p1, kv.y, 1)
+                                VDB_PARK8(p2, kv.z, 2)
+                                VDB_PARK8(p3, kv.w, 3)
+#undef VDB_PARK8
+                                if (pos > G8_WGBUF)  // buffer full: mark the query as overflowed (-> redone by the caller)
+                                    atomicAdd(&a.cnt[grp * G8_BQ + mt.y], a.cap + 1);
+                            }
+                        }
+                        stage_n = 0;
+                    }
+                    if (MODE != G8_FILTER || h_stop == NH) break;
+                    h_from = h_stop;
+                }
+            }
+        }
+        // ---- group end: hand the parked hits to the per-query candidate lists (one global atomic per query) ----
+        __syncthreads();
+        if (MODE == G8_FILTER) {
+            uint32_t total = hit_n[0];
+            if (total > G8_WGBUF) total = G8_WGBUF;
+            constexpr uint32_t NJ = (G8_WGBUF + NT - 1) / NT;
+            uint32_t rank[NJ];
+#pragma unroll
+            for (uint32_t j = 0; j < NJ; j++) {
+                uint32_t i = j * NT + threadIdx.x;
+                rank[j] = i < total ? atomicAdd(&hit_n[1 + hit_q[i]], 1u) : 0u;
+            }
+            __syncthreads();
+            if (threadIdx.x < G8_BQ && hit_n[1 + threadIdx.x] > 0)
+                hit_n[1 + G8_BQ + threadIdx.x] = atomicAdd(&a.cnt[grp * G8_BQ + threadIdx.x], hit_n[1 + threadIdx.x]);
+            __syncthreads();
+#pragma unroll
+            for (uint32_t j = 0; j < NJ; j++) {
+                uint32_t i = j * NT + threadIdx.x;
+                if (i < total) {
+                    uint32_t q = hit_q[i];
+                    uint32_t slot = hit_n[1 + G8_BQ + q] + rank[j];
+                    if (slot < a.cap) a.cand[(uint64_t(grp) * G8_BQ + q) * a.cap + slot] = hit_key[i];
+                }
+            }
+            __syncthreads();
+        }
+        slot_cur = slot_nxt;
+        slot_nxt = adv(slot_nxt);
+    }
+}
+
+static std::atomic<int> g_gemm8_nt{0};  // 0 auto (by mirror size), 1 never, 2 always
+void gemm8_set_nt(int v) { g_gemm8_nt = v; }
+
+// dims whose 64-column k-block count splits into chunks of 5, 3 or 2 k-blocks
+bool gemm8_supported(uint32_t dim) {
+    const uint32_t pad = mfma_dim_pad(dim);
+    const uint32_t kb = pad / 64;
+    return kb >= 2 && pad <= 2048 && (kb % 5 == 0 || kb % 3 == 0 || kb % 2 == 0);
+}
+
+template <int KC, int MODE, bool XNT, bool BURST>
+static void flat_gemm8_launch1(const Gemm8Args &a0, int num_cu, hipStream_t s) {
+    Gemm8Args a = a0;
+    const uint64_t n_tiles = (a.n + 15) / 16;
+    const uint32_t units_all = (uint32_t)((n_tiles + G8_TW - 1) / G8_TW);
+    uint32_t grid;
+    if (MODE == G8_SAMPLE) {
+        a.n_units = (units_all + a.unit_step - 1) / a.unit_step;  // sampled units: ordinal v scores unit v * unit_step
+        grid = (a.n_units + 7) / 8;                               // one step: a wave per sampled unit
+    } else {
+        a.unit_step = 1;
+        a.n_units = units_all;
+        grid = (uint32_t)num_cu;
+        const uint32_t need = (a.n_units + 7) / 8;
+        if (need < grid) grid = need;
+    }
+    if (grid == 0 || a.ngroups == 0) return;
+    const size_t lds = size_t(2) * KC * G8_NH * 64 * sizeof(uint4) + size_t(G8_WGBUF) * 12 + (4 + 4 * G8_BQ + 2 * 8 * 64) * 4 +
+                       size_t(8) * G8_STAGE * 24 + 16;
+    func_max_lds(reinterpret_cast<const void *>(&k_flat_gemm8<KC, MODE, XNT, BURST>), int(160 * 1024));
+    hipLaunchKernelGGL((k_flat_gemm8<KC, MODE, XNT, BURST>), dim3(grid, MODE == G8_SAMPLE ? a.ngroups : 1), dim3(512), lds, s, a);
+    VDB_HIP(hipGetLastError());
+}
+static std::atomic<int> g_gemm8_kc{0};  // 0 auto; 5 / 3 / 2: chunk length when the k-block count allows it
+void gemm8_set_kc(int v) { g_gemm8_kc = v; }
+static std::atomic<int> g_gemm8_burst{0};  // 0 auto (burst for KC <= 3), 1 per k-block, 2 burst
+void gemm8_set_burst(int v) { g_gemm8_burst = v; }
+
+template <int KC, int MODE>
+static void flat_gemm8_launch(const Gemm8Args &a, int num_cu, hipStream_t s) {
+    const bool nt = MODE == G8_FILTER && a.nt;
+    const int bm = g_gemm8_burst;
+    const bool burst = KC <= 3 && bm != 1;  // (KC = 5: the 16 extra registers do not fit)
+    if (nt) {
+        if (burst) {
+            if constexpr (KC <= 3) flat_gemm8_launch1<KC, MODE, true, true>(a, num_cu, s);
+        } else {
+            flat_gemm8_launch1<KC, MODE, true, false>(a, num_cu, s);
+        }
+    } else {
+        if (burst) {
+            if constexpr (KC <= 3) flat_gemm8_launch1<KC, MODE, false, true>(a, num_cu, s);
+        } else {
+            flat_gemm8_launch1<KC, MODE, false, false>(a, num_cu, s);
+        }
+    }
+}
+template <int MODE>
+static void flat_gemm8_dispatch(const Gemm8Args &a, int num_cu, hipStream_t s) {
+    const int want = g_gemm8_kc;
+    int kc = 0;
+    if (want == 5 || want == 3 || want == 2)
+        if (a.KB % uint32_t(want) == 0) kc = want;
+    if (kc == 0) kc = a.KB % 3 == 0 ? 3 : (a.KB % 5 == 0 ? 5 : 2);
+    VDB_REQUIRE(a.KB % uint32_t(kc) == 0, "flat_gemm8: k-block count must be divisible by 5, 3 or 2");
+    if (kc == 5)
+        flat_gemm8_launch<5, MODE>(a, num_cu, s);
+    else if (kc == 3)
+        flat_gemm8_launch<3, MODE>(a, num_cu, s);
+    else
+        flat_gemm8_launch<2, MODE>(a, num_cu, s);
+}
+
+static Gemm8Args gemm8_args(const void *XT, uint64_t n, uint32_t dim, const void *qfrag, const float *qscale, uint32_t ngroups,
+                            const float *rowc) {
+    VDB_REQUIRE(n < (1ull << 32), "flat_gemm8: too many rows for one shard");
+    VDB_REQUIRE(gemm8_supported(dim), "flat_gemm8: unsupported dimension");
+    Gemm8Args a{};
+    a.XT = reinterpret_cast<const uint4 *>(XT);
+    a.qfrag = reinterpret_cast<const uint4 *>(qfrag);
+    a.qscale = qscale;
+    a.rowc = reinterpret_cast<const float2 *>(rowc);
+    a.n = n;
+    a.KB = mfma_dim_pad(dim) / 64;
+    a.ngroups = ngroups;
+    a.unit_step = 1;
+    return a;
+}
+
+// rows past n up to a whole unit are read from the mirror (zero tiles) and from rowc ({+inf, 0}): see Index::i8_refresh
+void launch_flat_gemm8_filter(const void *XT, uint64_t n, uint32_t dim, const void *qfrag, const float *qscale, uint32_t ngroups,
+                              const float *rowc, const float *tau, uint64_t *cand, uint32_t *cnt, uint32_t cap, int num_cu,
+                              hipStream_t s) {
+    if (n == 0 || ngroups == 0) return;
+    Gemm8Args a = gemm8_args(XT, n, dim, qfrag, qscale, ngroups, rowc);
+    a.tau = tau;
+    a.cand = cand;
+    a.cnt = cnt;
+    a.cap = cap;
+    const double mirror_bytes = double((n + 15) / 16 * 16) * mfma_dim_pad(dim);
+    a.nt = g_gemm8_nt == 2 || (g_gemm8_nt == 0 && mirror_bytes > 384.0 * 1024 * 1024) ? 1u : 0u;
+    flat_gemm8_dispatch<G8_FILTER>(a, num_cu, s);
+}
+
+uint64_t gemm8_sample_rows(uint64_t n, uint32_t unit_step) {
+    const uint64_t units = ((n + 15) / 16 + G8_TW - 1) / G8_TW;
+    return (units + unit_step - 1) / unit_step * (16 * G8_TW);
+}
+// dense keys of the sample for every query of every group: out[q*ld + j], j < gemm8_sample_rows(n, unit_step), +inf past n
+void launch_flat_gemm8_sample(const void *XT, uint64_t n, uint32_t dim, const void *qfrag, const float *qscale, uint32_t ngroups,
+                              const float *rowc, uint32_t unit_step, float *out, uint64_t ld, int num_cu, hipStream_t s) {
+    if (n == 0 || ngroups == 0) return;
+    VDB_REQUIRE(unit_step >= 1 && (ld & 3) == 0 && ld >= gemm8_sample_rows(n, unit_step), "flat_gemm8: ld must cover the sample");
+    VDB_REQUIRE(ngroups <= 65535, "flat_gemm8: too many query groups");
+    Gemm8Args a = gemm8_args(XT, n, dim, qfrag, qscale, ngroups, rowc);
+    a.unit_step = unit_step;
+    a.out = out;
+    a.ld = ld;
+    flat_gemm8_dispatch<G8_SAMPLE>(a, num_cu, s);
+}
+
+}  // namespace vdb

@@ -35,6 +35,9 @@ void launch_iota_keys(uint64_t *rows, uint32_t nq, uint32_t n, uint32_t ld, hipS
 struct SplitErr {
     const float *qerr = nullptr;
     float dx_abs = 0.0f, dx_rel = 0.0f;
+    // 8-bit pass (k_gemm8.hip / k_i8.hip): the keys are lower bounds, D(r, q) >= key + qoff[q]; |mu| of the centring vector
+    const float *qoff = nullptr;
+    float mu_norm = 0.0f;
 };
 void launch_flat_finish(const uint64_t *exact_sorted, uint32_t lde, const uint64_t *approx_sorted, uint32_t lda,
                         uint32_t nq, uint32_t ksel, uint32_t kstride, uint32_t kprime, uint64_t n_rows, const float *qsq,
@@ -62,7 +65,11 @@ struct FlatTailArgs {
     uint64_t *out_idx;
     float *out_dist;
     uint64_t *out_count;
+    const float *tau = nullptr;  // k_flat_tail_lb: the filter pass's thresholds (the bound of every row outside the hit list)
 };
+// the exact stage behind the 8-bit pass: walks the hit list in key order, 64 keys per round (kprime / 64 rounds at most)
+bool flat_tail_lb_supported(uint32_t dim, uint32_t kprime, uint32_t ksel);
+void launch_flat_tail_lb(const FlatTailArgs &a, uint32_t nq, hipStream_t s);
 bool flat_tail64_supported(uint32_t dim, uint32_t kprime, uint32_t ksel);
 void launch_flat_tail64(const FlatTailArgs &a, uint32_t nq, hipStream_t s);
 // k_small.hip: FlatIndex::knn of a few queries over a small table in ONE launch (the db.search() shape): coalesced rows ->
@@ -207,6 +214,25 @@ void launch_pack_queries_h(const float *Q, uint32_t nq, uint32_t nq_cover, uint3
                            void *qfrag, hipStream_t s);
 void launch_mfma_pack_queries_nh(const float *Q, uint32_t nq, uint32_t nq_cover, uint32_t dim, uint32_t NH, float *qfrag,
                                  hipStream_t s);
+// k_gemm8.hip / k_i8.hip: the 8-bit pass (centred int8 mirror, lower-bound keys)
+constexpr uint32_t I8_MEAN_CHUNKS = 64;
+bool gemm8_supported(uint32_t dim);
+void gemm8_set_nt(int v);
+void gemm8_set_kc(int v);
+void gemm8_set_burst(int v);
+uint64_t gemm8_sample_rows(uint64_t n, uint32_t unit_step);
+void launch_flat_gemm8_filter(const void *XT, uint64_t n, uint32_t dim, const void *qfrag, const float *qscale, uint32_t ngroups,
+                              const float *rowc, const float *tau, uint64_t *cand, uint32_t *cnt, uint32_t cap, int num_cu,
+                              hipStream_t s);
+void launch_flat_gemm8_sample(const void *XT, uint64_t n, uint32_t dim, const void *qfrag, const float *qscale, uint32_t ngroups,
+                              const float *rowc, uint32_t unit_step, float *out, uint64_t ld, int num_cu, hipStream_t s);
+void launch_i8_col_mean(const float *X, uint64_t n, uint32_t dim, float *part /* I8_MEAN_CHUNKS * dim */, float *mu, hipStream_t s);
+void launch_i8_row_stats(const float *X, uint64_t n, uint32_t dim, const float *mu, uint64_t n_s, uint64_t stride,
+                         float *stats /* 2 * round_up(n_s, 16) */, hipStream_t s);
+void launch_tile_rows_i8(const float *X, uint64_t n, uint32_t dim, uint64_t tile0, uint64_t tile1, const float *mu, float l1, float l2,
+                         void *T, float *rowc, hipStream_t s);
+void launch_query_prep_i8(const float *Q, uint32_t nq, uint32_t nq_pad, uint32_t dim, const float *mu, float l1, float l2, float *qsq,
+                          float *qscale, float *qoff, uint32_t *hits, void *qfrag, hipStream_t s);
 void mfma_set_sample_thin(int v);
 void mfma_sample_plan(uint64_t n, uint32_t kprime, uint32_t *step, uint32_t *rank);
 uint64_t mfma_sample_rows(uint64_t n, uint32_t step);
