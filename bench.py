@@ -136,9 +136,9 @@ def pmc_traffic(kernel, rows, dim, nq):
 
 
 def flat_kernel_of(ix):
-    """dominant kernel of the Flat steps just timed: the fp16 first pass (k_flat_gemm<GEMM_F16>) when it ran, else the
-    split-bf16 pass (k_flat_gemm<GEMM_BF16X3> / k_flat_mfma), else the exact scan"""
-    return next((kn for kn in ("flat_half", "flat_mfma") if ix.prof_get(kn)["launches"]), "flat_exact")
+    """dominant kernel of the Flat steps just timed: the 8-bit first pass (k_flat_gemm8) when it ran, else the fp16 first pass
+    (k_flat_gemm<GEMM_F16>), else the split-bf16 pass (k_flat_gemm<GEMM_BF16X3> / k_flat_mfma), else the exact scan"""
+    return next((kn for kn in ("flat_i8", "flat_half", "flat_mfma") if ix.prof_get(kn)["launches"]), "flat_exact")
 
 
 def flat_roofline(ix, rows, dim, nq):
@@ -151,10 +151,10 @@ def flat_roofline(ix, rows, dim, nq):
     p = ix.prof_get(kernel)
     if not p["launches"]:
         return None
-    elem = 2 if kernel == "flat_half" else 4
+    elem = {"flat_i8": 1, "flat_half": 2}.get(kernel, 4)
     bpl = p["bytes"] / p["launches"]
     passes = round(bpl / (rows * dim * elem))
-    qpp = 128 if (nq > 64 or kernel == "flat_half") else 64  # the rule of Index::flat_knn_device
+    qpp = 128 if (nq > 64 or kernel in ("flat_half", "flat_i8")) else 64  # the rule of Index::flat_knn_device
     if kernel == "flat_exact":
         qpp = 8
     avg_s = p["ms"] / p["launches"] * 1e-3
@@ -163,7 +163,14 @@ def flat_roofline(ix, rows, dim, nq):
              "algorithmic_bytes": alg,
              "algorithmic_bytes_def": "SURVEY 8(d): corpus passes x N x d x 4 B (f32 rows)",
              "achieved_8d": round(alg / avg_s / 1e9, 1), "frac_8d": round(alg / avg_s / 1e9 / HBM_PEAK_GBS, 4)}
-    if kernel == "flat_half":
+    if kernel == "flat_i8":
+        extra["frac_of"] = ("operand bytes: the centred int8 mirror of the rows (1 B/element) the first pass streams; its keys are lower bounds of the "
+                            "distances, the exact f32 stage walks the hit list until the k-th distance is below the next bound")
+        extra["operand_bytes"] = bpl
+        tf = passes * rows * ((dim + 63) // 64 * 64) * 128 * 2 / avg_s / 1e12
+        extra["matrix_pipe"] = {"achieved_TOPs": round(tf, 1), "nominal_peak_TOPs": 5000.0, "frac_of_nominal": round(tf / 5000.0, 4),
+                                "instruction": "v_mfma_i32_16x16x64_i8"}
+    elif kernel == "flat_half":
         extra["frac_of"] = "operand bytes: the scaled fp16 mirror of the rows (2 B/element) the first pass streams; exact f32 re-rank + certification downstream"
         extra["operand_bytes"] = bpl
         # the filter is a dense contraction too: 2 flops per (row, column, query slot) with 128 slots per pass
@@ -196,6 +203,7 @@ def main():
                          "latent factor, for informative ANN recall")
     ap.add_argument("--mode", type=int, default=0, help="flat mode: 0 auto, 1 exact scan, 2 MFMA forced")
     ap.add_argument("--half", type=int, default=0, help="flat: fp16 first pass of large query batches: 0 auto, 1 off, 2 forced")
+    ap.add_argument("--i8", type=int, default=0, help="flat (L2Sqr): 8-bit first pass: 0 auto, 1 off, 2 forced")
     ap.add_argument("--half-kmul", type=int, default=0, help="flat: shortlist of the fp16 pass = max(64, kmul*k) (0: library default)")
     ap.add_argument("--dump", type=str, default="", help="rank 0 saves the last step's results to this .npz (tests)")
     ap.add_argument("--legs", choices=["auto", "all", "none"], default="auto",
@@ -312,6 +320,8 @@ def main():
         ix.set_param("flat_half", args.half)
     if args.half_kmul:
         ix.set_param("flat_half_kmul", args.half_kmul)
+    if args.i8:
+        ix.set_param("flat_i8", args.i8)
     host_base = None
     if rank == 0 and world == 1 and args.cpu_queries > 0:
         host_base = base.cpu().numpy()
@@ -526,15 +536,16 @@ def main():
         "scaling": "strong", "vs_baseline": None,
         # the arithmetic type of everything that leaves the library (strict-order f32 folds); the Flat filter in front of it ranks
         # its shortlist from a scaled fp16 mirror and every answer is certified against the f32 rows
-        "dtype": "f32 (certified fp16 filter pass)" if (roofline or {}).get("kernel") == "flat_half" else "f32",
+        "dtype": {"flat_half": "f32 (certified fp16 filter pass)", "flat_i8": "f32 (int8 lower-bound filter pass)"}.get((roofline or {}).get("kernel"), "f32"),
         "data": data_name,
         "config": {"workload": names[1], "rows": n, "dim": dim, "queries_per_step": nq, "k": k, "dist": dname,
                    "parallelism": par if world > 1 else "single GPU", "steps_in_flight": depth},
         "roofline": roofline, "recall_at_10": None,
     }
     if wl == "flat":
-        out["config"]["queries_per_corpus_pass"] = 128 if (nq > 64 or (roofline or {}).get("kernel") == "flat_half") else 64
+        out["config"]["queries_per_corpus_pass"] = 128 if (nq > 64 or (roofline or {}).get("kernel") in ("flat_half", "flat_i8")) else 64
         out["fallback_queries"] = ix.flat_fallback_count()
+        out["i8_pass"] = {"queries": ix.get_stat("flat_i8_queries"), "passed_on_to_fp16": ix.get_stat("flat_i8_redo")}
         out["half_pass"] = {"queries": ix.get_stat("flat_half_queries"), "redone_split_bf16": ix.get_stat("flat_half_redo")}
         out["hbm_bytes_per_row"] = ix.get_stat("hbm_bytes_per_row")
     else:
@@ -577,6 +588,14 @@ def main():
                                               "bytes_def": "SURVEY 8(d): corpus passes x N x d x 4 B, which this kernel really streams",
                                               "results_equal_headline": f32["results_equal_headline"]}
         bytes_per_row["flat_with_redo_tier"] = f32["hbm_bytes_per_row"]
+        if (out["roofline"] or {}).get("kernel") == "flat_i8":  # the previous rounds' headline path beside the new one
+            legs["flat_fp16_pass"] = h16 = leg_flat_f32(ix, timed, step_stats, queries, nq, k, outs, args, n, dim, res, attainable, fp16=True)
+            hr = h16["roofline"] or {}
+            out["roofline"]["fp16_pass_leg"] = {"qps": h16["value"], "ms_per_step": h16["ms_per_step"], "kernel": hr.get("kernel"),
+                                                "avg_launch_ms": hr.get("avg_launch_ms"), "bytes_per_launch": hr.get("bytes_per_launch"),
+                                                "achieved": hr.get("achieved"), "frac": hr.get("frac"), "unit": "GB/s",
+                                                "bytes_def": "corpus passes x N x d x 2 B (the scaled fp16 mirror)",
+                                                "results_equal_headline": h16["results_equal_headline"]}
         for b in (32, 1):
             legs[f"flat_B{b}"] = leg_flat_small(ix, timed, queries, b, k, outs, args, n, dim, res, attainable)
         ix.close()
@@ -592,7 +611,7 @@ def main():
                                         "row-major fp16 image of the walks / IVF scan and IVF's 8-bit image are built on first use)")
         out["legs"] = legs
     mp = (out.get("roofline") or {}).get("matrix_pipe")
-    if mp is not None and world == 1:
+    if mp is not None and world == 1 and mp.get("instruction", "").endswith("f16"):
         # the matrix pipe's rate under sustained load on this box (the chip is power-limited well below the nominal 2.5 PFLOP/s);
         # measured AFTER every timed region: half a second of nothing but MFMAs is not what a timed step should start behind
         from lab_1806_vec_db_amd.index import mfma_probe
@@ -667,16 +686,19 @@ def with_attainable(roofline, attainable):
     return roofline
 
 
-def leg_flat_f32(ix, timed, step_stats, queries, nq, k, outs, args, n, dim, ref, attainable):
-    """the headline step with the fp16 first pass off: every corpus pass streams the 4-B/element split-bf16 mirror, i.e.
-    SURVEY 8(d)'s N*d*4 algorithmic bytes; results must equal the headline's bit for bit"""
+def leg_flat_f32(ix, timed, step_stats, queries, nq, k, outs, args, n, dim, ref, attainable, fp16=False):
+    """the headline step with the 8-bit and fp16 first passes off: every corpus pass streams the 4-B/element split-bf16 mirror,
+    i.e. SURVEY 8(d)'s N*d*4 algorithmic bytes; results must equal the headline's bit for bit.  fp16=True: only the 8-bit
+    pass off (the headline path of rounds 2 - 3: 2 B/element)"""
     ref_idx, ref_dist = ref[0].clone(), ref[1].clone()
-    ix.set_param("flat_half", 1)
+    ix.set_param("flat_half", 2 if fp16 else 1)
+    ix.set_param("flat_i8", 1)
     fn = lambda: ix.flat_knn_device(queries.data_ptr(), nq, k, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr())  # noqa: E731
     el, _ = timed(ix, fn, args.steps, max(1, args.warmup))
     r = with_attainable(flat_roofline(ix, n, dim, nq), attainable)
     same = bool((outs[0] == ref_idx).all().item()) and bool((outs[1] == ref_dist).all().item())
     ix.set_param("flat_half", args.half)
+    ix.set_param("flat_i8", args.i8)
     return {"value": round(nq * args.steps / el, 1), "unit": "queries/s", "steps": args.steps,
             "ms_per_step": round(el / args.steps * 1e3, 3), "step_ms": step_stats(), "queries_per_step": nq, "queries_per_corpus_pass": 128,
             "roofline": r, "results_equal_headline": same, "fallback_queries_total": ix.flat_fallback_count(),

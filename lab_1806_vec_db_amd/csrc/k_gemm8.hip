@@ -46,6 +46,7 @@ struct Gemm8Args {
     uint32_t *cnt;        // [ngroups*128]
     uint32_t cap;
     uint32_t nt;          // non-temporal X loads (mirror beyond the Infinity Cache)
+    uint32_t debug;       // bit 0: thresholds of -inf (nothing passes: the no-hit detection downstream, tests)
 };
 
 enum { G8_FILTER = 0, G8_SAMPLE = 1 };
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
     for (uint32_t grp = g_begin; grp < g_end; grp++) {
         const uint4 *qgrp = a.qfrag + uint64_t(grp) * nchunk * CHUNK;
         if (MODE == G8_FILTER && threadIdx.x < 1 + 2 * G8_BQ) hit_n[threadIdx.x] = 0;  // ordered before the first append by the chunk barriers
-        if (MODE == G8_FILTER && threadIdx.x < G8_BQ) tau_s[threadIdx.x] = a.tau[grp * G8_BQ + threadIdx.x];
+        if (MODE == G8_FILTER && threadIdx.x < G8_BQ) tau_s[threadIdx.x] = (a.debug & 1) ? -INFINITY : a.tau[grp * G8_BQ + threadIdx.x];
         if (threadIdx.x < G8_BQ) qs_s[threadIdx.x] = a.qscale[grp * G8_BQ + threadIdx.x];
         const uint32_t steps = steps_of(slot_cur);
         for (uint32_t st = 0; st < steps; st++) {
@@ -476,10 +477,11 @@ static Gemm8Args gemm8_args(const void *XT, uint64_t n, uint32_t dim, const void
 
 // rows past n up to a whole unit are read from the mirror (zero tiles) and from rowc ({+inf, 0}): see Index::i8_refresh
 void launch_flat_gemm8_filter(const void *XT, uint64_t n, uint32_t dim, const void *qfrag, const float *qscale, uint32_t ngroups,
-                              const float *rowc, const float *tau, uint64_t *cand, uint32_t *cnt, uint32_t cap, int num_cu,
+                              const float *rowc, const float *tau, uint64_t *cand, uint32_t *cnt, uint32_t cap, int debug, int num_cu,
                               hipStream_t s) {
     if (n == 0 || ngroups == 0) return;
     Gemm8Args a = gemm8_args(XT, n, dim, qfrag, qscale, ngroups, rowc);
+    a.debug = (uint32_t)debug;
     a.tau = tau;
     a.cand = cand;
     a.cnt = cnt;

@@ -222,7 +222,7 @@ void gemm8_set_kc(int v);
 void gemm8_set_burst(int v);
 uint64_t gemm8_sample_rows(uint64_t n, uint32_t unit_step);
 void launch_flat_gemm8_filter(const void *XT, uint64_t n, uint32_t dim, const void *qfrag, const float *qscale, uint32_t ngroups,
-                              const float *rowc, const float *tau, uint64_t *cand, uint32_t *cnt, uint32_t cap, int num_cu,
+                              const float *rowc, const float *tau, uint64_t *cand, uint32_t *cnt, uint32_t cap, int debug, int num_cu,
                               hipStream_t s);
 void launch_flat_gemm8_sample(const void *XT, uint64_t n, uint32_t dim, const void *qfrag, const float *qscale, uint32_t ngroups,
                               const float *rowc, uint32_t unit_step, float *out, uint64_t ld, int num_cu, hipStream_t s);

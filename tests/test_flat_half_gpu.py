@@ -42,6 +42,7 @@ def test_half_pass_parity(mods, dist, kind, dim, n, nq):
     ix = vdb.GpuIndex(dim, dist)
     ix.batch_add(base)
     ix.set_flat_mode(2)
+    ix.set_param("flat_i8", 1)  # (this file drives the fp16 / split-bf16 tiers; the 8-bit pass in front of them: test_flat_i8_gpu.py)
     assert ix.get_stat("flat_half_valid") == 1
     idx, d, cnt = ix.flat_knn(qs, 10)
     assert ix.get_stat("flat_half_queries") == nq
@@ -75,6 +76,7 @@ def test_half_pass_redo_tier(mods):
     ix = vdb.GpuIndex(dim, "l2sqr")
     ix.batch_add(base)
     ix.set_flat_mode(2)
+    ix.set_param("flat_i8", 1)  # (this file drives the fp16 / split-bf16 tiers; the 8-bit pass in front of them: test_flat_i8_gpu.py)
     ix.set_param("flat_half", 2)
     idx, d, cnt = ix.flat_knn(qs, 10)
     assert ix.get_stat("flat_half_redo") > 0
@@ -103,6 +105,7 @@ def test_half_mirror_rescale_and_swap_remove(mods):
                          b[:40] + (3.0 * rng.standard_normal((40, dim))).astype(np.float32)])
     ix = vdb.GpuIndex(dim, "l2sqr")
     ix.set_flat_mode(2)
+    ix.set_param("flat_i8", 1)  # (this file drives the fp16 / split-bf16 tiers; the 8-bit pass in front of them: test_flat_i8_gpu.py)
     ix.batch_add(a)
     idx, d, cnt = ix.flat_knn(qs, 10)
     _check_all(idx, d, cnt, *O.flat_knn_batch(a, qs, 10, 0, nthreads=8))
@@ -128,6 +131,7 @@ def test_half_pass_unsupported_inputs(mods):
     ix = vdb.GpuIndex(320, "l2sqr")
     ix.batch_add(base)
     ix.set_flat_mode(2)
+    ix.set_param("flat_i8", 1)  # (this file drives the fp16 / split-bf16 tiers; the 8-bit pass in front of them: test_flat_i8_gpu.py)
     assert ix.get_stat("flat_half_valid") == 0
     idx, d, cnt = ix.flat_knn(qs, 10)
     _check_all(idx, d, cnt, *O.flat_knn_batch(base, qs, 10, 0, nthreads=8))
@@ -135,6 +139,7 @@ def test_half_pass_unsupported_inputs(mods):
     ix2 = vdb.GpuIndex(128, "cosine")
     ix2.batch_add(big)
     ix2.set_flat_mode(2)
+    ix2.set_param("flat_i8", 1)  # (this file drives the fp16 / split-bf16 tiers; the 8-bit pass in front of them: test_flat_i8_gpu.py)
     assert ix2.get_stat("flat_half_valid") == 0
     qb = (1e15 * rng.standard_normal((70, 128))).astype(np.float32)
     idx, d, cnt = ix2.flat_knn(qb, 10)
@@ -157,6 +162,7 @@ def test_half_pass_odd_queries(mods):
         ix = vdb.GpuIndex(128, dist)
         ix.batch_add(base)
         ix.set_flat_mode(2)
+        ix.set_param("flat_i8", 1)  # (this file drives the fp16 / split-bf16 tiers; the 8-bit pass in front of them: test_flat_i8_gpu.py)
         idx, d, cnt = ix.flat_knn(qs, 10)
         assert ix.get_stat("flat_half_queries") == 90
         _check_all(idx, d, cnt, *O.flat_knn_batch(base, qs, 10, kind, nthreads=8))
@@ -172,6 +178,7 @@ def test_fused_exact_stage_equals_separate_kernels(mods):
         ix = vdb.GpuIndex(960, dist)
         ix.batch_add(base)
         ix.set_flat_mode(2)
+        ix.set_param("flat_i8", 1)  # (this file drives the fp16 / split-bf16 tiers; the 8-bit pass in front of them: test_flat_i8_gpu.py)
         for half in (0, 1):
             ix.set_param("flat_half", half)
             for nq, k in ((150, 10), (150, 16), (7, 3), (70, 1)):
@@ -205,6 +212,7 @@ def test_row_blocked_filter_pass(mods):
     ix = vdb.GpuIndex(960, "l2sqr")
     ix.batch_add(base)
     ix.set_flat_mode(2)
+    ix.set_param("flat_i8", 1)  # (this file drives the fp16 / split-bf16 tiers; the 8-bit pass in front of them: test_flat_i8_gpu.py)
     try:
         for half in (0, 1):
             ix.set_param("flat_half", half)

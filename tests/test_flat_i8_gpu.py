@@ -1,0 +1,284 @@
+"""GPU parity: the 8-bit first pass of Flat L2Sqr searches (k_flat_gemm8 / k_i8.hip / k_flat_tail_lb).
+
+The pass streams a centred int8 mirror (1 B/element) and produces keys that are LOWER BOUNDS of the distances
+(D(r, q) >= key(r, q) + O_q for every row); the exact stage walks the hit list in key order and stops when the k-th exact
+distance is below the next bound; what it cannot close goes on to the fp16 / split-bf16 / exact tiers.  Tested here:
+(1) the bound itself, for every (row, query) pair of several corpora, against float64; (2) bit-equality of whole searches
+with the oracle, whichever tier answers; (3) the upkeep of the mirror (rows added after the first search, swap_remove, the
+re-centring when the table has doubled); (4) degenerate inputs.
+"""
+import numpy as np
+import pytest
+
+from conftest import gist_like
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import lab_1806_vec_db_amd as vdb
+    from oracle import oracle as O
+    return vdb, O
+
+
+def _check_all(idx, d, cnt, oi, od, oc):
+    assert cnt.tolist() == oc.tolist()
+    for q in range(idx.shape[0]):
+        assert idx[q].tolist() == oi[q].tolist(), (q, idx[q], oi[q])
+        assert np.array_equal(d[q], od[q]), (q, d[q], od[q])
+
+
+def _corpus(name, n, dim, rng):
+    if name == "gist":
+        return gist_like(n, dim=dim, seed=int(rng.integers(1 << 30)))
+    if name == "normal":
+        return rng.standard_normal((n, dim)).astype(np.float32)
+    if name == "offset":  # cancellation-heavy: one large common vector + small noise (what the centring is for)
+        c = (rng.standard_normal(dim) * 50 / np.sqrt(dim)).astype(np.float32)
+        return (c[None, :] + 1e-2 * rng.standard_normal((n, dim))).astype(np.float32)
+    if name == "decades":  # row norms over four decades
+        s = np.exp(rng.uniform(np.log(1e-2), np.log(1e2), size=(n, 1))).astype(np.float32)
+        return (rng.standard_normal((n, dim)) * s).astype(np.float32)
+    if name == "sparse":  # a few large coordinates per row: the per-row scale is set by outliers
+        x = 0.01 * rng.standard_normal((n, dim))
+        for r in range(n):
+            x[r, rng.integers(dim, size=3)] += rng.standard_normal(3) * 5
+        return x.astype(np.float32)
+    if name == "integers":  # exactly representable rows (rounding error zero for many of them)
+        return rng.integers(-3, 4, size=(n, dim)).astype(np.float32)
+    raise ValueError(name)
+
+
+@pytest.mark.parametrize("name", ["gist", "normal", "offset", "decades", "sparse", "integers"])
+@pytest.mark.parametrize("dim", [960, 192, 128, 320])
+def test_keys_are_lower_bounds(mods, name, dim):
+    """key + O_q <= D for EVERY (row, query) pair, queries from the corpus' distribution, from another one, and rows themselves"""
+    vdb, _ = mods
+    rng = np.random.default_rng(hash((name, dim)) % (1 << 31))
+    n, nq = 6000 + int(rng.integers(0, 50)), 48
+    base = _corpus(name, n, dim, rng)
+    qs = np.concatenate([_corpus(name, nq // 3, dim, rng), _corpus("normal", nq // 3, dim, rng), base[: nq // 3] * np.float32(1.0)])
+    ix = vdb.GpuIndex(dim, "l2sqr")
+    ix.batch_add(base)
+    keys, qsq, qoff, info = ix.flat_shortlist_keys(qs, 2)
+    D = ((qs.astype(np.float64)[:, None, :] - base.astype(np.float64)[None, :, :]) ** 2).sum(-1)
+    lb = keys.astype(np.float64) + qoff.astype(np.float64)[:, None]
+    # the two roundings of the key's own evaluation are part of the certification's margin (flat_certify_lb, k_exact.hip):
+    # 4 u (|x| + |q| + 2 |mu|)^2 -- restated here with the same norms
+    xn = np.sqrt((base.astype(np.float64) ** 2).sum(1))
+    qn = np.sqrt((qs.astype(np.float64) ** 2).sum(1))
+    slack = 4 * 2.0 ** -24 * (xn[None, :] + qn[:, None] + 2 * info["xsq_max"]) ** 2 + 1e-9 * D
+    bad = lb > D + slack
+    assert not bad.any(), (name, dim, int(bad.sum()), float((lb - D)[bad].max()))
+    # the bound is not vacuous: on average within a few percent of the distance where the data are not degenerate
+    if name in ("gist", "normal"):
+        far = D > 0.1 * D.mean()  # (a third of the queries are rows: D = 0 there)
+        assert float(((D - lb)[far] / D[far]).mean()) < 0.08
+
+
+@pytest.mark.parametrize("dim,n,nq", [(960, 40000, 200), (128, 50000, 130), (192, 30011, 97), (320, 20000, 70), (1024, 20000, 129)])
+def test_i8_pass_parity(mods, dim, n, nq):
+    """KB (64-column k-blocks) = 15, 2, 3, 5, 16: chunks of 3, 2, 3, 5, 2; ragged last group; rows not a multiple of a unit"""
+    vdb, O = mods
+    if dim == 960:
+        base, qs = gist_like(n, seed=41), gist_like(nq, seed=42)
+    else:
+        rng = np.random.default_rng(dim + 7)
+        base = rng.standard_normal((n, dim)).astype(np.float32)
+        qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    base[n - 1] = base[0]
+    ix = vdb.GpuIndex(dim, "l2sqr")
+    ix.batch_add(base)
+    ix.set_flat_mode(2)
+    idx, d, cnt = ix.flat_knn(qs, 10)
+    assert ix.get_stat("flat_i8_valid") == 1 and ix.get_stat("flat_i8_queries") == nq
+    redo = ix.get_stat("flat_i8_redo")
+    oi, od, oc = O.flat_knn_batch(base, qs, 10, 0, nthreads=8)
+    _check_all(idx, d, cnt, oi, od, oc)
+    print(f"dim {dim}: 8-bit pass passed on {redo} of {nq} queries")
+    assert redo <= nq // 4
+    for kc, burst in ((5, 0), (3, 1), (3, 2), (2, 1), (2, 2)):  # every kernel variant the dimension allows
+        ix.set_param("flat_gemm8_kc", kc)
+        ix.set_param("flat_gemm8_burst", burst)
+        idx2, d2, cnt2 = ix.flat_knn(qs, 10)
+        np.testing.assert_array_equal(idx, idx2)
+        np.testing.assert_array_equal(d, d2)
+    ix.set_param("flat_gemm8_kc", 0)
+    ix.set_param("flat_gemm8_burst", 0)
+    for nt in (1, 2):
+        ix.set_param("flat_gemm8_nt", nt)
+        idx2, d2, _ = ix.flat_knn(qs, 10)
+        np.testing.assert_array_equal(idx, idx2)
+        np.testing.assert_array_equal(d, d2)
+    ix.set_param("flat_gemm8_nt", 0)
+    ix.set_param("flat_i8", 1)  # off: the fp16 pass answers
+    q0 = ix.get_stat("flat_i8_queries")
+    idx2, d2, _ = ix.flat_knn(qs, 10)
+    assert ix.get_stat("flat_i8_queries") == q0
+    np.testing.assert_array_equal(idx, idx2)
+    np.testing.assert_array_equal(d, d2)
+    ix.set_param("flat_i8", 0)
+    for k in (1, 33, 64):
+        idx3, d3, cnt3 = ix.flat_knn(qs[:40], k)
+        oi, od, oc = O.flat_knn_batch(base, qs[:40], k, 0, nthreads=8)
+        _check_all(idx3, d3, cnt3, oi, od, oc)
+    q0 = ix.get_stat("flat_i8_queries")
+    idx3, d3, cnt3 = ix.flat_knn(qs[:20], 65)  # beyond the exact stage's 64 results: another tier
+    assert ix.get_stat("flat_i8_queries") == q0
+    oi, od, oc = O.flat_knn_batch(base, qs[:20], 65, 0, nthreads=8)
+    _check_all(idx3, d3, cnt3, oi, od, oc)
+
+
+def test_i8_pass_small_calls_and_rows_walked(mods):
+    """calls of 1 .. 130 queries all take the pass; the number of rounds the exact stage may walk is a parameter"""
+    vdb, O = mods
+    n, dim = 30000, 960
+    base, qs = gist_like(n, seed=5), gist_like(130, seed=6)
+    ix = vdb.GpuIndex(dim, "l2sqr")
+    ix.batch_add(base)
+    ix.set_flat_mode(2)
+    ix.set_param("flat_small", 1)
+    oi, od, oc = O.flat_knn_batch(base, qs, 10, 0, nthreads=8)
+    for nq in (1, 3, 64, 65, 128, 129, 130):
+        q0 = ix.get_stat("flat_i8_queries")
+        idx, d, cnt = ix.flat_knn(qs[:nq], 10)
+        assert ix.get_stat("flat_i8_queries") == q0 + nq
+        _check_all(idx, d, cnt, oi[:nq], od[:nq], oc[:nq])
+    # one round of 63 rows only: more queries are passed on, the answers stay
+    ix.set_param("flat_i8", 2)
+    ix.set_param("flat_i8_rows", 64)
+    r0 = ix.get_stat("flat_i8_redo")
+    idx, d, cnt = ix.flat_knn(qs, 10)
+    print("passed on with one round:", ix.get_stat("flat_i8_redo") - r0, "of", len(qs))
+    _check_all(idx, d, cnt, oi, od, oc)
+    ix.set_param("flat_i8_rows", 1024)
+    idx, d, cnt = ix.flat_knn(qs, 10)
+    _check_all(idx, d, cnt, oi, od, oc)
+
+
+def test_i8_pass_redo_tiers(mods):
+    """clusters of near-duplicates (margins far below the 8-bit bound) and exact duplicates across the cut: the pass cannot
+    close them and hands the queries on; the fp16 / split-bf16 / exact tiers answer; auto mode switches the pass off"""
+    vdb, O = mods
+    rng = np.random.default_rng(77)
+    dim, n, nq = 192, 30000, 140
+    centers = rng.standard_normal((30, dim)).astype(np.float32)
+    base = (centers[rng.integers(30, size=n)] + 1e-4 * rng.standard_normal((n, dim))).astype(np.float32)
+    base[100:140] = base[99]  # 41 identical rows
+    qs = (centers[rng.integers(30, size=nq)] + 1e-4 * rng.standard_normal((nq, dim))).astype(np.float32)
+    qs[0] = base[99]
+    ix = vdb.GpuIndex(dim, "l2sqr")
+    ix.batch_add(base)
+    ix.set_flat_mode(2)
+    oi, od, oc = O.flat_knn_batch(base, qs, 10, 0, nthreads=8)
+    idx, d, cnt = ix.flat_knn(qs, 10)
+    _check_all(idx, d, cnt, oi, od, oc)
+    redo = ix.get_stat("flat_i8_redo")
+    print("near-duplicate clusters: passed on", redo, "of", nq)
+    assert redo > nq // 2
+    for _ in range(10):  # auto mode gives up on this index once 1/8 of >= 1024 queries were passed on
+        idx, d, cnt = ix.flat_knn(qs, 10)
+        _check_all(idx, d, cnt, oi, od, oc)
+    q0 = ix.get_stat("flat_i8_queries")
+    ix.flat_knn(qs, 10)
+    assert ix.get_stat("flat_i8_queries") == q0
+    ix.set_param("flat_i8", 2)  # forced: still right
+    idx, d, cnt = ix.flat_knn(qs, 10)
+    assert ix.get_stat("flat_i8_queries") == q0 + nq
+    _check_all(idx, d, cnt, oi, od, oc)
+
+
+def test_i8_mirror_upkeep(mods):
+    """rows added after the first search (extension), a table that doubles (re-centring), swap_remove of rows in the middle,
+    at the end and down to a ragged tile -- every state against the oracle"""
+    vdb, O = mods
+    dim = 320
+    rng = np.random.default_rng(9)
+    allrows = (rng.standard_normal((70000, dim)) + rng.standard_normal(dim) * 3).astype(np.float32)
+    qs = (rng.standard_normal((70, dim)) + 1.5).astype(np.float32)
+    ix = vdb.GpuIndex(dim, "l2sqr")
+    ix.set_flat_mode(2)
+    ix.set_param("flat_i8", 2)
+    have = 0
+    for upto in (20000, 20001, 20017, 33000, 70000):  # 33000 < 2 x 20000: extension; 70000: rebuild with a new centre
+        ix.batch_add(allrows[have:upto])
+        have = upto
+        idx, d, cnt = ix.flat_knn(qs, 7)
+        oi, od, oc = O.flat_knn_batch(allrows[:have], qs, 7, 0, nthreads=8)
+        _check_all(idx, d, cnt, oi, od, oc)
+    cur = allrows.copy()
+    nn = have
+    for victim in (5, nn - 2, 12345, 40000, 16 * 1000 + 15):
+        ix.swap_remove(victim)
+        cur[victim] = cur[nn - 1]
+        nn -= 1
+        if victim in (5, 40000):
+            continue
+        idx, d, cnt = ix.flat_knn(qs, 7)
+        oi, od, oc = O.flat_knn_batch(cur[:nn], qs, 7, 0, nthreads=8)
+        _check_all(idx, d, cnt, oi, od, oc)
+    # removal right after an add (mirror behind the table): rebuilt by the next search
+    ix.batch_add(allrows[:33])
+    cur = np.concatenate([cur[:nn], allrows[:33]])
+    nn += 33
+    ix.swap_remove(3)
+    cur[3] = cur[nn - 1]
+    nn -= 1
+    idx, d, cnt = ix.flat_knn(qs, 7)
+    oi, od, oc = O.flat_knn_batch(cur[:nn], qs, 7, 0, nthreads=8)
+    _check_all(idx, d, cnt, oi, od, oc)
+    assert ix.get_stat("flat_i8_queries") > 0
+
+
+def test_i8_degenerate_inputs(mods):
+    """NaN / inf rows and queries, zero rows, zero queries, a constant table, tiny and huge magnitudes"""
+    vdb, O = mods
+    dim, n = 128, 20000
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    base[7] = 0
+    base[8, 5] = np.nan
+    base[9, 6] = np.inf
+    base[10] = 1e-20
+    base[11] = 3e18
+    base[12] = base[13]
+    qs = rng.standard_normal((70, dim)).astype(np.float32)
+    qs[0] = 0
+    qs[1, 3] = np.nan
+    qs[2, 4] = np.inf
+    qs[3] = base[7]
+    qs[4] = base[10]
+    qs[5] = base[11]
+    qs[6] = 1e-25
+    ix = vdb.GpuIndex(dim, "l2sqr")
+    ix.batch_add(base)
+    ix.set_flat_mode(2)
+    ix.set_param("flat_i8", 2)
+    for k in (1, 10):
+        idx, d, cnt = ix.flat_knn(qs, k)
+        oi, od, oc = O.flat_knn_batch(base, qs, k, 0, nthreads=8)
+        assert cnt.tolist() == oc.tolist()
+        for q in range(len(qs)):
+            assert idx[q].tolist() == oi[q].tolist(), (q, idx[q], oi[q])
+            assert np.array_equal(d[q], od[q], equal_nan=True), (q, d[q], od[q])
+    const = np.full((20000, dim), 0.25, dtype=np.float32)
+    const[::7] += np.float32(1e-3)
+    ix2 = vdb.GpuIndex(dim, "l2sqr")
+    ix2.batch_add(const)
+    ix2.set_flat_mode(2)
+    ix2.set_param("flat_i8", 2)
+    idx, d, cnt = ix2.flat_knn(qs[10:80], 5)
+    oi, od, oc = O.flat_knn_batch(const, qs[10:80], 5, 0, nthreads=8)
+    _check_all(idx, d, cnt, oi, od, oc)
+
+
+def test_i8_not_for_cosine_or_u8(mods):
+    vdb, _ = mods
+    rng = np.random.default_rng(1)
+    base = rng.standard_normal((20000, 128)).astype(np.float32)
+    ix = vdb.GpuIndex(128, "cosine")
+    ix.batch_add(base)
+    ix.set_flat_mode(2)
+    ix.flat_knn(base[:70], 5)
+    assert ix.get_stat("flat_i8_queries") == 0 and ix.get_stat("flat_i8_valid") == 0

@@ -81,7 +81,7 @@ def test_small_equals_general_exact_path_and_auto_rule(mods):
     a = jx.flat_knn(big[:1] + np.float32(0.001), 10)
     assert jx.prof_get("flat_small")["launches"] == 1
     b6 = jx.flat_knn(big[:6] + np.float32(0.001), 10)
-    assert jx.prof_get("flat_small")["launches"] == 1 and jx.get_stat("flat_half_queries") + jx.prof_get("flat_mfma")["launches"] > 0
+    assert jx.prof_get("flat_small")["launches"] == 1 and jx.get_stat("flat_i8_queries") + jx.get_stat("flat_half_queries") + jx.prof_get("flat_mfma")["launches"] > 0
     assert np.array_equal(a[0][0], b6[0][0]) and np.array_equal(a[1][0], b6[1][0])
     jx.close()
 
