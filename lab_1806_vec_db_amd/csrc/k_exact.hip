@@ -782,7 +782,7 @@ void launch_flat_tail64(const FlatTailArgs &a, uint32_t nq, hipStream_t s) {
 // The exact stage behind the 8-bit pass (k_gemm8.hip).  Its keys are not estimates but LOWER BOUNDS: D(r, q) >= key(r, q) +
 // O_q for every row (k_i8.hip), so nothing has to be known about the rows that were never looked at except the smallest key
 // among them.  The workgroup walks the query's hit list in key order, 64 keys per round (block_top64_above: the 64 smallest
-// keys above the previous round's last one), re-ranks them 32 / 31 at a time in the reference's order, keeps the k smallest
+// keys above the previous round's last one), re-ranks 63 of them at once (8 waves x 8 rows) in the reference's order, keeps the k smallest
 // exact pairs, and stops as soon as
 //     D_k  <  (kappa + O_q) (1 - (d + 8) u) - 4 u (|x|max + |q| + 2 |mu|)^2
 // with kappa = the smallest key not yet evaluated (tau[q] once the list is exhausted: every row outside it has key > tau).
@@ -790,11 +790,12 @@ void launch_flat_tail64(const FlatTailArgs &a, uint32_t nq, hipStream_t s) {
 // the key's own evaluation.  Most queries stop after 32 .. 96 rows; one that is still open after max_rounds is flagged and
 // redone by the next tier.  L2Sqr only.
 // ---------------------------------------------------------------------------------------------
+template <int NW>
 __device__ __forceinline__ uint64_t block_top64_above(const uint64_t *__restrict__ src, uint32_t total, uint64_t (*sbest)[64], uint64_t above) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t batches = (total + 255) / 256;
     uint64_t best = PAIR_NONE;
-    for (uint32_t bt = wave; bt < batches; bt += 4) {
+    for (uint32_t bt = wave; bt < batches; bt += NW) {
         uint64_t r[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -818,8 +819,10 @@ __device__ __forceinline__ uint64_t block_top64_above(const uint64_t *__restrict
     sbest[wave][lane] = best;
     __syncthreads();
     if (wave != 0) return PAIR_NONE;
-    const uint64_t a = merge64(sbest[0][lane], sbest[1][lane], lane), b = merge64(sbest[2][lane], sbest[3][lane], lane);
-    return merge64(a, b, lane);
+    uint64_t m = sbest[0][lane];
+#pragma unroll
+    for (int w = 1; w < NW; w++) m = merge64(m, sbest[w][lane], lane);
+    return m;
 }
 __device__ __forceinline__ uint8_t flat_certify_lb(uint64_t ek, float kappa, uint32_t q, const FlatTailArgs &a) {
     if (ek == PAIR_NONE) return 1;
@@ -831,16 +834,18 @@ __device__ __forceinline__ uint8_t flat_certify_lb(uint64_t ek, float kappa, uin
     lower = lower - float(a.dim + 8) * 5.9604645e-8f * 1.01f * fabsf(lower) - 4.0f * 5.9604645e-8f * nr * nr;
     return dk < lower ? 0 : 1;  // NaN anywhere -> not certified
 }
-template <int FOLD>
-__global__ __launch_bounds__(256) void k_flat_tail_lb(FlatTailArgs a) {
-    extern __shared__ float4 ftl_smem[];  // [dim/4] query, then 4 waves x [8 rows][9] float4 product tiles
-    __shared__ uint64_t sbest[4][64];
+// NW waves of 64: a round = one select + ONE re-rank stage of 8 NW - 1 rows (8 per wave; the last position opens the next round)
+template <int FOLD, int NW>
+__global__ __launch_bounds__(NW * 64) void k_flat_tail_lb(FlatTailArgs a) {
+    static_assert(NW == 8, "a stage covers the 64 keys of a round");
+    extern __shared__ float4 ftl_smem[];  // [dim/4] query, then NW waves x [8 rows][9] float4 product tiles
+    __shared__ uint64_t sbest[NW][64];
     __shared__ uint64_t skeys[64];
     __shared__ uint32_t s_flag;
     const uint32_t q = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t d4 = a.dim / 4;
     float4 *qs4 = ftl_smem, *tile = ftl_smem + d4 + wave * 72;
-    for (uint32_t i = threadIdx.x; i < d4; i += 256) qs4[i] = reinterpret_cast<const float4 *>(a.Q + uint64_t(q) * a.dim)[i];
+    for (uint32_t i = threadIdx.x; i < d4; i += NW * 64) qs4[i] = reinterpret_cast<const float4 *>(a.Q + uint64_t(q) * a.dim)[i];
     const uint32_t cnt_q = a.cnt[q];
     const uint32_t total = cnt_q <= a.cap ? cnt_q : 0;  // cnt > cap: slots are not all written, the query is redone
     const uint32_t kk = a.ksel;                         // (<= 64)
@@ -850,43 +855,35 @@ __global__ __launch_bounds__(256) void k_flat_tail_lb(FlatTailArgs a) {
     uint8_t flag = 1;
     const uint32_t rounds = cnt_q <= a.cap ? a.kprime / 64 : 0;
     for (uint32_t rd = 0; rd < rounds; rd++) {
-        const uint64_t best = block_top64_above(a.cand + uint64_t(q) * a.cap, total, sbest, above);  // (its barrier also covers qs4)
-        __syncthreads();  // every wave is done with sbest[1..3]
+        const uint64_t best = block_top64_above<NW>(a.cand + uint64_t(q) * a.cap, total, sbest, above);  // (its barrier also covers qs4)
+        __syncthreads();  // wave 0 is done with sbest[1..]
         if (wave == 0) sbest[0][lane] = best;
         if (threadIdx.x < 64) skeys[threadIdx.x] = PAIR_NONE;
         __syncthreads();
-        bool done = false;
-#pragma unroll 1
-        for (uint32_t stg = 0; stg < 2; stg++) {
-            const uint32_t j = stg * 32 + wave * 8 + (lane >> 3);  // position 63 is not evaluated: it opens the next round
-            const uint64_t c = sbest[0][j];
-            const bool live = c != PAIR_NONE && j < 63;
-            const uint32_t idx = live ? uint32_t(c) : 0u;
-            const float acc = group_rerank_fold<FOLD, 8>(a.X, a.dim, idx, live, qs4, tile, lane);
-            if (live && (lane & 7) == 0) skeys[j] = pair_key(epilogue(MET_L2_DIRECT, acc, 0.0f, 0.0f), idx);
-            __syncthreads();
-            if (wave == 0) {
-                const bool mine = lane >= stg * 32 && lane < stg * 32 + 32;
-                run = merge64(run, sort64(mine ? skeys[lane] : PAIR_NONE, lane), lane);
-                const uint64_t ek = __shfl(run, kk - 1), nxt = sbest[0][stg == 0 ? 32 : 63];
-                if (lane == 0) {
-                    const float kappa = nxt == PAIR_NONE ? tau_q : f32_from_orderable(uint32_t(nxt >> 32));
-                    s_flag = flat_certify_lb(ek, kappa, q, a) | (nxt == PAIR_NONE ? 2u : 0u);
-                }
+        const uint32_t j = wave * 8 + (lane >> 3);  // position 63 is not evaluated: it opens the next round
+        const uint64_t c = sbest[0][j];
+        const bool live = c != PAIR_NONE && j < 63;
+        const uint32_t idx = live ? uint32_t(c) : 0u;
+        const float acc = group_rerank_fold<FOLD, 8>(a.X, a.dim, idx, live, qs4, tile, lane);
+        if (live && (lane & 7) == 0) skeys[j] = pair_key(epilogue(MET_L2_DIRECT, acc, 0.0f, 0.0f), idx);
+        __syncthreads();
+        if (wave == 0) {
+            run = merge64(run, sort64(skeys[lane], lane), lane);
+            const uint64_t ek = __shfl(run, kk - 1), nxt = sbest[0][63];
+            if (lane == 0) {
+                const float kappa = nxt == PAIR_NONE ? tau_q : f32_from_orderable(uint32_t(nxt >> 32));
+                s_flag = flat_certify_lb(ek, kappa, q, a) | (nxt == PAIR_NONE ? 2u : 0u);
             }
-            __syncthreads();
-            const uint32_t f = s_flag;  // block-uniform
-            if ((f & 1u) == 0) {
-                flag = 0;
-                done = true;
-            } else if (f & 2u) {
-                done = true;  // the hit list is exhausted and the k-th distance is still above tau's bound
-            }
-            if (done) break;
         }
-        if (done) break;
+        __syncthreads();
+        const uint32_t f = s_flag;  // block-uniform
+        if ((f & 1u) == 0) {
+            flag = 0;
+            break;
+        }
+        if (f & 2u) break;  // the hit list is exhausted and the k-th distance is still above tau's bound
         above = sbest[0][62];
-        __syncthreads();  // sbest[0] is rewritten by the next round
+        __syncthreads();  // sbest is rewritten by the next round
     }
     if (wave != 0) return;
     const bool ok = lane < a.ksel && run != PAIR_NONE;
@@ -907,8 +904,8 @@ void launch_flat_tail_lb(const FlatTailArgs &a, uint32_t nq, hipStream_t s) {
     if (nq == 0) return;
     VDB_REQUIRE(flat_tail_lb_supported(a.dim, a.kprime, a.ksel) && a.metric == MET_L2_DIRECT && a.se.qoff && a.tau,
                 "flat_tail_lb: unsupported shape");
-    const size_t lds = (size_t(a.dim / 4) + 4 * 72) * sizeof(float4);
-    hipLaunchKernelGGL((k_flat_tail_lb<FOLD_L2>), dim3(nq), dim3(256), lds, s, a);
+    const size_t lds = (size_t(a.dim / 4) + 8 * 72) * sizeof(float4);
+    hipLaunchKernelGGL((k_flat_tail_lb<FOLD_L2, 8>), dim3(nq), dim3(512), lds, s, a);
     VDB_HIP(hipGetLastError());
 }
 

@@ -50,6 +50,11 @@ struct Gemm8Args {
 };
 
 enum { G8_FILTER = 0, G8_SAMPLE = 1 };
+// measurement builds only (make EXTRA=-DG8_ABLATE=n): 1 = the epilogue looks at one (tile, half) pair only, 2 = only the first
+// half's MFMAs are issued; loads, LDS traffic and barriers stay.  Results are wrong by design.
+#ifndef G8_ABLATE
+#define G8_ABLATE 0
+#endif
 
 // BURST: the next Q chunk's KC staged pieces are all loaded at the top of the chunk and written at its bottom, so that the
 // wait for them leaves every refill of the chunk in flight (vmcnt is in order: waiting for a staging load that was issued
@@ -189,8 +194,12 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
                             q_n = __builtin_bit_cast(i32x4, qcur[(pn * NH + hn) * 64]);
                         }
                         __builtin_amdgcn_sched_barrier(0);
+                        if ((G8_ABLATE & 2) && h > 0) {
+                            acc[0][h][0] += qv[0];  // keep the read
+                        } else {
 #pragma unroll
-                        for (int t = 0; t < TW; t++) acc[t][h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xv[t], qv, acc[t][h], 0, 0, 0);
+                            for (int t = 0; t < TW; t++) acc[t][h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xv[t], qv, acc[t][h], 0, 0, 0);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     // slot p is free: refill it (before the staging writes, the chunk barrier and a possible epilogue)
@@ -272,6 +281,10 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
 #pragma unroll
                     for (int h = 0; h < NH; h++) {
                         if (MODE == G8_FILTER && h < h_from) continue;
+                        if ((G8_ABLATE & 1) && (t > 0 || h > 0)) {
+                            if (acc[t][h][0] + acc[t][h][1] + acc[t][h][2] + acc[t][h][3] == 12345) atomicAdd(hit_n, 1u);
+                            continue;
+                        }
                         const float tau_h = tau_n, sq = qs_n;
                         {
                             const int hn = (h + 1) % NH;  // the next pair's query (h = 0 again for the next tile)
