@@ -89,7 +89,12 @@ void Index::add_rows(const void *rows, uint64_t count, bool on_device) {
         if (v > 0.0f && v < xsq_min_pos) xsq_min_pos = v;
     }
     h_sq.insert(h_sq.end(), sq.begin(), sq.end());
-    half_refresh(*ws, n, n + count);  // needs the new xsq_max
+    if (i8_defers_half() && half_n == n) {
+        // the 8-bit pass is this index's first tier: the fp16 mirror waits for its first use (ensure_half)
+    } else if (half_n == n) {
+        half_refresh(*ws, n, n + count);  // needs the new xsq_max
+        half_n = n + count;
+    }  // (else: already behind -- ensure_half catches up)
     {
         std::lock_guard<std::mutex> g(host_mu);
         if (on_device || elem_u8) {
@@ -119,8 +124,14 @@ void Index::swap_remove(uint64_t i) {
             for_tile_chunks(*ws, t, t + 1, last, [&](const float *v, uint64_t ta, uint64_t tb, uint64_t, uint64_t) {
                 if (tiled_built) launch_tile_rows(v, last, (uint32_t)dim, ta, tb, d_tiled.as<float>(), s);
                 // same scale; the moved row's rounding error is already part of half_dx_*
-                if (half_valid) launch_tile_rows_h(v, last, (uint32_t)dim, ta, tb, half_sx(), d_tiled_h.p, s);
+                if (half_valid && half_n == n) launch_tile_rows_h(v, last, (uint32_t)dim, ta, tb, half_sx(), d_tiled_h.p, s);
             });
+    }
+    if (half_n == n) {
+        half_n = last;
+    } else {  // the mirror was behind the table: rebuilt in full by its next use (the moved row's error was never measured)
+        half_valid = false;
+        half_n = 0;
     }
     if (i8_valid) {  // (f32 rows only) the moved row's and the removed row's tiles, codes and constants
         if (i8_n == n) {
@@ -272,8 +283,20 @@ void Index::ensure_i8(Workspace &ws) {
     i8_valid = true;
 }
 
+bool Index::i8_defers_half() const {
+    return !elem_u8 && dist == 0 && flat_i8_mode != 1 && (dim & 3) == 0 && gemm8_supported((uint32_t)dim);
+}
+bool Index::ensure_half(Workspace &ws) {
+    std::lock_guard<std::mutex> g(half_mu);
+    if (half_n != n) {
+        half_refresh(ws, half_n > n ? 0 : half_n, n);
+        half_n = n;
+    }
+    return half_valid;
+}
+
 bool Index::ensure_rows_h(Workspace &ws) {
-    if (elem_u8 || !half_valid || dim % 64 != 0 || dim > 4096 || n == 0) return false;
+    if (elem_u8 || dim % 64 != 0 || dim > 4096 || n == 0 || !ensure_half(ws)) return false;
     std::lock_guard<std::mutex> g(rows_h_mu);
     if (rows_h_n == n && rows_h_exp == half_exp) return true;
     uint64_t r0 = rows_h_n;
@@ -538,12 +561,14 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
     // the bytes of the small-batch kernel's -- 0.36 instead of 0.63 ms per pass at 1M x 960).
     const uint32_t kprime_h = std::max<uint32_t>(64, flat_half_kmul * ksel);
     const uint64_t hq = half_queries.load(), hr = half_redo.load();
-    const bool half_ok = allow_half && half_valid && flat_half_mode != 1 && kprime_h <= 1024 && n > kprime_h &&
-                         (flat_half_mode == 2 || hq < 1024 || hr * 8 <= hq);
+    const bool i8_first = allow_i8 && allow_half && kprime_min == 0 && flat_gemm_mode != 1 && i8_applicable(ksel);
+    const bool half_wanted = !i8_first && allow_half && flat_half_mode != 1 && kprime_h <= 1024 && n > kprime_h &&
+                             (flat_half_mode == 2 || hq < 1024 || hr * 8 <= hq);
+    const bool half_ok = half_wanted && ensure_half(ws);
     // First pass on the centred 8-bit mirror (k_gemm8.hip, L2Sqr): half the bytes of the fp16 pass again; its keys are lower
     // bounds of the distances, its exact stage walks the hit list until the k-th distance is below the next bound
     // (k_flat_tail_lb).  What it cannot close in flat_i8_kprime rows goes through this function again (fp16 pass next).
-    const bool i8 = allow_i8 && allow_half && kprime_min == 0 && flat_gemm_mode != 1 && i8_applicable(ksel);
+    const bool i8 = i8_first;
     const bool gemm = i8 || flat_gemm_mode == 2 || (flat_gemm_mode == 0 && (nq > 64 || half_ok));
     const bool half = !i8 && half_ok && gemm;
     if (half) kprime = kprime_h;
@@ -809,7 +834,7 @@ void Index::flat_debug_keys(Workspace &ws, const float *d_q, uint64_t nq, int ti
         return;
     }
     const bool half = tier == 0;
-    VDB_REQUIRE(!half || half_valid, "debug keys: the index holds no fp16 mirror");
+    VDB_REQUIRE(!half || ensure_half(ws), "debug keys: the index holds no fp16 mirror");
     if (!half) ensure_tiled(ws);
     const uint64_t n_s = gemm_sample_rows(n, 1), ld = (n_s + 63) & ~63ull;
     ws.qsq.reserve(nq_pad * sizeof(float));

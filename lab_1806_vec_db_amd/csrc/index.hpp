@@ -240,6 +240,13 @@ struct Index {
     uint32_t flat_half_kmul = 4;   // shortlist of the fp16 pass: max(64, kmul * k) rows per query
     std::atomic<uint64_t> half_queries{0}, half_redo{0};  // queries through the fp16 pass / redone with split-bf16
     void half_refresh(Workspace &ws, uint64_t n_old, uint64_t n_new);  // after rows [n_old, n_new) changed
+    // An index the 8-bit pass serves (i8_defers_half) builds this mirror on FIRST NEED instead of at add time: a query the
+    // 8-bit pass hands on, a call it does not take (k > 64), the walks' / IVF scan's row-major fp16 image (which shares its
+    // scale and measured error).  half_n = rows the mirror covers; ensure_half brings it up to n.
+    uint64_t half_n = 0;
+    std::mutex half_mu;
+    bool i8_defers_half() const;
+    bool ensure_half(Workspace &ws);  // false: this index has no fp16 mirror (dimension, extreme norms)
     float half_sx() const { return std::ldexp(1.0f, 13 - half_exp); }
     // Centred 8-bit mirror for k_flat_gemm8 (k_gemm8.hip, k_i8.hip; L2Sqr over f32 rows): 1 B/element in fragment order +
     // {C_r, M_r} per row.  Built by the first search that wants it (ensure_i8), extended after add_rows, kept in step by

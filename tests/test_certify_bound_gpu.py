@@ -71,6 +71,7 @@ def test_error_bound_holds_with_margin(dist, kind, dim):
     worst = {}
     for name, (base, qs) in _corpora(dim).items():
         ix = vdb.GpuIndex(dim, dist)
+        ix.set_param("flat_i8", 1)  # (the 8-bit pass's keys are lower bounds, not estimates: tests/test_flat_i8_gpu.py; off, the fp16 mirror is built at add time)
         ix.batch_add(base)
         x64, q64 = base.astype(np.float64), qs.astype(np.float64)
         rx = np.linalg.norm(x64, axis=1)

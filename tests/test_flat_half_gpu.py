@@ -40,9 +40,9 @@ def test_half_pass_parity(mods, dist, kind, dim, n, nq):
         qs = rng.standard_normal((nq, dim)).astype(np.float32)
     base[n - 1] = base[0]
     ix = vdb.GpuIndex(dim, dist)
+    ix.set_param("flat_i8", 1)  # (this file drives the fp16 / split-bf16 tiers; the 8-bit pass in front of them: test_flat_i8_gpu.py)
     ix.batch_add(base)
     ix.set_flat_mode(2)
-    ix.set_param("flat_i8", 1)  # (this file drives the fp16 / split-bf16 tiers; the 8-bit pass in front of them: test_flat_i8_gpu.py)
     assert ix.get_stat("flat_half_valid") == 1
     idx, d, cnt = ix.flat_knn(qs, 10)
     assert ix.get_stat("flat_half_queries") == nq
@@ -74,9 +74,9 @@ def test_half_pass_redo_tier(mods):
     base = np.repeat(centers, 100, axis=0) + (1e-4 * rng.standard_normal((n, dim))).astype(np.float32)
     qs = centers[:nq] + (1e-4 * rng.standard_normal((nq, dim))).astype(np.float32)
     ix = vdb.GpuIndex(dim, "l2sqr")
+    ix.set_param("flat_i8", 1)  # (this file drives the fp16 / split-bf16 tiers; the 8-bit pass in front of them: test_flat_i8_gpu.py)
     ix.batch_add(base)
     ix.set_flat_mode(2)
-    ix.set_param("flat_i8", 1)  # (this file drives the fp16 / split-bf16 tiers; the 8-bit pass in front of them: test_flat_i8_gpu.py)
     ix.set_param("flat_half", 2)
     idx, d, cnt = ix.flat_knn(qs, 10)
     assert ix.get_stat("flat_half_redo") > 0
@@ -129,17 +129,17 @@ def test_half_pass_unsupported_inputs(mods):
     base = rng.standard_normal((20000, 320)).astype(np.float32)
     qs = rng.standard_normal((70, 320)).astype(np.float32)
     ix = vdb.GpuIndex(320, "l2sqr")
+    ix.set_param("flat_i8", 1)  # (this file drives the fp16 / split-bf16 tiers; the 8-bit pass in front of them: test_flat_i8_gpu.py)
     ix.batch_add(base)
     ix.set_flat_mode(2)
-    ix.set_param("flat_i8", 1)  # (this file drives the fp16 / split-bf16 tiers; the 8-bit pass in front of them: test_flat_i8_gpu.py)
     assert ix.get_stat("flat_half_valid") == 0
     idx, d, cnt = ix.flat_knn(qs, 10)
     _check_all(idx, d, cnt, *O.flat_knn_batch(base, qs, 10, 0, nthreads=8))
     big = (1e15 * rng.standard_normal((20000, 128))).astype(np.float32)  # norms^2 ~ 1e32 > 2^80
     ix2 = vdb.GpuIndex(128, "cosine")
+    ix2.set_param("flat_i8", 1)  # (this file drives the fp16 / split-bf16 tiers; the 8-bit pass in front of them: test_flat_i8_gpu.py)
     ix2.batch_add(big)
     ix2.set_flat_mode(2)
-    ix2.set_param("flat_i8", 1)  # (this file drives the fp16 / split-bf16 tiers; the 8-bit pass in front of them: test_flat_i8_gpu.py)
     assert ix2.get_stat("flat_half_valid") == 0
     qb = (1e15 * rng.standard_normal((70, 128))).astype(np.float32)
     idx, d, cnt = ix2.flat_knn(qb, 10)
@@ -160,9 +160,9 @@ def test_half_pass_odd_queries(mods):
     qs[13] *= 1e-6
     for dist, kind in (("l2sqr", 0), ("cosine", 1)):
         ix = vdb.GpuIndex(128, dist)
+        ix.set_param("flat_i8", 1)  # (this file drives the fp16 / split-bf16 tiers; the 8-bit pass in front of them: test_flat_i8_gpu.py)
         ix.batch_add(base)
         ix.set_flat_mode(2)
-        ix.set_param("flat_i8", 1)  # (this file drives the fp16 / split-bf16 tiers; the 8-bit pass in front of them: test_flat_i8_gpu.py)
         idx, d, cnt = ix.flat_knn(qs, 10)
         assert ix.get_stat("flat_half_queries") == 90
         _check_all(idx, d, cnt, *O.flat_knn_batch(base, qs, 10, kind, nthreads=8))
@@ -176,9 +176,9 @@ def test_fused_exact_stage_equals_separate_kernels(mods):
     base[29999] = base[5]
     for dist, kind in (("l2sqr", 0), ("cosine", 1)):
         ix = vdb.GpuIndex(960, dist)
+        ix.set_param("flat_i8", 1)  # (this file drives the fp16 / split-bf16 tiers; the 8-bit pass in front of them: test_flat_i8_gpu.py)
         ix.batch_add(base)
         ix.set_flat_mode(2)
-        ix.set_param("flat_i8", 1)  # (this file drives the fp16 / split-bf16 tiers; the 8-bit pass in front of them: test_flat_i8_gpu.py)
         for half in (0, 1):
             ix.set_param("flat_half", half)
             for nq, k in ((150, 10), (150, 16), (7, 3), (70, 1)):
@@ -210,9 +210,9 @@ def test_row_blocked_filter_pass(mods):
     base, qs = gist_like(50000, seed=61), gist_like(300, seed=62)
     oi, od, oc = O.flat_knn_batch(base, qs, 10, 0, nthreads=8)
     ix = vdb.GpuIndex(960, "l2sqr")
+    ix.set_param("flat_i8", 1)  # (this file drives the fp16 / split-bf16 tiers; the 8-bit pass in front of them: test_flat_i8_gpu.py)
     ix.batch_add(base)
     ix.set_flat_mode(2)
-    ix.set_param("flat_i8", 1)  # (this file drives the fp16 / split-bf16 tiers; the 8-bit pass in front of them: test_flat_i8_gpu.py)
     try:
         for half in (0, 1):
             ix.set_param("flat_half", half)

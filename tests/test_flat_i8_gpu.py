@@ -94,6 +94,9 @@ def test_i8_pass_parity(mods, dim, n, nq):
     idx, d, cnt = ix.flat_knn(qs, 10)
     assert ix.get_stat("flat_i8_valid") == 1 and ix.get_stat("flat_i8_queries") == nq
     redo = ix.get_stat("flat_i8_redo")
+    if redo == 0:  # nothing needed the fp16 mirror yet: it has not been built (rows + norms + 1 B/element + 8 B of constants)
+        assert ix.get_stat("flat_half_valid") == 0
+        assert ix.get_stat("hbm_bytes_per_row") == dim * 4 + 4 + (dim + 63) // 64 * 64 + 8
     oi, od, oc = O.flat_knn_batch(base, qs, 10, 0, nthreads=8)
     _check_all(idx, d, cnt, oi, od, oc)
     print(f"dim {dim}: 8-bit pass passed on {redo} of {nq} queries")
@@ -112,10 +115,12 @@ def test_i8_pass_parity(mods, dim, n, nq):
         np.testing.assert_array_equal(idx, idx2)
         np.testing.assert_array_equal(d, d2)
     ix.set_param("flat_gemm8_nt", 0)
-    ix.set_param("flat_i8", 1)  # off: the fp16 pass answers
+    ix.set_param("flat_i8", 1)  # off: the fp16 pass answers (its mirror is built by this very call)
     q0 = ix.get_stat("flat_i8_queries")
     idx2, d2, _ = ix.flat_knn(qs, 10)
     assert ix.get_stat("flat_i8_queries") == q0
+    if dim != 320:  # (5 fp16 k-blocks: no fp16 mirror for this dimension, the split-bf16 pass answers)
+        assert ix.get_stat("flat_half_valid") == 1 and ix.get_stat("flat_half_queries") >= nq
     np.testing.assert_array_equal(idx, idx2)
     np.testing.assert_array_equal(d, d2)
     ix.set_param("flat_i8", 0)
