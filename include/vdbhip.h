@@ -121,11 +121,19 @@ int vdb_flat_shortlist_keys(vdb_index *idx, const float *queries, uint64_t nq, u
  *   mode 1 = exact scan only (strict-order f32 fold for every row),
  *   mode 2 = MFMA path forced (still certified, still falls back per query). */
 int vdb_flat_set_mode(vdb_index *idx, int mode);
-/* developer tuning knobs (kernel variants); results never depend on them.  "flat_half", "flat_half_kmul", "flat_gemm",
- * "flat_gemm_debug" and "flat_tail" are per index; ALL OTHER names set process-wide switches (the handle only routes the
+/* developer tuning knobs (kernel variants); results never depend on them.  "flat_half", "flat_half_kmul", "flat_i8",
+ * "flat_i8_rows", "flat_gemm", "flat_gemm_debug" and "flat_tail" are per index; ALL OTHER names set process-wide switches (the handle only routes the
  * call) and are not synchronised: set them before concurrent searches start, never while one is running.  Names:
  *   "flat_half"        fp16 first pass of the Flat pipeline: 0 auto (off once > 1/8 of its queries needed the redo), 1 off, 2 on
  *   "flat_half_kmul"   its shortlist = max(64, kmul * k) rows per query (default 4)
+ *   "flat_i8"          8-bit first pass in FRONT of it (L2Sqr over f32 rows, k <= 64, dim % 4 == 0 with a 64-column block count divisible by
+ *                      2, 3 or 5): a centred int8 mirror at 1 B/element whose keys are lower bounds of the distances; the exact stage walks the
+ *                      hit list until the k-th exact distance is below the next bound; what it cannot close goes on to the fp16 pass.
+ *                      0 auto (off once > 1/8 of its queries were handed on), 1 off, 2 on.  While it is the first tier the fp16 mirror is
+ *                      built by its first use instead of at add time (set "flat_i8" = 1 BEFORE adding rows to have it built at add time)
+ *   "flat_i8_rows"     rows its exact stage may walk per query before handing the query on (multiple of 64, default 256)
+ *   "flat_gemm8_kc", "flat_gemm8_burst", "flat_gemm8_nt"   variants of its kernel: k-blocks per Q chunk (0 auto, 5 / 3 / 2), staging of
+ *                      the next chunk (0 auto, 1 per k-block, 2 one burst per chunk), cache policy of the row stream (as "flat_gemm_nt")
  *   "flat_gemm"        128-queries-per-pass kernel: 0 auto, 1 off (small-batch kernel), 2 forced
  *   "flat_gemm_tw"     row tiles per wave (3 default, 2);  "flat_gemm_stagger" workgroup start delays (0 default)
  *   "flat_gemm_block_rows"  filter pass in row blocks, one launch per block over all query groups (measurement switch): 0 off, n rows
@@ -163,6 +171,8 @@ int vdb_flat_fallback_count(const vdb_index *idx, uint64_t *out);
  *   "flat_half_redo"     of those, the ones it could not certify (redone with the split-bf16 pass),
  *   "pq_adc16_queries"   queries whose ADC scan ran on the quantised 16-bit tables (k_pq_adc16) since the table was attached,
  *   "flat_half_valid"    1 when the index holds the fp16 mirror,
+ *   "flat_i8_queries", "flat_i8_redo", "flat_i8_valid"  the same three for the 8-bit first pass (queries through it, queries it handed
+ *                        on to the next tier, mirror present),
  *   "flat_bf16_mirror"   1 once the split-bf16 mirror (4 B/element) has been built -- lazily, by the first search that
  *                        needs it (redo tier, flat_half = 1, calls without an fp16 mirror),
  *   "hnsw_heap_walk_queries"  HNSW queries answered by the any-size heap walk (max(ef, k) > 1024, or the LDS candidate
