@@ -205,6 +205,8 @@ def main():
     ap.add_argument("--half", type=int, default=0, help="flat: fp16 first pass of large query batches: 0 auto, 1 off, 2 forced")
     ap.add_argument("--i8", type=int, default=0, help="flat (L2Sqr): 8-bit first pass: 0 auto, 1 off, 2 forced")
     ap.add_argument("--half-kmul", type=int, default=0, help="flat: shortlist of the fp16 pass = max(64, kmul*k) (0: library default)")
+    ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE",
+                    help="developer tuning switch passed to vdb_set_param before the first step (A/B runs; results never depend on them)")
     ap.add_argument("--dump", type=str, default="", help="rank 0 saves the last step's results to this .npz (tests)")
     ap.add_argument("--legs", choices=["auto", "all", "none"], default="auto",
                     help="the SURVEY 8(d) report items beside the headline (N=1, flat): auto = all when the headline runs at its "
@@ -322,6 +324,9 @@ def main():
         ix.set_param("flat_half_kmul", args.half_kmul)
     if args.i8:
         ix.set_param("flat_i8", args.i8)
+    for pv in args.param:
+        pn, _, pval = pv.partition("=")
+        ix.set_param(pn, int(pval))
     host_base = None
     if rank == 0 and world == 1 and args.cpu_queries > 0:
         host_base = base.cpu().numpy()
@@ -542,6 +547,8 @@ def main():
                    "parallelism": par if world > 1 else "single GPU", "steps_in_flight": depth},
         "roofline": roofline, "recall_at_10": None,
     }
+    if args.param:
+        out["config"]["tuning_switches"] = list(args.param)
     if wl == "flat":
         out["config"]["queries_per_corpus_pass"] = 128 if (nq > 64 or (roofline or {}).get("kernel") in ("flat_half", "flat_i8")) else 64
         out["fallback_queries"] = ix.flat_fallback_count()

@@ -516,6 +516,8 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         idx->ix.flat_gemm_debug = (int)value;
     else if (n == "flat_tail")  // exact stage of the Flat pipeline: 0 fused launch when the shortlist fits 64 rows, 1 separate kernels
         idx->ix.flat_tail_mode = (int)value;
+    else if (n == "flat_tail_lb_nw")  // exact stage of the 8-bit pass: waves per query (0 auto, 8 / 4 / 2 / 1)
+        flat_tail_lb_set_nw((int)value);
     else if (n == "flat_small")  // one-launch search of small tables (k_small.hip): 0 auto, 1 off, 2 whenever the shape allows
         idx->ix.flat_small_mode = (int)value;
     else if (n == "flat_small_max_rows")

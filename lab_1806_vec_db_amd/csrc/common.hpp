@@ -84,27 +84,88 @@ constexpr uint64_t PAIR_NONE = ~0ull;  // sorts after every real pair
 
 
 #if defined(__HIPCC__)
-// ---- 64-key bitonic networks across the lanes of a wave (shuffles, no LDS) ----------------------------------------
-__device__ __forceinline__ uint64_t cmpx64(uint64_t v, uint32_t lane, uint32_t j, bool up) {
-    const uint64_t o = __shfl_xor(v, j);
-    const bool take_min = ((lane & j) == 0) == up;
+// ---- 64-key bitonic networks across the lanes of a wave (no LDS) ---------------------------------------------------
+// The partner of a compare-exchange stage is lane ^ j with j a power of two known at compile time (the networks are fully
+// unrolled).  __shfl_xor is a ds_bpermute_b32 per 32-bit word -- an LDS-crossbar round trip of ~100 cycles that every stage of
+// the chain waits for.  The same exchange inside the vector ALU: j = 1, 2 one quad_perm DPP move, j = 4 two row-shift DPP moves
+// under complementary bank masks, j = 8 a row rotate by 8 (= ^ 8 in a ring of 16), j = 16 / 32 gfx950's v_permlane16_swap /
+// v_permlane32_swap (a copy of the word swapped against itself holds the partner rows in the other operand).  All lanes of the
+// wave must be active (as for the shuffle forms: a disabled lane supplies no data either way).
+template <uint32_t J>
+__device__ __forceinline__ uint32_t lane_xor32(uint32_t v, uint32_t lane) {
+    static_assert(J == 1 || J == 2 || J == 4 || J == 8 || J == 16 || J == 32, "partner distance");
+    if constexpr (J == 1) {
+        return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);  // quad_perm:[1,0,3,2]
+    } else if constexpr (J == 2) {
+        return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);  // quad_perm:[2,3,0,1]
+    } else if constexpr (J == 4) {
+        int t = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0x5, false);  // row_shl:4 -> banks 0, 2 read lane + 4
+        t = __builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xF, 0xA, false);          // row_shr:4 -> banks 1, 3 read lane - 4
+        return (uint32_t)t;
+    } else if constexpr (J == 8) {
+        return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false);  // row_ror:8
+    } else if constexpr (J == 16) {
+        // odd rows of the first operand <-> even rows of the second: first = [r0 r0 r2 r2], second = [r1 r1 r3 r3]
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (lane & 16) ? r[0] : r[1];
+    } else {
+        // upper half of the first operand <-> lower half of the second: first = [lo lo], second = [hi hi]
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return (lane & 32) ? r[0] : r[1];
+    }
+}
+template <uint32_t J>
+__device__ __forceinline__ uint64_t lane_xor64(uint64_t v, uint32_t lane) {
+    return (uint64_t(lane_xor32<J>(uint32_t(v >> 32), lane)) << 32) | lane_xor32<J>(uint32_t(v), lane);
+}
+// value of lane 63 - l (the reverse a bitonic merge starts with): mirror inside the rows of 16, then swap the rows
+__device__ __forceinline__ uint32_t lane_reverse32(uint32_t v, uint32_t lane) {
+    const uint32_t m = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
+    return lane_xor32<32>(lane_xor32<16>(m, lane), lane);
+}
+__device__ __forceinline__ uint64_t lane_reverse64(uint64_t v, uint32_t lane) {
+    return (uint64_t(lane_reverse32(uint32_t(v >> 32), lane)) << 32) | lane_reverse32(uint32_t(v), lane);
+}
+// compare-exchange with lane ^ J, keeping the smaller key where ((lane & J) == 0) == up
+template <uint32_t J>
+__device__ __forceinline__ uint64_t cmpx64_t(uint64_t v, uint32_t lane, bool up) {
+#ifndef VDB_SHUFFLE_NETWORKS  // (make EXTRA=-DVDB_SHUFFLE_NETWORKS: the ds_bpermute forms, for A/B runs)
+    const uint64_t o = lane_xor64<J>(v, lane);
+#else
+    const uint64_t o = __shfl_xor(v, J);
+#endif
+    const bool take_min = ((lane & J) == 0) == up;
     return ((v < o) == take_min) ? v : o;
 }
-// ascending sort of one key per lane (21 compare-exchange stages)
+// stages J, J/2, .. 1 of the bitonic network's step K over U independent key registers (interleaved: their latencies overlap)
+template <uint32_t K, uint32_t J, int U>
+__device__ __forceinline__ void bitonic_stages(uint64_t (&r)[U], uint32_t lane) {
+#pragma unroll
+    for (int u = 0; u < U; u++) r[u] = cmpx64_t<J>(r[u], lane, (lane & K) == 0);
+    if constexpr (J > 1) bitonic_stages<K, J / 2, U>(r, lane);
+}
+// steps K, 2K, .. 64: ascending sort of every register across the lanes (K = 2: the 21 compare-exchange stages)
+template <uint32_t K, int U>
+__device__ __forceinline__ void bitonic_sort_from(uint64_t (&r)[U], uint32_t lane) {
+    bitonic_stages<K, K / 2, U>(r, lane);
+    if constexpr (K < 64) bitonic_sort_from<2 * K, U>(r, lane);
+}
+// ascending sort of one key per lane
 __device__ __forceinline__ uint64_t sort64(uint64_t r, uint32_t lane) {
-#pragma unroll
-    for (uint32_t k = 2; k <= 64; k <<= 1)
-#pragma unroll
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) r = cmpx64(r, lane, j, (lane & k) == 0);
-    return r;
+    uint64_t a[1] = {r};
+    bitonic_sort_from<2, 1>(a, lane);
+    return a[0];
 }
 // a, b ascending across the lanes -> the 64 smallest of both, ascending
 __device__ __forceinline__ uint64_t merge64(uint64_t a, uint64_t b, uint32_t lane) {
+#ifndef VDB_SHUFFLE_NETWORKS
+    const uint64_t rev = lane_reverse64(b, lane);
+#else
     const uint64_t rev = __shfl(b, 63 - lane);
-    uint64_t m = a < rev ? a : rev;
-#pragma unroll
-    for (uint32_t j = 32; j > 0; j >>= 1) m = cmpx64(m, lane, j, true);
-    return m;
+#endif
+    uint64_t m[1] = {a < rev ? a : rev};
+    bitonic_stages<64, 32, 1>(m, lane);  // (lane & 64) == 0 everywhere: ascending
+    return m[0];
 }
 // The 64 smallest of `total` keys at src, ascending across the lanes of wave 0 (other waves: unspecified).  Block of
 // 256 threads; a wave takes every fourth batch of 4 x 64 keys, sorts the four runs (interleaved, so that the shuffle
@@ -133,12 +194,7 @@ __device__ __forceinline__ uint64_t block_top64(const uint64_t *__restrict__ src
         uint64_t lo = r[0] < r[1] ? r[0] : r[1], lo2 = r[2] < r[3] ? r[2] : r[3];
         lo = lo < lo2 ? lo : lo2;
         if (__ballot(lo < tau) == 0) continue;  // wave-uniform
-#pragma unroll
-        for (uint32_t k = 2; k <= 64; k <<= 1)
-#pragma unroll
-            for (uint32_t j = k >> 1; j > 0; j >>= 1)
-#pragma unroll
-                for (int u = 0; u < 4; u++) r[u] = cmpx64(r[u], lane, j, (lane & k) == 0);
+        bitonic_sort_from<2, 4>(r, lane);
         const uint64_t a = merge64(r[0], r[1], lane), b = merge64(r[2], r[3], lane);
         best = merge64(best, merge64(a, b, lane), lane);
     }

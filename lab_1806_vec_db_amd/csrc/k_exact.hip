@@ -5,6 +5,7 @@
 // ascending in the dimension.  The file is compiled with -ffp-contract=off and the pragma below
 // repeats that, so no v_fma is formed from a*b+c.
 #include <algorithm>
+#include <atomic>
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -409,6 +410,69 @@ __device__ __forceinline__ float group_rerank_fold(const float *__restrict__ X, 
     return acc;
 }
 
+// group_rerank_fold for a wave that takes RW = 8 NP rows (k_flat_tail_lb with fewer than 8 waves per query).  The fetch side is the
+// same in NP passes -- in pass i lane 8g + p fetches piece p of every chunk of the wave's row 8i + g and turns it into products --
+// and the 64 / RW lanes of chain r add row r's 32 values of a chunk in reference order.  What changes is the instruction count: a
+// chunk costs a wave 32 adds + 8 LDS reads whatever RW is, so 63 rows cost 8 waves x 8 rows 8 x (40 + 7) issue slots per chunk and
+// 2 waves x 32 rows 2 x (40 + 28).  The exact stage of a 1000-query call keeps every SIMD of the chip busy with several waves,
+// where issue slots, not the length of one chain, are what the stage waits for.
+template <int FOLD, int DEPTH, int RW>
+__device__ __forceinline__ float group_rerank_fold_n(const float *__restrict__ X, uint32_t dim, const uint32_t (&idx)[RW / 8],
+                                                     const bool (&live)[RW / 8], const float4 *qs4, float4 *tile /* this wave's [RW][9] */,
+                                                     uint32_t lane) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr int NP = RW / 8;
+    const uint32_t d4 = dim / 4, g = lane >> 3, p = lane & 7, r = lane / (64 / RW);
+    const f4 *rp[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) rp[i] = reinterpret_cast<const f4 *>(X + uint64_t(idx[i]) * dim) + p;
+    const f4 *q4 = reinterpret_cast<const f4 *>(qs4);
+    f4 *t4 = reinterpret_cast<f4 *>(tile);
+    const uint32_t nch = (d4 + 7) / 8;
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    f4 stg[DEPTH][NP];
+#pragma unroll
+    for (int st = 0; st < DEPTH; st++)
+#pragma unroll
+        for (int i = 0; i < NP; i++) stg[st][i] = (uint32_t(st) < nch && uint32_t(st) * 8 + p < d4 && live[i]) ? rp[i][st * 8] : zero;
+    float acc = 0.0f;
+    for (uint32_t ch0 = 0; ch0 < nch; ch0 += DEPTH) {
+#pragma unroll
+        for (int st = 0; st < DEPTH; st++) {
+            const uint32_t ch = ch0 + st;
+            if (ch >= nch) break;  // uniform
+            const bool inside = ch * 8 + p < d4;
+            const f4 w = inside ? q4[ch * 8 + p] : zero;
+            const uint32_t nx = ch + DEPTH;
+            const bool more = nx < nch && nx * 8 + p < d4;
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                f4 pr = zero;
+                if (inside) {
+                    const f4 x = stg[st][i];
+                    if (FOLD == FOLD_L2) {
+                        const f4 df = x - w;
+                        pr = df * df;
+                    } else {
+                        pr = x * w;
+                    }
+                }
+                t4[(8 * i + g) * 9 + p] = pr;
+                stg[st][i] = (more && live[i]) ? rp[i][nx * 8] : zero;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const f4 v = t4[r * 9 + j];
+                acc = acc + v.x;
+                acc = acc + v.y;
+                acc = acc + v.z;
+                acc = acc + v.w;
+            }
+        }
+    }
+    return acc;
+}
+
 // The same re-rank with coalesced row fetches (dim % 4 == 0): k_rerank lets every lane walk its own row 16 B at a time,
 // i.e. one load instruction touches 64 different 128-B lines and each line has to survive in the L1 across 8
 // instructions -- 35 us for 32 candidates x 1000 queries at dim 960, but 184 us for 64 (the lines of the waves
@@ -790,6 +854,11 @@ void launch_flat_tail64(const FlatTailArgs &a, uint32_t nq, hipStream_t s) {
 // the key's own evaluation.  Most queries stop after 32 .. 96 rows; one that is still open after max_rounds is flagged and
 // redone by the next tier.  L2Sqr only.
 // ---------------------------------------------------------------------------------------------
+// Waves per query of k_flat_tail_lb.  Measured (profiles/r03_probe_tail_lb_waves.txt): 4 waves x 16 rows beat 8 x 8 at every call size
+// (110 instead of 122 registers: four workgroups per CU instead of two, so a 1000-query call is ONE generation of workgroups;
+// a third fewer issue slots per round) -- 1000 queries: 136 -> 87 us on a 125k-row shard, 166 -> 148 us at 1M rows; 32 queries 65 -> 62,
+// one query 45.6 -> 43.6 us.  2 waves x 32 rows: 98 / 168 us, one wave: 121 us (the chain of a round grows with the rows a wave fetches).
+#define TAIL_LB_AUTO_NW(nq) 4
 template <int NW>
 __device__ __forceinline__ uint64_t block_top64_above(const uint64_t *__restrict__ src, uint32_t total, uint64_t (*sbest)[64], uint64_t above) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -807,12 +876,7 @@ __device__ __forceinline__ uint64_t block_top64_above(const uint64_t *__restrict
         uint64_t lo = r[0] < r[1] ? r[0] : r[1], lo2 = r[2] < r[3] ? r[2] : r[3];
         lo = lo < lo2 ? lo : lo2;
         if (__ballot(lo < tau) == 0) continue;  // wave-uniform
-#pragma unroll
-        for (uint32_t k = 2; k <= 64; k <<= 1)
-#pragma unroll
-            for (uint32_t j = k >> 1; j > 0; j >>= 1)
-#pragma unroll
-                for (int u = 0; u < 4; u++) r[u] = cmpx64(r[u], lane, j, (lane & k) == 0);
+        bitonic_sort_from<2, 4>(r, lane);
         const uint64_t a = merge64(r[0], r[1], lane), b = merge64(r[2], r[3], lane);
         best = merge64(best, merge64(a, b, lane), lane);
     }
@@ -834,17 +898,20 @@ __device__ __forceinline__ uint8_t flat_certify_lb(uint64_t ek, float kappa, uin
     lower = lower - float(a.dim + 8) * 5.9604645e-8f * 1.01f * fabsf(lower) - 4.0f * 5.9604645e-8f * nr * nr;
     return dk < lower ? 0 : 1;  // NaN anywhere -> not certified
 }
-// NW waves of 64: a round = one select + ONE re-rank stage of 8 NW - 1 rows (8 per wave; the last position opens the next round)
+// NW waves of 64 (8, 4, 2 or 1): a round = one select + ONE re-rank stage of 63 rows, 64 / NW per wave (the last position of
+// the round's 64 keys opens the next round)
 template <int FOLD, int NW>
 __global__ __launch_bounds__(NW * 64) void k_flat_tail_lb(FlatTailArgs a) {
-    static_assert(NW == 8, "a stage covers the 64 keys of a round");
-    extern __shared__ float4 ftl_smem[];  // [dim/4] query, then NW waves x [8 rows][9] float4 product tiles
+    static_assert(NW == 8 || NW == 4 || NW == 2 || NW == 1, "a stage covers the 64 keys of a round");
+    constexpr int RW = 64 / NW, NP = RW / 8;
+    constexpr int DEPTH = NW == 8 ? 8 : (NW == 4 ? 4 : (NW == 2 ? 3 : 2));  // chunks of row loads in flight per wave (NP KB each)
+    extern __shared__ float4 ftl_smem[];  // [dim/4] query, then NW waves x [RW rows][9] float4 product tiles
     __shared__ uint64_t sbest[NW][64];
     __shared__ uint64_t skeys[64];
     __shared__ uint32_t s_flag;
     const uint32_t q = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t d4 = a.dim / 4;
-    float4 *qs4 = ftl_smem, *tile = ftl_smem + d4 + wave * 72;
+    float4 *qs4 = ftl_smem, *tile = ftl_smem + d4 + wave * (RW * 9);
     for (uint32_t i = threadIdx.x; i < d4; i += NW * 64) qs4[i] = reinterpret_cast<const float4 *>(a.Q + uint64_t(q) * a.dim)[i];
     const uint32_t cnt_q = a.cnt[q];
     const uint32_t total = cnt_q <= a.cap ? cnt_q : 0;  // cnt > cap: slots are not all written, the query is redone
@@ -860,12 +927,26 @@ __global__ __launch_bounds__(NW * 64) void k_flat_tail_lb(FlatTailArgs a) {
         if (wave == 0) sbest[0][lane] = best;
         if (threadIdx.x < 64) skeys[threadIdx.x] = PAIR_NONE;
         __syncthreads();
-        const uint32_t j = wave * 8 + (lane >> 3);  // position 63 is not evaluated: it opens the next round
-        const uint64_t c = sbest[0][j];
-        const bool live = c != PAIR_NONE && j < 63;
-        const uint32_t idx = live ? uint32_t(c) : 0u;
-        const float acc = group_rerank_fold<FOLD, 8>(a.X, a.dim, idx, live, qs4, tile, lane);
-        if (live && (lane & 7) == 0) skeys[j] = pair_key(epilogue(MET_L2_DIRECT, acc, 0.0f, 0.0f), idx);
+        // position 63 is not evaluated: it opens the next round
+        uint32_t idx[NP];
+        bool live[NP];
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const uint32_t j = wave * RW + 8 * i + (lane >> 3);
+            const uint64_t c = sbest[0][j];
+            live[i] = c != PAIR_NONE && j < 63;
+            idx[i] = live[i] ? uint32_t(c) : 0u;
+        }
+        float acc;
+        if constexpr (NW == 8)
+            acc = group_rerank_fold<FOLD, 8>(a.X, a.dim, idx[0], live[0], qs4, tile, lane);
+        else
+            acc = group_rerank_fold_n<FOLD, DEPTH, RW>(a.X, a.dim, idx, live, qs4, tile, lane);
+        {
+            const uint32_t j = wave * RW + lane / NW;  // the row whose chain this lane added (NW lanes each)
+            const uint64_t c = sbest[0][j];
+            if (c != PAIR_NONE && j < 63 && lane % NW == 0) skeys[j] = pair_key(epilogue(MET_L2_DIRECT, acc, 0.0f, 0.0f), uint32_t(c));
+        }
         __syncthreads();
         if (wave == 0) {
             run = merge64(run, sort64(skeys[lane], lane), lane);
@@ -900,12 +981,23 @@ __global__ __launch_bounds__(NW * 64) void k_flat_tail_lb(FlatTailArgs a) {
 bool flat_tail_lb_supported(uint32_t dim, uint32_t kprime, uint32_t ksel) {
     return (dim & 3) == 0 && dim >= 64 && dim <= 8192 && kprime >= 64 && kprime % 64 == 0 && kprime <= 1024 && ksel >= 1 && ksel <= 64;
 }
+static std::atomic<int> g_tail_lb_nw{0};  // 0 auto; 8 / 4 / 2 / 1 waves per query
+void flat_tail_lb_set_nw(int v) { g_tail_lb_nw = v; }
 void launch_flat_tail_lb(const FlatTailArgs &a, uint32_t nq, hipStream_t s) {
     if (nq == 0) return;
     VDB_REQUIRE(flat_tail_lb_supported(a.dim, a.kprime, a.ksel) && a.metric == MET_L2_DIRECT && a.se.qoff && a.tau,
                 "flat_tail_lb: unsupported shape");
-    const size_t lds = (size_t(a.dim / 4) + 8 * 72) * sizeof(float4);
-    hipLaunchKernelGGL((k_flat_tail_lb<FOLD_L2, 8>), dim3(nq), dim3(512), lds, s, a);
+    const size_t lds = (size_t(a.dim / 4) + 64 * 9) * sizeof(float4);
+    int nw = g_tail_lb_nw;
+    if (nw != 8 && nw != 4 && nw != 2 && nw != 1) nw = TAIL_LB_AUTO_NW(nq);
+    if (nw == 8)
+        hipLaunchKernelGGL((k_flat_tail_lb<FOLD_L2, 8>), dim3(nq), dim3(512), lds, s, a);
+    else if (nw == 4)
+        hipLaunchKernelGGL((k_flat_tail_lb<FOLD_L2, 4>), dim3(nq), dim3(256), lds, s, a);
+    else if (nw == 2)
+        hipLaunchKernelGGL((k_flat_tail_lb<FOLD_L2, 2>), dim3(nq), dim3(128), lds, s, a);
+    else
+        hipLaunchKernelGGL((k_flat_tail_lb<FOLD_L2, 1>), dim3(nq), dim3(64), lds, s, a);
     VDB_HIP(hipGetLastError());
 }
 

@@ -70,6 +70,7 @@ struct FlatTailArgs {
 // the exact stage behind the 8-bit pass: walks the hit list in key order, 64 keys per round (kprime / 64 rounds at most)
 bool flat_tail_lb_supported(uint32_t dim, uint32_t kprime, uint32_t ksel);
 void launch_flat_tail_lb(const FlatTailArgs &a, uint32_t nq, hipStream_t s);
+void flat_tail_lb_set_nw(int v);  // waves per query: 0 auto, 8 / 4 / 2 / 1
 bool flat_tail64_supported(uint32_t dim, uint32_t kprime, uint32_t ksel);
 void launch_flat_tail64(const FlatTailArgs &a, uint32_t nq, hipStream_t s);
 // k_small.hip: FlatIndex::knn of a few queries over a small table in ONE launch (the db.search() shape): coalesced rows ->

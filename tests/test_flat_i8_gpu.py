@@ -115,6 +115,19 @@ def test_i8_pass_parity(mods, dim, n, nq):
         np.testing.assert_array_equal(idx, idx2)
         np.testing.assert_array_equal(d, d2)
     ix.set_param("flat_gemm8_nt", 0)
+    for nw in (8, 4, 2, 1):  # exact stage: waves per query (8 / 16 / 32 / 64 rows of a round per wave)
+        ix.set_param("flat_tail_lb_nw", nw)
+        r0 = ix.get_stat("flat_i8_redo")
+        idx2, d2, cnt2 = ix.flat_knn(qs, 10)
+        np.testing.assert_array_equal(idx, idx2)
+        np.testing.assert_array_equal(d, d2)
+        np.testing.assert_array_equal(cnt, cnt2)
+        assert ix.get_stat("flat_i8_redo") - r0 == redo  # the same queries close in the same rounds
+        for k in (1, 64):
+            idx3, d3, cnt3 = ix.flat_knn(qs[:40], k)
+            oi3, od3, oc3 = O.flat_knn_batch(base, qs[:40], k, 0, nthreads=8)
+            _check_all(idx3, d3, cnt3, oi3, od3, oc3)
+    ix.set_param("flat_tail_lb_nw", 0)
     ix.set_param("flat_i8", 1)  # off: the fp16 pass answers (its mirror is built by this very call)
     q0 = ix.get_stat("flat_i8_queries")
     idx2, d2, _ = ix.flat_knn(qs, 10)
