@@ -6,6 +6,9 @@
 // repeats that, so no v_fma is formed from a*b+c.
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -369,44 +372,57 @@ __device__ __forceinline__ float group_rerank_fold(const float *__restrict__ X, 
                                                    float4 *tile /* this wave's [8][9] */, uint32_t lane) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     const uint32_t d4 = dim / 4, g = lane >> 3, p = lane & 7;
-    const f4 *rp = reinterpret_cast<const f4 *>(X + uint64_t(idx) * dim) + p;
+    // EVERY load below is executed by every lane: pieces past the row (dim % 32 != 0) and chunks past the end re-read the
+    // row's last piece, rows that are not live read row `idx` = 0 all the same, and what must not count is zeroed as a PRODUCT.
+    // A load under a lane condition becomes a branch, and the wait-count pass then gives up counting: it puts
+    // `s_waitcnt vmcnt(0)` in front of the first use in every chunk, i.e. every chunk waited for the load issued one chunk
+    // before it -- a full memory round trip per chunk whatever DEPTH was (measured with cache-resident rows, -DVDB_TAIL_ABLATE=1:
+    // ~960 shader-clock ticks per chunk where the 32 adds take 350).
+    (void)live;
+    const f4 *rp = reinterpret_cast<const f4 *>(X + uint64_t(idx) * dim);
     const f4 *q4 = reinterpret_cast<const f4 *>(qs4);
     f4 *t4 = reinterpret_cast<f4 *>(tile);
-    const uint32_t nch = (d4 + 7) / 8;
+    const uint32_t nch = (d4 + 7) / 8, last = d4 - 1;
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    auto piece = [&](uint32_t ch) -> uint32_t {
+        const uint32_t i = ch * 8 + p;
+        return i < last ? i : last;
+    };
     f4 stg[DEPTH];
 #pragma unroll
-    for (int st = 0; st < DEPTH; st++) stg[st] = (uint32_t(st) < nch && uint32_t(st) * 8 + p < d4 && live) ? rp[st * 8] : zero;
+    for (int st = 0; st < DEPTH; st++) stg[st] = rp[piece(uint32_t(st))];
     float acc = 0.0f;
-    for (uint32_t ch0 = 0; ch0 < nch; ch0 += DEPTH) {
-#pragma unroll
-        for (int st = 0; st < DEPTH; st++) {
-            const uint32_t ch = ch0 + st;
-            if (ch >= nch) break;  // uniform
-            const bool inside = ch * 8 + p < d4;
-            f4 pr = zero;
-            if (inside) {
-                const f4 x = stg[st], w = q4[ch * 8 + p];
-                if (FOLD == FOLD_L2) {
-                    const f4 df = x - w;
-                    pr = df * df;
-                } else {
-                    pr = x * w;
-                }
-            }
-            t4[g * 9 + p] = pr;
-            const uint32_t nx = ch + DEPTH;
-            stg[st] = (nx < nch && nx * 8 + p < d4 && live) ? rp[nx * 8] : zero;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const f4 v = t4[g * 9 + j];
-                acc = acc + v.x;
-                acc = acc + v.y;
-                acc = acc + v.z;
-                acc = acc + v.w;
-            }
+    auto chunk = [&](uint32_t ch, f4 &sg) {
+        const bool inside = ch * 8 + p < d4;
+        const f4 x = sg, w = q4[piece(ch)];
+        f4 pr;
+        if (FOLD == FOLD_L2) {
+            const f4 df = x - w;
+            pr = df * df;
+        } else {
+            pr = x * w;
         }
+        t4[g * 9 + p] = inside ? pr : zero;
+        sg = rp[piece(ch + DEPTH)];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const f4 v = t4[g * 9 + j];
+            acc = acc + v.x;
+            acc = acc + v.y;
+            acc = acc + v.z;
+            acc = acc + v.w;
+        }
+    };
+    // whole groups of DEPTH chunks without a branch between them (the register ring keeps its places and the waits their counts),
+    // then the last nch % DEPTH chunks
+    uint32_t ch0 = 0;
+    for (; ch0 + DEPTH <= nch; ch0 += DEPTH) {
+#pragma unroll
+        for (int st = 0; st < DEPTH; st++) chunk(ch0 + st, stg[st]);
     }
+#pragma unroll
+    for (int st = 0; st < DEPTH - 1; st++)
+        if (ch0 + st < nch) chunk(ch0 + st, stg[st]);  // uniform
     return acc;
 }
 
@@ -423,51 +439,157 @@ __device__ __forceinline__ float group_rerank_fold_n(const float *__restrict__ X
     typedef float f4 __attribute__((ext_vector_type(4)));
     constexpr int NP = RW / 8;
     const uint32_t d4 = dim / 4, g = lane >> 3, p = lane & 7, r = lane / (64 / RW);
+    (void)live;  // (unconditional loads: see group_rerank_fold)
     const f4 *rp[NP];
 #pragma unroll
-    for (int i = 0; i < NP; i++) rp[i] = reinterpret_cast<const f4 *>(X + uint64_t(idx[i]) * dim) + p;
+    for (int i = 0; i < NP; i++) rp[i] = reinterpret_cast<const f4 *>(X + uint64_t(idx[i]) * dim);
     const f4 *q4 = reinterpret_cast<const f4 *>(qs4);
     f4 *t4 = reinterpret_cast<f4 *>(tile);
-    const uint32_t nch = (d4 + 7) / 8;
+    const uint32_t nch = (d4 + 7) / 8, last = d4 - 1;
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    auto piece = [&](uint32_t ch) -> uint32_t {
+        const uint32_t i = ch * 8 + p;
+        return i < last ? i : last;
+    };
     f4 stg[DEPTH][NP];
 #pragma unroll
     for (int st = 0; st < DEPTH; st++)
 #pragma unroll
-        for (int i = 0; i < NP; i++) stg[st][i] = (uint32_t(st) < nch && uint32_t(st) * 8 + p < d4 && live[i]) ? rp[i][st * 8] : zero;
+        for (int i = 0; i < NP; i++) stg[st][i] = rp[i][piece(uint32_t(st))];
     float acc = 0.0f;
-    for (uint32_t ch0 = 0; ch0 < nch; ch0 += DEPTH) {
+    auto chunk = [&](uint32_t ch, f4(&sg)[NP]) {
+        const bool inside = ch * 8 + p < d4;
+        const f4 w = q4[piece(ch)];
+        const uint32_t nxp = piece(ch + DEPTH);
 #pragma unroll
-        for (int st = 0; st < DEPTH; st++) {
-            const uint32_t ch = ch0 + st;
-            if (ch >= nch) break;  // uniform
-            const bool inside = ch * 8 + p < d4;
-            const f4 w = inside ? q4[ch * 8 + p] : zero;
-            const uint32_t nx = ch + DEPTH;
-            const bool more = nx < nch && nx * 8 + p < d4;
+        for (int i = 0; i < NP; i++) {
+            const f4 x = sg[i];
+            f4 pr;
+            if (FOLD == FOLD_L2) {
+                const f4 df = x - w;
+                pr = df * df;
+            } else {
+                pr = x * w;
+            }
+            t4[(8 * i + g) * 9 + p] = inside ? pr : zero;
+            sg[i] = rp[i][nxp];
+        }
 #pragma unroll
-            for (int i = 0; i < NP; i++) {
-                f4 pr = zero;
-                if (inside) {
-                    const f4 x = stg[st][i];
-                    if (FOLD == FOLD_L2) {
-                        const f4 df = x - w;
-                        pr = df * df;
-                    } else {
-                        pr = x * w;
-                    }
-                }
-                t4[(8 * i + g) * 9 + p] = pr;
-                stg[st][i] = (more && live[i]) ? rp[i][nx * 8] : zero;
+        for (int j = 0; j < 8; j++) {
+            const f4 v = t4[r * 9 + j];
+            acc = acc + v.x;
+            acc = acc + v.y;
+            acc = acc + v.z;
+            acc = acc + v.w;
+        }
+    };
+    uint32_t ch0 = 0;
+    for (; ch0 + DEPTH <= nch; ch0 += DEPTH) {
+#pragma unroll
+        for (int st = 0; st < DEPTH; st++) chunk(ch0 + st, stg[st]);
+    }
+#pragma unroll
+    for (int st = 0; st < DEPTH - 1; st++)
+        if (ch0 + st < nch) chunk(ch0 + st, stg[st]);  // uniform
+    return acc;
+}
+
+// The fold of a 64-row round with ONE chain per lane (k_flat_tail_lb, 4 waves).  In the forms above a row's chain is added by
+// all the lanes that fetched the row (8, 4 or 2 of them): a round of 63 rows spends 4 waves x 32 add instructions per chunk on 16
+// distinct chains each, and with four workgroups per CU the stage is bound by issue slots (measured: 48k shader-clock ticks per
+// round where 960 dependent adds take 10.5k).  Here the four waves only PRODUCE: wave w fetches rows 16w .. 16w + 15 as before (8
+// lanes per row and chunk, a whole 128-B line per instruction, DEPTH chunks ahead) and writes the products of a 32-column chunk into
+// one of two [64 rows][9] float4 tiles; after the chunk's barrier ONE wave (`consumer`, rotated over the workgroups so that the
+// consumers of a CU's workgroups spread over its SIMDs) adds row `lane`'s 32 values in reference order -- 8 LDS reads + 32 adds
+// per chunk for all 64 rows.  The reads are split in halves that alternate with the adds of the previous half, so the chain
+// never waits for LDS; __syncthreads() is `s_waitcnt lgkmcnt(0); s_barrier` here (row loads stay in flight across it), which
+// is also what makes two tiles enough: a tile is rewritten two barriers after the consumer's reads of it were waited for.
+// Returns row `lane`'s sum in the consumer wave (garbage elsewhere).  All 256 threads must call it.
+template <int FOLD, int DEPTH>
+__device__ __forceinline__ float pc_rerank_fold(const float *__restrict__ X, uint32_t dim, const uint32_t (&idx)[2], const bool (&live)[2],
+                                                const float4 *qs4, float4 *tiles /* [2][64][9] */, uint32_t wave, uint32_t lane,
+                                                bool consumer) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const uint32_t d4 = dim / 4, g = lane >> 3, p = lane & 7;
+    (void)live;  // (unconditional loads: see group_rerank_fold)
+    const f4 *rp[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) rp[i] = reinterpret_cast<const f4 *>(X + uint64_t(idx[i]) * dim);
+    const f4 *q4 = reinterpret_cast<const f4 *>(qs4);
+    f4 *t4 = reinterpret_cast<f4 *>(tiles);
+    const uint32_t nch = (d4 + 7) / 8, last = d4 - 1;
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    auto piece = [&](uint32_t ch) -> uint32_t {
+        const uint32_t i = ch * 8 + p;
+        return i < last ? i : last;
+    };
+    f4 stg[DEPTH][2];
+#pragma unroll
+    for (int st = 0; st < DEPTH; st++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) stg[st][i] = rp[i][piece(uint32_t(st))];
+    float acc = 0.0f;
+    f4 hb[4] = {zero, zero, zero, zero};  // second half of the previous chunk (+0.0 before the first: exact, the sum is never -0.0)
+    uint32_t buf = 0;
+    auto chunk = [&](uint32_t ch, f4(&sg)[2]) {
+        const bool inside = ch * 8 + p < d4;
+        const f4 w = q4[piece(ch)];
+        const uint32_t nxp = piece(ch + DEPTH);
+        f4 *tb = t4 + buf * (64 * 9);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const f4 x = sg[i];
+            f4 pr;
+            if (FOLD == FOLD_L2) {
+                const f4 df = x - w;
+                pr = df * df;
+            } else {
+                pr = x * w;
+            }
+            tb[(16 * wave + 8 * i + g) * 9 + p] = inside ? pr : zero;
+            sg[i] = rp[i][nxp];
+        }
+        __syncthreads();
+        if (consumer) {
+            f4 ha[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) ha[j] = tb[lane * 9 + j];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                acc = acc + hb[j].x;
+                acc = acc + hb[j].y;
+                acc = acc + hb[j].z;
+                acc = acc + hb[j].w;
             }
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const f4 v = t4[r * 9 + j];
-                acc = acc + v.x;
-                acc = acc + v.y;
-                acc = acc + v.z;
-                acc = acc + v.w;
+            for (int j = 0; j < 4; j++) hb[j] = tb[lane * 9 + 4 + j];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                acc = acc + ha[j].x;
+                acc = acc + ha[j].y;
+                acc = acc + ha[j].z;
+                acc = acc + ha[j].w;
             }
+        }
+        buf ^= 1u;
+    };
+    // whole groups of DEPTH chunks without a branch between them (the register ring keeps its places and the waits their counts),
+    // then the last nch % DEPTH chunks
+    uint32_t ch0 = 0;
+    for (; ch0 + DEPTH <= nch; ch0 += DEPTH) {
+#pragma unroll
+        for (int st = 0; st < DEPTH; st++) chunk(ch0 + st, stg[st]);
+    }
+#pragma unroll
+    for (int st = 0; st < DEPTH - 1; st++)
+        if (ch0 + st < nch) chunk(ch0 + st, stg[st]);  // uniform
+    if (consumer) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            acc = acc + hb[j].x;
+            acc = acc + hb[j].y;
+            acc = acc + hb[j].z;
+            acc = acc + hb[j].w;
         }
     }
     return acc;
@@ -854,11 +976,11 @@ void launch_flat_tail64(const FlatTailArgs &a, uint32_t nq, hipStream_t s) {
 // the key's own evaluation.  Most queries stop after 32 .. 96 rows; one that is still open after max_rounds is flagged and
 // redone by the next tier.  L2Sqr only.
 // ---------------------------------------------------------------------------------------------
-// Waves per query of k_flat_tail_lb.  Measured (profiles/r03_probe_tail_lb_waves.txt): 4 waves x 16 rows beat 8 x 8 at every call size
-// (110 instead of 122 registers: four workgroups per CU instead of two, so a 1000-query call is ONE generation of workgroups;
-// a third fewer issue slots per round) -- 1000 queries: 136 -> 87 us on a 125k-row shard, 166 -> 148 us at 1M rows; 32 queries 65 -> 62,
-// one query 45.6 -> 43.6 us.  2 waves x 32 rows: 98 / 168 us, one wave: 121 us (the chain of a round grows with the rows a wave fetches).
-#define TAIL_LB_AUTO_NW(nq) 4
+// Variant of k_flat_tail_lb ("flat_tail_lb_nw": 8 / 4 / 2 / 1 = waves per query with the chains on the fetching lanes, 40 / 41 = four
+// waves with one chain per lane, loads 3 / 5 chunks deep).  Measured (profiles/r03_probe_tail_lb_waves.txt; 1000 queries on a 125k-row
+// shard | at 1M rows | 32 queries | 1 query, us): 8 waves 97 | 125 | 50 | 35, 4 waves 72 | 110 | 50 | 35, 40: 67 | 106 | 44 | 31,
+// 41: 71 | 108 | 45 | 32 (its extra depth costs the spills of a 128-register budget).
+#define TAIL_LB_AUTO_NW(nq) 40
 template <int NW>
 __device__ __forceinline__ uint64_t block_top64_above(const uint64_t *__restrict__ src, uint32_t total, uint64_t (*sbest)[64], uint64_t above) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -900,12 +1022,14 @@ __device__ __forceinline__ uint8_t flat_certify_lb(uint64_t ek, float kappa, uin
 }
 // NW waves of 64 (8, 4, 2 or 1): a round = one select + ONE re-rank stage of 63 rows, 64 / NW per wave (the last position of
 // the round's 64 keys opens the next round)
-template <int FOLD, int NW>
-__global__ __launch_bounds__(NW * 64) void k_flat_tail_lb(FlatTailArgs a) {
+template <int FOLD, int NW, int PCD>  // PCD: 0, or the load depth of the producer / consumer fold
+__global__ __launch_bounds__(NW * 64, PCD ? 4 : 1) void k_flat_tail_lb(FlatTailArgs a) {
+    constexpr bool PC = PCD != 0;
     static_assert(NW == 8 || NW == 4 || NW == 2 || NW == 1, "a stage covers the 64 keys of a round");
+    static_assert(!PC || NW == 4, "producer / consumer fold: four waves");
     constexpr int RW = 64 / NW, NP = RW / 8;
-    constexpr int DEPTH = NW == 8 ? 8 : (NW == 4 ? 4 : (NW == 2 ? 3 : 2));  // chunks of row loads in flight per wave (NP KB each)
-    extern __shared__ float4 ftl_smem[];  // [dim/4] query, then NW waves x [RW rows][9] float4 product tiles
+    constexpr int DEPTH = PC ? PCD : (NW == 8 ? 8 : (NW == 4 ? 4 : (NW == 2 ? 3 : 2)));  // chunks of row loads in flight per wave (NP KB each)
+    extern __shared__ float4 ftl_smem[];  // [dim/4] query, then NW waves x [RW rows][9] float4 product tiles (PC: two [64][9] tiles)
     __shared__ uint64_t sbest[NW][64];
     __shared__ uint64_t skeys[64];
     __shared__ uint32_t s_flag;
@@ -921,12 +1045,26 @@ __global__ __launch_bounds__(NW * 64) void k_flat_tail_lb(FlatTailArgs a) {
     uint64_t above = 0;        // every pair key is > 0 (the smallest orderable float is 0x007fffff)
     uint8_t flag = 1;
     const uint32_t rounds = cnt_q <= a.cap ? a.kprime / 64 : 0;
+// measurement builds (make EXTRA=-DVDB_TAIL_STAMPS, run with VDB_TAIL_STAMPS=<call number>): thread 0 of every workgroup stamps the
+// shader clock at the phase boundaries of every round (start | select | fold | merge + certify ...), launch_flat_tail_lb prints
+// the averages.  -DVDB_TAIL_ABLATE=1 on top: every row index is taken modulo 64 (row fetches hit the caches; results wrong by design).
+#ifdef VDB_TAIL_STAMPS
+    uint32_t ns = 0;
+#define TAIL_STAMP()                                                                                      \
+    do {                                                                                                  \
+        if (a.stamps && threadIdx.x == 0 && ns < 30) a.stamps[q * 32 + ns++] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define TAIL_STAMP() do { } while (0)
+#endif
+    TAIL_STAMP();
     for (uint32_t rd = 0; rd < rounds; rd++) {
         const uint64_t best = block_top64_above<NW>(a.cand + uint64_t(q) * a.cap, total, sbest, above);  // (its barrier also covers qs4)
         __syncthreads();  // wave 0 is done with sbest[1..]
         if (wave == 0) sbest[0][lane] = best;
         if (threadIdx.x < 64) skeys[threadIdx.x] = PAIR_NONE;
         __syncthreads();
+        TAIL_STAMP();
         // position 63 is not evaluated: it opens the next round
         uint32_t idx[NP];
         bool live[NP];
@@ -936,18 +1074,27 @@ __global__ __launch_bounds__(NW * 64) void k_flat_tail_lb(FlatTailArgs a) {
             const uint64_t c = sbest[0][j];
             live[i] = c != PAIR_NONE && j < 63;
             idx[i] = live[i] ? uint32_t(c) : 0u;
+#if defined(VDB_TAIL_ABLATE) && VDB_TAIL_ABLATE == 1
+            idx[i] &= 63u;
+#endif
         }
         float acc;
-        if constexpr (NW == 8)
-            acc = group_rerank_fold<FOLD, 8>(a.X, a.dim, idx[0], live[0], qs4, tile, lane);
-        else
-            acc = group_rerank_fold_n<FOLD, DEPTH, RW>(a.X, a.dim, idx, live, qs4, tile, lane);
-        {
+        if constexpr (PC) {
+            const bool consumer = wave == (blockIdx.x & 3u);
+            acc = pc_rerank_fold<FOLD, DEPTH>(a.X, a.dim, idx, live, qs4, ftl_smem + d4, wave, lane, consumer);
+            const uint64_t c = sbest[0][lane];  // the consumer's lane added row `lane`
+            if (consumer && c != PAIR_NONE && lane < 63) skeys[lane] = pair_key(epilogue(MET_L2_DIRECT, acc, 0.0f, 0.0f), uint32_t(c));
+        } else {
+            if constexpr (NW == 8)
+                acc = group_rerank_fold<FOLD, 8>(a.X, a.dim, idx[0], live[0], qs4, tile, lane);
+            else
+                acc = group_rerank_fold_n<FOLD, DEPTH, RW>(a.X, a.dim, idx, live, qs4, tile, lane);
             const uint32_t j = wave * RW + lane / NW;  // the row whose chain this lane added (NW lanes each)
             const uint64_t c = sbest[0][j];
             if (c != PAIR_NONE && j < 63 && lane % NW == 0) skeys[j] = pair_key(epilogue(MET_L2_DIRECT, acc, 0.0f, 0.0f), uint32_t(c));
         }
         __syncthreads();
+        TAIL_STAMP();
         if (wave == 0) {
             run = merge64(run, sort64(skeys[lane], lane), lane);
             const uint64_t ek = __shfl(run, kk - 1), nxt = sbest[0][63];
@@ -957,6 +1104,7 @@ __global__ __launch_bounds__(NW * 64) void k_flat_tail_lb(FlatTailArgs a) {
             }
         }
         __syncthreads();
+        TAIL_STAMP();
         const uint32_t f = s_flag;  // block-uniform
         if ((f & 1u) == 0) {
             flag = 0;
@@ -966,6 +1114,12 @@ __global__ __launch_bounds__(NW * 64) void k_flat_tail_lb(FlatTailArgs a) {
         above = sbest[0][62];
         __syncthreads();  // sbest is rewritten by the next round
     }
+#ifdef VDB_TAIL_STAMPS
+    if (a.stamps && threadIdx.x == 0) {
+        a.stamps[q * 32 + 30] = ns;
+        a.stamps[q * 32 + 31] = total;
+    }
+#endif
     if (wave != 0) return;
     const bool ok = lane < a.ksel && run != PAIR_NONE;
     if (lane < a.ksel) {
@@ -983,22 +1137,64 @@ bool flat_tail_lb_supported(uint32_t dim, uint32_t kprime, uint32_t ksel) {
 }
 static std::atomic<int> g_tail_lb_nw{0};  // 0 auto; 8 / 4 / 2 / 1 waves per query
 void flat_tail_lb_set_nw(int v) { g_tail_lb_nw = v; }
-void launch_flat_tail_lb(const FlatTailArgs &a, uint32_t nq, hipStream_t s) {
+#ifdef VDB_TAIL_STAMPS
+static void tail_stamps_report(unsigned long long *d, uint32_t nq, hipStream_t s) {
+    VDB_SYNC(s);
+    std::vector<unsigned long long> h(size_t(nq) * 32);
+    VDB_HIP(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost));
+    VDB_HIP(hipFree(d));
+    uint32_t hist[8] = {0}, nr = 0;
+    double sel = 0, fold = 0, cert = 0, life = 0;
+    for (uint32_t q = 0; q < nq; q++) {
+        const unsigned long long *t = &h[size_t(q) * 32];
+        const uint32_t ns = (uint32_t)t[30], r = ns ? (ns - 1) / 3 : 0;
+        hist[r < 7 ? r : 7]++;
+        if (ns) life += double(t[ns - 1] - t[0]);
+        for (uint32_t i = 0; i < r; i++, nr++) {
+            sel += double(t[1 + 3 * i] - t[3 * i]);
+            fold += double(t[2 + 3 * i] - t[1 + 3 * i]);
+            cert += double(t[3 + 3 * i] - t[2 + 3 * i]);
+        }
+    }
+    fprintf(stderr, "TAIL_STAMPS nq %u  queries by rounds 0:%u 1:%u 2:%u 3:%u 4:%u 5+:%u  ticks per round: select %.0f fold %.0f merge+certify %.0f  per workgroup %.0f\n",
+            nq, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5] + hist[6] + hist[7], sel / (nr ? nr : 1), fold / (nr ? nr : 1),
+            cert / (nr ? nr : 1), life / nq);
+}
+#endif
+void launch_flat_tail_lb(const FlatTailArgs &a0, uint32_t nq, hipStream_t s) {
     if (nq == 0) return;
+    FlatTailArgs a = a0;
+#ifdef VDB_TAIL_STAMPS
+    static std::atomic<int> calls{0};
+    const char *want = getenv("VDB_TAIL_STAMPS");
+    unsigned long long *stamps = nullptr;
+    if (want && ++calls == atoi(want)) {
+        VDB_HIP(hipMalloc(&stamps, size_t(nq) * 32 * 8));
+        VDB_HIP(hipMemset(stamps, 0, size_t(nq) * 32 * 8));
+        a.stamps = stamps;
+    }
+#endif
     VDB_REQUIRE(flat_tail_lb_supported(a.dim, a.kprime, a.ksel) && a.metric == MET_L2_DIRECT && a.se.qoff && a.tau,
                 "flat_tail_lb: unsupported shape");
-    const size_t lds = (size_t(a.dim / 4) + 64 * 9) * sizeof(float4);
+    const size_t lds = (size_t(a.dim / 4) + 2 * 64 * 9) * sizeof(float4);
     int nw = g_tail_lb_nw;
-    if (nw != 8 && nw != 4 && nw != 2 && nw != 1) nw = TAIL_LB_AUTO_NW(nq);
-    if (nw == 8)
-        hipLaunchKernelGGL((k_flat_tail_lb<FOLD_L2, 8>), dim3(nq), dim3(512), lds, s, a);
+    if (nw != 8 && nw != 4 && nw != 2 && nw != 1 && nw != 40 && nw != 41) nw = TAIL_LB_AUTO_NW(nq);
+    if (nw == 40)  // four waves, producer / consumer fold
+        hipLaunchKernelGGL((k_flat_tail_lb<FOLD_L2, 4, 3>), dim3(nq), dim3(256), lds, s, a);
+    else if (nw == 41)
+        hipLaunchKernelGGL((k_flat_tail_lb<FOLD_L2, 4, 5>), dim3(nq), dim3(256), lds, s, a);
+    else if (nw == 8)
+        hipLaunchKernelGGL((k_flat_tail_lb<FOLD_L2, 8, 0>), dim3(nq), dim3(512), lds, s, a);
     else if (nw == 4)
-        hipLaunchKernelGGL((k_flat_tail_lb<FOLD_L2, 4>), dim3(nq), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((k_flat_tail_lb<FOLD_L2, 4, 0>), dim3(nq), dim3(256), lds, s, a);
     else if (nw == 2)
-        hipLaunchKernelGGL((k_flat_tail_lb<FOLD_L2, 2>), dim3(nq), dim3(128), lds, s, a);
+        hipLaunchKernelGGL((k_flat_tail_lb<FOLD_L2, 2, 0>), dim3(nq), dim3(128), lds, s, a);
     else
-        hipLaunchKernelGGL((k_flat_tail_lb<FOLD_L2, 1>), dim3(nq), dim3(64), lds, s, a);
+        hipLaunchKernelGGL((k_flat_tail_lb<FOLD_L2, 1, 0>), dim3(nq), dim3(64), lds, s, a);
     VDB_HIP(hipGetLastError());
+#ifdef VDB_TAIL_STAMPS
+    if (stamps) tail_stamps_report(stamps, nq, s);
+#endif
 }
 
 void launch_certify(const uint64_t *exact_sorted, uint32_t lde, const uint64_t *approx_sorted, uint32_t lda,

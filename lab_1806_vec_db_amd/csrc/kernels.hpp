@@ -65,6 +65,7 @@ struct FlatTailArgs {
     uint64_t *out_idx;
     float *out_dist;
     uint64_t *out_count;
+    unsigned long long *stamps = nullptr;  // k_flat_tail_lb, builds with -DVDB_TAIL_STAMPS: [nq][32] phase stamps (s_memtime)
     const float *tau = nullptr;  // k_flat_tail_lb: the filter pass's thresholds (the bound of every row outside the hit list)
 };
 // the exact stage behind the 8-bit pass: walks the hit list in key order, 64 keys per round (kprime / 64 rounds at most)

@@ -115,7 +115,7 @@ def test_i8_pass_parity(mods, dim, n, nq):
         np.testing.assert_array_equal(idx, idx2)
         np.testing.assert_array_equal(d, d2)
     ix.set_param("flat_gemm8_nt", 0)
-    for nw in (8, 4, 2, 1):  # exact stage: waves per query (8 / 16 / 32 / 64 rows of a round per wave)
+    for nw in (40, 41, 8, 4, 2, 1):  # exact stage: 4 waves with one chain per lane (40); 8 / 16 / 32 / 64 rows of a round per wave
         ix.set_param("flat_tail_lb_nw", nw)
         r0 = ix.get_stat("flat_i8_redo")
         idx2, d2, cnt2 = ix.flat_knn(qs, 10)
