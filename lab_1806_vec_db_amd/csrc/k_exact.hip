@@ -317,15 +317,18 @@ __device__ __forceinline__ float wave_rerank_fold(const float *__restrict__ X, u
         rp[i] = reinterpret_cast<const float4 *>(X + uint64_t(ri) * dim) + (lane & 7);
     }
     const uint32_t nch = (d4 + 7) / 8;
+    const int32_t last = int32_t(d4) - 1 - int32_t(lane & 7);  // the row's last piece, relative to rp[] (which points at piece lane & 7)
     float4 stg[DEPTH][8];
+    // unconditional loads (group_rerank_fold: why): pieces past the row and chunks past the end re-read the row's last piece -- the
+    // fold below never looks at them --, rows that are not live read row 0 (idx = 0) and their sums are dropped by the caller
+    (void)rl;
     auto fetch = [&](float4(&dst)[8], uint32_t ch) {
-        const bool inside = ch * 8 + (lane & 7) < d4;
+        const int32_t o = ch * 8 + (lane & 7) < d4 ? int32_t(ch * 8) : last;
 #pragma unroll
-        for (int i = 0; i < 8; i++) dst[i] = (inside && rl[i]) ? rp[i][ch * 8] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < 8; i++) dst[i] = rp[i][o];
     };
 #pragma unroll
-    for (int st = 0; st < DEPTH; st++)
-        if (uint32_t(st) < nch) fetch(stg[st], st);
+    for (int st = 0; st < DEPTH; st++) fetch(stg[st], st);
     float acc = 0.0f;
     for (uint32_t ch0 = 0; ch0 < nch; ch0 += DEPTH) {
 #pragma unroll
@@ -334,7 +337,7 @@ __device__ __forceinline__ float wave_rerank_fold(const float *__restrict__ X, u
             if (ch >= nch) break;  // uniform
 #pragma unroll
             for (int i = 0; i < 8; i++) tile[(8 * i + (lane >> 3)) * 9 + (lane & 7)] = stg[st][i];
-            if (ch + DEPTH < nch) fetch(stg[st], ch + DEPTH);
+            fetch(stg[st], ch + DEPTH);
             const uint32_t np = d4 - ch * 8 < 8 ? d4 - ch * 8 : 8;  // uniform
             if (np == 8) {
 #pragma unroll
