@@ -298,77 +298,13 @@ __global__ __launch_bounds__(64) void k_rerank(const float *__restrict__ X, uint
     out[uint64_t(q) * ldc + j] = pair_key(epilogue(metric, acc, xs, qs), idx);
 }
 
-// Strict-order fold of a wave's (up to) 64 candidate rows against one query, rows fetched cooperatively: the wave reads a
-// 32-column chunk of all its rows together (8 lanes per row: every 128-B line is fetched whole by one instruction), parks
-// it in LDS (row stride 36 floats: conflict-free b128 accesses) and every lane folds ITS row's 32 values in reference
-// order against the query chunk (LDS broadcast).  DEPTH chunks of global loads are in flight during the folds (three instead
-// of two bought nothing, nor did capping the registers for a fourth workgroup per CU: 64 x 1000 rows of 3 840 B in ~45 us
-// is ~5.4 TB/s of random row gathers, the rate the hardware guide quotes for them).  qs4 = the query in LDS, tile = [64][9] float4.
-template <int FOLD, int DEPTH>
-__device__ __forceinline__ float wave_rerank_fold(const float *__restrict__ X, uint32_t dim, uint32_t idx, bool live,
-                                                  const float4 *qs4, float4 *tile, uint32_t lane) {
-    const uint32_t d4 = dim / 4;
-    const float4 *rp[8];  // the 8 rows this lane helps to fetch: rows 8*i + lane/8, piece lane%8 of each chunk
-    bool rl[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint32_t ri = __shfl(idx, 8 * i + (lane >> 3));
-        rl[i] = __shfl(live ? 1 : 0, 8 * i + (lane >> 3)) != 0;
-        rp[i] = reinterpret_cast<const float4 *>(X + uint64_t(ri) * dim) + (lane & 7);
-    }
-    const uint32_t nch = (d4 + 7) / 8;
-    const int32_t last = int32_t(d4) - 1 - int32_t(lane & 7);  // the row's last piece, relative to rp[] (which points at piece lane & 7)
-    float4 stg[DEPTH][8];
-    // unconditional loads (group_rerank_fold: why): pieces past the row and chunks past the end re-read the row's last piece -- the
-    // fold below never looks at them --, rows that are not live read row 0 (idx = 0) and their sums are dropped by the caller
-    (void)rl;
-    auto fetch = [&](float4(&dst)[8], uint32_t ch) {
-        const int32_t o = ch * 8 + (lane & 7) < d4 ? int32_t(ch * 8) : last;
-#pragma unroll
-        for (int i = 0; i < 8; i++) dst[i] = rp[i][o];
-    };
-#pragma unroll
-    for (int st = 0; st < DEPTH; st++) fetch(stg[st], st);
-    float acc = 0.0f;
-    for (uint32_t ch0 = 0; ch0 < nch; ch0 += DEPTH) {
-#pragma unroll
-        for (int st = 0; st < DEPTH; st++) {
-            const uint32_t ch = ch0 + st;
-            if (ch >= nch) break;  // uniform
-#pragma unroll
-            for (int i = 0; i < 8; i++) tile[(8 * i + (lane >> 3)) * 9 + (lane & 7)] = stg[st][i];
-            fetch(stg[st], ch + DEPTH);
-            const uint32_t np = d4 - ch * 8 < 8 ? d4 - ch * 8 : 8;  // uniform
-            if (np == 8) {
-#pragma unroll
-                for (int p = 0; p < 8; p++) {
-                    const float4 x = tile[lane * 9 + p], w = qs4[ch * 8 + p];
-                    acc = fold1<FOLD>(acc, x.x, w.x);
-                    acc = fold1<FOLD>(acc, x.y, w.y);
-                    acc = fold1<FOLD>(acc, x.z, w.z);
-                    acc = fold1<FOLD>(acc, x.w, w.w);
-                }
-            } else {
-                for (uint32_t p = 0; p < np; p++) {
-                    const float4 x = tile[lane * 9 + p], w = qs4[ch * 8 + p];
-                    acc = fold1<FOLD>(acc, x.x, w.x);
-                    acc = fold1<FOLD>(acc, x.y, w.y);
-                    acc = fold1<FOLD>(acc, x.z, w.z);
-                    acc = fold1<FOLD>(acc, x.w, w.w);
-                }
-            }
-        }
-    }
-    return acc;
-}
-
 // The same fold with the work of a row spread over the 8 lanes that fetch it (k_flat_tail64, round 3).  A wave takes 8 rows:
 // lane 8g + p fetches piece p (16 B) of every 32-column chunk of row g -- a whole 128-B line per row and instruction, DEPTH
 // chunks ahead -- and turns it into PRODUCTS itself: (x - q)^2 or x * q, each separately rounded exactly as distance/mod.rs:
 // 72-77 rounds them; which lane computes a product is immaterial.  The products of a chunk meet in a [8][9]-float4 LDS tile and
 // every lane of group g adds row g's 32 values in reference order (the 8 lanes compute the same sum; only one chain matters).
-// Against wave_rerank_fold -- 64 rows per wave, every lane subtracts, multiplies AND adds its own row: 96 dependent-issue VALU
-// operations per chunk -- a chunk costs 4 packed product operations + 32 adds, and the four waves of a workgroup take 8 rows each
+// Against a wave that folds 64 rows with every lane subtracting, multiplying AND adding its own row (96 dependent-issue VALU
+// operations per chunk) a chunk costs 4 packed product operations + 32 adds, and the four waves of a workgroup take 8 rows each
 // instead of leaving 3 waves idle.  Columns past dim contribute +0.0 (exact: the running sum is never -0.0).
 template <int FOLD, int DEPTH>
 __device__ __forceinline__ float group_rerank_fold(const float *__restrict__ X, uint32_t dim, uint32_t idx, bool live, const float4 *qs4,
@@ -598,39 +534,50 @@ __device__ __forceinline__ float pc_rerank_fold(const float *__restrict__ X, uin
     return acc;
 }
 
-// The same re-rank with coalesced row fetches (dim % 4 == 0): k_rerank lets every lane walk its own row 16 B at a time,
-// i.e. one load instruction touches 64 different 128-B lines and each line has to survive in the L1 across 8
-// instructions -- 35 us for 32 candidates x 1000 queries at dim 960, but 184 us for 64 (the lines of the waves
-// resident on a CU no longer fit).  Here the wave fetches a 32-column chunk of all its 64 rows together (8 lanes per
-// row: every 128-B line is fetched whole by one instruction), parks it in LDS (row stride 36 floats: conflict-free
-// b128 accesses) and every lane then folds ITS row's 32 values in reference order against the query chunk (LDS
-// broadcast).  Next chunk's global loads are in flight during the fold.
+// The re-rank of candidate rows with coalesced row fetches, dim % 4 == 0 (PQ-Flat's ef rows per query, the separate-kernels exact
+// stage of the Flat pipeline; k_rerank above lets every lane walk its own row 16 B at a time: one load instruction touches 64
+// different 128-B lines).  Producer / consumer fold: a workgroup of four waves takes 64 candidates of one query, the four waves
+// fetch 16 rows each (8 lanes per row: whole lines) and write products, one wave adds row `lane`.  It replaced k_rerank_t (rounds
+// 1 - 3: one wave per 64 candidates with its 8 loads, 8 LDS writes and 96 fold operations per chunk in ONE instruction stream
+// and loads under lane conditions, i.e. one memory round trip per chunk): 1000 queries x 100 rows at dim 960 361 -> 70 us
+// (profiles/r03_probe_tail_lb_waves.txt), PQ-Flat step 6.49 -> 6.10 ms on the same box.
 template <int FOLD>
-__global__ __launch_bounds__(64) void k_rerank_t(const float *__restrict__ X, uint32_t dim, const float *__restrict__ Q,
-                                                 int metric, const float *__restrict__ xsq, const float *__restrict__ qsq,
-                                                 const uint64_t *__restrict__ cand, uint64_t *__restrict__ out,
-                                                 uint32_t ncand, uint32_t ldc) {
-    extern __shared__ float4 rr_smem[];  // [dim/4] query, then [64 rows][9] float4 (8 used)
-    const uint32_t q = blockIdx.y, lane = threadIdx.x, j = blockIdx.x * 64 + lane;
-    if (blockIdx.x * 64 >= ncand) {  // block-uniform: this block only pads the row
-        if (j < ldc) out[uint64_t(q) * ldc + j] = PAIR_NONE;
+__global__ __launch_bounds__(256, 4) void k_rerank_pc(const float *__restrict__ X, uint32_t dim, const float *__restrict__ Q,
+                                                      int metric, const float *__restrict__ xsq, const float *__restrict__ qsq,
+                                                      const uint64_t *__restrict__ cand, uint64_t *__restrict__ out,
+                                                      uint32_t ncand, uint32_t ldc) {
+    extern __shared__ float4 rp_smem[];  // [dim/4] query, then two [64 rows][9] float4 product tiles
+    __shared__ uint64_t scand[64];
+    const uint32_t q = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j0 = blockIdx.x * 64;
+    if (j0 >= ncand) {  // block-uniform: this block only pads the row
+        if (threadIdx.x < 64 && j0 + threadIdx.x < ldc) out[uint64_t(q) * ldc + j0 + threadIdx.x] = PAIR_NONE;
         return;
     }
-    const uint64_t c = j < ncand ? cand[uint64_t(q) * ldc + j] : PAIR_NONE;
-    const bool live = c != PAIR_NONE;
-    const uint32_t idx = live ? uint32_t(c) : 0u;
+    if (threadIdx.x < 64) scand[threadIdx.x] = j0 + threadIdx.x < ncand ? cand[uint64_t(q) * ldc + j0 + threadIdx.x] : PAIR_NONE;
     const uint32_t d4 = dim / 4;
-    float4 *qs4 = rr_smem, *tile = rr_smem + d4;
-    for (uint32_t i = lane; i < d4; i += 64) qs4[i] = reinterpret_cast<const float4 *>(Q + uint64_t(q) * dim)[i];
-    const float acc = wave_rerank_fold<FOLD, 2>(X, dim, idx, live, qs4, tile, lane);
-    if (j < ldc) {
+    float4 *qs4 = rp_smem;
+    for (uint32_t i = threadIdx.x; i < d4; i += 256) qs4[i] = reinterpret_cast<const float4 *>(Q + uint64_t(q) * dim)[i];
+    __syncthreads();
+    uint32_t idx[2];
+    bool live[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const uint64_t c = scand[16 * wave + 8 * i + (lane >> 3)];
+        live[i] = c != PAIR_NONE;
+        idx[i] = live[i] ? uint32_t(c) : 0u;
+    }
+    const bool consumer = wave == ((blockIdx.x + blockIdx.y) & 3u);
+    const float acc = pc_rerank_fold<FOLD, 3>(X, dim, idx, live, qs4, rp_smem + d4, wave, lane, consumer);
+    if (consumer && j0 + lane < ldc) {
+        const uint64_t c = scand[lane];
         uint64_t r = PAIR_NONE;
-        if (live) {
-            const float xs = (metric == MET_L2_DIRECT) ? 0.0f : xsq[idx];
+        if (c != PAIR_NONE) {
+            const uint32_t ix = uint32_t(c);
+            const float xs = (metric == MET_L2_DIRECT) ? 0.0f : xsq[ix];
             const float qs = (metric == MET_L2_DIRECT) ? 0.0f : qsq[q];
-            r = pair_key(epilogue(metric, acc, xs, qs), idx);
+            r = pair_key(epilogue(metric, acc, xs, qs), ix);
         }
-        out[uint64_t(q) * ldc + j] = r;
+        out[uint64_t(q) * ldc + j0 + lane] = r;
     }
 }
 
@@ -639,12 +586,12 @@ void launch_rerank(const float *X, uint32_t dim, const float *Q, uint32_t nq, in
                    hipStream_t s) {
     if (nq == 0 || ncand == 0) return;
     if ((dim & 3) == 0 && dim >= 64 && dim <= 8192) {
-        dim3 grid((std::max(ncand, ldc) + 63) / 64, nq), block(64);
-        const size_t lds = (size_t(dim / 4) + 64 * 9) * sizeof(float4);
+        dim3 grid((std::max(ncand, ldc) + 63) / 64, nq), block(256);
+        const size_t lds = (size_t(dim / 4) + 2 * 64 * 9) * sizeof(float4);
         if (metric == MET_L2_DIRECT)
-            hipLaunchKernelGGL((k_rerank_t<FOLD_L2>), grid, block, lds, s, X, dim, Q, metric, xsq, qsq, cand, out, ncand, ldc);
+            hipLaunchKernelGGL((k_rerank_pc<FOLD_L2>), grid, block, lds, s, X, dim, Q, metric, xsq, qsq, cand, out, ncand, ldc);
         else
-            hipLaunchKernelGGL((k_rerank_t<FOLD_DOT>), grid, block, lds, s, X, dim, Q, metric, xsq, qsq, cand, out, ncand, ldc);
+            hipLaunchKernelGGL((k_rerank_pc<FOLD_DOT>), grid, block, lds, s, X, dim, Q, metric, xsq, qsq, cand, out, ncand, ldc);
         return;
     }
     dim3 grid((std::max(ncand, ldc) + 63) / 64, nq), block(64);  // the tail blocks only pad
@@ -869,8 +816,8 @@ void launch_flat_finish(const uint64_t *exact_sorted, uint32_t lde, const uint64
 // ---------------------------------------------------------------------------------------------
 // The whole exact stage of the Flat pipeline in ONE launch (shortlists of at most 64 rows, dim % 4 == 0): per query a
 // workgroup (i) selects the k' smallest approximate pairs of the query's hit list (block_top64, 4 waves), then wave 0
-// (ii) re-ranks them in reference order (the coalesced scheme of k_rerank_t), (iii) sorts the exact pairs across its
-// lanes and writes the first ksel, (iv) certifies (flat_certify_flag).  Replaces k_top64_counted + k_rerank_t +
+// (ii) re-ranks them in reference order (group_rerank_fold), (iii) sorts the exact pairs across its
+// lanes and writes the first ksel, (iv) certifies (flat_certify_flag).  Replaces k_top64_counted + the re-rank kernel +
 // k_topk_merge + k_flat_finish: 4 launches and 3 round trips through HBM scratch per step (~110 -> ~60 us per 1000
 // queries; at a 125k-row shard the step is 0.5 ms, so this is what is left to trim there).
 // ---------------------------------------------------------------------------------------------
