@@ -139,6 +139,9 @@ int vdb_flat_set_mode(vdb_index *idx, int mode);
  *   "flat_gemm_block_rows"  filter pass in row blocks, one launch per block over all query groups (measurement switch): 0 off, n rows
  *   "flat_gemm_nt"     cache policy of the row stream: 0 auto (non-temporal when the mirror exceeds the Infinity Cache), 1 default, 2 non-temporal
  *   "flat_tail"        exact stage: 0 fused launch when the shortlist fits 64 rows, 1 separate kernels
+ *   "flat_tail_lb_nw"  form of the 8-bit pass's exact stage (k_flat_tail_lb): 0 auto (= 40), 40 / 41 four waves per query with ONE fold chain
+ *                      per lane (products by all four waves, adds by one; row loads 3 / 5 chunks deep), 8 / 4 / 2 / 1 that many waves with the
+ *                      chains on the lanes that fetched the rows (process-wide)
  *   "flat_share", "mfma_variant", "flat_sample_thin", "flat_gemm_debug"   small-batch kernel / sample plan / measurement hooks
  *   "pq_adc_fast", "hnsw_dma"   inner-loop variants of the ADC scan and of the HNSW walk (hnsw_dma: 1 rows staged through
  *                      registers (default), 2 through LDS by DMA, 0 plain per-lane loads)
