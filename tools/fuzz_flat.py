@@ -8,6 +8,7 @@ from oracle import oracle as O
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1806)
+rng2 = np.random.default_rng(7 + (int(sys.argv[2]) if len(sys.argv) > 2 else 1806))
 min_n = int(sys.argv[4]) if len(sys.argv) > 4 else 17000  # (below 16 384 rows calls of < 32 queries take the one-launch kernel)
 t_end = time.time() + budget
 it = bad = 0
@@ -42,12 +43,15 @@ while time.time() < t_end:
     ix.set_flat_mode(int(rng.choice([0, 2])))
     ix.set_param("flat_half", int(rng.choice([0, 0, 1, 2])))
     ix.set_param("flat_tail", int(rng.choice([0, 0, 1])))
+    # (a generator of its own: the draws above stay those of the logged soaks, tools/replay_fuzz_flat.py)
+    nw = int(rng2.choice([0, 0, 0, 40, 41, 8, 4, 2, 1]))
+    ix.set_param("flat_tail_lb_nw", nw)
     idx, d, cnt = ix.flat_knn(qs, k)
     oi, od, oc = O.flat_knn_batch(base, qs, k, kind, nthreads=16)
     ok = cnt.tolist() == oc.tolist() and all(idx[q, :int(cnt[q])].tolist() == oi[q][:int(cnt[q])].tolist() and
                                              np.array_equal(d[q, :int(cnt[q])], od[q][:int(cnt[q])]) for q in range(nq))
     print(f"#{it} dim {dim} n {n} nq {nq} k {k} {dist} style {style}: {'ok' if ok else 'MISMATCH'} "
-          f"half {ix.get_stat('flat_half_queries')} redo {ix.get_stat('flat_half_redo')} fallback {ix.flat_fallback_count()}", flush=True)
+          f"i8 {ix.get_stat('flat_i8_queries')} tail {nw} half {ix.get_stat('flat_half_queries')} redo {ix.get_stat('flat_half_redo')} fallback {ix.flat_fallback_count()}", flush=True)
     bad += 0 if ok else 1
     del ix
 print(f"done: {it} configurations, {bad} mismatches")
