@@ -132,6 +132,8 @@ int vdb_flat_set_mode(vdb_index *idx, int mode);
  *                      0 auto (off once > 1/8 of its queries were handed on), 1 off, 2 on.  While it is the first tier the fp16 mirror is
  *                      built by its first use instead of at add time (set "flat_i8" = 1 BEFORE adding rows to have it built at add time)
  *   "flat_i8_rows"     rows its exact stage may walk per query before handing the query on (multiple of 64, default 256)
+ *   "flat_gemm8_res"   its kernel keeps the query group's whole 1-B/element image in LDS (dimensions up to 960: no workgroup barrier per chunk;
+ *                      0 auto = on when the image fits, 1 off = chunked staging through two buffers)
  *   "flat_gemm8_kc", "flat_gemm8_burst", "flat_gemm8_nt"   variants of its kernel: k-blocks per Q chunk (0 auto, 5 / 3 / 2), staging of
  *                      the next chunk (0 auto, 1 per k-block, 2 one burst per chunk), cache policy of the row stream (as "flat_gemm_nt")
  *   "flat_gemm"        128-queries-per-pass kernel: 0 auto, 1 off (small-batch kernel), 2 forced

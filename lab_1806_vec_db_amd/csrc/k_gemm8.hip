@@ -28,6 +28,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr uint32_t G8_NH = 8;            // 16-query halves per group
 constexpr uint32_t G8_BQ = 16 * G8_NH;   // 128 queries per pass (= gemm_group())
 constexpr uint32_t G8_WGBUF = 3072;      // LDS hit buffer entries per workgroup and group
+constexpr uint32_t G8_WGBUF_RES = 1536;  // ... of the resident form (expected ~512 at 1000 hits per query; a full buffer flags the query)
 constexpr uint32_t G8_STAGE = 64;        // per wave and unit: lanes whose (tile, half) key quartet passed the threshold
 constexpr uint32_t G8_TW = 3;            // 16-row tiles per unit (the mirror is padded to whole units of 12 tiles: index.hip)
 
@@ -50,7 +51,8 @@ struct Gemm8Args {
 };
 
 enum { G8_FILTER = 0, G8_SAMPLE = 1 };
-// measurement builds only (make EXTRA=-DG8_ABLATE=n): 1 = the epilogue looks at one (tile, half) pair only, 2 = only the first
+// measurement builds only (make EXTRA=-DG8_ABLATE=n): 4 = no Q staging and no chunk barrier (every chunk multiplies with the group's
+// first chunk: what the per-chunk rendezvous of the 8 waves costs), 1 = the epilogue looks at one (tile, half) pair only, 2 = only the first
 // half's MFMAs are issued; loads, LDS traffic and barriers stay.  Results are wrong by design.
 #ifndef G8_ABLATE
 #define G8_ABLATE 0
@@ -60,16 +62,25 @@ enum { G8_FILTER = 0, G8_SAMPLE = 1 };
 // wait for them leaves every refill of the chunk in flight (vmcnt is in order: waiting for a staging load that was issued
 // AFTER a ring refill forces that refill to have landed; with one piece per k-block the ring is effectively one k-block
 // deep -- 1.5 us of matrix work in the fp16 kernel, only half that here).  Costs 4 (KC - 1) registers.
-template <int KC, int MODE, bool XNT, bool BURST>
+// RES (round 3, last sessions): the whole query group's image (KB x 8 KB, 120 KB at dim 960) stays in LDS for the group's pass
+// instead of being staged chunk by chunk through two 24-KB buffers.  What that removes is the workgroup barrier per chunk: with it
+// the 8 waves consumed their ring slots in lockstep, so every chunk waited for the SLOWEST of the workgroup's 72 loads in flight
+// (tools/inflight_probe.cpp: a wave that only waits for its own oldest load streams 7.0 TB/s non-temporally with 48 KB per CU in
+// flight; the chunked kernel got 5.3 - 5.7; the ablation build -DG8_ABLATE=4, no staging and no chunk barrier: -11 % kernel time).
+// Each wave now runs on its own counted waits, the ring is KC k-blocks deep without the staging registers, and a barrier is
+// left per group (Q image load, hit hand-over).  The hit buffer shrinks to G8_WGBUF_RES entries to make room.
+template <int KC, int MODE, bool XNT, bool BURST, bool RES>
 __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
     constexpr int TW = G8_TW, NT = 512, NW = 8, NH = G8_NH, R = KC;
     constexpr uint32_t CHUNK = KC * NH * 64;  // uint4 per Q chunk (KC k-blocks of 8 KB)
     constexpr int QST = CHUNK / NT;           // staged uint4 per thread and chunk: one per k-block
     static_assert(CHUNK % NT == 0 && QST == KC, "one staged uint4 per thread and k-block");
-    extern __shared__ __attribute__((aligned(16))) uint4 smem8[];  // [2][CHUNK] Q chunks, then the hit buffer
-    uint64_t *hit_key = reinterpret_cast<uint64_t *>(smem8 + 2 * CHUNK);
-    uint32_t *hit_q = reinterpret_cast<uint32_t *>(hit_key + G8_WGBUF);
-    uint32_t *hit_n = hit_q + G8_WGBUF;  // [0] entries, [1..128] per-query counts, [129..256] per-query bases
+    static_assert(!(RES && BURST), "the resident form stages nothing");
+    constexpr uint32_t WGBUF = RES ? G8_WGBUF_RES : G8_WGBUF;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem8[];  // [2][CHUNK] Q chunks (RES: the group's [KB / KC][CHUNK]), then the hit buffer
+    uint64_t *hit_key = reinterpret_cast<uint64_t *>(smem8 + (RES ? (a.KB / KC) * CHUNK : 2 * CHUNK));
+    uint32_t *hit_q = reinterpret_cast<uint32_t *>(hit_key + WGBUF);
+    uint32_t *hit_n = hit_q + WGBUF;  // [0] entries, [1..128] per-query counts, [129..256] per-query bases
     float *tau_s = reinterpret_cast<float *>(hit_n + 4 + 2 * G8_BQ);  // [128] thresholds of the current group
     float *qs_s = tau_s + G8_BQ;                                      // [128] query scales
     float *c_s = qs_s + G8_BQ;                                        // [8 waves][64] C_r of the wave's current unit
@@ -126,20 +137,30 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    {
+    if constexpr (!RES) {
         const uint4 *src = a.qfrag + (MODE == G8_SAMPLE ? uint64_t(blockIdx.y) * nchunk * CHUNK : 0);
 #pragma unroll
         for (int j = 0; j < QST; j++) smem8[j * NT + threadIdx.x] = src[j * NT + threadIdx.x];
     }
     uint32_t buf = 0;
-    __syncthreads();
+    if constexpr (!RES) __syncthreads();
 
     const uint32_t g_begin = MODE == G8_SAMPLE ? blockIdx.y : 0, g_end = MODE == G8_SAMPLE ? blockIdx.y + 1 : a.ngroups;
     for (uint32_t grp = g_begin; grp < g_end; grp++) {
         const uint4 *qgrp = a.qfrag + uint64_t(grp) * nchunk * CHUNK;
-        if (MODE == G8_FILTER && threadIdx.x < 1 + 2 * G8_BQ) hit_n[threadIdx.x] = 0;  // ordered before the first append by the chunk barriers
+        if constexpr (RES) {  // (the previous group's readers are past the hand-over's last barrier)
+            for (uint32_t c = 0; c < nchunk; c++) {
+                uint4 t[QST];
+#pragma unroll
+                for (int j = 0; j < QST; j++) t[j] = qgrp[(c * QST + j) * NT + threadIdx.x];
+#pragma unroll
+                for (int j = 0; j < QST; j++) smem8[(c * QST + j) * NT + threadIdx.x] = t[j];
+            }
+        }
+        if (MODE == G8_FILTER && threadIdx.x < 1 + 2 * G8_BQ) hit_n[threadIdx.x] = 0;  // ordered before the first append by the chunk barriers (RES: the one below)
         if (MODE == G8_FILTER && threadIdx.x < G8_BQ) tau_s[threadIdx.x] = (a.debug & 1) ? -INFINITY : a.tau[grp * G8_BQ + threadIdx.x];
         if (threadIdx.x < G8_BQ) qs_s[threadIdx.x] = a.qscale[grp * G8_BQ + threadIdx.x];
+        if constexpr (RES) __syncthreads();
         const uint32_t steps = steps_of(slot_cur);
         for (uint32_t st = 0; st < steps; st++) {
             const uint32_t u_raw = unit_of(slot_cur, st);
@@ -158,7 +179,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
                                     : (st + 1 < steps ? qgrp : (grp + 1 < a.ngroups ? qgrp + uint64_t(nchunk) * CHUNK : a.qfrag)));
                 const uint32_t tid16 = threadIdx.x * 16;
                 uint4 *qdst = smem8 + (buf ^ 1) * CHUNK + threadIdx.x;
-                const uint4 *qcur = smem8 + buf * CHUNK + lane;
+                const uint4 *qcur = smem8 + (RES ? c : buf) * CHUNK + lane;
                 const bool last_c = c + 1 == nchunk;
                 i32x4 q_n = __builtin_bit_cast(i32x4, qcur[0]);
                 float2 rc_stage = make_float2(0.0f, 0.0f);
@@ -178,8 +199,12 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
                 };
                 auto kblock = [&](auto P) {
                     constexpr int p = decltype(P)::value;
-                    if constexpr (!BURST) {
+                    if constexpr (!BURST && !RES) {
                         stage_load(P);
+                        if (p == 0) rc_stage = *reinterpret_cast<const float2 *>(rc_base + rc_off);
+                    }
+                    if constexpr (RES) {  // the unit's row constants: every chunk fetches and parks them (no branch around a load: the
+                        // wait counts stay exact); the epilogue reads what the last chunk parked
                         if (p == 0) rc_stage = *reinterpret_cast<const float2 *>(rc_base + rc_off);
                     }
                     __builtin_amdgcn_sched_barrier(0);  // pin the issue order (k_flat_gemm: why)
@@ -205,7 +230,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
                     // slot p is free: refill it (before the staging writes, the chunk barrier and a possible epilogue)
                     fetch_at(ring[p], last_c ? cp_nxt : cp_cur, last_c ? uint32_t(p) : (c + 1) * KC + p);
                     __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (!BURST) {
+                    if constexpr (!BURST && !RES) {
                         qdst[p * NT] = stage_ref(P);
                         if (p == 0) {
                             c_s[wave * 64 + lane] = rc_stage.x;
@@ -219,7 +244,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
                 using I2 = std::integral_constant<int, 2>;
                 using I3 = std::integral_constant<int, 3>;
                 using I4 = std::integral_constant<int, 4>;
-                if constexpr (BURST) {
+                if constexpr (BURST && !(G8_ABLATE & 4)) {
                     stage_load(I0{});
                     stage_load(I1{});
                     if constexpr (KC > 2) stage_load(I2{});
@@ -232,7 +257,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
                 if constexpr (KC > 2) kblock(I2{});
                 if constexpr (KC > 3) kblock(I3{});
                 if constexpr (KC > 4) kblock(I4{});
-                if constexpr (BURST) {
+                if constexpr (BURST && !(G8_ABLATE & 4)) {
                     qdst[0 * NT] = qs0;
                     qdst[1 * NT] = qs1;
                     if constexpr (KC > 2) qdst[2 * NT] = qs2;
@@ -241,8 +266,13 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
                     c_s[wave * 64 + lane] = rc_stage.x;
                     m_s[wave * 64 + lane] = rc_stage.y;
                 }
-                __syncthreads();
-                buf ^= 1;
+                if constexpr (RES) {  // this wave's own [64] slice: written and read by the same wave, LDS is in order per wave
+                    c_s[wave * 64 + lane] = rc_stage.x;
+                    m_s[wave * 64 + lane] = rc_stage.y;
+                } else if constexpr (!(G8_ABLATE & 4)) {
+                    __syncthreads();
+                    buf ^= 1;
+                }
             }
             cp_cur = cp_nxt;
             {
@@ -342,10 +372,10 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
                             const uint32_t mine = uint32_t(p0) + uint32_t(p1) + uint32_t(p2) + uint32_t(p3);
                             if (mine) {
                                 uint32_t pos = atomicAdd(hit_n, mine);
-                                // every reserved slot below G8_WGBUF is written (the hand-off reads min(total, G8_WGBUF) slots)
+                                // every reserved slot below WGBUF is written (the hand-off reads min(total, WGBUF) slots)
 #define VDB_PARK8(P, KEY, E)                          \
     if (P) {                                          \
-        if (pos < G8_WGBUF) {                         \
+        if (pos < WGBUF) {                         \
             hit_key[pos] = pair_key(KEY, mt.x + E);   \
             hit_q[pos] = mt.y;                        \
         }                                             \
@@ -356,7 +386,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
                                 VDB_PARK8(p2, kv.z, 2)
                                 VDB_PARK8(p3, kv.w, 3)
 #undef VDB_PARK8
-                                if (pos > G8_WGBUF)  // buffer full: mark the query as overflowed (-> redone by the caller)
+                                if (pos > WGBUF)  // buffer full: mark the query as overflowed (-> redone by the caller)
                                     atomicAdd(&a.cnt[grp * G8_BQ + mt.y], a.cap + 1);
                             }
                         }
@@ -371,8 +401,8 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
         __syncthreads();
         if (MODE == G8_FILTER) {
             uint32_t total = hit_n[0];
-            if (total > G8_WGBUF) total = G8_WGBUF;
-            constexpr uint32_t NJ = (G8_WGBUF + NT - 1) / NT;
+            if (total > WGBUF) total = WGBUF;
+            constexpr uint32_t NJ = (WGBUF + NT - 1) / NT;
             uint32_t rank[NJ];
 #pragma unroll
             for (uint32_t j = 0; j < NJ; j++) {
@@ -409,7 +439,11 @@ bool gemm8_supported(uint32_t dim) {
     return kb >= 2 && pad <= 2048 && (kb % 5 == 0 || kb % 3 == 0 || kb % 2 == 0);
 }
 
-template <int KC, int MODE, bool XNT, bool BURST>
+// LDS of the resident form: the group's whole image + the smaller hit buffer; it exists for dimensions whose image fits
+static size_t gemm8_res_lds(uint32_t KB) {
+    return size_t(KB) * G8_NH * 64 * sizeof(uint4) + size_t(G8_WGBUF_RES) * 12 + (4 + 4 * G8_BQ + 2 * 8 * 64) * 4 + size_t(8) * G8_STAGE * 24 + 16;
+}
+template <int KC, int MODE, bool XNT, bool BURST, bool RES>
 static void flat_gemm8_launch1(const Gemm8Args &a0, int num_cu, hipStream_t s) {
     Gemm8Args a = a0;
     const uint64_t n_tiles = (a.n + 15) / 16;
@@ -426,33 +460,43 @@ static void flat_gemm8_launch1(const Gemm8Args &a0, int num_cu, hipStream_t s) {
         if (need < grid) grid = need;
     }
     if (grid == 0 || a.ngroups == 0) return;
-    const size_t lds = size_t(2) * KC * G8_NH * 64 * sizeof(uint4) + size_t(G8_WGBUF) * 12 + (4 + 4 * G8_BQ + 2 * 8 * 64) * 4 +
-                       size_t(8) * G8_STAGE * 24 + 16;
-    func_max_lds(reinterpret_cast<const void *>(&k_flat_gemm8<KC, MODE, XNT, BURST>), int(160 * 1024));
-    hipLaunchKernelGGL((k_flat_gemm8<KC, MODE, XNT, BURST>), dim3(grid, MODE == G8_SAMPLE ? a.ngroups : 1), dim3(512), lds, s, a);
+    const size_t lds = RES ? gemm8_res_lds(a.KB)
+                           : size_t(2) * KC * G8_NH * 64 * sizeof(uint4) + size_t(G8_WGBUF) * 12 + (4 + 4 * G8_BQ + 2 * 8 * 64) * 4 +
+                                 size_t(8) * G8_STAGE * 24 + 16;
+    func_max_lds(reinterpret_cast<const void *>(&k_flat_gemm8<KC, MODE, XNT, BURST, RES>), int(160 * 1024));
+    hipLaunchKernelGGL((k_flat_gemm8<KC, MODE, XNT, BURST, RES>), dim3(grid, MODE == G8_SAMPLE ? a.ngroups : 1), dim3(512), lds, s, a);
     VDB_HIP(hipGetLastError());
 }
 static std::atomic<int> g_gemm8_kc{0};  // 0 auto; 5 / 3 / 2: chunk length when the k-block count allows it
 void gemm8_set_kc(int v) { g_gemm8_kc = v; }
 static std::atomic<int> g_gemm8_burst{0};  // 0 auto (burst for KC <= 3), 1 per k-block, 2 burst
 void gemm8_set_burst(int v) { g_gemm8_burst = v; }
+static std::atomic<int> g_gemm8_res{0};  // 0 auto (resident image when it fits the LDS), 1 off (chunked staging), 2 as 0
+void gemm8_set_res(int v) { g_gemm8_res = v; }
 
 template <int KC, int MODE>
 static void flat_gemm8_launch(const Gemm8Args &a, int num_cu, hipStream_t s) {
     const bool nt = MODE == G8_FILTER && a.nt;
+    if (g_gemm8_res != 1 && gemm8_res_lds(a.KB) <= size_t(160) * 1024) {
+        if (nt)
+            flat_gemm8_launch1<KC, MODE, true, false, true>(a, num_cu, s);
+        else
+            flat_gemm8_launch1<KC, MODE, false, false, true>(a, num_cu, s);
+        return;
+    }
     const int bm = g_gemm8_burst;
     const bool burst = KC <= 3 && bm != 1;  // (KC = 5: the 16 extra registers do not fit)
     if (nt) {
         if (burst) {
-            if constexpr (KC <= 3) flat_gemm8_launch1<KC, MODE, true, true>(a, num_cu, s);
+            if constexpr (KC <= 3) flat_gemm8_launch1<KC, MODE, true, true, false>(a, num_cu, s);
         } else {
-            flat_gemm8_launch1<KC, MODE, true, false>(a, num_cu, s);
+            flat_gemm8_launch1<KC, MODE, true, false, false>(a, num_cu, s);
         }
     } else {
         if (burst) {
-            if constexpr (KC <= 3) flat_gemm8_launch1<KC, MODE, false, true>(a, num_cu, s);
+            if constexpr (KC <= 3) flat_gemm8_launch1<KC, MODE, false, true, false>(a, num_cu, s);
         } else {
-            flat_gemm8_launch1<KC, MODE, false, false>(a, num_cu, s);
+            flat_gemm8_launch1<KC, MODE, false, false, false>(a, num_cu, s);
         }
     }
 }
@@ -462,7 +506,9 @@ static void flat_gemm8_dispatch(const Gemm8Args &a, int num_cu, hipStream_t s) {
     int kc = 0;
     if (want == 5 || want == 3 || want == 2)
         if (a.KB % uint32_t(want) == 0) kc = want;
-    if (kc == 0) kc = a.KB % 3 == 0 ? 3 : (a.KB % 5 == 0 ? 5 : 2);
+    const bool res = g_gemm8_res != 1 && gemm8_res_lds(a.KB) <= size_t(160) * 1024;
+    // (resident form: the chunk length is only the depth of the X ring -- the deepest that divides the k-block count)
+    if (kc == 0) kc = res ? (a.KB % 5 == 0 ? 5 : (a.KB % 3 == 0 ? 3 : 2)) : (a.KB % 3 == 0 ? 3 : (a.KB % 5 == 0 ? 5 : 2));
     VDB_REQUIRE(a.KB % uint32_t(kc) == 0, "flat_gemm8: k-block count must be divisible by 5, 3 or 2");
     if (kc == 5)
         flat_gemm8_launch<5, MODE>(a, num_cu, s);

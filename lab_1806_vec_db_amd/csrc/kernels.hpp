@@ -222,6 +222,7 @@ bool gemm8_supported(uint32_t dim);
 void gemm8_set_nt(int v);
 void gemm8_set_kc(int v);
 void gemm8_set_burst(int v);
+void gemm8_set_res(int v);    // 0 auto (the query group's whole image resident in LDS when it fits), 1 off (chunked staging)
 uint64_t gemm8_sample_rows(uint64_t n, uint32_t unit_step);
 void launch_flat_gemm8_filter(const void *XT, uint64_t n, uint32_t dim, const void *qfrag, const float *qscale, uint32_t ngroups,
                               const float *rowc, const float *tau, uint64_t *cand, uint32_t *cnt, uint32_t cap, int debug, int num_cu,

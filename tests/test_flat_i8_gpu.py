@@ -101,12 +101,16 @@ def test_i8_pass_parity(mods, dim, n, nq):
     _check_all(idx, d, cnt, oi, od, oc)
     print(f"dim {dim}: 8-bit pass passed on {redo} of {nq} queries")
     assert redo <= nq // 4
-    for kc, burst in ((5, 0), (3, 1), (3, 2), (2, 1), (2, 2)):  # every kernel variant the dimension allows
+    # every kernel variant the dimension allows: the query group's image resident in LDS (res 0: dims up to 960; the chunk length is
+    # then the depth of the row ring) and staged chunk by chunk through two buffers (res 1; per k-block or in one burst per chunk)
+    for res, kc, burst in ((0, 5, 0), (0, 3, 0), (0, 2, 0), (1, 5, 0), (1, 3, 1), (1, 3, 2), (1, 2, 1), (1, 2, 2), (1, 0, 0)):
+        ix.set_param("flat_gemm8_res", res)
         ix.set_param("flat_gemm8_kc", kc)
         ix.set_param("flat_gemm8_burst", burst)
         idx2, d2, cnt2 = ix.flat_knn(qs, 10)
         np.testing.assert_array_equal(idx, idx2)
         np.testing.assert_array_equal(d, d2)
+    ix.set_param("flat_gemm8_res", 0)
     ix.set_param("flat_gemm8_kc", 0)
     ix.set_param("flat_gemm8_burst", 0)
     for nt in (1, 2):
