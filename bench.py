@@ -518,6 +518,8 @@ def main():
     if roofline and attainable:
         roofline["attainable_peak_GBps"] = attainable
         roofline["frac_of_attainable"] = round(roofline["achieved"] / attainable, 4)
+        roofline["attainable_peak_how"] = ("vdb_stream_probe in this run: best of contiguous-chunk and grid-stride streaming reads of a 3.84-GB buffer, "
+                                           "default and non-temporal loads (the non-temporal forms reach ~7.0 TB/s on this chip, the default ones ~6.2)")
 
     if rank != 0:
         if world > 1:
