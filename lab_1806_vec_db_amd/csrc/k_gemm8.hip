@@ -294,7 +294,14 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
             float4 *stage_k = reinterpret_cast<float4 *>(stage_s) + wave * G8_STAGE;
             uint32_t *stage_r = reinterpret_cast<uint32_t *>(reinterpret_cast<float4 *>(stage_s) + 8 * G8_STAGE) + wave * G8_STAGE;
             uint32_t *stage_q = stage_r + 8 * G8_STAGE;
-            float tau_n = MODE == G8_FILTER ? tau_s[r] : 0.0f, qs_n = qs_s[r];
+            // the lane's query of every half: thresholds and scales for the whole unit, fetched in one batch (per pair, one pair ahead,
+            // the ~100-cycle LDS round trip was not covered by the ~45 cycles of a pair's arithmetic)
+            float tauv[NH], qsv[NH];
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                tauv[h] = MODE == G8_FILTER ? tau_s[h * 16 + r] : 0.0f;
+                qsv[h] = qs_s[h * 16 + r];
+            }
             // the wave's stage -> the workgroup's hit buffer (per key: exact test against the query's threshold, rows past n dropped)
             auto drain = [&]() {
                 const uint32_t cnt = stage_n < G8_STAGE ? stage_n : G8_STAGE;
@@ -339,12 +346,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
                         if (acc[t][h][0] + acc[t][h][1] + acc[t][h][2] + acc[t][h][3] == 12345) atomicAdd(hit_n, 1u);
                         continue;
                     }
-                    const float tau_h = tau_n, sq = qs_n;
-                    {
-                        const int hn = (h + 1) % NH;  // the next pair's query (h = 0 again for the next tile)
-                        if (MODE == G8_FILTER) tau_n = tau_s[hn * 16 + r];
-                        qs_n = qs_s[hn * 16 + r];
-                    }
+                    const float tau_h = tauv[h], sq = qsv[h];
                     // I is an exact integer (|I| <= 127^2 dim); the conversion is exact up to 2^24, one rounding beyond.
                     // key = C + M * (s_q * I): two roundings, covered by the certification's rounding term
                     const f32x2 sq2 = {sq, sq};
