@@ -48,6 +48,8 @@ struct Gemm8Args {
     uint32_t cap;
     uint32_t nt;          // non-temporal X loads (mirror beyond the Infinity Cache)
     uint32_t debug;       // bit 0: thresholds of -inf (nothing passes: the no-hit detection downstream, tests)
+    uint32_t coop;        // resident filter form: > 1 = the workgroups of an XCD in sets of `coop` that share one row stream (see the kernel)
+    uint32_t coop_block;  // ... units a wave scores between two hand-overs of the workgroup's hit buffer
 };
 
 enum { G8_FILTER = 0, G8_SAMPLE = 1 };
@@ -97,13 +99,32 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
     const uint32_t S0 = a.n_units / nwaves, rem = a.n_units - S0 * nwaves;
     const uint32_t rem_wg = (rem + NW - 1) / NW;
     const uint32_t rw = S0 == 0 ? 0u : rem_wg;
-    auto adv = [&](uint32_t slot) -> uint32_t { return slot >= rw ? slot - rw : slot + gridDim.x - rw; };
+    // COOPERATIVE form (RES filter, 256 workgroups = 8 XCDs x 32 CUs, a.coop = S in {2, 4, 8} dividing the group count): workgroup b runs
+    // on XCD b % 8 (round-robin dispatch; tools/l2share_probe.cpp: 256 of 256), and the 32 workgroups of an XCD form 32 / S slices of S
+    // members.  The members of a slice take S DIFFERENT query groups and walk the SAME units in the same order at the same time, so a
+    // unit comes from HBM once per S groups and from the XCD's 4-MB L2 for the other members (the probe: 8 x 0.96 GB read in 0.42 ms
+    // = 18 TB/s where 8 passes from HBM take 1.10 ms).  A member that runs ahead misses and slows down, one that lags hits: the set
+    // holds together by itself.  A workgroup handles ngroups / S groups (one image load and hand-over chain each) over 1 / (8 x 32 / S)
+    // of the units, i.e. S x the hits per group: the hit buffer is handed over every a.coop_block units.  Nothing here is needed for
+    // correctness -- on a chip that dispatches differently the members only stop sharing.
+    const uint32_t coopS = (RES && MODE == G8_FILTER) ? a.coop : 0u;
+    const bool coop = coopS > 1;
+    const uint32_t c_li = blockIdx.x >> 3, c_member = coop ? c_li % coopS : 0u, c_slices = coop ? 32u / coopS : 1u;
+    const uint32_t c_stride = c_slices * 64u, c_base0 = ((coop ? c_li / coopS : 0u) * 8u) * 8u + (blockIdx.x & 7u), c_base = c_base0 + wave * 8u;
+    const uint32_t c_steps = c_base < a.n_units ? (a.n_units - c_base + c_stride - 1) / c_stride : 0u;       // this wave's units per group
+    const uint32_t c_steps_max = c_base0 < a.n_units ? (a.n_units - c_base0 + c_stride - 1) / c_stride : 0u;  // wave 0's: the most of the workgroup
+    auto adv = [&](uint32_t slot) -> uint32_t {
+        if (coop) return slot;
+        return slot >= rw ? slot - rw : slot + gridDim.x - rw;
+    };
     auto steps_of = [&](uint32_t slot) -> uint32_t {
+        if (coop) return c_steps;
         if (rem == 0) return S0;
         if (S0 == 0) return 1;
         return S0 + (slot < rem_wg ? 1u : 0u);
     };
     auto unit_of = [&](uint32_t slot, uint32_t st) -> uint32_t {  // may be >= n_units (idle wave of the window's tail)
+        if (coop) return c_base + st * c_stride;
         return st < S0 ? st * nwaves + gw : S0 * nwaves + slot * NW + wave;
     };
     auto unit_ptr = [&](uint32_t u) -> const char * {  // wave-uniform
@@ -146,7 +167,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
     if constexpr (!RES) __syncthreads();
 
     const uint32_t g_begin = MODE == G8_SAMPLE ? blockIdx.y : 0, g_end = MODE == G8_SAMPLE ? blockIdx.y + 1 : a.ngroups;
-    for (uint32_t grp = g_begin; grp < g_end; grp++) {
+    for (uint32_t grp = g_begin + c_member; grp < g_end; grp += coop ? coopS : 1u) {
         const uint4 *qgrp = a.qfrag + uint64_t(grp) * nchunk * CHUNK;
         if constexpr (RES) {  // (the previous group's readers are past the hand-over's last barrier)
             for (uint32_t c = 0; c < nchunk; c++) {
@@ -162,7 +183,12 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
         if (threadIdx.x < G8_BQ) qs_s[threadIdx.x] = a.qscale[grp * G8_BQ + threadIdx.x];
         if constexpr (RES) __syncthreads();
         const uint32_t steps = steps_of(slot_cur);
-        for (uint32_t st = 0; st < steps; st++) {
+        const uint32_t steps_all = coop ? c_steps_max : steps;                       // workgroup-uniform
+        const uint32_t blk = coop && a.coop_block ? a.coop_block : 0xFFFFFFFFu;      // units between two hand-overs
+        for (uint32_t b0 = 0;;) {  // blocks of units [b0, b1) (one block unless cooperative), a hand-over after each
+        const uint32_t b1 = blk >= steps_all - b0 ? steps_all : b0 + blk;  // workgroup-uniform (b0 <= steps_all)
+        const uint32_t st_end = b1 < steps ? b1 : steps;                   // this wave's share of the block
+        for (uint32_t st = b0; st < st_end; st++) {
             const uint32_t u_raw = unit_of(slot_cur, st);
             const uint32_t u = u_raw < a.n_units ? u_raw : a.n_units - 1;
             i32x4 acc[TW][NH];
@@ -389,7 +415,8 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
             }
             if (MODE == G8_FILTER && stage_n) drain();  // once per unit
         }
-        // ---- group end: hand the parked hits to the per-query candidate lists (one global atomic per query) ----
+        // ---- group end (cooperative form: end of a block of units): hand the parked hits to the per-query candidate lists (one
+        // global atomic per query) ----
         __syncthreads();
         if (MODE == G8_FILTER) {
             uint32_t total = hit_n[0];
@@ -415,6 +442,13 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
                 }
             }
             __syncthreads();
+            if (coop) {  // the next block parks into an empty buffer
+                if (threadIdx.x < 1 + 2 * G8_BQ) hit_n[threadIdx.x] = 0;
+                __syncthreads();
+            }
+        }
+        b0 = b1;
+        if (b0 >= steps_all) break;  // (a workgroup without units hands over once, an empty buffer)
         }
         slot_cur = slot_nxt;
         slot_nxt = adv(slot_nxt);
@@ -466,10 +500,29 @@ void gemm8_set_burst(int v) { g_gemm8_burst = v; }
 static std::atomic<int> g_gemm8_res{0};  // 0 auto (resident image when it fits the LDS), 1 off (chunked staging), 2 as 0
 void gemm8_set_res(int v) { g_gemm8_res = v; }
 
+static std::atomic<int> g_gemm8_coop{0};  // 0 auto (cooperative sets when the shape allows), 1 off
+void gemm8_set_coop(int v) { g_gemm8_coop = v; }
+
 template <int KC, int MODE>
-static void flat_gemm8_launch(const Gemm8Args &a, int num_cu, hipStream_t s) {
+static void flat_gemm8_launch(const Gemm8Args &a0, int num_cu, hipStream_t s) {
+    Gemm8Args a = a0;
     const bool nt = MODE == G8_FILTER && a.nt;
     if (g_gemm8_res != 1 && gemm8_res_lds(a.KB) <= size_t(160) * 1024) {
+        // cooperative sets (see the kernel): the chip's 8 x 32 CUs, a set size that divides the group count, every wave of a slice with
+        // units to score; hand-overs sized for ~1000 hits per query (the sample plan's target): a block of B units parks about
+        // 8 waves x B x 48 rows x 128 queries x 1024 / n hits, kept below half the buffer
+        if (MODE == G8_FILTER && g_gemm8_coop != 1 && num_cu == 256) {
+            const uint32_t S = a.ngroups % 8 == 0 ? 8u : (a.ngroups % 4 == 0 ? 4u : (a.ngroups % 2 == 0 ? 2u : 1u));
+            const uint64_t units = ((a.n + 15) / 16 + G8_TW - 1) / G8_TW;
+            if (S > 1 && units >= 2048) {
+                a.coop = S;
+                const double per_unit = 8.0 * 48.0 * 128.0 * 1024.0 / double(a.n);
+                const double b = double(G8_WGBUF_RES) * 0.45 / per_unit;
+                a.coop_block = b < 1.0 ? 1u : (b > 4096.0 ? 4096u : uint32_t(b));
+                flat_gemm8_launch1<KC, MODE, false, false, true>(a, num_cu, s);  // default loads: the members meet in the L2
+                return;
+            }
+        }
         if (nt)
             flat_gemm8_launch1<KC, MODE, true, false, true>(a, num_cu, s);
         else

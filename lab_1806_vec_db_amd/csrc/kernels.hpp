@@ -222,6 +222,7 @@ bool gemm8_supported(uint32_t dim);
 void gemm8_set_nt(int v);
 void gemm8_set_kc(int v);
 void gemm8_set_burst(int v);
+void gemm8_set_coop(int v);   // 0 auto (the workgroups of an XCD share one row stream through its L2 when the shape allows), 1 off
 void gemm8_set_res(int v);    // 0 auto (the query group's whole image resident in LDS when it fits), 1 off (chunked staging)
 uint64_t gemm8_sample_rows(uint64_t n, uint32_t unit_step);
 void launch_flat_gemm8_filter(const void *XT, uint64_t n, uint32_t dim, const void *qfrag, const float *qscale, uint32_t ngroups,

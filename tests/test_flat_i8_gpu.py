@@ -304,3 +304,39 @@ def test_i8_not_for_cosine_or_u8(mods):
     ix.set_flat_mode(2)
     ix.flat_knn(base[:70], 5)
     assert ix.get_stat("flat_i8_queries") == 0 and ix.get_stat("flat_i8_valid") == 0
+
+
+@pytest.mark.parametrize("dim,n,nq", [(128, 130000, 1024), (960, 100000, 512), (192, 99000, 256 + 128)])
+def test_i8_cooperative_sets(mods, dim, n, nq):
+    """the resident filter kernel with the workgroups of an XCD in sets that share one row stream (8 / 4 groups per set; 3 groups: no
+    sets): same hit lists, so the same answers as with the sets switched off, bit for bit, and as the oracle on a sample; the hit
+    buffer is handed over in blocks (ragged last unit, rows not a multiple of a unit, a wave without units at the end of a slice)"""
+    vdb, O = mods
+    rng = np.random.default_rng(n + nq)
+    if dim == 960:
+        base, qs = gist_like(n, seed=77), gist_like(nq, seed=78)
+    else:
+        base = rng.standard_normal((n, dim)).astype(np.float32)
+        qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    ix = vdb.GpuIndex(dim, "l2sqr")
+    ix.batch_add(base)
+    ix.set_flat_mode(2)
+    ix.set_param("flat_gemm8_coop", 1)  # off
+    idx0, d0, cnt0 = ix.flat_knn(qs, 10)
+    r0 = ix.get_stat("flat_i8_redo")
+    ix.set_param("flat_gemm8_coop", 0)  # auto: sets of gcd(groups, 8) workgroups
+    idx1, d1, cnt1 = ix.flat_knn(qs, 10)
+    assert ix.get_stat("flat_i8_queries") == 2 * nq
+    np.testing.assert_array_equal(idx0, idx1)
+    np.testing.assert_array_equal(d0, d1)
+    np.testing.assert_array_equal(cnt0, cnt1)
+    assert ix.get_stat("flat_i8_redo") - r0 == r0  # the same queries passed on
+    assert r0 <= nq // 8
+    sel = rng.choice(nq, 48, replace=False)
+    oi, od, oc = O.flat_knn_batch(base, qs[sel], 10, 0, nthreads=8)
+    _check_all(idx1[sel], d1[sel], cnt1[sel], oi, od, oc)
+    for k in (1, 64):
+        idx3, d3, cnt3 = ix.flat_knn(qs, k)
+        oi, od, oc = O.flat_knn_batch(base, qs[sel[:16]], k, 0, nthreads=8)
+        _check_all(idx3[sel[:16]], d3[sel[:16]], cnt3[sel[:16]], oi, od, oc)
+    ix.close()
