@@ -170,6 +170,21 @@ def flat_roofline(ix, rows, dim, nq):
         tf = passes * rows * ((dim + 63) // 64 * 64) * 128 * 2 / avg_s / 1e12
         extra["matrix_pipe"] = {"achieved_TOPs": round(tf, 1), "nominal_peak_TOPs": 5000.0, "frac_of_nominal": round(tf / 5000.0, 4),
                                 "instruction": "v_mfma_i32_16x16x64_i8"}
+        coop = ix.get_stat("flat_gemm8_coop_sets")
+        if coop > 1:
+            # cooperative sets: `coop` workgroups of an XCD walk the same rows for different query groups, so a row is read from HBM once
+            # per set and from the XCD's L2 by the other members.  The operand bytes the CUs consume then exceed what HBM delivers (and
+            # can exceed its peak): HBM is no longer what bounds the kernel, the matrix pipe is -- the roofline is quoted on it, the
+            # byte rates stay beside it
+            r = hbm_roofline(kernel, p, extra)
+            r["hbm_operand_rate"] = {"achieved": r["achieved"], "peak": r["peak"], "unit": "GB/s", "frac": r["frac"],
+                                     "note": f"operand bytes consumed per second; sets of {coop} workgroups share one row stream through their XCD's L2, "
+                                             "HBM-side traffic per launch is `traffic` (PMC), about 1 / set size of the operand bytes"}
+            r.update({"bound": "mfma", "achieved": round(tf, 1), "peak": 5000.0, "unit": "TOP/s", "frac": round(tf / 5000.0, 4),
+                      "peak_def": "dense int8 MFMA peak of the chip (MI355X_MICROARCH.md: 2 x the ~2.5 PF BF16 rate); what back-to-back "
+                                  "v_mfma issue sustains on a box is about half of it (vdb_mfma_probe)",
+                      "cooperative_set": coop})
+            return r
     elif kernel == "flat_half":
         extra["frac_of"] = "operand bytes: the scaled fp16 mirror of the rows (2 B/element) the first pass streams; exact f32 re-rank + certification downstream"
         extra["operand_bytes"] = bpl
@@ -515,7 +530,12 @@ def main():
             alg = offers * (dim * 4 + 4)  # SURVEY 8(d)-style figure: every offered row as f32
             tot_ms = sum(ix.prof_get(kn)["ms"] for kn in ("ivf_q8", "ivf_half", "ivf_rerank")) / max(ix.prof_get("ivf_rerank")["launches"], 1)
             roofline["f32_equivalent_GBps"] = round(alg / (tot_ms * 1e-3) / 1e9, 1) if tot_ms > 0 else None
-    if roofline and attainable:
+    if roofline and attainable and roofline.get("bound") != "hbm":  # (cooperative sets: the byte rates sit in hbm_operand_rate)
+        h = roofline.get("hbm_operand_rate")
+        if h:
+            h["attainable_peak_GBps"] = attainable
+            h["frac_of_attainable"] = round(h["achieved"] / attainable, 4)
+    elif roofline and attainable:
         roofline["attainable_peak_GBps"] = attainable
         roofline["frac_of_attainable"] = round(roofline["achieved"] / attainable, 4)
         roofline["attainable_peak_how"] = ("vdb_stream_probe in this run: best of contiguous-chunk and grid-stride streaming reads of a 3.84-GB buffer, "
@@ -689,6 +709,12 @@ def cpu_and_parity(O, wl, ix, host_base, queries, res, gt, ncpu, k, ef, okind, t
 
 
 def with_attainable(roofline, attainable):
+    if roofline and attainable and roofline.get("bound") != "hbm":
+        h = roofline.get("hbm_operand_rate")
+        if h:
+            h["attainable_peak_GBps"] = attainable
+            h["frac_of_attainable"] = round(h["achieved"] / attainable, 4)
+        return roofline
     if roofline and attainable:
         roofline["attainable_peak_GBps"] = attainable
         roofline["frac_of_attainable"] = round(roofline["achieved"] / attainable, 4)

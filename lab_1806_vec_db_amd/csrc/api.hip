@@ -567,6 +567,8 @@ int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out) {
         *out = idx->ix.half_redo.load();
     else if (n == "flat_half_valid")
         *out = idx->ix.half_valid ? 1 : 0;
+    else if (n == "flat_gemm8_coop_sets")  // workgroups per cooperative set of the most recent 8-bit filter launch of the process (0: none)
+        *out = gemm8_last_coop();
     else if (n == "flat_i8_queries")
         *out = idx->ix.i8_queries.load();
     else if (n == "flat_i8_redo")

@@ -502,6 +502,8 @@ void gemm8_set_res(int v) { g_gemm8_res = v; }
 
 static std::atomic<int> g_gemm8_coop{0};  // 0 auto (cooperative sets when the shape allows), 1 off
 void gemm8_set_coop(int v) { g_gemm8_coop = v; }
+static std::atomic<uint32_t> g_gemm8_last_coop{0};  // set size of the most recent filter launch (0: no sets)
+uint32_t gemm8_last_coop() { return g_gemm8_last_coop; }
 
 template <int KC, int MODE>
 static void flat_gemm8_launch(const Gemm8Args &a0, int num_cu, hipStream_t s) {
@@ -516,6 +518,7 @@ static void flat_gemm8_launch(const Gemm8Args &a0, int num_cu, hipStream_t s) {
             const uint64_t units = ((a.n + 15) / 16 + G8_TW - 1) / G8_TW;
             if (S > 1 && units >= 2048) {
                 a.coop = S;
+                g_gemm8_last_coop = S;
                 const double per_unit = 8.0 * 48.0 * 128.0 * 1024.0 / double(a.n);
                 const double b = double(G8_WGBUF_RES) * 0.45 / per_unit;
                 a.coop_block = b < 1.0 ? 1u : (b > 4096.0 ? 4096u : uint32_t(b));
@@ -523,6 +526,7 @@ static void flat_gemm8_launch(const Gemm8Args &a0, int num_cu, hipStream_t s) {
                 return;
             }
         }
+        if (MODE == G8_FILTER) g_gemm8_last_coop = 0;
         if (nt)
             flat_gemm8_launch1<KC, MODE, true, false, true>(a, num_cu, s);
         else
