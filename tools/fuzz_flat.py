@@ -15,8 +15,10 @@ it = bad = 0
 while time.time() < t_end:
     it += 1
     dim = int(rng.choice([64, 96, 100, 128, 192, 256, 320, 384, 512, 768, 960, 1000, 1024, 1536]))
-    n = int(rng.integers(min_n, 60000))
-    nq = int(rng.choice([1, 3, 17, 64, 65, 100, 128, 129, 200, 257]))
+    if min_n >= 60000: dim = int(rng.choice([64, 128, 192, 320, 960]))  # (keeps the oracle's share of a configuration in seconds)
+    big = min_n >= 60000  # (tables of >= 98 304 rows and calls of an even number of 128-query groups: the filter's cooperative sets)
+    n = int(rng.integers(min_n, int(min_n * 1.6))) if big else int(rng.integers(min_n, 60000))
+    nq = int(rng.choice([130, 256, 300, 512, 513, 700, 1024])) if big else int(rng.choice([1, 3, 17, 64, 65, 100, 128, 129, 200, 257]))
     k = int(rng.choice([1, 2, 5, 10, 16, 17, 33, 64, 70]))
     dist = str(rng.choice(["l2sqr", "cosine"]))
     kind = 0 if dist == "l2sqr" else 1
@@ -51,7 +53,7 @@ while time.time() < t_end:
     ok = cnt.tolist() == oc.tolist() and all(idx[q, :int(cnt[q])].tolist() == oi[q][:int(cnt[q])].tolist() and
                                              np.array_equal(d[q, :int(cnt[q])], od[q][:int(cnt[q])]) for q in range(nq))
     print(f"#{it} dim {dim} n {n} nq {nq} k {k} {dist} style {style}: {'ok' if ok else 'MISMATCH'} "
-          f"i8 {ix.get_stat('flat_i8_queries')} tail {nw} half {ix.get_stat('flat_half_queries')} redo {ix.get_stat('flat_half_redo')} fallback {ix.flat_fallback_count()}", flush=True)
+          f"i8 {ix.get_stat('flat_i8_queries')} tail {nw} sets {ix.get_stat('flat_gemm8_coop_sets')} half {ix.get_stat('flat_half_queries')} redo {ix.get_stat('flat_half_redo')} fallback {ix.flat_fallback_count()}", flush=True)
     bad += 0 if ok else 1
     del ix
 print(f"done: {it} configurations, {bad} mismatches")
