@@ -132,6 +132,7 @@ int vdb_flat_set_mode(vdb_index *idx, int mode);
  *                      0 auto (off once > 1/8 of its queries were handed on), 1 off, 2 on.  While it is the first tier the fp16 mirror is
  *                      built by its first use instead of at add time (set "flat_i8" = 1 BEFORE adding rows to have it built at add time)
  *   "flat_i8_rows"     rows its exact stage may walk per query before handing the query on (multiple of 64, default 256)
+ *   "flat_gemm_coop"   the same sets for the fp16 / split-bf16 filter kernel (0 auto = on, 1 off)
  *   "flat_gemm8_coop"  cooperative sets of the resident form (calls whose group count is even, tables of >= 98 304 rows, 256-CU chips): the 32
  *                      workgroups of an XCD in sets of 8 / 4 / 2 that take different query groups and walk the same rows at the same time, so
  *                      a row comes from HBM once per set and from the XCD's L2 for the other members; 0 auto = on, 1 off

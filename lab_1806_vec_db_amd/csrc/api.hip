@@ -540,6 +540,8 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         gemm8_set_res((int)value);
     else if (n == "flat_gemm8_coop")
         gemm8_set_coop((int)value);
+    else if (n == "flat_gemm_coop")
+        gemm_set_coop((int)value);
     else if (n == "flat_half_kmul") {  // its shortlist: max(64, kmul * k) rows per query
         VDB_REQUIRE(value >= 1 && value <= 64, "flat_half_kmul must be in [1, 64]");
         idx->ix.flat_half_kmul = (uint32_t)value;

@@ -69,6 +69,8 @@ struct GemmArgs {
     uint32_t nt;       // GEMM_FILTER: non-temporal X loads (host-side choice, see GEMM_NT_BIT)
     uint32_t zigzag;   // GEMM_FILTER: odd query groups walk their full steps in reverse (the rows the previous pass read last are still in the Infinity Cache)
     uint32_t row_base; // GEMM_FILTER: first row of the block this launch scans (XT, xsq and n are the block's; ids are global)
+    uint32_t coop;        // GEMM_FILTER: > 1 = cooperative sets of that many workgroups per XCD (k_gemm8.hip: the same scheme)
+    uint32_t coop_block;  // ... unit steps between two hand-overs of the workgroup's hit buffer
 };
 
 enum { GEMM_FILTER = 0, GEMM_SAMPLE = 1 };
@@ -134,8 +136,22 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
     const uint32_t rem_wg = (rem + NW - 1) / NW;  // workgroups in the window
     // slot = this workgroup's position relative to the window's start; the window moves by rem_wg per group
     const uint32_t rw = S0 == 0 ? 0u : rem_wg;
-    auto adv = [&](uint32_t slot) -> uint32_t { return slot >= rw ? slot - rw : slot + gridDim.x - rw; };
+    // Cooperative sets (a.coop = S, 256 workgroups; derived and measured in k_gemm8.hip): the 32 workgroups of an XCD (workgroup b runs
+    // on XCD b % 8) form 32 / S slices of S members that take S different query groups and walk the SAME units at the same time, so
+    // a unit comes from HBM once per S groups and from the XCD's L2 for the other members.  Here the chunk barriers need the same
+    // number of unit steps in every wave: all run wave 0's count, a wave past its last unit scores the clamped unit masked.
+    const uint32_t coopS = MODE == GEMM_FILTER ? a.coop : 0u;
+    const bool coop = coopS > 1;
+    const uint32_t c_li = blockIdx.x >> 3, c_member = coop ? c_li % coopS : 0u, c_slices = coop ? 32u / coopS : 1u;
+    const uint32_t c_stride = c_slices * 64u, c_base0 = ((coop ? c_li / coopS : 0u) * 8u) * 8u + (blockIdx.x & 7u), c_base = c_base0 + wave * 8u;
+    const uint32_t c_steps_max = c_base0 < a.n_units ? (a.n_units - c_base0 + c_stride - 1) / c_stride : 0u;
+    const uint32_t gstep = coop ? coopS : 1u;
+    auto adv = [&](uint32_t slot) -> uint32_t {
+        if (coop) return slot;
+        return slot >= rw ? slot - rw : slot + gridDim.x - rw;
+    };
     auto steps_of = [&](uint32_t slot) -> uint32_t {
+        if (coop) return c_steps_max;
         if (rem == 0) return S0;
         if (S0 == 0) return 1;
         return S0 + (slot < rem_wg ? 1u : 0u);
@@ -143,6 +159,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
     // Odd query groups may walk the full steps backwards (a.zigzag): a pass then starts on the rows the previous pass
     // read last -- up to an Infinity Cache worth of the mirror is still resident -- instead of on the rows it evicted first.
     auto unit_of = [&](uint32_t slot, uint32_t st, uint32_t g) -> uint32_t {  // may be >= n_units (idle wave of the window's tail)
+        if (coop) return c_base + st * c_stride;
         const uint32_t sw = (MODE == GEMM_FILTER && a.zigzag && (g & 1)) ? S0 - 1 - st : st;
         return st < S0 ? sw * nwaves + gw : S0 * nwaves + slot * NW + wave;
     };
@@ -189,7 +206,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
     constexpr int QP = QST / KC;
     static_assert(QST % KC == 0, "staging must split evenly over the k-blocks of a chunk");
     {
-        const uint4 *src = a.qfrag + (MODE == GEMM_SAMPLE ? uint64_t(blockIdx.y) * nchunk * CHUNK : 0);
+        const uint4 *src = a.qfrag + (MODE == GEMM_SAMPLE ? uint64_t(blockIdx.y) : uint64_t(c_member)) * nchunk * CHUNK;
 #pragma unroll
         for (int j = 0; j < QST; j++) smem[j * NT + threadIdx.x] = src[j * NT + threadIdx.x];
     }
@@ -197,14 +214,17 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
     __syncthreads();
 
     const uint32_t g_begin = MODE == GEMM_SAMPLE ? blockIdx.y : 0, g_end = MODE == GEMM_SAMPLE ? blockIdx.y + 1 : a.ngroups;
-    for (uint32_t grp = g_begin; grp < g_end; grp++) {
+    for (uint32_t grp = g_begin + c_member; grp < g_end; grp += gstep) {
         const uint4 *qgrp = a.qfrag + uint64_t(grp) * nchunk * CHUNK;
         if (MODE == GEMM_FILTER && threadIdx.x < 1 + 2 * GEMM_BQ) hit_n[threadIdx.x] = 0;  // ordered before the first append by the chunk barriers
         if (MODE == GEMM_FILTER && threadIdx.x < GEMM_BQ)  // thresholds live in LDS, not in 8 registers per lane
             tau_s[threadIdx.x] = (a.debug & 1) ? -INFINITY : a.tau[grp * GEMM_BQ + threadIdx.x];
         if (PREC == GEMM_F16 && threadIdx.x < GEMM_BQ) qm_s[threadIdx.x] = a.qmul[grp * GEMM_BQ + threadIdx.x];
         const uint32_t steps = steps_of(slot_cur);
-        for (uint32_t st = 0; st < steps; st++) {
+        const uint32_t blk = coop && a.coop_block ? a.coop_block : 0xFFFFFFFFu;  // unit steps between two hand-overs
+        for (uint32_t b0 = 0;;) {  // blocks of unit steps [b0, b1) (one block unless cooperative), a hand-over after each
+        const uint32_t b1 = blk >= steps - b0 ? steps : b0 + blk;
+        for (uint32_t st = b0; st < b1; st++) {
             const uint32_t u_raw = unit_of(slot_cur, st, grp);
             const uint32_t u = u_raw < a.n_units ? u_raw : a.n_units - 1;
             f32x4 acc[TW][NH];
@@ -223,7 +243,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
             for (uint32_t c = 0; c < nchunk; c++) {
                 // next chunk in consumption order: same group until its last step is done
                 const uint4 *nxt = (c + 1 < nchunk ? qgrp + uint64_t(c + 1) * CHUNK
-                                    : (st + 1 < steps ? qgrp : (grp + 1 < a.ngroups ? qgrp + uint64_t(nchunk) * CHUNK : a.qfrag)));
+                                    : (st + 1 < steps ? qgrp : (grp + gstep < a.ngroups ? qgrp + uint64_t(gstep) * nchunk * CHUNK : a.qfrag)));
                 const uint32_t tid16 = threadIdx.x * 16;
                 uint4 *qdst = smem + (buf ^ 1) * CHUNK + threadIdx.x;
                 const uint4 *qcur = smem + buf * CHUNK + lane;
@@ -495,6 +515,13 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
                 }
             }
             __syncthreads();
+            if (coop) {  // the next block parks into an empty buffer
+                if (threadIdx.x < 1 + 2 * GEMM_BQ) hit_n[threadIdx.x] = 0;
+                __syncthreads();
+            }
+        }
+        b0 = b1;
+        if (b0 >= steps) break;
         }
         slot_cur = slot_nxt;
         slot_nxt = adv(slot_nxt);
@@ -503,9 +530,27 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
 
 template <int TW, int KC, int MODE, int PREC>
 static void flat_gemm_launch1(const GemmArgs &a0, int num_cu, hipStream_t s);
+static std::atomic<int> g_gemm_coop{0};  // 0 auto (cooperative sets when the shape allows), 1 off
+void gemm_set_coop(int v) { g_gemm_coop = v; }
 template <int TW, int KC, int MODE, int PREC>
-static void flat_gemm_launch(const GemmArgs &a, int num_cu, hipStream_t s) {
+static void flat_gemm_launch(const GemmArgs &a0, int num_cu, hipStream_t s) {
+    GemmArgs a = a0;
     if constexpr (MODE == GEMM_FILTER) {
+        // cooperative sets (k_gemm8.hip): the chip's 8 x 32 CUs, a set size that divides the group count, whole-table launches, every
+        // wave of a slice with units to score; blocks sized so that ~1000 hits per query fill less than half the hit buffer
+        if (g_gemm_coop != 1 && num_cu == 256 && a.row_base == 0 && !a.stagger) {
+            const uint32_t S = a.ngroups % 8 == 0 ? 8u : (a.ngroups % 4 == 0 ? 4u : (a.ngroups % 2 == 0 ? 2u : 1u));
+            const uint64_t units = ((a.n + 15) / 16 + TW - 1) / TW;
+            if (S > 1 && units >= 2048) {
+                a.coop = S;
+                a.zigzag = 0;
+                const double per_step = 8.0 * 16.0 * TW * 128.0 * 1024.0 / double(a.n);
+                const double b = double(GEMM_WGBUF) * 0.45 / per_step;
+                a.coop_block = b < 1.0 ? 1u : (b > 4096.0 ? 4096u : uint32_t(b));
+                flat_gemm_launch1<TW, KC, MODE, PREC>(a, num_cu, s);  // default loads: the members meet in the L2
+                return;
+            }
+        }
         if (a.nt) {
             flat_gemm_launch1<TW, KC, MODE, PREC | GEMM_NT_BIT>(a, num_cu, s);
             return;

@@ -223,3 +223,36 @@ def test_row_blocked_filter_pass(mods):
     finally:
         ix.set_param("flat_gemm_block_rows", 0)
     assert ix.flat_fallback_count() == 0
+
+
+@pytest.mark.parametrize("dist,kind,dim,n,nq,half", [("cosine", 1, 960, 100000, 512, 0), ("l2sqr", 0, 128, 120000, 1024, 0), ("cosine", 1, 192, 99000, 256, 1)])
+def test_cooperative_sets_of_the_fp16_and_split_bf16_filter(mods, dist, kind, dim, n, nq, half):
+    """k_flat_gemm with the workgroups of an XCD in sets that share one row stream (k_gemm8.hip's scheme; sets of 4 / 8 / 2 here): the
+    same answers as with the sets switched off, bit for bit, and as the oracle on a sample -- fp16 pass (Cosine, and L2Sqr with the
+    8-bit pass off) and the split-bf16 pass alone (flat_half = 1)"""
+    vdb, O = mods
+    rng = np.random.default_rng(n + nq)
+    if dim == 960:
+        base, qs = gist_like(n, seed=91), gist_like(nq, seed=92)
+    else:
+        base = rng.standard_normal((n, dim)).astype(np.float32)
+        qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    ix = vdb.GpuIndex(dim, dist)
+    ix.batch_add(base)
+    ix.set_flat_mode(2)
+    ix.set_param("flat_i8", 1)
+    ix.set_param("flat_half", 1 if half else 0)
+    ix.set_param("flat_gemm_coop", 1)  # off
+    idx0, d0, cnt0 = ix.flat_knn(qs, 10)
+    ix.set_param("flat_gemm_coop", 0)  # auto
+    idx1, d1, cnt1 = ix.flat_knn(qs, 10)
+    assert ix.get_stat("flat_i8_queries") == 0
+    if not half:
+        assert ix.get_stat("flat_half_queries") == 2 * nq
+    np.testing.assert_array_equal(idx0, idx1)
+    np.testing.assert_array_equal(d0, d1)
+    np.testing.assert_array_equal(cnt0, cnt1)
+    sel = rng.choice(nq, 32, replace=False)
+    oi, od, oc = O.flat_knn_batch(base, qs[sel], 10, kind, nthreads=8)
+    _check_all(idx1[sel], d1[sel], cnt1[sel], oi, od, oc)
+    ix.close()
