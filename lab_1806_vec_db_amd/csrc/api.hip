@@ -569,6 +569,8 @@ int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out) {
         *out = idx->ix.half_redo.load();
     else if (n == "flat_half_valid")
         *out = idx->ix.half_valid ? 1 : 0;
+    else if (n == "flat_gemm_coop_sets")  // the same of the fp16 / split-bf16 filter kernel
+        *out = gemm_last_coop();
     else if (n == "flat_gemm8_coop_sets")  // workgroups per cooperative set of the most recent 8-bit filter launch of the process (0: none)
         *out = gemm8_last_coop();
     else if (n == "flat_i8_queries")

@@ -532,6 +532,8 @@ template <int TW, int KC, int MODE, int PREC>
 static void flat_gemm_launch1(const GemmArgs &a0, int num_cu, hipStream_t s);
 static std::atomic<int> g_gemm_coop{0};  // 0 auto (cooperative sets when the shape allows), 1 off
 void gemm_set_coop(int v) { g_gemm_coop = v; }
+static std::atomic<uint32_t> g_gemm_last_coop{0};  // set size of the most recent filter launch (0: no sets)
+uint32_t gemm_last_coop() { return g_gemm_last_coop; }
 template <int TW, int KC, int MODE, int PREC>
 static void flat_gemm_launch(const GemmArgs &a0, int num_cu, hipStream_t s) {
     GemmArgs a = a0;
@@ -543,6 +545,7 @@ static void flat_gemm_launch(const GemmArgs &a0, int num_cu, hipStream_t s) {
             const uint64_t units = ((a.n + 15) / 16 + TW - 1) / TW;
             if (S > 1 && units >= 2048) {
                 a.coop = S;
+                g_gemm_last_coop = S;
                 a.zigzag = 0;
                 const double per_step = 8.0 * 16.0 * TW * 128.0 * 1024.0 / double(a.n);
                 const double b = double(GEMM_WGBUF) * 0.45 / per_step;
@@ -551,6 +554,7 @@ static void flat_gemm_launch(const GemmArgs &a0, int num_cu, hipStream_t s) {
                 return;
             }
         }
+        g_gemm_last_coop = 0;
         if (a.nt) {
             flat_gemm_launch1<TW, KC, MODE, PREC | GEMM_NT_BIT>(a, num_cu, s);
             return;
