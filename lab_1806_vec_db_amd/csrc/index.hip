@@ -815,7 +815,7 @@ void Index::flat_debug_keys(Workspace &ws, const float *d_q, uint64_t nq, int ti
         ws.qfrag_g.reserve(nq_pad * size_t(mfma_dim_pad((uint32_t)dim)));
         ws.dense.reserve(nq_pad * ld8 * sizeof(float));
         ws.qaux.reserve(2 * nq_pad * sizeof(float));
-        ws.misc.reserve(nq_pad * sizeof(uint32_t));
+        ws.misc.reserve((nq_pad + 128) * sizeof(uint32_t));  // (the preparation kernel also zeroes the 128 rendezvous words behind the counters)
         float *d_qs8 = ws.qaux.as<float>(), *d_qoff = d_qs8 + nq_pad;
         launch_query_prep_i8(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, d_mu_i8.as<float>(), i8_l1, i8_l2, ws.qsq.as<float>(), d_qs8,
                              d_qoff, ws.misc.as<uint32_t>(), ws.qfrag_g.p, s);
@@ -841,7 +841,7 @@ void Index::flat_debug_keys(Workspace &ws, const float *d_q, uint64_t nq, int ti
     ws.qfrag_g.reserve(nq_pad * size_t(mfma_dim_pad((uint32_t)dim)) * sizeof(float));
     ws.dense.reserve(nq_pad * ld * sizeof(float));
     ws.qaux.reserve(3 * nq_pad * sizeof(float));
-    ws.misc.reserve(nq_pad * sizeof(uint32_t));
+    ws.misc.reserve((nq_pad + 128) * sizeof(uint32_t));  // (the preparation kernel also zeroes the 128 rendezvous words behind the counters)
     float *d_qscale = ws.qaux.as<float>(), *d_qmul = d_qscale + nq_pad, *d_qerr = d_qmul + nq_pad;
     if (half) {
         launch_query_prep_h(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, half_sx(), ws.qsq.as<float>(), d_qscale, d_qmul, d_qerr,

@@ -71,6 +71,7 @@ struct GemmArgs {
     uint32_t row_base; // GEMM_FILTER: first row of the block this launch scans (XT, xsq and n are the block's; ids are global)
     uint32_t coop;        // GEMM_FILTER: > 1 = cooperative sets of that many workgroups per XCD (k_gemm8.hip: the same scheme)
     uint32_t coop_block;  // ... unit steps between two hand-overs of the workgroup's hit buffer
+    uint32_t *sync;       // ... 128 zeroed words: one arrival counter per set (cnt + ngroups * 128)
 };
 
 enum { GEMM_FILTER = 0, GEMM_SAMPLE = 1 };
@@ -167,6 +168,21 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
         if (u >= a.n_units) u = a.n_units - 1;  // idle waves re-read the last unit (L2 hits, results masked)
         return reinterpret_cast<const char *>(a.XT) + uint64_t(u) * a.unit_step * TW * KB * 2048;
     };
+    // Set rendezvous (k_gemm8.hip: why): the members of a set have to START together -- a member that comes tens of microseconds late (its CU was
+    // still held by another call's exact stage: pipelined or concurrent callers) finds nothing of the others' rows in the L2 any
+    // more and never catches up, and eight members streaming apart with allocating loads are slower than the plain form (measured:
+    // 3 steps in flight at 1M rows 2.33 ms per step against 1.03 alone).  One counter per set behind the hit counters (zeroed by
+    // the query preparation); the wait is bounded, so two such grids can never hold each other up for good.
+    if (coop && a.sync) {
+        if (threadIdx.x == 0) {
+            uint32_t *ctr = a.sync + (blockIdx.x & 7u) * 16u + c_li / coopS;
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < coopS && __builtin_readcyclecounter() - t0 < 1000000ull)
+                __builtin_amdgcn_s_sleep(16);
+        }
+        __syncthreads();
+    }
     // Every workgroup does the same work at the same rate, so without help all 256 CUs reach their unit epilogues -- where a
     // workgroup issues no loads for ~2.5 us -- at the same moments and HBM idles chip-wide once per unit step.  A one-off
     // start delay of 0..15/16 of a unit step, different for neighbouring workgroups, spreads those gaps over the period.
@@ -646,6 +662,7 @@ void launch_flat_gemm_filter(const float *XT, uint64_t n, uint32_t dim, const fl
     a.tau = tau;
     a.cand = cand;
     a.cnt = cnt;
+    a.sync = cnt + uint64_t(ngroups) * GEMM_BQ;  // (Index::flat_knn_enqueue: the rendezvous words follow the padded counters, zeroed)
     a.cap = cap;
     a.debug = (uint32_t)debug;
     {   // mirror bytes of this shard against the Infinity Cache (256 MB): stream past it, or let it serve passes 2..

@@ -50,6 +50,7 @@ struct Gemm8Args {
     uint32_t debug;       // bit 0: thresholds of -inf (nothing passes: the no-hit detection downstream, tests)
     uint32_t coop;        // resident filter form: > 1 = the workgroups of an XCD in sets of `coop` that share one row stream (see the kernel)
     uint32_t coop_block;  // ... units a wave scores between two hand-overs of the workgroup's hit buffer
+    uint32_t *sync;       // ... 128 zeroed words: one arrival counter per set (cnt + ngroups * 128)
 };
 
 enum { G8_FILTER = 0, G8_SAMPLE = 1 };
@@ -131,6 +132,21 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
         if (u >= a.n_units) u = a.n_units - 1;  // idle waves re-read the last unit (L2 hits, results masked)
         return reinterpret_cast<const char *>(a.XT) + uint64_t(u) * a.unit_step * TW * KB * 1024;
     };
+    // Set rendezvous: the members of a set have to START together -- a member that comes tens of microseconds late (its CU was
+    // still held by another call's exact stage: pipelined or concurrent callers) finds nothing of the others' rows in the L2 any
+    // more and never catches up, and eight members streaming apart with allocating loads are slower than the plain form (measured:
+    // 3 steps in flight at 1M rows 2.33 ms per step against 1.03 alone).  One counter per set behind the hit counters (zeroed by
+    // the query preparation); the wait is bounded, so two such grids can never hold each other up for good.
+    if (coop && a.sync) {
+        if (threadIdx.x == 0) {
+            uint32_t *ctr = a.sync + (blockIdx.x & 7u) * 16u + c_li / coopS;
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < coopS && __builtin_readcyclecounter() - t0 < 1000000ull)
+                __builtin_amdgcn_s_sleep(16);
+        }
+        __syncthreads();
+    }
     uint32_t slot_cur = blockIdx.x, slot_nxt = adv(slot_cur);
     const char *cp_cur = unit_ptr(unit_of(slot_cur, 0)),
                *cp_nxt = unit_ptr(1 < steps_of(slot_cur) ? unit_of(slot_cur, 1) : unit_of(slot_nxt, 0));
@@ -593,6 +609,7 @@ void launch_flat_gemm8_filter(const void *XT, uint64_t n, uint32_t dim, const vo
     a.tau = tau;
     a.cand = cand;
     a.cnt = cnt;
+    a.sync = cnt + uint64_t(ngroups) * G8_BQ;  // (Index::flat_knn_enqueue: the rendezvous words follow the padded counters)
     a.cap = cap;
     const double mirror_bytes = double((n + 15) / 16 * 16) * mfma_dim_pad(dim);
     a.nt = g_gemm8_nt == 2 || (g_gemm8_nt == 0 && mirror_bytes > 384.0 * 1024 * 1024) ? 1u : 0u;

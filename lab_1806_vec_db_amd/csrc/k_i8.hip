@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256) void k_query_prep_i8(const float *__restrict__
                                                        uint32_t *__restrict__ hits, uint4 *__restrict__ qfrag) {
     extern __shared__ float qp8_smem[];  // [4 waves][dim]
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x < 128) hits[nq_pad + threadIdx.x] = 0;  // the filter's set rendezvous words (k_gemm8.hip), behind the counters
     const uint32_t q = blockIdx.x * 4 + wave;
     if (q >= nq_pad) return;
     constexpr uint32_t NH = 8;
