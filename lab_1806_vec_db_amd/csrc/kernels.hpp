@@ -186,7 +186,8 @@ size_t mfma_sync_words(uint32_t nbatch, int num_cu);
 // k_gemm.hip: the same filter for groups of gemm_group() = 128 queries per corpus pass; qfrag = images packed with
 // launch_mfma_pack_queries_nh(.., 8, ..), tau / cand / cnt indexed by the global query number as above
 // qmul == nullptr: split-bf16 operands (launch_tile_rows / launch_mfma_pack_queries_nh); otherwise the scaled fp16
-// operands of k_half.hip and qmul[q] = 1 / (row scale * query scale)
+// operands of k_half.hip and qmul[q] = 1 / (row scale * query scale).  cnt[ngroups * 128 .. + 127] are the arrival counters of the
+// cooperative sets: ZERO on entry (launch_query_prep_h / the caller's memset), part of the same allocation as cnt
 void launch_flat_gemm_filter(const float *XT, uint64_t n, uint32_t dim, const float *qfrag, const float *qmul, uint32_t ngroups,
                              const float *xsq, int cosine, const float *tau, uint64_t *cand, uint32_t *cnt,
                              uint32_t cap, int debug, int num_cu, hipStream_t s);
@@ -228,6 +229,7 @@ void gemm_set_coop(int v);    // the same for the fp16 / split-bf16 filter kerne
 void gemm8_set_coop(int v);   // 0 auto (the workgroups of an XCD share one row stream through its L2 when the shape allows), 1 off
 void gemm8_set_res(int v);    // 0 auto (the query group's whole image resident in LDS when it fits), 1 off (chunked staging)
 uint64_t gemm8_sample_rows(uint64_t n, uint32_t unit_step);
+// (cnt[ngroups * 128 .. + 127]: the arrival counters of the cooperative sets, zero on entry -- launch_query_prep_i8 clears them)
 void launch_flat_gemm8_filter(const void *XT, uint64_t n, uint32_t dim, const void *qfrag, const float *qscale, uint32_t ngroups,
                               const float *rowc, const float *tau, uint64_t *cand, uint32_t *cnt, uint32_t cap, int debug, int num_cu,
                               hipStream_t s);
