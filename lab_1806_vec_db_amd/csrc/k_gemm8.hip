@@ -528,7 +528,7 @@ static void flat_gemm8_launch(const Gemm8Args &a0, int num_cu, hipStream_t s) {
     if (g_gemm8_res != 1 && gemm8_res_lds(a.KB) <= size_t(160) * 1024) {
         // cooperative sets (see the kernel): the chip's 8 x 32 CUs, a set size that divides the group count, every wave of a slice with
         // units to score; hand-overs sized for ~1000 hits per query (the sample plan's target): a block of B units parks about
-        // 8 waves x B x 48 rows x 128 queries x 1024 / n hits, kept below half the buffer
+        // 8 waves x B x 48 rows x 128 queries x 1024 / n hits, kept near half the buffer (0.55: two units per block on a 125k-row shard)
         if (MODE == G8_FILTER && g_gemm8_coop != 1 && num_cu == 256) {
             const uint32_t S = a.ngroups % 8 == 0 ? 8u : (a.ngroups % 4 == 0 ? 4u : (a.ngroups % 2 == 0 ? 2u : 1u));
             const uint64_t units = ((a.n + 15) / 16 + G8_TW - 1) / G8_TW;
@@ -536,7 +536,7 @@ static void flat_gemm8_launch(const Gemm8Args &a0, int num_cu, hipStream_t s) {
                 a.coop = S;
                 g_gemm8_last_coop = S;
                 const double per_unit = 8.0 * 48.0 * 128.0 * 1024.0 / double(a.n);
-                const double b = double(G8_WGBUF_RES) * 0.45 / per_unit;
+                const double b = double(G8_WGBUF_RES) * 0.55 / per_unit;
                 a.coop_block = b < 1.0 ? 1u : (b > 4096.0 ? 4096u : uint32_t(b));
                 flat_gemm8_launch1<KC, MODE, false, false, true>(a, num_cu, s);  // default loads: the members meet in the L2
                 return;
