@@ -2,7 +2,9 @@
 """bench.py -- headline benchmark: Flat brute-force k-NN, Gist1M-shaped corpus, queries/s at recall@10.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
-torch.distributed.run, one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
+torch.distributed.run, one rank per GPU (RCCL).  Rank 0 prints ONE JSON line on stdout: the COMPACT record
+(< 6 KB: the contract's fields, roofline incl. the N*d*4 leg, cpu_baseline, parity, one brief object per leg); the full record
+with every leg's roofline / notes goes to gpurun_out/bench_full.json (--full-out).
 
 Headline workload (BASELINE.json configs[1] / configs[4]): corpus N=1,000,000 x 960 f32, L2Sqr, k=10, one step = one
 batch of nq=1000 queries (the size of data/gist_test.bin) through FlatIndex::knn semantics.  Gist1M is not
@@ -167,7 +169,7 @@ def flat_roofline(ix, rows, dim, nq):
         extra["frac_of"] = ("operand bytes: the centred int8 mirror of the rows (1 B/element) the first pass streams; its keys are lower bounds of the "
                             "distances, the exact f32 stage walks the hit list until the k-th distance is below the next bound")
         extra["operand_bytes"] = bpl
-        tf = passes * rows * ((dim + 63) // 64 * 64) * 128 * 2 / avg_s / 1e12
+        tf = nq * rows * dim * 2 / avg_s / 1e12  # the call's queries (not the padded slots of its last pass) x rows x dim x 2
         extra["matrix_pipe"] = {"achieved_TOPs": round(tf, 1), "nominal_peak_TOPs": 5000.0, "frac_of_nominal": round(tf / 5000.0, 4),
                                 "instruction": "v_mfma_i32_16x16x64_i8"}
         coop = ix.get_stat("flat_gemm8_coop_sets")
@@ -189,13 +191,13 @@ def flat_roofline(ix, rows, dim, nq):
         extra["frac_of"] = "operand bytes: the scaled fp16 mirror of the rows (2 B/element) the first pass streams; exact f32 re-rank + certification downstream"
         extra["operand_bytes"] = bpl
         # the filter is a dense contraction too: 2 flops per (row, column, query slot) with 128 slots per pass
-        tf = passes * rows * ((dim + 63) // 64 * 64) * 128 * 2 / avg_s / 1e12
+        tf = nq * rows * dim * 2 / avg_s / 1e12
         extra["matrix_pipe"] = {"achieved_TFLOPs": round(tf, 1), "nominal_peak_TFLOPs": 2500.0, "frac_of_nominal": round(tf / 2500.0, 4),
                                 "instruction": "v_mfma_f32_16x16x32_f16"}
     else:
         extra["frac_of"] = "SURVEY 8(d) algorithmic bytes (the kernel streams 4 B/element)"
         if kernel == "flat_mfma":  # the split-bf16 kernel: three bf16 MFMAs per operand pair (hi*hi, hi*lo, lo*hi)
-            tf = passes * rows * ((dim + 63) // 64 * 64) * 128 * 2 * 3 / avg_s / 1e12
+            tf = nq * rows * dim * 2 * 3 / avg_s / 1e12
             extra["matrix_pipe"] = {"achieved_TFLOPs": round(tf, 1), "nominal_peak_TFLOPs": 2500.0, "frac_of_nominal": round(tf / 2500.0, 4),
                                     "instruction": "v_mfma_f32_16x16x16_bf16 x 3 (split operands)"}
     r = hbm_roofline(kernel, p, extra)
@@ -208,6 +210,97 @@ def flat_roofline(ix, rows, dim, nq):
         r.update({"bound": "mfma", "achieved": mp["achieved_TFLOPs"], "peak": mp["nominal_peak_TFLOPs"], "unit": "TFLOP/s",
                   "frac": mp["frac_of_nominal"], "cooperative_set": coop})
     return r
+
+
+COMPACT_LIMIT = 6144  # the driver keeps the last 8 KB of stdout: the FINAL line must fit with room to spare
+
+
+def _leg_brief(leg):
+    """{qps, ms_per_step, frac, parity_ok} of one leg of the full record (plus the two or three numbers a leg is judged on)"""
+    if not isinstance(leg, dict):
+        return None
+    r = leg.get("roofline") or {}
+    b = {"qps": leg.get("value"), "ms_per_step": leg.get("ms_per_step"), "frac": r.get("frac"), "bound": r.get("bound")}
+    par = leg.get("parity")
+    if par is not None:
+        b["parity_ok"] = bool(par.get("indices_identical") and par.get("distances_bit_exact"))
+    elif "results_equal_headline" in leg:
+        b["parity_ok"] = bool(leg["results_equal_headline"])
+    if leg.get("recall_at_10") is not None:
+        b["recall_at_10"] = round(leg["recall_at_10"], 4)
+    if (leg.get("cpu_baseline") or {}).get("value") is not None:
+        b["cpu_qps"] = leg["cpu_baseline"]["value"]
+    for nm in ("one_call_of_1000", "one_call_of_1"):
+        if nm in leg:
+            b[nm + "_ms"] = leg[nm].get("ms_per_step")
+    lf = r.get("latency_floor")
+    if lf:
+        b["latency_floor_frac"] = lf.get("frac")
+    return {k_: v for k_, v in b.items() if v is not None}
+
+
+def compact_line(out, full_path=None):
+    """The FINAL stdout line of a run: the contract's fields of the full record `out`, no prose, < COMPACT_LIMIT bytes.
+    The full record (every leg's roofline / cpu_baseline / notes) goes to `full_path`."""
+    r = out.get("roofline") or {}
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "launches", "units_per_launch",
+            "bytes_per_launch", "algorithmic_bytes", "cooperative_set", "attainable_peak_GBps", "frac_of_attainable")
+    cr = {k_: r[k_] for k_ in keep if r.get(k_) is not None or k_ == "traffic"} if r else None
+    if cr is not None:
+        if r.get("traffic") and r.get("avg_launch_ms"):
+            cr["hbm_from_pmc_GBps"] = round(r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9, 1)
+        h = r.get("hbm_operand_rate")
+        if h:
+            cr["operand_GBps"] = h.get("achieved")
+            cr["attainable_peak_GBps"] = h.get("attainable_peak_GBps")
+        mp = r.get("matrix_pipe") or {}
+        for k_ in ("instruction", "sustained_peak_TOPs", "sustained_peak_TFLOPs", "frac_of_sustained", "clock_GHz_at_sustained_peak"):
+            if mp.get(k_) is not None:
+                cr[k_] = mp[k_]
+        for nm in ("f32_operand_leg", "fp16_pass_leg", "one_step_in_flight"):
+            leg = r.get(nm)
+            if leg:
+                cr[nm] = {k_: leg[k_] for k_ in ("qps", "ms_per_step", "kernel", "avg_launch_ms", "achieved", "frac", "unit", "results_equal_headline")
+                          if leg.get(k_) is not None}
+    sm = out.get("step_ms")
+    cb = out.get("cpu_baseline")
+    c = {"metric": out["metric"], "value": out["value"], "unit": out["unit"], "n_gpus": out["n_gpus"], "steps": out["steps"],
+         "warmup": out["warmup"], "ms_per_step": out["ms_per_step"],
+         "step_ms": {k_: sm[k_] for k_ in ("min", "median", "max")} if sm else None,
+         "higher_is_better": out["higher_is_better"], "scaling": out["scaling"], "vs_baseline": out["vs_baseline"],
+         "dtype": out["dtype"], "data": out["data"], "config": out["config"], "recall_at_10": out.get("recall_at_10"),
+         "parity": out.get("parity"), "roofline": cr,
+         "cpu_baseline": {k_: cb[k_] for k_ in ("value", "unit", "cores", "kind", "sample")} if cb else None}
+    for k_ in ("i8_pass", "half_pass", "fallback_queries", "filter_work"):
+        if out.get(k_) is not None:
+            c[k_] = out[k_]
+    legs = out.get("legs")
+    if legs:
+        cl = {}
+        for nm, leg in legs.items():
+            if nm == "ivf":  # SURVEY 2: out of scope; stays in the full record only
+                continue
+            if nm == "config1_gist_1000":
+                cl[nm] = {"gpu_one_call_qps": leg["gpu_one_call"]["value"], "gpu_per_query_calls_qps": leg["gpu_per_query_calls"]["value"],
+                          "gpu_per_query_calls_threads_qps": leg["gpu_per_query_calls_threads"]["value"],
+                          "cpu_qps": (leg.get("cpu_baseline") or {}).get("value"),
+                          "cpu_serial_qps": ((leg.get("cpu_baseline") or {}).get("serial") or {}).get("value"),
+                          "parity_ok": bool((leg.get("parity") or {}).get("indices_identical") and (leg.get("parity") or {}).get("distances_bit_exact"))}
+                continue
+            cl[nm] = _leg_brief(leg)
+            if isinstance(leg.get("n_bits_8"), dict):
+                cl[nm + "_8bit"] = _leg_brief(leg["n_bits_8"])
+        c["legs"] = cl
+    if full_path:
+        c["full_record"] = full_path
+    line = json.dumps(c, separators=(",", ":"))
+    if len(line) >= COMPACT_LIMIT:  # never let prose push the line past what the driver keeps: drop the optional parts, largest first
+        for k_ in ("legs", "filter_work", "half_pass", "i8_pass"):
+            c.pop(k_, None)
+            line = json.dumps(c, separators=(",", ":"))
+            if len(line) < COMPACT_LIMIT:
+                break
+    return line
 
 
 def main():
@@ -235,6 +328,7 @@ def main():
     ap.add_argument("--half-kmul", type=int, default=0, help="flat: shortlist of the fp16 pass = max(64, kmul*k) (0: library default)")
     ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE",
                     help="developer tuning switch passed to vdb_set_param before the first step (A/B runs; results never depend on them)")
+    ap.add_argument("--full-out", type=str, default="", help="file of the full record (default gpurun_out/bench_full.json); stdout gets the compact line")
     ap.add_argument("--dump", type=str, default="", help="rank 0 saves the last step's results to this .npz (tests)")
     ap.add_argument("--legs", choices=["auto", "all", "none"], default="auto",
                     help="the SURVEY 8(d) report items beside the headline (N=1, flat): auto = all when the headline runs at its "
@@ -482,13 +576,13 @@ def main():
     step_times = []  # ms per step of the LAST timed() region (host clock between consecutive step returns)
 
     def step_stats():
+        """host clock between consecutive step returns inside the one timed region (a Flat / PQ / HNSW step at N=1 ends in the library's own
+        stream synchronisation; with N>1 the exchange of step i overlaps step i+1, so single steps are enqueue-to-enqueue and only the
+        total is fenced)"""
         st = sorted(step_times)
         if not st:
             return None
-        return {"min": round(st[0], 4), "median": round(st[len(st) // 2], 4), "max": round(st[-1], 4),
-                "how": "host clock between consecutive step returns inside the one timed region (a Flat / PQ / HNSW step at N=1 ends in the "
-                       "library's own stream synchronisation; with N>1 the exchange of step i overlaps step i+1, so single steps are "
-                       "enqueue-to-enqueue and only the total is fenced)"}
+        return {"min": round(st[0], 4), "median": round(st[len(st) // 2], 4), "max": round(st[-1], 4)}
 
     elapsed, res = timed(ix, step, args.steps, args.warmup, drain if depth > 1 else None)
     head_steps = step_stats()
@@ -663,7 +757,17 @@ def main():
         mp.update({"sustained_peak_TFLOPs": tfl, "clock_GHz_at_sustained_peak": ghz, "frac_of_sustained": round(mp["achieved_TFLOPs"] / tfl, 4),
                    "note": "sustained peak = vdb_mfma_probe at the end of this run: the same instruction back to back on every SIMD, "
                            "4 waves per SIMD; the chip lowers its clock under that load"})
-    print(json.dumps(out))
+    # the full record goes to a side file (and stays out of stdout); the FINAL stdout line is the compact one the driver parses
+    full_path = args.full_out or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(full_path)), exist_ok=True)
+        with open(full_path, "w") as fh:
+            json.dump(out, fh)
+            fh.write("\n")
+        shown = os.path.relpath(full_path, ROOT)
+    except OSError:
+        shown = None
+    print(compact_line(out, shown), flush=True)
     if world > 1 or force_x:
         dist.destroy_process_group()
 
