@@ -137,7 +137,7 @@ void Index::swap_remove(uint64_t i) {
         if (i8_n == n) {
             for (uint64_t t : {i / 16, last / 16})
                 launch_tile_rows_i8(d_rows.as<float>(), last, (uint32_t)dim, t, t + 1, d_mu_i8.as<float>(), i8_l1, i8_l2, d_tiled_i8.p,
-                                    d_rowc_i8.as<float>(), s);
+                                    d_rowc_i8.as<float>(), s, dist == 1 ? d_sq.as<float>() : nullptr);  // (d_sq[i] already holds the moved row's)
             i8_n = last;
         } else {
             i8_valid = false;  // rows were added since the last search: rebuilt by the next one
@@ -232,7 +232,7 @@ void Index::half_refresh(Workspace &ws, uint64_t n_old, uint64_t n_new) {
 
 // ---- centred 8-bit mirror (k_i8.hip) ---------------------------------------------------------------
 bool Index::i8_applicable(uint32_t ksel) const {
-    if (elem_u8 || dist != 0 || flat_i8_mode == 1 || (dim & 3) != 0 || !gemm8_supported((uint32_t)dim)) return false;
+    if (elem_u8 || flat_i8_mode == 1 || (dim & 3) != 0 || !gemm8_supported((uint32_t)dim)) return false;
     if (!flat_tail_lb_supported((uint32_t)dim, flat_i8_kprime, ksel) || n <= 64) return false;
     if (!(xsq_max <= 0x1p80f)) return false;  // extreme data: the other tiers' own guards decide
     const uint64_t iq = i8_queries.load(), ir = i8_redo.load();
@@ -246,6 +246,7 @@ void Index::ensure_i8(Workspace &ws) {
     const uint64_t tiles = ((n + 15) / 16 + 11) / 12 * 12;  // whole units of k_flat_gemm8
     const uint64_t tile_bytes = 16 * size_t(mfma_dim_pad(d));
     const bool rebuild = !i8_valid || i8_n > n || n >= 2 * i8_mu_rows;
+    const float *xsq_cos = dist == 1 ? d_sq.as<float>() : nullptr;  // Cosine: the mirror of the UNIT rows (k_i8.hip)
     uint64_t t0 = rebuild ? 0 : i8_n / 16;
     d_tiled_i8.grow(tiles * tile_bytes, t0 * tile_bytes, s);
     d_rowc_i8.grow(tiles * 16 * 2 * sizeof(float), t0 * 16 * 2 * sizeof(float), s);
@@ -254,10 +255,10 @@ void Index::ensure_i8(Workspace &ws) {
         // positive pair is valid, this one is tight for queries that look like rows)
         d_mu_i8.reserve(size_t(d) * sizeof(float));
         ws.dense.reserve(size_t(I8_MEAN_CHUNKS) * d * sizeof(float) + 2 * 16384 * sizeof(float));
-        launch_i8_col_mean(d_rows.as<float>(), n, d, ws.dense.as<float>(), d_mu_i8.as<float>(), s);
+        launch_i8_col_mean(d_rows.as<float>(), n, d, ws.dense.as<float>(), d_mu_i8.as<float>(), s, xsq_cos);
         const uint64_t n_s = std::min<uint64_t>(n, 16384), stride = n / n_s, n_s16 = (n_s + 15) / 16 * 16;
         float *d_stats = ws.dense.as<float>() + size_t(I8_MEAN_CHUNKS) * d;
-        launch_i8_row_stats(d_rows.as<float>(), n, d, d_mu_i8.as<float>(), n_s, stride, d_stats, s);
+        launch_i8_row_stats(d_rows.as<float>(), n, d, d_mu_i8.as<float>(), n_s, stride, d_stats, s, xsq_cos);
         std::vector<float> st(2 * n_s16), mu(d);
         VDB_HIP(hipMemcpyAsync(st.data(), d_stats, st.size() * sizeof(float), hipMemcpyDeviceToHost, s));
         VDB_HIP(hipMemcpyAsync(mu.data(), d_mu_i8.p, d * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -277,14 +278,14 @@ void Index::ensure_i8(Workspace &ws) {
         i8_mu_norm = (float)std::sqrt(m2) * 1.001f;
         i8_mu_rows = n;
     }
-    launch_tile_rows_i8(d_rows.as<float>(), n, d, t0, tiles, d_mu_i8.as<float>(), i8_l1, i8_l2, d_tiled_i8.p, d_rowc_i8.as<float>(), s);
+    launch_tile_rows_i8(d_rows.as<float>(), n, d, t0, tiles, d_mu_i8.as<float>(), i8_l1, i8_l2, d_tiled_i8.p, d_rowc_i8.as<float>(), s, xsq_cos);
     VDB_SYNC(s);
     i8_n = n;
     i8_valid = true;
 }
 
 bool Index::i8_defers_half() const {
-    return !elem_u8 && dist == 0 && flat_i8_mode != 1 && (dim & 3) == 0 && gemm8_supported((uint32_t)dim);
+    return !elem_u8 && flat_i8_mode != 1 && (dim & 3) == 0 && gemm8_supported((uint32_t)dim);
 }
 bool Index::ensure_half(Workspace &ws) {
     std::lock_guard<std::mutex> g(half_mu);
@@ -613,7 +614,7 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
             d_qscale = ws.qaux.as<float>();
             d_qoff = d_qscale + nq_pad;
             launch_query_prep_i8(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, d_mu_i8.as<float>(), i8_l1, i8_l2, ws.qsq.as<float>(),
-                                 d_qscale, d_qoff, d_hits, ws.qfrag_g.p, s);
+                                 d_qscale, d_qoff, d_hits, ws.qfrag_g.p, s, cosine);
         } else if (half) {
             ws.qaux.reserve(3 * nq_pad * sizeof(float));
             d_qscale = ws.qaux.as<float>();
@@ -808,7 +809,7 @@ void Index::flat_debug_keys(Workspace &ws, const float *d_q, uint64_t nq, int ti
     const int cosine = dist == 1 ? 1 : 0;
     const uint64_t gq = gemm_group(), ngroups = (nq + gq - 1) / gq, nq_pad = ngroups * gq;
     if (tier == 2) {  // 8-bit operands: keys are lower bounds, D >= key + qoff (h_qerr = qoff; h_dx = l1, l2, |mu|, 0)
-        VDB_REQUIRE(!elem_u8 && dist == 0 && (dim & 3) == 0 && gemm8_supported((uint32_t)dim), "debug keys: the index has no 8-bit pass");
+        VDB_REQUIRE(!elem_u8 && (dim & 3) == 0 && gemm8_supported((uint32_t)dim), "debug keys: the index has no 8-bit pass");
         ensure_i8(ws);
         const uint64_t n_s8 = gemm8_sample_rows(n, 1), ld8 = (n_s8 + 63) & ~63ull;
         ws.qsq.reserve(nq_pad * sizeof(float));
@@ -818,7 +819,7 @@ void Index::flat_debug_keys(Workspace &ws, const float *d_q, uint64_t nq, int ti
         ws.misc.reserve((nq_pad + 128) * sizeof(uint32_t));  // (the preparation kernel also zeroes the 128 rendezvous words behind the counters)
         float *d_qs8 = ws.qaux.as<float>(), *d_qoff = d_qs8 + nq_pad;
         launch_query_prep_i8(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, d_mu_i8.as<float>(), i8_l1, i8_l2, ws.qsq.as<float>(), d_qs8,
-                             d_qoff, ws.misc.as<uint32_t>(), ws.qfrag_g.p, s);
+                             d_qoff, ws.misc.as<uint32_t>(), ws.qfrag_g.p, s, cosine);
         launch_flat_gemm8_sample(d_tiled_i8.p, n, (uint32_t)dim, ws.qfrag_g.p, d_qs8, (uint32_t)ngroups, d_rowc_i8.as<float>(), 1,
                                  ws.dense.as<float>(), ld8, num_cu, s);
         VDB_HIP(hipMemcpy2DAsync(h_keys, n * sizeof(float), ws.dense.p, ld8 * sizeof(float), n * sizeof(float), nq, hipMemcpyDeviceToHost, s));

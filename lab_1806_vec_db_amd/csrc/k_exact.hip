@@ -924,7 +924,8 @@ void launch_flat_tail64(const FlatTailArgs &a, uint32_t nq, hipStream_t s) {
 // with kappa = the smallest key not yet evaluated (tau[q] once the list is exhausted: every row outside it has key > tau).
 // The first factor covers the strict fold of a row outside (e >= D (1 - gamma_{d+2})), the last term the two roundings of
 // the key's own evaluation.  Most queries stop after 32 .. 96 rows; one that is still open after max_rounds is flagged and
-// redone by the next tier.  L2Sqr only.
+// redone by the next tier.  Cosine (round 4): the same walk with the dot fold and the reference's epilogue on the cached norms;
+// the keys then bound the L2Sqr distance of the unit vectors, i.e. twice the cosine distance (flat_certify_lb).
 // ---------------------------------------------------------------------------------------------
 // Variant of k_flat_tail_lb ("flat_tail_lb_nw": 8 / 4 / 2 / 1 = waves per query with the chains on the fetching lanes, 40 / 41 = four
 // waves with one chain per lane, loads 3 / 5 chunks deep).  Measured (profiles/r03_probe_tail_lb_waves.txt; 1000 queries on a 125k-row
@@ -963,6 +964,21 @@ __device__ __forceinline__ uint64_t block_top64_above(const uint64_t *__restrict
 __device__ __forceinline__ uint8_t flat_certify_lb(uint64_t ek, float kappa, uint32_t q, const FlatTailArgs &a) {
     if (ek == PAIR_NONE) return 1;
     const float dk = f32_from_orderable(uint32_t(ek >> 32));
+    if (a.cosine) {
+        // The keys bound the L2Sqr distance of the UNIT vectors: 1 - cos >= (kappa + O_q) / 2 for every row outside (k_i8.hip).  The
+        // reference's f32 value of a row outside (strict dot fold, two strict norm folds, sqrt, product, quotient, 1 - r:
+        // distance/mod.rs:60-69) is within (2 d + 8) u of the real-number cosine distance -- |dot_f - <x, q>| <= d u |x||q|, each norm
+        // (d / 2 + 1) u relative, |cos| <= 1 -- provided the max(|x||q|, 1e-10) clamp is inactive and no norm leaves [1e-30, 1e30]
+        // (checked here through the smallest positive row norm of the index; rows the cached |x|^2 does not describe carry keys of
+        // -FLT_MAX and are always evaluated).  The key's own two roundings: 2 u (|x~||q~| + |key|) <= 4 u (2 + 2 |mu|)^2 as for
+        // L2Sqr with unit norms, halved with the key; 4 u |lower| for kappa + O_q.
+        const float qs = a.qsq[q], qn = sqrtf(qs);
+        const bool plain = a.xsq_min_pos >= 1e-30f && qs >= 1e-30f && qs <= 1e30f && sqrtf(a.xsq_min_pos) * qn > 1e-9f;
+        const float nr = 2.0f + 2.0f * a.se.mu_norm;
+        float lower = 0.5f * (kappa + a.se.qoff[q]);
+        lower = lower - 4.0f * 5.9604645e-8f * fabsf(lower) - float(2 * a.dim + 16) * 5.9604645e-8f * 1.01f - 2.0f * 5.9604645e-8f * nr * nr;
+        return (plain && dk < lower) ? 0 : 1;  // NaN anywhere -> not certified
+    }
     const float qn = sqrtf(a.qsq[q]);
     const float rx = fminf(sqrtf(a.xsq_max), (qn + sqrtf(fmaxf(dk, 0.0f))) * 1.001f);  // (flat_certify_flag: why)
     const float nr = rx + qn + 2.0f * a.se.mu_norm;
@@ -1033,7 +1049,8 @@ __global__ __launch_bounds__(NW * 64, PCD ? 4 : 1) void k_flat_tail_lb(FlatTailA
             const bool consumer = wave == (blockIdx.x & 3u);
             acc = pc_rerank_fold<FOLD, DEPTH>(a.X, a.dim, idx, live, qs4, ftl_smem + d4, wave, lane, consumer);
             const uint64_t c = sbest[0][lane];  // the consumer's lane added row `lane`
-            if (consumer && c != PAIR_NONE && lane < 63) skeys[lane] = pair_key(epilogue(MET_L2_DIRECT, acc, 0.0f, 0.0f), uint32_t(c));
+            if (consumer && c != PAIR_NONE && lane < 63)
+                skeys[lane] = pair_key(FOLD == FOLD_L2 ? acc : epilogue(MET_COSINE, acc, a.xsq[uint32_t(c)], a.qsq[q]), uint32_t(c));
         } else {
             if constexpr (NW == 8)
                 acc = group_rerank_fold<FOLD, 8>(a.X, a.dim, idx[0], live[0], qs4, tile, lane);
@@ -1041,7 +1058,8 @@ __global__ __launch_bounds__(NW * 64, PCD ? 4 : 1) void k_flat_tail_lb(FlatTailA
                 acc = group_rerank_fold_n<FOLD, DEPTH, RW>(a.X, a.dim, idx, live, qs4, tile, lane);
             const uint32_t j = wave * RW + lane / NW;  // the row whose chain this lane added (NW lanes each)
             const uint64_t c = sbest[0][j];
-            if (c != PAIR_NONE && j < 63 && lane % NW == 0) skeys[j] = pair_key(epilogue(MET_L2_DIRECT, acc, 0.0f, 0.0f), uint32_t(c));
+            if (c != PAIR_NONE && j < 63 && lane % NW == 0)
+                skeys[j] = pair_key(FOLD == FOLD_L2 ? acc : epilogue(MET_COSINE, acc, a.xsq[uint32_t(c)], a.qsq[q]), uint32_t(c));
         }
         __syncthreads();
         TAIL_STAMP();
@@ -1124,12 +1142,20 @@ void launch_flat_tail_lb(const FlatTailArgs &a0, uint32_t nq, hipStream_t s) {
         a.stamps = stamps;
     }
 #endif
-    VDB_REQUIRE(flat_tail_lb_supported(a.dim, a.kprime, a.ksel) && a.metric == MET_L2_DIRECT && a.se.qoff && a.tau,
+    VDB_REQUIRE(flat_tail_lb_supported(a.dim, a.kprime, a.ksel) && (a.metric == MET_L2_DIRECT || a.metric == MET_COSINE) && a.se.qoff && a.tau,
                 "flat_tail_lb: unsupported shape");
+    VDB_REQUIRE((a.metric == MET_COSINE) == (a.cosine != 0) && (a.metric == MET_L2_DIRECT || (a.xsq && a.qsq)), "flat_tail_lb: metric / norms");
     const size_t lds = (size_t(a.dim / 4) + 2 * 64 * 9) * sizeof(float4);
     int nw = g_tail_lb_nw;
     if (nw != 8 && nw != 4 && nw != 2 && nw != 1 && nw != 40 && nw != 41) nw = TAIL_LB_AUTO_NW(nq);
-    if (nw == 40)  // four waves, producer / consumer fold
+    if (a.metric == MET_COSINE) {  // (Cosine: the producer / consumer form and the plain 8-wave form)
+        if (nw == 8)
+            hipLaunchKernelGGL((k_flat_tail_lb<FOLD_DOT, 8, 0>), dim3(nq), dim3(512), lds, s, a);
+        else if (nw == 41)
+            hipLaunchKernelGGL((k_flat_tail_lb<FOLD_DOT, 4, 5>), dim3(nq), dim3(256), lds, s, a);
+        else
+            hipLaunchKernelGGL((k_flat_tail_lb<FOLD_DOT, 4, 3>), dim3(nq), dim3(256), lds, s, a);
+    } else if (nw == 40)  // four waves, producer / consumer fold
         hipLaunchKernelGGL((k_flat_tail_lb<FOLD_L2, 4, 3>), dim3(nq), dim3(256), lds, s, a);
     else if (nw == 41)
         hipLaunchKernelGGL((k_flat_tail_lb<FOLD_L2, 4, 5>), dim3(nq), dim3(256), lds, s, a);

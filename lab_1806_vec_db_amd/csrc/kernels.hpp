@@ -235,13 +235,15 @@ void launch_flat_gemm8_filter(const void *XT, uint64_t n, uint32_t dim, const vo
                               hipStream_t s);
 void launch_flat_gemm8_sample(const void *XT, uint64_t n, uint32_t dim, const void *qfrag, const float *qscale, uint32_t ngroups,
                               const float *rowc, uint32_t unit_step, float *out, uint64_t ld, int num_cu, hipStream_t s);
-void launch_i8_col_mean(const float *X, uint64_t n, uint32_t dim, float *part /* I8_MEAN_CHUNKS * dim */, float *mu, hipStream_t s);
+// xsq_cos != null / cosine != 0: the Cosine form -- unit rows / unit queries (k_i8.hip); xsq_cos = the rows' cached strict-fold |x|^2
+void launch_i8_col_mean(const float *X, uint64_t n, uint32_t dim, float *part /* I8_MEAN_CHUNKS * dim */, float *mu, hipStream_t s,
+                        const float *xsq_cos = nullptr);
 void launch_i8_row_stats(const float *X, uint64_t n, uint32_t dim, const float *mu, uint64_t n_s, uint64_t stride,
-                         float *stats /* 2 * round_up(n_s, 16) */, hipStream_t s);
+                         float *stats /* 2 * round_up(n_s, 16) */, hipStream_t s, const float *xsq_cos = nullptr);
 void launch_tile_rows_i8(const float *X, uint64_t n, uint32_t dim, uint64_t tile0, uint64_t tile1, const float *mu, float l1, float l2,
-                         void *T, float *rowc, hipStream_t s);
+                         void *T, float *rowc, hipStream_t s, const float *xsq_cos = nullptr);
 void launch_query_prep_i8(const float *Q, uint32_t nq, uint32_t nq_pad, uint32_t dim, const float *mu, float l1, float l2, float *qsq,
-                          float *qscale, float *qoff, uint32_t *hits, void *qfrag, hipStream_t s);
+                          float *qscale, float *qoff, uint32_t *hits, void *qfrag, hipStream_t s, int cosine = 0);
 void mfma_set_sample_thin(int v);
 void mfma_sample_plan(uint64_t n, uint32_t kprime, uint32_t *step, uint32_t *rank);
 uint64_t mfma_sample_rows(uint64_t n, uint32_t step);

@@ -295,14 +295,15 @@ def test_i8_degenerate_inputs(mods):
     _check_all(idx, d, cnt, oi, od, oc)
 
 
-def test_i8_not_for_cosine_or_u8(mods):
+def test_i8_not_for_u8(mods):
+    """u8 tables keep their own path (Cosine takes the pass since round 4: tests/test_flat_i8_cosine_gpu.py)"""
     vdb, _ = mods
     rng = np.random.default_rng(1)
-    base = rng.standard_normal((20000, 128)).astype(np.float32)
-    ix = vdb.GpuIndex(128, "cosine")
-    ix.batch_add(base)
+    base = rng.integers(0, 255, size=(20000, 128)).astype(np.uint8)
+    ix = vdb.GpuIndex(128, "l2sqr", scalar="u8")
+    ix.batch_add_u8(base)
     ix.set_flat_mode(2)
-    ix.flat_knn(base[:70], 5)
+    ix.flat_knn(base[:70].astype(np.float32), 5)
     assert ix.get_stat("flat_i8_queries") == 0 and ix.get_stat("flat_i8_valid") == 0
 
 
@@ -323,9 +324,12 @@ def test_i8_cooperative_sets(mods, dim, n, nq):
     ix.set_flat_mode(2)
     ix.set_param("flat_gemm8_coop", 1)  # off
     idx0, d0, cnt0 = ix.flat_knn(qs, 10)
+    assert ix.get_stat("flat_gemm8_coop_sets") <= 1  # the plain resident form ran
     r0 = ix.get_stat("flat_i8_redo")
     ix.set_param("flat_gemm8_coop", 0)  # auto: sets of gcd(groups, 8) workgroups
     idx1, d1, cnt1 = ix.flat_knn(qs, 10)
+    groups = (nq + 127) // 128
+    assert ix.get_stat("flat_gemm8_coop_sets") == (8 if groups % 8 == 0 else 4 if groups % 4 == 0 else 2 if groups % 2 == 0 else 0)
     assert ix.get_stat("flat_i8_queries") == 2 * nq
     np.testing.assert_array_equal(idx0, idx1)
     np.testing.assert_array_equal(d0, d1)
