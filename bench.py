@@ -748,15 +748,18 @@ def main():
                                         "row-major fp16 image of the walks / IVF scan and IVF's 8-bit image are built on first use)")
         out["legs"] = legs
     mp = (out.get("roofline") or {}).get("matrix_pipe")
-    if mp is not None and world == 1 and mp.get("instruction", "").endswith("f16"):
-        # the matrix pipe's rate under sustained load on this box (the chip is power-limited well below the nominal 2.5 PFLOP/s);
+    if mp is not None and world == 1 and mp.get("instruction", "").endswith(("f16", "i8")):
+        # the matrix pipe's rate under sustained load on this box (the chip is power-limited well below the nominal peaks);
         # measured AFTER every timed region: half a second of nothing but MFMAs is not what a timed step should start behind
         from lab_1806_vec_db_amd.index import mfma_probe
 
-        tfl, ghz = (round(v, 2) for v in mfma_probe(local_rank, 4, 200_000))
-        mp.update({"sustained_peak_TFLOPs": tfl, "clock_GHz_at_sustained_peak": ghz, "frac_of_sustained": round(mp["achieved_TFLOPs"] / tfl, 4),
-                   "note": "sustained peak = vdb_mfma_probe at the end of this run: the same instruction back to back on every SIMD, "
-                           "4 waves per SIMD; the chip lowers its clock under that load"})
+        is8 = mp["instruction"].endswith("i8")
+        best = max((tuple(round(v, 2) for v in mfma_probe(local_rank, w, 200_000, i8=is8)) + (w,) for w in (1, 2, 4)), key=lambda t: t[0])
+        unit = "TOPs" if is8 else "TFLOPs"
+        mp.update({f"sustained_peak_{unit}": best[0], "clock_GHz_at_sustained_peak": best[1], "waves_per_simd_at_sustained_peak": best[2],
+                   "frac_of_sustained": round(mp[f"achieved_{unit}"] / best[0], 4),
+                   "note": "sustained peak = vdb_mfma_probe(_i8) at the end of this run: the same instruction back to back on every SIMD, "
+                           "best of 1 / 2 / 4 waves per SIMD; the chip lowers its clock under that load"})
     # the full record goes to a side file (and stays out of stdout); the FINAL stdout line is the compact one the driver parses
     full_path = args.full_out or os.path.join(ROOT, "gpurun_out", "bench_full.json")
     try:

@@ -394,6 +394,9 @@ int vdb_stream_probe_rows(int device_id, uint64_t bytes, int iters, uint32_t row
  * by `waves_per_simd` waves on every SIMD, `iters` x 8 independent tiles per wave; dense TFLOP/s of the launch and the shader
  * clock (GHz) the chip held meanwhile.  Measurement hook. */
 int vdb_mfma_probe(int device_id, int waves_per_simd, int iters, double *out_tflops, double *out_clock_ghz);
+/* the same for v_mfma_i32_16x16x64_i8, the instruction of the 8-bit Flat filter (k_gemm8.hip): dense integer TOP/s.  The filter's
+ * matrix-pipe roofline is quoted against the chip's nominal int8 peak AND against this sustained rate.  Measurement hook. */
+int vdb_mfma_probe_i8(int device_id, int waves_per_simd, int iters, double *out_tops, double *out_clock_ghz);
 /* latency of one DEPENDENT HBM access on this box: a single lane follows a random cycle over the 128-B lines of a `bytes`-sized
  * buffer (larger than L2 and the Infinity Cache) for `hops` loads; nanoseconds per load.  The floor of the graph walks
  * (hnsw_index.rs:258-291 is a chain of dependent accesses per expansion) is quoted on it.  Measurement hook. */

@@ -112,6 +112,7 @@ SIGNATURES = {
     "vdb_stream_probe": [C.c_int, u64, C.c_int, f64p],
     "vdb_stream_probe_rows": [C.c_int, u64, C.c_int, C.c_uint32, f64p],
     "vdb_mfma_probe": [C.c_int, C.c_int, C.c_int, f64p, f64p],
+    "vdb_mfma_probe_i8": [C.c_int, C.c_int, C.c_int, f64p, f64p],
     "vdb_latency_probe": [C.c_int, C.c_uint64, C.c_uint32, f64p],
     "vdb_fold_probe": [C.c_int, C.c_uint32, f64p],
     "vdb_prof_enable": [vp, C.c_int],

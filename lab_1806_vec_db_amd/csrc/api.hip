@@ -530,6 +530,12 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         VDB_REQUIRE(value >= 64 && value <= 1024 && value % 64 == 0, "flat_i8_rows must be a multiple of 64 in [64, 1024]");
         idx->ix.flat_i8_kprime = (uint32_t)value;
     }
+    else if (n == "flat_i8_hits") {  // expected hits per query its threshold sample aims at
+        VDB_REQUIRE(value >= 256 && value <= 4096, "flat_i8_hits must be in [256, 4096]");
+        idx->ix.flat_i8_hits = (uint32_t)value;
+    }
+    else if (n == "flat_gemm8_sample_res")  // threshold sample of the 8-bit pass: 0 = the filter's kernel form, 1 = chunked staging (no whole-image load first)
+        gemm8_set_sample_res((int)value);
     else if (n == "flat_gemm8_nt")
         gemm8_set_nt((int)value);
     else if (n == "flat_gemm8_kc")
@@ -1069,6 +1075,13 @@ int vdb_mfma_probe(int device_id, int waves_per_simd, int iters, double *out_tfl
     VDB_REQUIRE(out_tflops && out_clock_ghz, "null out");
     require_gpu();
     mfma_probe(device_id, waves_per_simd, iters, out_tflops, out_clock_ghz);
+    VDB_API_END
+}
+int vdb_mfma_probe_i8(int device_id, int waves_per_simd, int iters, double *out_tops, double *out_clock_ghz) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(out_tops && out_clock_ghz, "null out");
+    require_gpu();
+    mfma_probe(device_id, waves_per_simd, iters, out_tops, out_clock_ghz, 1);
     VDB_API_END
 }
 int vdb_latency_probe(int device_id, uint64_t bytes, uint32_t hops, double *out_ns_per_load) {

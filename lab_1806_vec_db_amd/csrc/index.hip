@@ -588,7 +588,7 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
     uint32_t s_step = 1, s_rank = kprime;  // threshold sample: every s_step-th item, tau = s_rank-th smallest sampled key
     // (8-bit pass: planned for 64 guaranteed hits, ~1000 expected -- its exact stage takes tau itself as the bound of everything
     // outside the hit list, so a list shorter than flat_i8_kprime is no failure)
-    mfma_sample_plan(n, i8 ? 64u : kprime, &s_step, &s_rank);
+    mfma_sample_plan(n, i8 ? 64u : kprime, &s_step, &s_rank, i8 ? flat_i8_hits : 1024u);
     const uint64_t n_s = i8 ? gemm8_sample_rows(n, s_step) : (gemm ? gemm_sample_rows(n, s_step) : mfma_sample_rows(n, s_step));
     const uint64_t ld_s = (n_s + 63) & ~63ull;
     const uint32_t nl_s = topk_num_lists(n_s);

@@ -258,6 +258,7 @@ struct Index {
     float i8_l1 = 0.0f, i8_l2 = 0.0f, i8_mu_norm = 0.0f;
     int flat_i8_mode = 0;       // 0 auto, 1 off, 2 on even after many uncertified queries
     uint32_t flat_i8_kprime = 256;  // rows the exact stage may walk per query (64 per round)
+    uint32_t flat_i8_hits = 1024;   // expected hits per query the threshold sample of the 8-bit pass aims at (>= 256 = 4 x the 64 guaranteed)
     std::atomic<uint64_t> i8_queries{0}, i8_redo{0};  // queries through the 8-bit pass / passed on to the next tier
     std::atomic<uint64_t> i8_rows_walked{0};          // (measurement) not maintained in production
     std::mutex i8_mu;

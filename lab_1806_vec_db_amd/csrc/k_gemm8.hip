@@ -198,6 +198,17 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
         if (MODE == G8_FILTER && threadIdx.x < G8_BQ) tau_s[threadIdx.x] = (a.debug & 1) ? -INFINITY : a.tau[grp * G8_BQ + threadIdx.x];
         if (threadIdx.x < G8_BQ) qs_s[threadIdx.x] = a.qscale[grp * G8_BQ + threadIdx.x];
         if constexpr (RES) __syncthreads();
+        // RES: the B fragments run through a ring of FOUR registers sets, three (tile-triple) steps ahead of their MFMAs and across
+        // chunk and unit boundaries (a unit is KB x 8 steps, a multiple of 4, so the ring keeps its places; the last chunk of a unit
+        // prefetches the first fragments of the image again, for the next unit).  One step ahead (rounds 3: ds_read, then
+        // lgkmcnt(1) in front of the next triple) left 48 matrix cycles for an LDS round trip of ~100+ with eight waves reading.
+        i32x4 qr0 = {0, 0, 0, 0}, qr1 = qr0, qr2 = qr0, qr3 = qr0;
+        if constexpr (RES) {
+            const uint4 *q0p = smem8 + lane;
+            qr0 = __builtin_bit_cast(i32x4, q0p[0]);
+            qr1 = __builtin_bit_cast(i32x4, q0p[64]);
+            qr2 = __builtin_bit_cast(i32x4, q0p[128]);
+        }
         const uint32_t steps = steps_of(slot_cur);
         const uint32_t steps_all = coop ? c_steps_max : steps;                       // workgroup-uniform
         const uint32_t blk = coop && a.coop_block ? a.coop_block : 0xFFFFFFFFu;      // units between two hand-overs
@@ -223,7 +234,9 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
                 uint4 *qdst = smem8 + (buf ^ 1) * CHUNK + threadIdx.x;
                 const uint4 *qcur = smem8 + (RES ? c : buf) * CHUNK + lane;
                 const bool last_c = c + 1 == nchunk;
-                i32x4 q_n = __builtin_bit_cast(i32x4, qcur[0]);
+                i32x4 q_n = {0, 0, 0, 0};
+                if constexpr (!RES) q_n = __builtin_bit_cast(i32x4, qcur[0]);
+                const uint4 *qnx = smem8 + (last_c ? 0u : (c + 1) * CHUNK) + lane;  // RES: the fragments that follow this chunk's
                 float2 rc_stage = make_float2(0.0f, 0.0f);
                 // staged pieces as named scalars (a local array stays in scratch: k_flat_gemm); piece p lives in qs<p>
                 uint4 qs0, qs1, qs2, qs3, qs4;
@@ -255,10 +268,21 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
                     for (int t = 0; t < TW; t++) xv[t] = __builtin_bit_cast(i32x4, ring[p][t]);
 #pragma unroll
                     for (int h = 0; h < NH; h++) {
-                        const i32x4 qv = q_n;
-                        if (!(p == KC - 1 && h == NH - 1)) {  // B fragments one step ahead of their MFMAs
-                            const int pn = h + 1 < NH ? p : p + 1, hn = h + 1 < NH ? h + 1 : 0;
-                            q_n = __builtin_bit_cast(i32x4, qcur[(pn * NH + hn) * 64]);
+                        i32x4 qv;
+                        if constexpr (RES) {
+                            const int sidx = p * NH + h, f = sidx + 3;  // this step's ring place is sidx & 3; fragment f goes to (sidx + 3) & 3
+                            qv = (sidx & 3) == 0 ? qr0 : ((sidx & 3) == 1 ? qr1 : ((sidx & 3) == 2 ? qr2 : qr3));
+                            const i32x4 ld = __builtin_bit_cast(i32x4, f < KC * NH ? qcur[f * 64] : qnx[(f - KC * NH) * 64]);
+                            if ((f & 3) == 0) qr0 = ld;
+                            else if ((f & 3) == 1) qr1 = ld;
+                            else if ((f & 3) == 2) qr2 = ld;
+                            else qr3 = ld;
+                        } else {
+                            qv = q_n;
+                            if (!(p == KC - 1 && h == NH - 1)) {  // B fragments one step ahead of their MFMAs
+                                const int pn = h + 1 < NH ? p : p + 1, hn = h + 1 < NH ? h + 1 : 0;
+                                q_n = __builtin_bit_cast(i32x4, qcur[(pn * NH + hn) * 64]);
+                            }
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         if ((G8_ABLATE & 2) && h > 0) {
@@ -516,6 +540,9 @@ void gemm8_set_burst(int v) { g_gemm8_burst = v; }
 static std::atomic<int> g_gemm8_res{0};  // 0 auto (resident image when it fits the LDS), 1 off (chunked staging), 2 as 0
 void gemm8_set_res(int v) { g_gemm8_res = v; }
 
+static std::atomic<int> g_gemm8_sample_res{0};  // SAMPLE mode: 0 = as the filter, 1 = chunked staging
+void gemm8_set_sample_res(int v) { g_gemm8_sample_res = v; }
+
 static std::atomic<int> g_gemm8_coop{0};  // 0 auto (cooperative sets when the shape allows), 1 off
 void gemm8_set_coop(int v) { g_gemm8_coop = v; }
 static std::atomic<uint32_t> g_gemm8_last_coop{0};  // set size of the most recent filter launch (0: no sets)
@@ -525,7 +552,7 @@ template <int KC, int MODE>
 static void flat_gemm8_launch(const Gemm8Args &a0, int num_cu, hipStream_t s) {
     Gemm8Args a = a0;
     const bool nt = MODE == G8_FILTER && a.nt;
-    if (g_gemm8_res != 1 && gemm8_res_lds(a.KB) <= size_t(160) * 1024) {
+    if (g_gemm8_res != 1 && !(MODE == G8_SAMPLE && g_gemm8_sample_res == 1) && gemm8_res_lds(a.KB) <= size_t(160) * 1024) {
         // cooperative sets (see the kernel): the chip's 8 x 32 CUs, a set size that divides the group count, every wave of a slice with
         // units to score; hand-overs sized for ~1000 hits per query (the sample plan's target): a block of B units parks about
         // 8 waves x B x 48 rows x 128 queries x 1024 / n hits, kept near half the buffer (0.55: two units per block on a 125k-row shard)
@@ -571,7 +598,7 @@ static void flat_gemm8_dispatch(const Gemm8Args &a, int num_cu, hipStream_t s) {
     int kc = 0;
     if (want == 5 || want == 3 || want == 2)
         if (a.KB % uint32_t(want) == 0) kc = want;
-    const bool res = g_gemm8_res != 1 && gemm8_res_lds(a.KB) <= size_t(160) * 1024;
+    const bool res = g_gemm8_res != 1 && !(MODE == G8_SAMPLE && g_gemm8_sample_res == 1) && gemm8_res_lds(a.KB) <= size_t(160) * 1024;
     // (resident form: the chunk length is only the depth of the X ring -- the deepest that divides the k-block count)
     if (kc == 0) kc = res ? (a.KB % 5 == 0 ? 5 : (a.KB % 3 == 0 ? 3 : 2)) : (a.KB % 3 == 0 ? 3 : (a.KB % 5 == 0 ? 5 : 2));
     VDB_REQUIRE(a.KB % uint32_t(kc) == 0, "flat_gemm8: k-block count must be divisible by 5, 3 or 2");

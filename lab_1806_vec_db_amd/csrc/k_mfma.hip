@@ -524,8 +524,8 @@ uint32_t mfma_num_items(uint64_t n) { return (uint32_t)((n + 16 * MFMA_RT - 1) /
 //    query with fewer than k' hits is redone like any other uncertified query.
 static std::atomic<int> g_sample_thin{1};
 void mfma_set_sample_thin(int v) { g_sample_thin = v; }
-void mfma_sample_plan(uint64_t n, uint32_t kprime, uint32_t *step_out, uint32_t *rank_out) {
-    const uint32_t items = mfma_num_items(n), target = std::max<uint32_t>(1024, 4 * kprime);
+void mfma_sample_plan(uint64_t n, uint32_t kprime, uint32_t *step_out, uint32_t *rank_out, uint32_t target_floor) {
+    const uint32_t items = mfma_num_items(n), target = std::max<uint32_t>(target_floor, 4 * kprime);
     uint32_t rank = kprime < 1 ? 1 : kprime;
     uint32_t step = items / 256;  // >= 256 sampled items (8192 rows) when the shard has them
     step = step < 1 ? 1 : step;

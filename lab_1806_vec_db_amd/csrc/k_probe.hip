@@ -189,7 +189,30 @@ __global__ __launch_bounds__(256) void k_probe_mfma(uint32_t iters, float *out, 
     if (sum == 12345.678f) out[0] = sum;
     if (blockIdx.x == 0 && threadIdx.x == 0) cycles[0] = c1 - c0;
 }
-void mfma_probe(int device, int waves_per_simd, int iters, double *tflops, double *clock_ghz) {
+// the 8-bit filter's instruction (k_gemm8.hip): v_mfma_i32_16x16x64_i8, 2 x 16 x 16 x 64 integer operations each
+typedef int pi32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_probe_mfma_i8(uint32_t iters, float *out, unsigned long long *cycles) {
+    pi32x4 acc[8], a, b;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        a[i] = int(threadIdx.x * 0x01010101u + i * 0x00010203u);
+        b[i] = int(threadIdx.x * 0x01020304u - i * 0x01000100u);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) acc[t] = (pi32x4){0, 0, 0, 0};
+    const unsigned long long c0 = clock64();
+    for (uint32_t it = 0; it < iters; it++) {
+#pragma unroll
+        for (int t = 0; t < 8; t++) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[t], 0, 0, 0);
+    }
+    const unsigned long long c1 = clock64();
+    int sum = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) sum += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+    if (sum == 0x12345678) out[0] = float(sum);
+    if (blockIdx.x == 0 && threadIdx.x == 0) cycles[0] = c1 - c0;
+}
+void mfma_probe(int device, int waves_per_simd, int iters, double *tflops, double *clock_ghz, int i8) {
     VDB_HIP(hipSetDevice(device));
     VDB_REQUIRE(waves_per_simd >= 1 && waves_per_simd <= 8 && iters >= 1 && iters <= (1 << 24), "mfma probe: waves_per_simd in 1..8, iters in 1..2^24");
     hipDeviceProp_t prop;
@@ -204,9 +227,10 @@ void mfma_probe(int device, int waves_per_simd, int iters, double *tflops, doubl
         VDB_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         VDB_HIP(hipEventCreate(&ea));
         VDB_HIP(hipEventCreate(&eb));
-        hipLaunchKernelGGL(k_probe_mfma, dim3(grid), dim3(256), 0, s, (uint32_t)iters, static_cast<float *>(out), static_cast<unsigned long long *>(cyc));
+        auto kern = i8 ? k_probe_mfma_i8 : k_probe_mfma;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, (uint32_t)iters, static_cast<float *>(out), static_cast<unsigned long long *>(cyc));
         VDB_HIP(hipEventRecord(ea, s));
-        hipLaunchKernelGGL(k_probe_mfma, dim3(grid), dim3(256), 0, s, (uint32_t)iters, static_cast<float *>(out), static_cast<unsigned long long *>(cyc));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, (uint32_t)iters, static_cast<float *>(out), static_cast<unsigned long long *>(cyc));
         VDB_HIP(hipEventRecord(eb, s));
         VDB_HIP(hipEventSynchronize(eb));
         VDB_HIP(hipGetLastError());
@@ -214,7 +238,7 @@ void mfma_probe(int device, int waves_per_simd, int iters, double *tflops, doubl
         VDB_HIP(hipEventElapsedTime(&ms, ea, eb));
         unsigned long long c = 0;
         VDB_HIP(hipMemcpy(&c, cyc, sizeof(c), hipMemcpyDeviceToHost));
-        const double flops = double(grid) * 4.0 * double(iters) * 8.0 * (2.0 * 16 * 16 * 32);
+        const double flops = double(grid) * 4.0 * double(iters) * 8.0 * (2.0 * 16 * 16 * (i8 ? 64 : 32));
         *tflops = flops / (double(ms) * 1e-3) / 1e12;
         *clock_ghz = double(c) / (double(ms) * 1e-3) / 1e9;  // (the timed wave runs for all but the launch overhead of the event window)
     } catch (...) {

@@ -144,7 +144,7 @@ void launch_rerank_u8(const uint8_t *X, uint32_t dim, const float *Q, uint32_t n
 // attainable HBM read bandwidth in GB/s: pure streaming read of `bytes`, `iters` timed passes, best of two patterns
 double stream_probe(int device, uint64_t bytes, int iters);
 double stream_probe_pattern(int device, uint64_t bytes, int iters, int pattern, uint32_t row_bytes);  // 1: MFMA-fragment loads from row-major rows
-void mfma_probe(int device, int waves_per_simd, int iters, double *tflops, double *clock_ghz);
+void mfma_probe(int device, int waves_per_simd, int iters, double *tflops, double *clock_ghz, int i8 = 0);
 double latency_probe(int device, uint64_t bytes, uint32_t hops);
 double fold_probe(int device, uint32_t adds);  // ns per dependent f32 add (the strict fold's chain)  // ns per dependent HBM load (pointer chase over 128-B lines)
 
@@ -227,7 +227,8 @@ uint32_t gemm8_last_coop();   // set size of the most recent 8-bit filter launch
 uint32_t gemm_last_coop();
 void gemm_set_coop(int v);    // the same for the fp16 / split-bf16 filter kernel
 void gemm8_set_coop(int v);   // 0 auto (the workgroups of an XCD share one row stream through its L2 when the shape allows), 1 off
-void gemm8_set_res(int v);    // 0 auto (the query group's whole image resident in LDS when it fits), 1 off (chunked staging)
+void gemm8_set_res(int v);
+void gemm8_set_sample_res(int v);    // 0 auto (the query group's whole image resident in LDS when it fits), 1 off (chunked staging)
 uint64_t gemm8_sample_rows(uint64_t n, uint32_t unit_step);
 // (cnt[ngroups * 128 .. + 127]: the arrival counters of the cooperative sets, zero on entry -- launch_query_prep_i8 clears them)
 void launch_flat_gemm8_filter(const void *XT, uint64_t n, uint32_t dim, const void *qfrag, const float *qscale, uint32_t ngroups,
@@ -245,7 +246,7 @@ void launch_tile_rows_i8(const float *X, uint64_t n, uint32_t dim, uint64_t tile
 void launch_query_prep_i8(const float *Q, uint32_t nq, uint32_t nq_pad, uint32_t dim, const float *mu, float l1, float l2, float *qsq,
                           float *qscale, float *qoff, uint32_t *hits, void *qfrag, hipStream_t s, int cosine = 0);
 void mfma_set_sample_thin(int v);
-void mfma_sample_plan(uint64_t n, uint32_t kprime, uint32_t *step, uint32_t *rank);
+void mfma_sample_plan(uint64_t n, uint32_t kprime, uint32_t *step, uint32_t *rank, uint32_t target_floor = 1024);  // target_floor: expected hits per query
 uint64_t mfma_sample_rows(uint64_t n, uint32_t step);
 size_t mfma_qfrag_floats(uint32_t dim);
 uint32_t mfma_dim_pad(uint32_t dim);  // columns of the mirror / Q images (dim rounded up to 64, zero filled)

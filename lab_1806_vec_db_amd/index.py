@@ -472,10 +472,12 @@ def stream_probe_rows(device: int = 0, nbytes: int = 1_920_000_000, iters: int =
     return float(v.value)
 
 
-def mfma_probe(device: int = 0, waves_per_simd: int = 2, iters: int = 200_000):
-    """(dense fp16 TFLOP/s, shader clock in GHz) of back-to-back v_mfma_f32_16x16x32_f16 on every SIMD of this box."""
+def mfma_probe(device: int = 0, waves_per_simd: int = 2, iters: int = 200_000, i8: bool = False):
+    """(dense fp16 TFLOP/s, shader clock in GHz) of back-to-back v_mfma_f32_16x16x32_f16 on every SIMD of this box;
+    i8=True: (dense int8 TOP/s, clock) of v_mfma_i32_16x16x64_i8, the 8-bit Flat filter's instruction."""
     t, c = C.c_double(), C.c_double()
-    L.check(L.load().vdb_mfma_probe(int(device), int(waves_per_simd), int(iters), C.byref(t), C.byref(c)))
+    fn = L.load().vdb_mfma_probe_i8 if i8 else L.load().vdb_mfma_probe
+    L.check(fn(int(device), int(waves_per_simd), int(iters), C.byref(t), C.byref(c)))
     return float(t.value), float(c.value)
 
 

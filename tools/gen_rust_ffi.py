@@ -69,5 +69,20 @@ def rust_block() -> str:
     return "\n".join(lines)
 
 
+def rewrite_doc() -> None:
+    """replace INTEGRATION.md's extern "C" block in place (`python tools/gen_rust_ffi.py --write`)"""
+    path = os.path.join(ROOT, "INTEGRATION.md")
+    text = open(path).read()
+    blocks = [m for m in re.finditer(r"```rust\n(.*?)```", text, flags=re.S) if 'extern "C" {' in m.group(1) and "pub fn vdb_last_error" in m.group(1)]
+    assert len(blocks) == 1
+    m = blocks[0]
+    open(path, "w").write(text[:m.start(1)] + rust_block() + "\n" + text[m.end(1):])
+
+
 if __name__ == "__main__":
-    print(rust_block())
+    import sys
+
+    if "--write" in sys.argv:
+        rewrite_doc()
+    else:
+        print(rust_block())
