@@ -178,7 +178,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm(GemmArgs a) {
             uint32_t *ctr = a.sync + (blockIdx.x & 7u) * 16u + c_li / coopS;
             __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long t0 = __builtin_readcyclecounter();
-            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < coopS && __builtin_readcyclecounter() - t0 < 1000000ull)
+            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < coopS && __builtin_readcyclecounter() - t0 < 250000ull)  // ~0.1 ms (k_gemm8.hip: why)
                 __builtin_amdgcn_s_sleep(16);
         }
         __syncthreads();

@@ -142,7 +142,9 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
             uint32_t *ctr = a.sync + (blockIdx.x & 7u) * 16u + c_li / coopS;
             __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long t0 = __builtin_readcyclecounter();
-            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < coopS && __builtin_readcyclecounter() - t0 < 1000000ull)
+            // (bounded at the lateness that matters: ~0.1 ms -- a member later than that is held by ANOTHER grid (a second index's pass, a
+            // walk), and waiting longer only adds its delay to this call; the set then runs unshared, nothing else changes)
+            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < coopS && __builtin_readcyclecounter() - t0 < 250000ull)
                 __builtin_amdgcn_s_sleep(16);
         }
         __syncthreads();

@@ -94,3 +94,60 @@ def test_vecdb_search_interleaved_with_writes():
         t.join()
     assert not errors, errors
     assert db.get_len("t") == 64
+
+
+def test_two_indexes_searching_at_once_with_cooperative_sets():
+    """Two tables on one GPU searched from two threads, both through the 8-bit pass with cooperative sets: the sets' start rendezvous
+    (k_gemm8.hip) is bounded (~0.1 ms), so a pass whose members are held up by the OTHER index's grid runs unshared instead of
+    waiting -- answers unchanged (oracle on a sample), and a call never takes longer than the two calls back to back plus the bound"""
+    import time
+
+    import lab_1806_vec_db_amd as vdb
+    from oracle import oracle as O
+
+    n, dim, nq = 110_000, 128, 1024
+    rng = np.random.default_rng(42)
+    tables = []
+    for t in range(2):
+        base = rng.standard_normal((n, dim)).astype(np.float32)
+        qs = rng.standard_normal((nq, dim)).astype(np.float32)
+        ix = vdb.GpuIndex(dim, "l2sqr" if t == 0 else "cosine")
+        ix.batch_add(base)
+        ix.set_flat_mode(2)
+        ref = ix.flat_knn(qs, 10)  # alone (also builds the mirror)
+        assert ix.get_stat("flat_gemm8_coop_sets") == 8 and ix.get_stat("flat_i8_queries") == nq
+        sel = rng.choice(nq, 24, replace=False)
+        oi, od, oc = O.flat_knn_batch(base, qs[sel], 10, O.L2SQR if t == 0 else O.COSINE, nthreads=8)
+        assert np.array_equal(ref[0][sel], oi) and np.array_equal(ref[1][sel], od)
+        tables.append((ix, qs, ref))
+    alone = []
+    for ix, qs, _ in tables:
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ix.flat_knn(qs, 10)
+        alone.append((time.perf_counter() - t0) / 5)
+    errors, worst = [], [0.0, 0.0]
+
+    def worker(t):
+        ix, qs, ref = tables[t]
+        try:
+            for _ in range(20):
+                t0 = time.perf_counter()
+                r = ix.flat_knn(qs, 10)
+                worst[t] = max(worst[t], time.perf_counter() - t0)
+                assert np.array_equal(r[0], ref[0]) and np.array_equal(r[1], ref[1])
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    print(f"alone {alone[0] * 1e3:.3f} / {alone[1] * 1e3:.3f} ms per call; worst concurrent call {worst[0] * 1e3:.3f} / {worst[1] * 1e3:.3f} ms")
+    # two grids that each want every CU take turns at worst: the sum of both calls, plus the rendezvous bound and host jitter
+    for t in range(2):
+        assert worst[t] <= 3.0 * (alone[0] + alone[1]) + 2e-3, (worst, alone)
+    for ix, _, _ in tables:
+        ix.close()

@@ -244,8 +244,11 @@ def test_cooperative_sets_of_the_fp16_and_split_bf16_filter(mods, dist, kind, di
     ix.set_param("flat_half", 1 if half else 0)
     ix.set_param("flat_gemm_coop", 1)  # off
     idx0, d0, cnt0 = ix.flat_knn(qs, 10)
+    assert ix.get_stat("flat_gemm_coop_sets") <= 1  # the plain form ran
     ix.set_param("flat_gemm_coop", 0)  # auto
     idx1, d1, cnt1 = ix.flat_knn(qs, 10)
+    groups = (nq + 127) // 128
+    assert ix.get_stat("flat_gemm_coop_sets") == (8 if groups % 8 == 0 else 4 if groups % 4 == 0 else 2)  # the sets really ran
     assert ix.get_stat("flat_i8_queries") == 0
     if not half:
         assert ix.get_stat("flat_half_queries") == 2 * nq

@@ -2,7 +2,8 @@
 oracle needs ~1 s per query per core at this size: (a) the MFMA path equals the strict-order exact scan,
 (b) four row shards merged by (distance, index) equal the unsharded answer, (c) a row queried against the
 corpus finds itself first at distance exactly 0, (d) results ascend in (distance, index), (e) a handful of
-queries are checked against the oracle itself."""
+queries are checked against the oracle itself.  The 1M case runs 256 queries (two groups: cooperative sets of 2, the hit buffer
+handed over in blocks, the exact stage of the 8-bit pass over full-size hit lists), L2Sqr and Cosine."""
 import numpy as np
 import pytest
 
@@ -20,7 +21,7 @@ def world():
 
     dev = torch.device("cuda", 0)
     base = gist_like_gpu(torch, N, DIM, 1806, dev)
-    qs = gist_like_gpu(torch, 96, DIM, 1807, dev)
+    qs = gist_like_gpu(torch, 256, DIM, 1807, dev)
     ix = vdb.GpuIndex(DIM, "l2sqr")
     ix.add_device(base.data_ptr(), N)
     return vdb, torch, base, qs.cpu().numpy(), ix
@@ -29,9 +30,17 @@ def world():
 def test_mfma_equals_exact_scan_and_properties(world):
     vdb, torch, base, qs, ix = world
     ix.set_flat_mode(0)
+    q0 = ix.get_stat("flat_i8_queries")
     idx, d, cnt = ix.flat_knn(qs, K)
     assert (cnt == K).all()
     assert ix.flat_fallback_count() == 0
+    # the headline path answered: the 8-bit pass with cooperative sets (2 groups -> sets of 2), nothing passed on
+    assert ix.get_stat("flat_i8_queries") == q0 + len(qs) and ix.get_stat("flat_gemm8_coop_sets") == 2
+    assert ix.get_stat("flat_i8_redo") == 0
+    ix.set_param("flat_gemm8_coop", 1)  # the plain resident form: same hit lists, same answers
+    idx_p, d_p, _ = ix.flat_knn(qs, K)
+    ix.set_param("flat_gemm8_coop", 0)
+    assert np.array_equal(idx, idx_p) and np.array_equal(d, d_p)
     ix.set_flat_mode(1)
     e_idx, e_d, _ = ix.flat_knn(qs[:24], K)
     ix.set_flat_mode(0)
@@ -73,3 +82,27 @@ def test_against_oracle_sample(world):
     oi, od, oc = O.flat_knn_batch(host, qs[:16], K, O.L2SQR, nthreads=16)
     gi, gd, _ = ix.flat_knn(qs[:16], K)
     assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+
+
+def test_cosine_full_size(world):
+    """the reference's default metric at full size: the 8-bit pass on unit rows (sets of 2) equals the strict-order exact scan and the
+    oracle; results ascend"""
+    vdb, torch, base, qs, ix = world
+    from oracle import oracle as O
+
+    cx = vdb.GpuIndex(DIM, "cosine")
+    cx.add_device(base.data_ptr(), N)
+    idx, d, cnt = cx.flat_knn(qs, K)
+    assert (cnt == K).all() and cx.get_stat("flat_i8_queries") == len(qs) and cx.get_stat("flat_gemm8_coop_sets") == 2
+    assert cx.get_stat("flat_i8_redo") <= len(qs) // 8
+    cx.set_flat_mode(1)
+    e_idx, e_d, _ = cx.flat_knn(qs[:16], K)
+    cx.set_flat_mode(0)
+    assert np.array_equal(idx[:16], e_idx) and np.array_equal(d[:16], e_d)
+    for q in range(qs.shape[0]):
+        pairs = list(zip(d[q].tolist(), idx[q].tolist()))
+        assert pairs == sorted(pairs)
+    host = base.cpu().numpy()
+    oi, od, oc = O.flat_knn_batch(host, qs[248:256], K, O.COSINE, nthreads=16)
+    assert np.array_equal(idx[248:256], oi) and np.array_equal(d[248:256], od)
+    cx.close()
