@@ -89,6 +89,49 @@ def gist_lowrank_gpu(torch, n, dim, seed, device, latent=32, chunk=131072):
     return out
 
 
+def gist_clustered_gpu(torch, n, dim, seed, device, clusters=1024, spread=0.15, chunk=131072):
+    """`clusters` Gaussian clusters with the gist-like marginals: the centres are gist-like rows (seed 4711: part of the distribution,
+    the same for base and queries), a row is its centre + spread x sigma_j noise -- squared distances ~ 2 spread^2 sum sigma_j^2 inside a
+    cluster (0.09 at 0.15) against ~3.9 between clusters.  Neighbours are then separated by margins far below the resolution of an
+    8-bit (or fp16) key: the case the Flat filter's auto-off rule exists for.  `--data clustered`, `--cluster-spread`."""
+    stats = np.load(os.path.join(ROOT, "tests", "golden", "gist_dim_stats.npy"))
+    sd = torch.from_numpy(np.resize(stats[1], dim).astype(np.float32)).to(device)
+    centres = gist_like_gpu(torch, clusters, dim, 4711, device)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = torch.empty((n, dim), dtype=torch.float32, device=device)
+    for r0 in range(0, n, chunk):
+        r1 = min(n, r0 + chunk)
+        c = torch.randint(0, clusters, (r1 - r0,), generator=g, device=device)
+        x = torch.randn((r1 - r0, dim), generator=g, device=device, dtype=torch.float32)
+        x.mul_(sd * spread).add_(centres[c]).abs_().clamp_(0.0, 0.8)
+        x.mul_(10000.0).round_().div_(10000.0)
+        out[r0:r1] = x
+    return out
+
+
+def gist_neardup_gpu(torch, n, dim, seed, device, frac=0.01, group=20):
+    """gist-like rows of which `frac` are near-duplicates: groups of `group` copies of one source row each, every copy off by one or two
+    steps of the 4-decimal grid in a few coordinates -- more near-identical neighbours than k for the queries that land on them.  For the
+    queries (seed != 1806) the same fraction sits on source rows of the base.  `--data neardup`."""
+    out = gist_like_gpu(torch, n, dim, seed, device)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed + 99)
+    ndup = int(n * frac)
+    if ndup == 0:
+        return out
+    if seed == 1806:  # base: rows [n - ndup, n) are the copies, sources are rows 0, 1, ... (deterministic: queries can aim at them)
+        nsrc = max(1, ndup // group)
+        src = torch.arange(ndup, device=device) % nsrc
+        noise = (torch.rand((ndup, dim), generator=g, device=device) < 0.01).float() * 1e-4
+        out[n - ndup:] = (out[src] + noise).clamp_(0.0, 0.8)
+    else:  # queries: the first max(1, frac * nq) of them sit next to source rows 0, 1, ... of the base
+        base_head = gist_like_gpu(torch, max(ndup, 1), dim, 1806, device)[:ndup]
+        noise = (torch.rand((ndup, dim), generator=g, device=device) < 0.01).float() * 1e-4
+        out[:ndup] = (base_head + noise).clamp_(0.0, 0.8)
+    return out
+
+
 def load_rows_file(torch, path, dim, r0, r1, device, chunk=131072, cycle=False):
     """rows [r0, r1) of a raw row-major f32 file without header (src/bin/convert_fvecs.rs:29-31 writes exactly this), streamed
     through a memory map; cycle=True repeats the file's rows when it holds fewer than r1"""
@@ -319,9 +362,11 @@ def main():
     ap.add_argument("--ef", type=int, default=0, help="pq_flat: ADC shortlist (default 100); hnsw: search ef (default 128); ivf: n_probes (default 4)")
     ap.add_argument("--dist", choices=["l2sqr", "cosine"], default="l2sqr",
                     help="l2sqr = the BASELINE metric; cosine = the reference's default table distance (pyo3/mod.rs:73)")
-    ap.add_argument("--data", choices=["gistlike", "lowrank"], default="gistlike",
+    ap.add_argument("--data", choices=["gistlike", "lowrank", "clustered", "neardup"], default="gistlike",
                     help="gistlike = per-dimension Gaussians (SURVEY 8d generator); lowrank = same marginals with a 32-d "
-                         "latent factor, for informative ANN recall")
+                         "latent factor, for informative ANN recall; clustered = 1024 Gaussian clusters (--cluster-spread x sigma inside); "
+                         "neardup = gistlike with 1 %% near-duplicate rows in groups of 20")
+    ap.add_argument("--cluster-spread", type=float, default=0.15, help="--data clustered: noise inside a cluster in units of the per-dimension sigma")
     ap.add_argument("--mode", type=int, default=0, help="flat mode: 0 auto, 1 exact scan, 2 MFMA forced")
     ap.add_argument("--half", type=int, default=0, help="flat: fp16 first pass of large query batches: 0 auto, 1 off, 2 forced")
     ap.add_argument("--i8", type=int, default=0, help="flat (L2Sqr): 8-bit first pass: 0 auto, 1 off, 2 forced")
@@ -412,7 +457,9 @@ def main():
     if args.rows <= 0:
         args.rows = 1_000_000
     data_name = (f"file: {os.path.basename(args.base_file)} x {os.path.basename(args.query_file)} (raw row-major f32, convert_fvecs.rs layout)"
-                 if from_file else ("synthetic" if args.data == "gistlike" else "synthetic (low-rank gist-like)"))
+                 if from_file else {"gistlike": "synthetic", "lowrank": "synthetic (low-rank gist-like)",
+                                    "clustered": f"synthetic (1024 gist-like clusters, spread {args.cluster_spread} sigma)",
+                                    "neardup": "synthetic (gist-like, 1 % near-duplicate rows in groups of 20)"}[args.data])
     legs_on = world == 1 and wl == "flat" and (args.legs == "all" or (args.legs == "auto" and default_size))
     ef = args.ef or {"pq_flat": 100, "hnsw": 128, "hnsw_pq": 128, "ivf": 4}.get(wl, 0)
     n, dim, nq, k = args.rows, args.dim, args.nq, args.k
@@ -425,7 +472,8 @@ def main():
         attainable = round(stream_probe(local_rank, 3_840_000_000, 5), 1)  # before the corpus exists: 3.84 GB of its own
 
     # identical corpus on every rank (same seed), each keeps its row block
-    gen = gist_like_gpu if args.data == "gistlike" else gist_lowrank_gpu
+    gen = {"gistlike": gist_like_gpu, "lowrank": gist_lowrank_gpu, "neardup": gist_neardup_gpu,
+           "clustered": lambda t, n_, d_, sd_, dev_: gist_clustered_gpu(t, n_, d_, sd_, dev_, spread=args.cluster_spread)}[args.data]
     if from_file:
         base = load_rows_file(torch, args.base_file, dim, 0, n, device)
         queries = load_rows_file(torch, args.query_file, dim, 0, nq, device)
@@ -648,6 +696,20 @@ def main():
         roofline["attainable_peak_how"] = ("vdb_stream_probe in this run: best of contiguous-chunk and grid-stride streaming reads of a 3.84-GB buffer, "
                                            "default and non-temporal loads (the non-temporal forms reach ~7.0 TB/s on this chip, the default ones ~6.2)")
 
+    filter_work = None
+    if wl == "flat" and world == 1 and roofline and roofline.get("kernel") == "flat_i8":
+        # what the 8-bit pass's exact stage had to do on THIS data: one more step with per-query statistics (after the timed region)
+        if depth > 1:
+            drain()
+        ix.set_param("flat_i8_stats", 1)
+        r0_ = ix.get_stat("flat_i8_redo")
+        ix.flat_knn_device(queries.data_ptr(), nq, k, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr())
+        sq_ = max(ix.get_stat("flat_i8_stat_queries"), 1)
+        filter_work = {"queries": sq_, "hits_per_query_mean": round(ix.get_stat("flat_i8_hits_sum") / sq_, 1), "hits_per_query_max": ix.get_stat("flat_i8_hits_max"),
+                       "queries_by_rounds_of_63_rows": {str(r_): ix.get_stat(f"flat_i8_rounds_{r_}") for r_ in range(9) if ix.get_stat(f"flat_i8_rounds_{r_}")},
+                       "passed_on": ix.get_stat("flat_i8_redo") - r0_}
+        ix.set_param("flat_i8_stats", 0)
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -684,6 +746,8 @@ def main():
         out["i8_pass"] = {"queries": ix.get_stat("flat_i8_queries"), "passed_on_to_fp16": ix.get_stat("flat_i8_redo")}
         out["half_pass"] = {"queries": ix.get_stat("flat_half_queries"), "redone_split_bf16": ix.get_stat("flat_half_redo")}
         out["hbm_bytes_per_row"] = ix.get_stat("hbm_bytes_per_row")
+        if filter_work:
+            out["filter_work"] = filter_work
     else:
         out["config"]["ef"] = ef
     if wl == "ivf":

@@ -530,6 +530,13 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         VDB_REQUIRE(value >= 64 && value <= 1024 && value % 64 == 0, "flat_i8_rows must be a multiple of 64 in [64, 1024]");
         idx->ix.flat_i8_kprime = (uint32_t)value;
     }
+    else if (n == "flat_i8_stats") {  // (measurement) collect per-query rounds / hits of the 8-bit pass's exact stage; setting it resets them
+        idx->ix.flat_i8_stats = (int)value;
+        for (auto &h : idx->ix.i8_rounds_hist) h = 0;
+        idx->ix.i8_hits_sum = 0;
+        idx->ix.i8_hits_max = 0;
+        idx->ix.i8_stat_queries = 0;
+    }
     else if (n == "flat_i8_hits") {  // expected hits per query its threshold sample aims at
         VDB_REQUIRE(value >= 256 && value <= 4096, "flat_i8_hits must be in [256, 4096]");
         idx->ix.flat_i8_hits = (uint32_t)value;
@@ -585,6 +592,14 @@ int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out) {
         *out = idx->ix.i8_redo.load();
     else if (n == "flat_i8_valid")
         *out = idx->ix.i8_valid.load() ? 1 : 0;
+    else if (n.rfind("flat_i8_rounds_", 0) == 0 && n.size() == 16 && n[15] >= '0' && n[15] <= '8')  // queries whose exact stage walked N rounds (8: 8 or more)
+        *out = idx->ix.i8_rounds_hist[n[15] - '0'].load();
+    else if (n == "flat_i8_hits_sum")
+        *out = idx->ix.i8_hits_sum.load();
+    else if (n == "flat_i8_hits_max")
+        *out = idx->ix.i8_hits_max.load();
+    else if (n == "flat_i8_stat_queries")
+        *out = idx->ix.i8_stat_queries.load();
     else if (n == "flat_i8_rows_walked")
         *out = idx->ix.i8_rows_walked.load();
     else if (n == "flat_bf16_mirror")

@@ -707,7 +707,10 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
         t.cosine = cosine;
         t.se = se;
         t.id_offset = id_offset;
-        t.flags = static_cast<uint8_t *>(ws.pinned(nq));
+        // (flags, then -- measurement builds of a call, flat_i8_stats -- one word per query of exact-stage statistics)
+        const size_t st_off = (nq + 15) & ~size_t(15);
+        t.flags = static_cast<uint8_t *>(ws.pinned(i8 && flat_i8_stats ? st_off + nq * sizeof(uint32_t) : nq));
+        if (i8 && flat_i8_stats) t.qstat = reinterpret_cast<uint32_t *>(t.flags + st_off);
         t.out_idx = d_idx;
         t.out_dist = d_dist;
         t.out_count = d_cnt;
@@ -765,6 +768,21 @@ void Index::flat_knn_finish(Workspace &ws, FlatPending &p) {
     if (i8) {
         i8_queries += nq;
         i8_redo += redo.size();
+        if (flat_i8_stats) {
+            const uint32_t *qs = reinterpret_cast<const uint32_t *>(flags + ((nq + 15) & ~size_t(15)));
+            uint64_t hs = 0, hm = 0;
+            for (uint64_t q = 0; q < nq; q++) {
+                const uint32_t r = qs[q] & 0xFFu, h = qs[q] >> 8;
+                i8_rounds_hist[r < 8 ? r : 8] += 1;
+                hs += h;
+                hm = std::max<uint64_t>(hm, h);
+            }
+            i8_hits_sum += hs;
+            i8_stat_queries += nq;
+            uint64_t cur = i8_hits_max.load();
+            while (hm > cur && !i8_hits_max.compare_exchange_weak(cur, hm)) {
+            }
+        }
     }
     if (redo.empty()) return;
     if (!half && !i8) fallback_count += redo.size();

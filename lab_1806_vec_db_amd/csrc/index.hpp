@@ -260,6 +260,10 @@ struct Index {
     uint32_t flat_i8_kprime = 256;  // rows the exact stage may walk per query (64 per round)
     uint32_t flat_i8_hits = 1024;   // expected hits per query the threshold sample of the 8-bit pass aims at (>= 256 = 4 x the 64 guaranteed)
     std::atomic<uint64_t> i8_queries{0}, i8_redo{0};  // queries through the 8-bit pass / passed on to the next tier
+    // (measurement, flat_i8_stats = 1) per-query work of the 8-bit pass's exact stage: queries by rounds walked, hits per query
+    int flat_i8_stats = 0;
+    std::atomic<uint64_t> i8_rounds_hist[9] = {};
+    std::atomic<uint64_t> i8_hits_sum{0}, i8_hits_max{0}, i8_stat_queries{0};
     std::atomic<uint64_t> i8_rows_walked{0};          // (measurement) not maintained in production
     std::mutex i8_mu;
     bool i8_applicable(uint32_t ksel) const;

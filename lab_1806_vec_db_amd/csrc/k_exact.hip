@@ -1024,7 +1024,9 @@ __global__ __launch_bounds__(NW * 64, PCD ? 4 : 1) void k_flat_tail_lb(FlatTailA
 #define TAIL_STAMP() do { } while (0)
 #endif
     TAIL_STAMP();
+    uint32_t rounds_done = 0;
     for (uint32_t rd = 0; rd < rounds; rd++) {
+        rounds_done = rd + 1;
         const uint64_t best = block_top64_above<NW>(a.cand + uint64_t(q) * a.cap, total, sbest, above);  // (its barrier also covers qs4)
         __syncthreads();  // wave 0 is done with sbest[1..]
         if (wave == 0) sbest[0][lane] = best;
@@ -1098,6 +1100,7 @@ __global__ __launch_bounds__(NW * 64, PCD ? 4 : 1) void k_flat_tail_lb(FlatTailA
     if (lane == 0) {
         if (a.out_count) a.out_count[q] = count;
         a.flags[q] = flag;
+        if (a.qstat) a.qstat[q] = rounds_done | ((cnt_q < 0xFFFFFFu ? cnt_q : 0xFFFFFFu) << 8);
     }
 }
 bool flat_tail_lb_supported(uint32_t dim, uint32_t kprime, uint32_t ksel) {

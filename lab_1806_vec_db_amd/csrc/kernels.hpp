@@ -67,6 +67,7 @@ struct FlatTailArgs {
     uint64_t *out_count;
     unsigned long long *stamps = nullptr;  // k_flat_tail_lb, builds with -DVDB_TAIL_STAMPS: [nq][32] phase stamps (s_memtime)
     const float *tau = nullptr;  // k_flat_tail_lb: the filter pass's thresholds (the bound of every row outside the hit list)
+    uint32_t *qstat = nullptr;   // k_flat_tail_lb, optional (flat_i8_stats): per query rounds walked | hit count << 8
 };
 // the exact stage behind the 8-bit pass: walks the hit list in key order, 64 keys per round (kprime / 64 rounds at most)
 bool flat_tail_lb_supported(uint32_t dim, uint32_t kprime, uint32_t ksel);

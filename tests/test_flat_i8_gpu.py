@@ -344,3 +344,48 @@ def test_i8_cooperative_sets(mods, dim, n, nq):
         oi, od, oc = O.flat_knn_batch(base, qs[sel[:16]], k, 0, nthreads=8)
         _check_all(idx3[sel[:16]], d3[sel[:16]], cnt3[sel[:16]], oi, od, oc)
     ix.close()
+
+
+@pytest.mark.parametrize("dist,spread", [("l2sqr", 0.15), ("l2sqr", 0.6), ("cosine", 0.15)])
+def test_i8_on_clustered_rows_and_the_auto_off_rule(mods, dist, spread):
+    """tight Gaussian clusters (bench.py --data clustered): the k-th neighbour and hundreds of other cluster members lie within the 8-bit
+    bound's gap of each other, so the exact stage cannot close most queries in its rows and hands them on -- the answers must be the
+    oracle's whichever tier gives them, and in auto mode the pass must switch itself off for this index (>= 1/8 of >= 1024 queries passed
+    on); looser clusters (0.6 sigma: still ~1900 members within a few gaps of each other) are reported and held to the same rule"""
+    from conftest import gist_clustered
+
+    vdb, O = mods
+    n, dim, nq = 120_000, 960, 384
+    # 64 clusters: ~1900 members each, far more than the 252 rows the exact stage may walk (1M rows in 1024 clusters: ~980)
+    base = gist_clustered(n, dim=dim, seed=11, clusters=64, spread=spread)
+    qs = gist_clustered(nq, dim=dim, seed=12, clusters=64, spread=spread)
+    kind = O.L2SQR if dist == "l2sqr" else O.COSINE
+    ix = vdb.GpuIndex(dim, dist)
+    ix.batch_add(base)
+    ix.set_param("flat_i8_stats", 1)
+    idx, d, cnt = ix.flat_knn(qs, 10)
+    assert ix.get_stat("flat_i8_queries") == nq
+    sel = np.arange(0, nq, 8)
+    oi, od, oc = O.flat_knn_batch(base, qs[sel], 10, kind, nthreads=8)
+    _check_all(idx[sel], d[sel], cnt[sel], oi, od, oc)
+    redo = ix.get_stat("flat_i8_redo")
+    hist = {r: ix.get_stat(f"flat_i8_rounds_{r}") for r in range(9)}
+    print(f"{dist} spread {spread}: passed on {redo} of {nq}; queries by rounds {hist}; hits per query mean "
+          f"{ix.get_stat('flat_i8_hits_sum') / nq:.0f} max {ix.get_stat('flat_i8_hits_max')}")
+    assert sum(hist.values()) == nq
+    for _ in range(4):  # 5 x 384 queries: past the 1024 the auto rule wants to have seen
+        idx2, d2, _ = ix.flat_knn(qs, 10)
+        np.testing.assert_array_equal(idx, idx2)
+        np.testing.assert_array_equal(d, d2)
+    q0 = ix.get_stat("flat_i8_queries")
+    idx2, d2, _ = ix.flat_knn(qs, 10)
+    np.testing.assert_array_equal(idx, idx2)
+    np.testing.assert_array_equal(d, d2)
+    if spread < 0.3:
+        assert redo > nq // 4  # tight clusters: the pass cannot close them ...
+    # ... and the rule follows what happened: off once more than 1/8 of the (>= 1024) queries seen were passed on, on otherwise
+    if redo * 8 > nq:
+        assert ix.get_stat("flat_i8_queries") == q0
+    else:
+        assert ix.get_stat("flat_i8_queries") == q0 + nq
+    ix.close()
