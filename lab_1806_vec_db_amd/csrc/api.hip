@@ -527,9 +527,11 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
     else if (n == "flat_i8")  // 8-bit first pass (L2Sqr): 0 auto, 1 off, 2 on regardless of the redo rate
         idx->ix.flat_i8_mode = (int)value;
     else if (n == "flat_i8_rows") {  // rows its exact stage may walk per query before giving up (multiple of 64)
-        VDB_REQUIRE(value >= 64 && value <= 1024 && value % 64 == 0, "flat_i8_rows must be a multiple of 64 in [64, 1024]");
+        VDB_REQUIRE(value >= 64 && value <= 8192 && value % 64 == 0, "flat_i8_rows must be a multiple of 64 in [64, 8192]");
         idx->ix.flat_i8_kprime = (uint32_t)value;
     }
+    else if (n == "flat_i8_second")  // second 8-bit attempt with thresholds from the first walk's k-th distances: 0 on, 1 off
+        idx->ix.flat_i8_second = (int)value;
     else if (n == "flat_i8_stats") {  // (measurement) collect per-query rounds / hits of the 8-bit pass's exact stage; setting it resets them
         idx->ix.flat_i8_stats = (int)value;
         for (auto &h : idx->ix.i8_rounds_hist) h = 0;
@@ -594,6 +596,10 @@ int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out) {
         *out = idx->ix.i8_valid.load() ? 1 : 0;
     else if (n.rfind("flat_i8_rounds_", 0) == 0 && n.size() == 16 && n[15] >= '0' && n[15] <= '8')  // queries whose exact stage walked N rounds (8: 8 or more)
         *out = idx->ix.i8_rounds_hist[n[15] - '0'].load();
+    else if (n == "flat_i8_second_queries")  // queries that took the second 8-bit attempt / that it passed on to the fp16 tier
+        *out = idx->ix.i8_second_queries.load();
+    else if (n == "flat_i8_second_redo")
+        *out = idx->ix.i8_second_redo.load();
     else if (n == "flat_i8_hits_sum")
         *out = idx->ix.i8_hits_sum.load();
     else if (n == "flat_i8_hits_max")

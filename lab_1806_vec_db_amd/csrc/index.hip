@@ -500,9 +500,9 @@ void Index::flat_small_device(Workspace &ws, const float *q, uint64_t nq, uint64
 
 // ---- Flat: full pipeline ---------------------------------------------------------------------------
 void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t *d_idx,
-                            float *d_dist, uint64_t *d_cnt, bool allow_half, uint32_t kprime_min, bool allow_i8) {
+                            float *d_dist, uint64_t *d_cnt, bool allow_half, uint32_t kprime_min, bool allow_i8, const float *d_dk_hint) {
     FlatPending p;
-    flat_knn_enqueue(ws, d_q, nq, k, d_idx, d_dist, d_cnt, allow_half, kprime_min, p, allow_i8);
+    flat_knn_enqueue(ws, d_q, nq, k, d_idx, d_dist, d_cnt, allow_half, kprime_min, p, allow_i8, d_dk_hint);
     flat_knn_finish(ws, p);
 }
 
@@ -510,7 +510,7 @@ void Index::flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64
 // pipeline is enqueued on ws.stream and flat_knn_finish must follow (same workspace); otherwise the call took one of the
 // synchronous-by-nature paths (small table, exact scan, k > 1024) and is enqueued in full -- nothing left but the stream sync.
 void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t *d_idx, float *d_dist,
-                             uint64_t *d_cnt, bool allow_half, uint32_t kprime_min, FlatPending &p, bool allow_i8) {
+                             uint64_t *d_cnt, bool allow_half, uint32_t kprime_min, FlatPending &p, bool allow_i8, const float *d_dk_hint) {
     hipStream_t s = ws.stream;
     p = FlatPending{};
     if (nq == 0) return;
@@ -562,7 +562,7 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
     // the bytes of the small-batch kernel's -- 0.36 instead of 0.63 ms per pass at 1M x 960).
     const uint32_t kprime_h = std::max<uint32_t>(64, flat_half_kmul * ksel);
     const uint64_t hq = half_queries.load(), hr = half_redo.load();
-    const bool i8_first = allow_i8 && allow_half && kprime_min == 0 && flat_gemm_mode != 1 && i8_applicable(ksel);
+    const bool i8_first = allow_i8 && allow_half && kprime_min == 0 && flat_gemm_mode != 1 && (d_dk_hint ? i8_valid.load() : i8_applicable(ksel));
     const bool half_wanted = !i8_first && allow_half && flat_half_mode != 1 && kprime_h <= 1024 && n > kprime_h &&
                              (flat_half_mode == 2 || hq < 1024 || hr * 8 <= hq);
     const bool half_ok = half_wanted && ensure_half(ws);
@@ -573,13 +573,15 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
     const bool gemm = i8 || flat_gemm_mode == 2 || (flat_gemm_mode == 0 && (nq > 64 || half_ok));
     const bool half = !i8 && half_ok && gemm;
     if (half) kprime = kprime_h;
+    constexpr uint32_t CAND_CAP = 8192;
+    const bool i8_second = i8 && d_dk_hint != nullptr;
     if (i8) {
-        kprime = flat_i8_kprime;
+        kprime = i8_second ? CAND_CAP : flat_i8_kprime;  // (second attempt: the exact stage may walk the whole candidate list)
         ensure_i8(ws);
     }
     if (!half && !i8) ensure_tiled(ws);
     if (!half && !i8) launch_row_sqnorm(d_q, nq, (uint32_t)dim, ws.qsq.as<float>(), s);  // (the fp16 / 8-bit passes: k_query_prep_*)
-    const uint32_t capp = topk_capacity(kprime);
+    const uint32_t capp = topk_capacity(i8 ? 64u : kprime);  // (8-bit pass: only its sample's lists -- rank <= 64 -- use these buffers)
     const uint32_t capk = topk_capacity(ksel);
     const uint64_t gq = gemm_group();
     const uint64_t ngroups = gemm ? (nq + gq - 1) / gq : 0;
@@ -592,7 +594,6 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
     const uint64_t n_s = i8 ? gemm8_sample_rows(n, s_step) : (gemm ? gemm_sample_rows(n, s_step) : mfma_sample_rows(n, s_step));
     const uint64_t ld_s = (n_s + 63) & ~63ull;
     const uint32_t nl_s = topk_num_lists(n_s);
-    constexpr uint32_t CAND_CAP = 8192;
     const size_t qf = mfma_qfrag_floats((uint32_t)dim);
     ws.qfrag.reserve(nbatch * qf * sizeof(float));
     ws.dense.reserve(nq_pad * ld_s * sizeof(float));
@@ -626,26 +627,34 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
             launch_mfma_pack_queries_nh(d_q, (uint32_t)nq, (uint32_t)nq_pad, (uint32_t)dim, 8, ws.qfrag_g.as<float>(), s);
         }
     }
-    if (i8)
-        launch_flat_gemm8_sample(d_tiled_i8.p, n, (uint32_t)dim, ws.qfrag_g.p, d_qscale, (uint32_t)ngroups, d_rowc_i8.as<float>(), s_step,
-                                 ws.dense.as<float>(), ld_s, num_cu, s);
-    else if (gemm)  // the sample through the 128-query kernel too: same arithmetic as the filter, 4x fewer re-reads of the sample
-        launch_flat_gemm_sample(xt, n, (uint32_t)dim, ws.qfrag_g.as<float>(), d_qmul, (uint32_t)ngroups,
-                                d_sq.as<float>(), cosine, s_step, ws.dense.as<float>(), ld_s, num_cu, s);
-    else
-        launch_flat_mfma_sample(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>(), (uint32_t)nbatch,
-                                d_sq.as<float>(), cosine, s_step, ws.dense.as<float>(), ld_s, num_cu, s);
-    if (n_s <= select_tau_max_n()) {  // tau only needs the k'-th smallest sampled key, not a sorted sample shortlist
-        launch_select_tau(ws.dense.as<float>(), ld_s, (uint32_t)n_s, (uint32_t)nq_pad, (uint32_t)nq, s_rank, d_tau, s);
+    if (i8_second) {
+        // thresholds from the k-th exact distances the first walk left behind (k_redo.hip): no sample, no selection
+        launch_i8_tau_from_dk(d_dk_hint, (uint32_t)nq, (uint32_t)nq_pad, d_qoff, ws.qsq.as<float>(), xsq_max, i8_mu_norm, (uint32_t)dim, cosine,
+                              d_tau, s);
     } else {
-        launch_topk_dense(ws.dense.as<float>(), ld_s, n_s, (uint32_t)nq_pad, s_rank, ws.lists.as<uint64_t>(), s);
-        launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, capp, (uint32_t)nq_pad, s_rank, ws.keys_a.as<uint64_t>(), s);
-        launch_extract_tau(ws.keys_a.as<uint64_t>(), capp, (uint32_t)nq_pad, s_rank, d_tau, s);
+        if (i8)
+            launch_flat_gemm8_sample(d_tiled_i8.p, n, (uint32_t)dim, ws.qfrag_g.p, d_qscale, (uint32_t)ngroups, d_rowc_i8.as<float>(), s_step,
+                                     ws.dense.as<float>(), ld_s, num_cu, s);
+        else if (gemm)  // the sample through the 128-query kernel too: same arithmetic as the filter, 4x fewer re-reads of the sample
+            launch_flat_gemm_sample(xt, n, (uint32_t)dim, ws.qfrag_g.as<float>(), d_qmul, (uint32_t)ngroups,
+                                    d_sq.as<float>(), cosine, s_step, ws.dense.as<float>(), ld_s, num_cu, s);
+        else
+            launch_flat_mfma_sample(d_tiled.as<float>(), n, (uint32_t)dim, ws.qfrag.as<float>(), (uint32_t)nbatch,
+                                    d_sq.as<float>(), cosine, s_step, ws.dense.as<float>(), ld_s, num_cu, s);
+        if (n_s <= select_tau_max_n()) {  // tau only needs the k'-th smallest sampled key, not a sorted sample shortlist
+            launch_select_tau(ws.dense.as<float>(), ld_s, (uint32_t)n_s, (uint32_t)nq_pad, (uint32_t)nq, s_rank, d_tau, s);
+        } else {
+            // (lists of topk_capacity(s_rank) slots -- NOT of k' slots: a thinned sample's rank is below k', and so is the 8-bit pass's)
+            const uint32_t cap_s = topk_capacity(s_rank);
+            launch_topk_dense(ws.dense.as<float>(), ld_s, n_s, (uint32_t)nq_pad, s_rank, ws.lists.as<uint64_t>(), s);
+            launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, cap_s, (uint32_t)nq_pad, s_rank, ws.keys_a.as<uint64_t>(), s);
+            launch_extract_tau(ws.keys_a.as<uint64_t>(), cap_s, (uint32_t)nq_pad, s_rank, d_tau, s);
+        }
+        // padding queries are zero vectors: under Cosine every row ties at key 0 = tau and would flood the hit buffers of
+        // the real queries that share their workgroup batch; tau = -inf lets nothing through
+        if (nq_pad > nq && n_s > select_tau_max_n())  // (k_select_tau does it itself)
+            VDB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_tau + nq), (int)0xFF800000u, nq_pad - nq, s));
     }
-    // padding queries are zero vectors: under Cosine every row ties at key 0 = tau and would flood the hit buffers of
-    // the real queries that share their workgroup batch; tau = -inf lets nothing through
-    if (nq_pad > nq && n_s > select_tau_max_n())  // (k_select_tau does it itself)
-        VDB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_tau + nq), (int)0xFF800000u, nq_pad - nq, s));
     uint64_t *d_cand = ws.lists.as<uint64_t>();  // the sample lists are dead now
     uint32_t *d_sync = d_hits + nq_pad;
     if (!half && !i8) VDB_HIP(hipMemsetAsync(d_hits, 0, (nq_pad + sync_words) * sizeof(uint32_t), s));  // (k_query_prep_* zero the counters)
@@ -663,7 +672,7 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
                double(hbm_passes) * double(n) * dim * (i8 ? 1 : (half ? sizeof(uint16_t) : sizeof(float))));
     if (i8)
         launch_flat_gemm8_filter(d_tiled_i8.p, n, (uint32_t)dim, ws.qfrag_g.p, d_qscale, (uint32_t)ngroups, d_rowc_i8.as<float>(), d_tau,
-                                 d_cand, d_hits, CAND_CAP, flat_gemm_debug, num_cu, s);
+                                 d_cand, d_hits, CAND_CAP, flat_gemm_debug, num_cu, s, i8_second ? CAND_CAP : 0u);
     else if (gemm)
         launch_flat_gemm_filter(xt, n, (uint32_t)dim, ws.qfrag_g.as<float>(), d_qmul, (uint32_t)ngroups,
                                 d_sq.as<float>(), cosine, d_tau, d_cand, d_hits, CAND_CAP, flat_gemm_debug, num_cu, s);
@@ -731,6 +740,7 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
     p.active = true;
     p.half = half;
     p.i8 = i8;
+    p.i8_second = i8_second;
     p.kprime = kprime;
     p.ksel = ksel;
     p.nq = nq;
@@ -746,7 +756,7 @@ void Index::flat_knn_finish(Workspace &ws, FlatPending &p) {
     hipStream_t s = ws.stream;
     if (!p.active) return;
     p.active = false;
-    const bool half = p.half, i8 = p.i8;
+    const bool half = p.half, i8 = p.i8, i8_second = p.i8_second;
     const uint32_t kprime = p.kprime, ksel = p.ksel;
     const uint64_t nq = p.nq, k = p.k;
     const float *d_q = p.d_q;
@@ -756,8 +766,9 @@ void Index::flat_knn_finish(Workspace &ws, FlatPending &p) {
     // the flags go straight to pinned host memory (device-visible): no copy kernel between the last kernel and the sync
     const uint8_t *flags = static_cast<const uint8_t *>(ws.pinned(nq));
     VDB_SYNC(s);
-    // uncertified queries: gather them, redo them (fp16 pass: through this function again with the split-bf16
-    // operands; split-bf16 pass: 8 per corpus pass with the exact scan), scatter the results
+    // uncertified queries: gather them, redo them (8-bit pass: once more with thresholds from the k-th distances the first walk found,
+    // then the fp16 pass; fp16 pass: through this function again with the split-bf16 operands; split-bf16 pass: 8 per corpus pass with
+    // the exact scan), scatter the results
     std::vector<uint64_t> redo;
     for (uint64_t q = 0; q < nq; q++)
         if (flags[q]) redo.push_back(q);
@@ -765,9 +776,14 @@ void Index::flat_knn_finish(Workspace &ws, FlatPending &p) {
         half_queries += nq;
         half_redo += redo.size();
     }
-    if (i8) {
+    if (i8 && i8_second) {
+        i8_second_queries += nq;
+        i8_second_redo += redo.size();
+    }
+    const bool try_second = i8 && !i8_second && flat_i8_second != 1 && !redo.empty();
+    if (i8 && !i8_second) {
         i8_queries += nq;
-        i8_redo += redo.size();
+        if (!try_second) i8_redo += redo.size();  // (with a second attempt: what THAT passes on, counted below)
         if (flat_i8_stats) {
             const uint32_t *qs = reinterpret_cast<const uint32_t *>(flags + ((nq + 15) & ~size_t(15)));
             uint64_t hs = 0, hm = 0;
@@ -787,30 +803,36 @@ void Index::flat_knn_finish(Workspace &ws, FlatPending &p) {
     if (redo.empty()) return;
     if (!half && !i8) fallback_count += redo.size();
     const uint64_t nr = redo.size();
-    DevBuf rq, rqs, ri, rd, rc;  // small, rare: allocated on demand
+    DevBuf rx, rq, rqs, ri, rd, rc, rdk;  // rare: allocated on demand
+    rx.reserve(nr * sizeof(uint64_t));
     rq.reserve(nr * dim * sizeof(float));
     rqs.reserve(nr * sizeof(float));
     ri.reserve(nr * k * sizeof(uint64_t));
     rd.reserve(nr * k * sizeof(float));
     rc.reserve(nr * sizeof(uint64_t));
-    for (uint64_t j = 0; j < nr; j++) {
-        VDB_HIP(hipMemcpyAsync(rq.as<float>() + j * dim, d_q + redo[j] * dim, dim * sizeof(float), hipMemcpyDeviceToDevice, s));
-        VDB_HIP(hipMemcpyAsync(rqs.as<float>() + j, ws.qsq.as<float>() + redo[j], sizeof(float), hipMemcpyDeviceToDevice, s));
+    VDB_HIP(hipMemcpyAsync(rx.p, redo.data(), nr * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    launch_gather_rows_f32(d_q, rx.as<uint64_t>(), nr, (uint32_t)dim, rq.as<float>(), s);
+    launch_gather_rows_f32(ws.qsq.as<float>(), rx.as<uint64_t>(), nr, 1, rqs.as<float>(), s);
+    if (try_second) {
+        rdk.reserve(nr * sizeof(float));
+        launch_gather_dk(d_dist, d_cnt, rx.as<uint64_t>(), nr, (uint32_t)k, ksel, rdk.as<float>(), s);
     }
     VDB_HIP(hipMemsetAsync(ri.p, 0, nr * k * sizeof(uint64_t), s));
     VDB_HIP(hipMemsetAsync(rd.p, 0, nr * k * sizeof(float), s));
-    if (i8)  // next tier: the fp16 pass (or whatever this index has instead), with its own shortlist rules
+    VDB_SYNC(s);  // (`redo` is pageable host memory: the copy above must have read it before it goes out of scope in a nested call's unwinding)
+    if (try_second) {
+        // the second 8-bit attempt; what it still cannot close goes to the fp16 tier from inside that call
+        const uint64_t before = i8_second_redo.load();
+        flat_knn_device(ws, rq.as<float>(), nr, k, ri.as<uint64_t>(), rd.as<float>(), rc.as<uint64_t>(), true, 0, true, rdk.as<float>());
+        i8_redo += i8_second_redo.load() - before;  // the auto rule counts what left the 8-bit tier for good
+    } else if (i8)  // next tier: the fp16 pass (or whatever this index has instead), with its own shortlist rules
         flat_knn_device(ws, rq.as<float>(), nr, k, ri.as<uint64_t>(), rd.as<float>(), rc.as<uint64_t>(), true, 0, false);
     else if (half)
         flat_knn_device(ws, rq.as<float>(), nr, k, ri.as<uint64_t>(), rd.as<float>(), rc.as<uint64_t>(), false, kprime);
     else
         flat_exact_device(ws, rq.as<float>(), rqs.as<float>(), nr, ksel, k, ri.as<uint64_t>(), rd.as<float>(), rc.as<uint64_t>());
-    for (uint64_t j = 0; j < nr; j++) {
-        VDB_HIP(hipMemcpyAsync(d_idx + redo[j] * k, ri.as<uint64_t>() + j * k, k * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
-        VDB_HIP(hipMemcpyAsync(d_dist + redo[j] * k, rd.as<float>() + j * k, k * sizeof(float), hipMemcpyDeviceToDevice, s));
-        VDB_HIP(hipMemcpyAsync(d_cnt + redo[j], rc.as<uint64_t>() + j, sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
-    }
-    VDB_SYNC(s);  // rq..rc are freed on return
+    launch_scatter_results(ri.as<uint64_t>(), rd.as<float>(), rc.as<uint64_t>(), rx.as<uint64_t>(), nr, (uint32_t)k, d_idx, d_dist, d_cnt, s);
+    VDB_SYNC(s);  // rx..rc are freed on return
 }
 
 // ---- the approximate keys of the Flat shortlist pass, for every row ------------------------------------------------

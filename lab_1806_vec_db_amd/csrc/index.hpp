@@ -166,6 +166,7 @@ struct FlatPending {
     bool active = false;  // the MFMA pipeline is on the stream, its certification flags are still to be read
     bool half = false;
     bool i8 = false;      // first pass on the 8-bit mirror (its uncertified queries go to the fp16 / split-bf16 tiers)
+    bool i8_second = false;  // ... its second attempt: thresholds from the first walk's k-th distances (k_redo.hip)
     uint32_t kprime = 0, ksel = 0;
     uint64_t nq = 0, k = 0;
     const float *d_q = nullptr;
@@ -257,7 +258,9 @@ struct Index {
     uint64_t i8_mu_rows = 0;    // table size when mu / lambda were measured
     float i8_l1 = 0.0f, i8_l2 = 0.0f, i8_mu_norm = 0.0f;
     int flat_i8_mode = 0;       // 0 auto, 1 off, 2 on even after many uncertified queries
-    uint32_t flat_i8_kprime = 256;  // rows the exact stage may walk per query (64 per round)
+    uint32_t flat_i8_kprime = 256;  // rows the exact stage of the FIRST attempt may walk per query (64 per round); the second walks the whole list
+    int flat_i8_second = 0;         // second 8-bit attempt with thresholds from the first walk (k_redo.hip): 0 on, 1 off
+    std::atomic<uint64_t> i8_second_queries{0}, i8_second_redo{0};
     uint32_t flat_i8_hits = 1024;   // expected hits per query the threshold sample of the 8-bit pass aims at (>= 256 = 4 x the 64 guaranteed)
     std::atomic<uint64_t> i8_queries{0}, i8_redo{0};  // queries through the 8-bit pass / passed on to the next tier
     // (measurement, flat_i8_stats = 1) per-query work of the 8-bit pass's exact stage: queries by rounds walked, hits per query
@@ -335,10 +338,13 @@ struct Index {
     void prof_collect(Workspace &ws);  // after a stream sync
 
     // search entry points; d_* are device pointers, results [nq][k]
+    // d_dk_hint (8-bit pass only): per query an upper bound of its k-th distance -> the pass runs with thresholds derived from it
+    // instead of sampled ones and its exact stage may walk the whole candidate list (the second attempt of k_redo.hip)
     void flat_knn_device(Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t *d_idx, float *d_dist,
-                         uint64_t *d_cnt, bool allow_half = true, uint32_t kprime_min = 0, bool allow_i8 = true);
+                         uint64_t *d_cnt, bool allow_half = true, uint32_t kprime_min = 0, bool allow_i8 = true,
+                         const float *d_dk_hint = nullptr);
     void flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t *d_idx, float *d_dist, uint64_t *d_cnt,
-                          bool allow_half, uint32_t kprime_min, FlatPending &p, bool allow_i8 = true);
+                          bool allow_half, uint32_t kprime_min, FlatPending &p, bool allow_i8 = true, const float *d_dk_hint = nullptr);
     void flat_knn_finish(Workspace &ws, FlatPending &p);
     void flat_sorted_device(Workspace &ws, const float *d_q, uint64_t nq, uint64_t ksel, uint64_t k, uint64_t *d_idx,
                             float *d_dist, uint64_t *d_cnt);

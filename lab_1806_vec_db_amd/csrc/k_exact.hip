@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(NW * 64, PCD ? 4 : 1) void k_flat_tail_lb(FlatTailA
     }
 }
 bool flat_tail_lb_supported(uint32_t dim, uint32_t kprime, uint32_t ksel) {
-    return (dim & 3) == 0 && dim >= 64 && dim <= 8192 && kprime >= 64 && kprime % 64 == 0 && kprime <= 1024 && ksel >= 1 && ksel <= 64;
+    return (dim & 3) == 0 && dim >= 64 && dim <= 8192 && kprime >= 64 && kprime % 64 == 0 && kprime <= 8192 && ksel >= 1 && ksel <= 64;
 }
 static std::atomic<int> g_tail_lb_nw{0};  // 0 auto; 8 / 4 / 2 / 1 waves per query
 void flat_tail_lb_set_nw(int v) { g_tail_lb_nw = v; }

@@ -49,7 +49,8 @@ struct Gemm8Args {
     uint32_t nt;          // non-temporal X loads (mirror beyond the Infinity Cache)
     uint32_t debug;       // bit 0: thresholds of -inf (nothing passes: the no-hit detection downstream, tests)
     uint32_t coop;        // resident filter form: > 1 = the workgroups of an XCD in sets of `coop` that share one row stream (see the kernel)
-    uint32_t coop_block;  // ... units a wave scores between two hand-overs of the workgroup's hit buffer
+    uint32_t coop_block;  // ... units a wave scores between two hand-overs of the workgroup's hit buffer (plain resident form: 0 = one hand-over per group)
+    uint32_t hits_expected;  // hits per query the thresholds were made for (sizes the hand-over blocks; 0 = the sample plan's ~1000)
     uint32_t *sync;       // ... 128 zeroed words: one arrival counter per set (cnt + ngroups * 128)
 };
 
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
         }
         const uint32_t steps = steps_of(slot_cur);
         const uint32_t steps_all = coop ? c_steps_max : steps;                       // workgroup-uniform
-        const uint32_t blk = coop && a.coop_block ? a.coop_block : 0xFFFFFFFFu;      // units between two hand-overs
+        const uint32_t blk = RES && a.coop_block ? a.coop_block : 0xFFFFFFFFu;       // units between two hand-overs
         for (uint32_t b0 = 0;;) {  // blocks of units [b0, b1) (one block unless cooperative), a hand-over after each
         const uint32_t b1 = blk >= steps_all - b0 ? steps_all : b0 + blk;  // workgroup-uniform (b0 <= steps_all)
         const uint32_t st_end = b1 < steps ? b1 : steps;                   // this wave's share of the block
@@ -382,22 +383,26 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
                     const uint32_t mine = uint32_t(p0) + uint32_t(p1) + uint32_t(p2) + uint32_t(p3);
                     if (mine) {
                         uint32_t pos = atomicAdd(hit_n, mine);
-                        // every reserved slot below WGBUF is written (the hand-off reads min(total, WGBUF) slots)
-#define VDB_PARK8(P, KEY, E)                          \
-    if (P) {                                          \
-        if (pos < WGBUF) {                            \
-            hit_key[pos] = pair_key(KEY, mt.x + E);   \
-            hit_q[pos] = mt.y;                        \
-        }                                             \
-        pos++;                                        \
+                        // every reserved slot below WGBUF is written (the hand-off reads min(total, WGBUF) slots); a key that finds the
+                        // buffer full goes straight to its query's candidate list (one global atomic per key: the slow path of hit
+                        // densities above ~3 % of the rows -- small tables with long lists, the second attempt of k_redo.hip -- where
+                        // rounds 3 flagged the query as overflowed and sent it to the next tier)
+#define VDB_PARK8(P, KEY, E)                                                                          \
+    if (P) {                                                                                          \
+        if (pos < WGBUF) {                                                                            \
+            hit_key[pos] = pair_key(KEY, mt.x + E);                                                   \
+            hit_q[pos] = mt.y;                                                                        \
+        } else {                                                                                      \
+            const uint32_t gslot = atomicAdd(&a.cnt[grp * G8_BQ + mt.y], 1u);                         \
+            if (gslot < a.cap) a.cand[(uint64_t(grp) * G8_BQ + mt.y) * a.cap + gslot] = pair_key(KEY, mt.x + E); \
+        }                                                                                             \
+        pos++;                                                                                        \
     }
                         VDB_PARK8(p0, kv.x, 0)
                         VDB_PARK8(p1, kv.y, 1)
                         VDB_PARK8(p2, kv.z, 2)
                         VDB_PARK8(p3, kv.w, 3)
 #undef VDB_PARK8
-                        if (pos > WGBUF)  // buffer full: mark the query as overflowed (-> redone by the caller)
-                            atomicAdd(&a.cnt[grp * G8_BQ + mt.y], a.cap + 1);
                     }
                 }
                 stage_n = 0;
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
                 }
             }
             __syncthreads();
-            if (coop) {  // the next block parks into an empty buffer
+            if (blk != 0xFFFFFFFFu) {  // the next block parks into an empty buffer
                 if (threadIdx.x < 1 + 2 * G8_BQ) hit_n[threadIdx.x] = 0;
                 __syncthreads();
             }
@@ -564,7 +569,7 @@ static void flat_gemm8_launch(const Gemm8Args &a0, int num_cu, hipStream_t s) {
             if (S > 1 && units >= 2048) {
                 a.coop = S;
                 g_gemm8_last_coop = S;
-                const double per_unit = 8.0 * 48.0 * 128.0 * 1024.0 / double(a.n);
+                const double per_unit = 8.0 * 48.0 * 128.0 * double(a.hits_expected ? a.hits_expected : 1024u) / double(a.n);
                 const double b = double(G8_WGBUF_RES) * 0.55 / per_unit;
                 a.coop_block = b < 1.0 ? 1u : (b > 4096.0 ? 4096u : uint32_t(b));
                 flat_gemm8_launch1<KC, MODE, false, false, true>(a, num_cu, s);  // default loads: the members meet in the L2
@@ -572,6 +577,13 @@ static void flat_gemm8_launch(const Gemm8Args &a0, int num_cu, hipStream_t s) {
             }
         }
         if (MODE == G8_FILTER) g_gemm8_last_coop = 0;
+        if (MODE == G8_FILTER && a.hits_expected > 1024) {
+            // thresholds made for long hit lists (the second attempt, k_redo.hip): the plain form hands its buffer over in blocks too
+            // (a workgroup's share of a group's hits: 128 queries x hits / workgroups, against 1536 entries)
+            const double per_unit = 8.0 * 48.0 * 128.0 * double(a.hits_expected) / double(a.n);
+            const double b = double(G8_WGBUF_RES) * 0.55 / per_unit;
+            a.coop_block = b < 1.0 ? 1u : (b > 4096.0 ? 4096u : uint32_t(b));
+        }
         if (nt)
             flat_gemm8_launch1<KC, MODE, true, false, true>(a, num_cu, s);
         else
@@ -631,7 +643,7 @@ static Gemm8Args gemm8_args(const void *XT, uint64_t n, uint32_t dim, const void
 // rows past n up to a whole unit are read from the mirror (zero tiles) and from rowc ({+inf, 0}): see Index::i8_refresh
 void launch_flat_gemm8_filter(const void *XT, uint64_t n, uint32_t dim, const void *qfrag, const float *qscale, uint32_t ngroups,
                               const float *rowc, const float *tau, uint64_t *cand, uint32_t *cnt, uint32_t cap, int debug, int num_cu,
-                              hipStream_t s) {
+                              hipStream_t s, uint32_t hits_expected) {
     if (n == 0 || ngroups == 0) return;
     Gemm8Args a = gemm8_args(XT, n, dim, qfrag, qscale, ngroups, rowc);
     a.debug = (uint32_t)debug;
@@ -640,6 +652,7 @@ void launch_flat_gemm8_filter(const void *XT, uint64_t n, uint32_t dim, const vo
     a.cnt = cnt;
     a.sync = cnt + uint64_t(ngroups) * G8_BQ;  // (Index::flat_knn_enqueue: the rendezvous words follow the padded counters)
     a.cap = cap;
+    a.hits_expected = hits_expected;
     const double mirror_bytes = double((n + 15) / 16 * 16) * mfma_dim_pad(dim);
     a.nt = g_gemm8_nt == 2 || (g_gemm8_nt == 0 && mirror_bytes > 384.0 * 1024 * 1024) ? 1u : 0u;
     flat_gemm8_dispatch<G8_FILTER>(a, num_cu, s);

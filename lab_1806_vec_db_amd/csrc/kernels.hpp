@@ -234,7 +234,7 @@ uint64_t gemm8_sample_rows(uint64_t n, uint32_t unit_step);
 // (cnt[ngroups * 128 .. + 127]: the arrival counters of the cooperative sets, zero on entry -- launch_query_prep_i8 clears them)
 void launch_flat_gemm8_filter(const void *XT, uint64_t n, uint32_t dim, const void *qfrag, const float *qscale, uint32_t ngroups,
                               const float *rowc, const float *tau, uint64_t *cand, uint32_t *cnt, uint32_t cap, int debug, int num_cu,
-                              hipStream_t s);
+                              hipStream_t s, uint32_t hits_expected = 0);
 void launch_flat_gemm8_sample(const void *XT, uint64_t n, uint32_t dim, const void *qfrag, const float *qscale, uint32_t ngroups,
                               const float *rowc, uint32_t unit_step, float *out, uint64_t ld, int num_cu, hipStream_t s);
 // xsq_cos != null / cosine != 0: the Cosine form -- unit rows / unit queries (k_i8.hip); xsq_cos = the rows' cached strict-fold |x|^2
@@ -246,6 +246,14 @@ void launch_tile_rows_i8(const float *X, uint64_t n, uint32_t dim, uint64_t tile
                          void *T, float *rowc, hipStream_t s, const float *xsq_cos = nullptr);
 void launch_query_prep_i8(const float *Q, uint32_t nq, uint32_t nq_pad, uint32_t dim, const float *mu, float l1, float l2, float *qsq,
                           float *qscale, float *qoff, uint32_t *hits, void *qfrag, hipStream_t s, int cosine = 0);
+// k_redo.hip: second attempts of a Flat call
+void launch_gather_rows_f32(const float *src, const uint64_t *rows, uint64_t nr, uint32_t width, float *dst, hipStream_t s);
+void launch_scatter_results(const uint64_t *ri, const float *rd, const uint64_t *rc, const uint64_t *rows, uint64_t nr, uint32_t k,
+                            uint64_t *o_idx, float *o_dist, uint64_t *o_cnt, hipStream_t s);
+void launch_gather_dk(const float *o_dist, const uint64_t *o_cnt, const uint64_t *rows, uint64_t nr, uint32_t k, uint32_t ksel, float *dk,
+                      hipStream_t s);
+void launch_i8_tau_from_dk(const float *dk, uint32_t nq, uint32_t nq_pad, const float *qoff, const float *qsq, float xsq_max, float mu_norm,
+                           uint32_t dim, int cosine, float *tau, hipStream_t s);
 void mfma_set_sample_thin(int v);
 void mfma_sample_plan(uint64_t n, uint32_t kprime, uint32_t *step, uint32_t *rank, uint32_t target_floor = 1024);  // target_floor: expected hits per query
 uint64_t mfma_sample_rows(uint64_t n, uint32_t step);

@@ -194,11 +194,28 @@ def test_i8_pass_redo_tiers(mods):
     ix.batch_add(base)
     ix.set_flat_mode(2)
     oi, od, oc = O.flat_knn_batch(base, qs, 10, 0, nthreads=8)
+    # (i) the way a caller gets it: the first walk (252 rows) cannot close a cluster of ~1000 members; the second 8-bit attempt -- thresholds
+    # from the k-th distances the first walk found, the whole list walked (k_redo.hip) -- does, and little is left for the other tiers
+    idx, d, cnt = ix.flat_knn(qs, 10)
+    _check_all(idx, d, cnt, oi, od, oc)
+    second, left = ix.get_stat("flat_i8_second_queries"), ix.get_stat("flat_i8_redo")
+    print("near-duplicate clusters: second attempt for", second, "of", nq, "; passed on to the fp16 tier:", left)
+    assert second > nq // 2 and left == ix.get_stat("flat_i8_second_redo") and left <= nq // 8
+    for _ in range(10):  # ... so auto mode keeps the pass for this index
+        idx, d, cnt = ix.flat_knn(qs, 10)
+        _check_all(idx, d, cnt, oi, od, oc)
+    assert ix.get_stat("flat_i8_queries") == 11 * nq
+    ix.close()
+    # (ii) without the second attempt (flat_i8_second = 1): the fp16 / split-bf16 / exact tiers answer, and auto mode switches the pass off
+    ix = vdb.GpuIndex(dim, "l2sqr")
+    ix.batch_add(base)
+    ix.set_flat_mode(2)
+    ix.set_param("flat_i8_second", 1)
     idx, d, cnt = ix.flat_knn(qs, 10)
     _check_all(idx, d, cnt, oi, od, oc)
     redo = ix.get_stat("flat_i8_redo")
-    print("near-duplicate clusters: passed on", redo, "of", nq)
-    assert redo > nq // 2
+    print("near-duplicate clusters, no second attempt: passed on", redo, "of", nq)
+    assert redo > nq // 2 and ix.get_stat("flat_i8_second_queries") == 0
     for _ in range(10):  # auto mode gives up on this index once 1/8 of >= 1024 queries were passed on
         idx, d, cnt = ix.flat_knn(qs, 10)
         _check_all(idx, d, cnt, oi, od, oc)
@@ -349,9 +366,9 @@ def test_i8_cooperative_sets(mods, dim, n, nq):
 @pytest.mark.parametrize("dist,spread", [("l2sqr", 0.15), ("l2sqr", 0.6), ("cosine", 0.15)])
 def test_i8_on_clustered_rows_and_the_auto_off_rule(mods, dist, spread):
     """tight Gaussian clusters (bench.py --data clustered): the k-th neighbour and hundreds of other cluster members lie within the 8-bit
-    bound's gap of each other, so the exact stage cannot close most queries in its rows and hands them on -- the answers must be the
-    oracle's whichever tier gives them, and in auto mode the pass must switch itself off for this index (>= 1/8 of >= 1024 queries passed
-    on); looser clusters (0.6 sigma: still ~1900 members within a few gaps of each other) are reported and held to the same rule"""
+    bound's gap of each other, so the first walk (252 rows) cannot close most queries; the second 8-bit attempt must (k_redo.hip), the answers
+    must be the oracle's whichever tier gives them, and the auto-off rule must follow what left the 8-bit tier for good; looser clusters
+    (0.6 sigma: still ~1900 members within a few gaps of each other) are reported and held to the same rule"""
     from conftest import gist_clustered
 
     vdb, O = mods
@@ -368,11 +385,14 @@ def test_i8_on_clustered_rows_and_the_auto_off_rule(mods, dist, spread):
     sel = np.arange(0, nq, 8)
     oi, od, oc = O.flat_knn_batch(base, qs[sel], 10, kind, nthreads=8)
     _check_all(idx[sel], d[sel], cnt[sel], oi, od, oc)
-    redo = ix.get_stat("flat_i8_redo")
+    redo, second = ix.get_stat("flat_i8_redo"), ix.get_stat("flat_i8_second_queries")
     hist = {r: ix.get_stat(f"flat_i8_rounds_{r}") for r in range(9)}
-    print(f"{dist} spread {spread}: passed on {redo} of {nq}; queries by rounds {hist}; hits per query mean "
-          f"{ix.get_stat('flat_i8_hits_sum') / nq:.0f} max {ix.get_stat('flat_i8_hits_max')}")
+    print(f"{dist} spread {spread}: second attempt for {second} of {nq}, passed on to the fp16 tier {redo}; queries by rounds of the first walk "
+          f"{hist}; hits per query mean {ix.get_stat('flat_i8_hits_sum') / nq:.0f} max {ix.get_stat('flat_i8_hits_max')}")
     assert sum(hist.values()) == nq
+    if spread < 0.3:
+        assert second > nq // 4  # tight clusters: the first walk cannot close them ...
+        assert redo <= nq // 8   # ... the second attempt (thresholds from the first walk's k-th distances, whole list walked) does
     for _ in range(4):  # 5 x 384 queries: past the 1024 the auto rule wants to have seen
         idx2, d2, _ = ix.flat_knn(qs, 10)
         np.testing.assert_array_equal(idx, idx2)
@@ -381,11 +401,18 @@ def test_i8_on_clustered_rows_and_the_auto_off_rule(mods, dist, spread):
     idx2, d2, _ = ix.flat_knn(qs, 10)
     np.testing.assert_array_equal(idx, idx2)
     np.testing.assert_array_equal(d, d2)
-    if spread < 0.3:
-        assert redo > nq // 4  # tight clusters: the pass cannot close them ...
-    # ... and the rule follows what happened: off once more than 1/8 of the (>= 1024) queries seen were passed on, on otherwise
-    if redo * 8 > nq:
+    # the rule follows what LEFT the 8-bit tier: off once more than 1/8 of the (>= 1024) queries seen were passed on, on otherwise
+    if ix.get_stat("flat_i8_redo") * 8 > 6 * nq:
         assert ix.get_stat("flat_i8_queries") == q0
     else:
         assert ix.get_stat("flat_i8_queries") == q0 + nq
+    # without the second attempt the same index hands (nearly) everything on and the answers stay
+    ix.set_param("flat_i8", 2)
+    ix.set_param("flat_i8_second", 1)
+    r0 = ix.get_stat("flat_i8_redo")
+    idx2, d2, _ = ix.flat_knn(qs, 10)
+    np.testing.assert_array_equal(idx, idx2)
+    np.testing.assert_array_equal(d, d2)
+    if spread < 0.3:
+        assert ix.get_stat("flat_i8_redo") - r0 > nq // 4
     ix.close()
