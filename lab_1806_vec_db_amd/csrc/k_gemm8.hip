@@ -387,14 +387,20 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
                         // buffer full goes straight to its query's candidate list (one global atomic per key: the slow path of hit
                         // densities above ~3 % of the rows -- small tables with long lists, the second attempt of k_redo.hip -- where
                         // rounds 3 flagged the query as overflowed and sent it to the next tier)
+#ifdef G8_NOSPILL  /* measurement builds: the full buffer flags the query (rounds 3) */
+#define G8_SPILL(KEY, E) atomicAdd(&a.cnt[grp * G8_BQ + mt.y], a.cap + 1);
+#else
+#define G8_SPILL(KEY, E)                                                                  \
+    const uint32_t gslot = atomicAdd(&a.cnt[grp * G8_BQ + mt.y], 1u);                     \
+    if (gslot < a.cap) a.cand[(uint64_t(grp) * G8_BQ + mt.y) * a.cap + gslot] = pair_key(KEY, mt.x + E);
+#endif
 #define VDB_PARK8(P, KEY, E)                                                                          \
     if (P) {                                                                                          \
         if (pos < WGBUF) {                                                                            \
             hit_key[pos] = pair_key(KEY, mt.x + E);                                                   \
             hit_q[pos] = mt.y;                                                                        \
         } else {                                                                                      \
-            const uint32_t gslot = atomicAdd(&a.cnt[grp * G8_BQ + mt.y], 1u);                         \
-            if (gslot < a.cap) a.cand[(uint64_t(grp) * G8_BQ + mt.y) * a.cap + gslot] = pair_key(KEY, mt.x + E); \
+            G8_SPILL(KEY, E)                                                                          \
         }                                                                                             \
         pos++;                                                                                        \
     }
@@ -403,6 +409,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
                         VDB_PARK8(p2, kv.z, 2)
                         VDB_PARK8(p3, kv.w, 3)
 #undef VDB_PARK8
+#undef G8_SPILL
                     }
                 }
                 stage_n = 0;
