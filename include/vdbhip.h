@@ -172,6 +172,12 @@ int vdb_flat_set_mode(vdb_index *idx, int mode);
  *                      tables: while rows x (0.9 queries - 0.3) < 75 000, i.e. one query up to ~125k rows, where the MFMA pipeline's
  *                      fixed ~0.1 ms of dependent launches costs more than re-reading the rows per query), 1 off, 2 whenever the shape allows */
 int vdb_set_param(vdb_index *idx, const char *name, int64_t value);
+/* Builds NOW the operand mirrors the first Flat search of this index would otherwise build inside that search (the centred 8-bit
+ * mirror, or the fp16 / split-bf16 mirror where the 8-bit pass does not apply); all_tiers != 0: the mirrors of the tiers behind it too
+ * (what a query the first pass cannot certify needs).  A latency-sensitive caller calls it after add / batch_add
+ * (metadata_vec_table.rs:63-86 has no counterpart: the reference's Flat index has nothing to build).  A mirror that does not fit the
+ * device memory is skipped -- searches then use the next tier, down to the exact scan over the rows -- and is not an error. */
+int vdb_index_prepare(vdb_index *idx, int all_tiers);
 /* number of queries whose MFMA shortlist failed certification and were redone by the exact scan */
 int vdb_flat_fallback_count(const vdb_index *idx, uint64_t *out);
 /* counters of the Flat pipeline (diagnostics; results never depend on them):

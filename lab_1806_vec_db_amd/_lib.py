@@ -45,6 +45,7 @@ SIGNATURES = {
     "vdb_flat_knn_device_end": [vp],
     "vdb_flat_shortlist_keys": [vp, f32p, u64, u64, C.c_int, f32p, f32p, f32p, f32p],
     "vdb_flat_set_mode": [vp, C.c_int],
+    "vdb_index_prepare": [vp, C.c_int],
     "vdb_flat_fallback_count": [vp, u64p],
     "vdb_get_stat": [vp, C.c_char_p, u64p],
     "vdb_set_param": [vp, C.c_char_p, C.c_int64],

@@ -530,6 +530,8 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         VDB_REQUIRE(value >= 64 && value <= 8192 && value % 64 == 0, "flat_i8_rows must be a multiple of 64 in [64, 8192]");
         idx->ix.flat_i8_kprime = (uint32_t)value;
     }
+    else if (n == "debug_alloc_fail_over")  // (testing aid, process-wide) device allocations of at least this many bytes fail; 0 = off
+        devbuf_fail_over() = (size_t)value;
     else if (n == "flat_i8_second")  // second 8-bit attempt with thresholds from the first walk's k-th distances: 0 on, 1 off
         idx->ix.flat_i8_second = (int)value;
     else if (n == "flat_i8_stats") {  // (measurement) collect per-query rounds / hits of the 8-bit pass's exact stage; setting it resets them
@@ -565,6 +567,13 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         throw Error(VDB_ERR_INVALID, "unknown parameter " + n);
     VDB_API_END
 }
+int vdb_index_prepare(vdb_index *idx, int all_tiers) {
+    VDB_API_BEGIN
+    VDB_REQUIRE(idx, "null index");
+    require_gpu();
+    idx->ix.prepare_flat(all_tiers != 0);
+    VDB_API_END
+}
 int vdb_flat_fallback_count(const vdb_index *idx, uint64_t *out) {
     VDB_API_BEGIN
     VDB_REQUIRE(idx && out, "null argument");
@@ -596,6 +605,8 @@ int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out) {
         *out = idx->ix.i8_valid.load() ? 1 : 0;
     else if (n.rfind("flat_i8_rounds_", 0) == 0 && n.size() == 16 && n[15] >= '0' && n[15] <= '8')  // queries whose exact stage walked N rounds (8: 8 or more)
         *out = idx->ix.i8_rounds_hist[n[15] - '0'].load();
+    else if (n == "mirror_alloc_failures")  // mirrors of this index whose allocation failed (the tier was left to the next one)
+        *out = idx->ix.mirror_alloc_failures.load();
     else if (n == "flat_i8_second_queries")  // queries that took the second 8-bit attempt / that it passed on to the fp16 tier
         *out = idx->ix.i8_second_queries.load();
     else if (n == "flat_i8_second_redo")

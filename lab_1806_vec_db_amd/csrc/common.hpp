@@ -17,6 +17,11 @@ struct Error : std::runtime_error {
     Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
 };
 
+// a device allocation that failed: the one failure a search can route around (a mirror that cannot be built leaves the tier to the next)
+struct AllocError : Error {
+    explicit AllocError(const std::string &m) : Error(2, m) {}
+};
+
 #define VDB_HIP(expr)                                                                                   \
     do {                                                                                                \
         hipError_t _e = (expr);                                                                         \

@@ -390,6 +390,10 @@ static void sharded_set_rows(vdb_sharded *sh, const float *rows, uint64_t n_tota
             ix.id_offset = s.r0;
         });
     } catch (...) {
+        // Other processes may have kept their blocks: this rank would refuse the next search before its collective while they enter
+        // it and wait for ever.  The object is poisoned on this rank (every later call fails loudly; vdb_sharded_poisoned tells the
+        // launcher to tear the job down) -- a multi-process job cannot be rolled back from one side.
+        if (multi_process(*sh)) sh->poisoned = true;
         for (size_t i = 0; i < sh->shards.size(); i++) {
             (void)hipSetDevice(sh->ctx->devices[i]);
             try {
@@ -586,12 +590,33 @@ int vdb_sharded_knn_pq(vdb_sharded *sh, const float *queries, uint64_t nq, uint6
 }
 
 // ---- HNSW behind the context: replicas, the third search DynamicIndex dispatches (dynamic_index.rs:68-93) --------
-// The graph is built ONCE per process on the first local GPU (the host builder is deterministic for a given seed, batch size
-// and thread count, so the processes of a multi-process job build equal graphs) and attached to the other local replicas.
+// The graph is built ONCE per process on the first local GPU and attached to the other local replicas.  The host builder is
+// deterministic for a given seed, batch size AND thread count, so a multi-process job must name its thread count (the default, the
+// hardware concurrency, differs between hosts) -- and because a query's answer depends on the graph of the rank its block landed on,
+// the processes compare a hash of what they built (level-0 links and lengths, upper links, levels, entry) in one all-gather: a
+// mismatch poisons the object instead of serving answers that differ from the single-process result.
+static uint64_t hnsw_graph_hash(const HNSWState &h) {
+    uint64_t x = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t bytes) {
+        const unsigned char *b = static_cast<const unsigned char *>(p);
+        for (size_t i = 0; i < bytes; i++) x = (x ^ b[i]) * 1099511628211ull;
+    };
+    mix(h.level0.data(), h.level0.size() * sizeof(h.level0[0]));
+    mix(h.len0.data(), h.len0.size() * sizeof(h.len0[0]));
+    mix(h.vec_level.data(), h.vec_level.size() * sizeof(h.vec_level[0]));
+    mix(h.upper.data(), h.upper.size() * sizeof(h.upper[0]));
+    mix(h.upper_len.data(), h.upper_len.size() * sizeof(h.upper_len[0]));
+    const uint64_t tail[3] = {h.has_enter ? 1ull : 0ull, h.enter_point, h.enter_level};
+    mix(tail, sizeof(tail));
+    return x;
+}
 int vdb_sharded_hnsw_build(vdb_sharded *sh, uint64_t M, uint64_t ef_construction, uint64_t seed, uint64_t batch, int nthreads) {
     VDB_API_BEGIN
     VDB_REQUIRE(sh, "null index");
     VDB_REQUIRE(sh->layout == LAYOUT_REPLICA, "HNSW does not shard by rows (edges cross any partition): use vdb_sharded_set_rows_replica");
+    VDB_REQUIRE(!multi_process(*sh) || nthreads > 0,
+                "vdb_sharded_hnsw_build in a multi-process job needs an explicit nthreads (the graph depends on it; every process must build the same)");
+    VDB_SHARDED_SEARCH_BEGIN(sh)
     Index &ix0 = sh->shards[0]->handle->ix;
     ix0.use_device();
     hnsw_build(ix0, M, ef_construction, seed, batch, nthreads);
@@ -602,6 +627,30 @@ int vdb_sharded_hnsw_build(vdb_sharded *sh, uint64_t M, uint64_t ef_construction
         hnsw_attach(ix, h.m, h.ef_construction, h.level0.data(), h.len0.data(), h.vec_level.data(), h.upper.data(), h.upper_len.data(),
                     h.has_enter ? 1 : 0, h.enter_point, h.enter_level);
     }
+    if (!sh->ctx->comms.empty() && sh->ctx->world > 1) {
+        const uint64_t mine = hnsw_graph_hash(h), S = (uint64_t)sh->ctx->world;
+        std::vector<std::pair<const void *, void *>> bufs;
+        for (size_t i = 0; i < sh->shards.size(); i++) {
+            Shard &s = *sh->shards[i];
+            s.handle->ix.use_device();
+            s.send.reserve(8);
+            s.recv.reserve(S * 8);
+            VDB_HIP(hipMemcpyAsync(s.send.p, &mine, 8, hipMemcpyHostToDevice, s.stream));
+            bufs.push_back({s.send.p, s.recv.p});
+        }
+        all_gather(*sh, bufs, 1, 8);
+        Shard &s0 = *sh->shards[0];
+        s0.handle->ix.use_device();
+        std::vector<uint64_t> all(S);
+        VDB_HIP(hipMemcpyAsync(all.data(), s0.recv.p, S * 8, hipMemcpyDeviceToHost, s0.stream));
+        for (auto &sp : sh->shards) {
+            sp->handle->ix.use_device();
+            VDB_SYNC(sp->stream);
+        }
+        for (uint64_t r = 0; r < S; r++)
+            VDB_REQUIRE(all[r] == mine, "vdb_sharded_hnsw_build: rank " + std::to_string(r) + " built a different graph (thread count, batch size or rows differ between the processes)");
+    }
+    VDB_SHARDED_SEARCH_END(sh)
     VDB_API_END
 }
 int vdb_sharded_hnsw_attach(vdb_sharded *sh, uint64_t M, uint64_t ef_construction, const uint32_t *level0, const uint64_t *len0,

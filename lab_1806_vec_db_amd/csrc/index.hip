@@ -67,12 +67,19 @@ void Index::add_rows(const void *rows, uint64_t count, bool on_device) {
     d_sq.grow((n + count + 128) * sizeof(float), n * sizeof(float), s);  // +128: kernels may read a few entries past n
     char *dst = d_rows.as<char>() + n * row_bytes;
     VDB_HIP(hipMemcpyAsync(dst, rows, count * row_bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
-    const bool mirror = mfma_supported((uint32_t)dim) && tiled_built;
+    bool mirror = mfma_supported((uint32_t)dim) && tiled_built;
     uint64_t tiles_new = ((n + count + 15) / 16 + 11) / 12 * 12;  // whole 64-row items (k_flat_mfma) and whole 2/3-tile units (k_flat_gemm)
     uint64_t tiles_old = n / 16;                                // the partially filled tile is rewritten
     if (mirror) {
         uint64_t tile_bytes = 16 * size_t(mfma_dim_pad((uint32_t)dim)) * sizeof(float);
-        d_tiled.grow(tiles_new * tile_bytes, tiles_old * tile_bytes, s);
+        try {
+            d_tiled.grow(tiles_new * tile_bytes, tiles_old * tile_bytes, s);
+        } catch (const AllocError &) {  // the rows went in; the mirror is dropped and rebuilt (or not) by the search that wants it
+            d_tiled.release();
+            tiled_built = false;
+            mirror = false;
+            mirror_alloc_failures += 1;
+        }
     }
     // row norms of the new rows and the fragment-ordered mirror of every 16-row tile that received rows (a u8 index feeds
     // these f32 build kernels widened chunks; the rows themselves stay at one byte per element)
@@ -92,8 +99,15 @@ void Index::add_rows(const void *rows, uint64_t count, bool on_device) {
     if (i8_defers_half() && half_n == n) {
         // the 8-bit pass is this index's first tier: the fp16 mirror waits for its first use (ensure_half)
     } else if (half_n == n) {
-        half_refresh(*ws, n, n + count);  // needs the new xsq_max
-        half_n = n + count;
+        try {
+            half_refresh(*ws, n, n + count);  // needs the new xsq_max
+            half_n = n + count;
+        } catch (const AllocError &) {  // (as above: ensure_half decides at the next search)
+            d_tiled_h.release();
+            half_valid = false;
+            half_n = 0;
+            mirror_alloc_failures += 1;
+        }
     }  // (else: already behind -- ensure_half catches up)
     {
         std::lock_guard<std::mutex> g(host_mu);
@@ -161,17 +175,27 @@ void Index::swap_remove(uint64_t i) {
 }
 
 // ---- split-bf16 mirror, on first need ----------------------------------------------------------------
-void Index::ensure_tiled(Workspace &ws) {
+// A mirror that cannot be allocated is not an error of the search that wanted it: the tier is left to the next one (8-bit -> fp16 ->
+// split-bf16 -> exact scan over the rows themselves) and the allocation is not tried again until the table changes.
+bool Index::ensure_tiled(Workspace &ws) {
     std::lock_guard<std::mutex> g(tiled_mu);
-    if (tiled_built || n == 0) return;
+    if (tiled_built || n == 0) return true;
+    if (tiled_failed_n == n) return false;
     const uint64_t tiles = ((n + 15) / 16 + 11) / 12 * 12;  // whole 64-row items (k_flat_mfma) and whole 2/3-tile units (k_flat_gemm)
     const uint64_t tile_bytes = 16 * size_t(mfma_dim_pad((uint32_t)dim)) * sizeof(float);
-    d_tiled.reserve(tiles * tile_bytes);
+    try {
+        d_tiled.reserve(tiles * tile_bytes);
+    } catch (const AllocError &) {
+        tiled_failed_n = n;
+        mirror_alloc_failures += 1;
+        return false;
+    }
     for_tile_chunks(ws, 0, tiles, n, [&](const float *v, uint64_t ta, uint64_t tb, uint64_t, uint64_t) {
         launch_tile_rows(v, n, (uint32_t)dim, ta, tb, d_tiled.as<float>(), ws.stream);
     });
     VDB_SYNC(ws.stream);
     tiled_built = true;
+    return true;
 }
 
 uint64_t Index::hbm_bytes_per_row() const {
@@ -238,9 +262,24 @@ bool Index::i8_applicable(uint32_t ksel) const {
     const uint64_t iq = i8_queries.load(), ir = i8_redo.load();
     return flat_i8_mode == 2 || iq < 1024 || ir * 8 <= iq;
 }
-void Index::ensure_i8(Workspace &ws) {
+bool Index::ensure_i8(Workspace &ws) {
     std::lock_guard<std::mutex> g(i8_mu);
-    if (i8_valid && i8_n == n) return;
+    if (i8_valid && i8_n == n) return true;
+    if (i8_failed_n == n) return false;
+    try {
+        ensure_i8_locked(ws);
+    } catch (const AllocError &) {
+        d_tiled_i8.release();
+        d_rowc_i8.release();
+        i8_valid = false;
+        i8_n = 0;
+        i8_failed_n = n;
+        mirror_alloc_failures += 1;
+        return false;
+    }
+    return true;
+}
+void Index::ensure_i8_locked(Workspace &ws) {
     hipStream_t s = ws.stream;
     const uint32_t d = (uint32_t)dim;
     const uint64_t tiles = ((n + 15) / 16 + 11) / 12 * 12;  // whole units of k_flat_gemm8
@@ -290,10 +329,31 @@ bool Index::i8_defers_half() const {
 bool Index::ensure_half(Workspace &ws) {
     std::lock_guard<std::mutex> g(half_mu);
     if (half_n != n) {
-        half_refresh(ws, half_n > n ? 0 : half_n, n);
-        half_n = n;
+        if (half_failed_n == n) return false;
+        try {
+            half_refresh(ws, half_n > n ? 0 : half_n, n);
+            half_n = n;
+        } catch (const AllocError &) {  // (DevBuf::grow allocates before it frees: the old mirror, if any, is intact but stale)
+            d_tiled_h.release();
+            half_valid = false;
+            half_n = 0;
+            half_failed_n = n;
+            mirror_alloc_failures += 1;
+            return false;
+        }
     }
     return half_valid;
+}
+
+void Index::prepare_flat(bool all_tiers) {
+    if (n == 0) return;
+    use_device();
+    WsLease ws(*this);
+    if (!mfma_supported((uint32_t)dim) || elem_u8) return;  // the exact scan needs nothing beyond the rows
+    bool first = false;
+    if (i8_defers_half() && n > 64) first = ensure_i8(*ws);
+    if (!first || all_tiers) first = ensure_half(*ws) || first;
+    if (!first || all_tiers) (void)ensure_tiled(*ws);
 }
 
 bool Index::ensure_rows_h(Workspace &ws) {
@@ -562,25 +622,26 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
     // the bytes of the small-batch kernel's -- 0.36 instead of 0.63 ms per pass at 1M x 960).
     const uint32_t kprime_h = std::max<uint32_t>(64, flat_half_kmul * ksel);
     const uint64_t hq = half_queries.load(), hr = half_redo.load();
-    const bool i8_first = allow_i8 && allow_half && kprime_min == 0 && flat_gemm_mode != 1 && (d_dk_hint ? i8_valid.load() : i8_applicable(ksel));
-    const bool half_wanted = !i8_first && allow_half && flat_half_mode != 1 && kprime_h <= 1024 && n > kprime_h &&
-                             (flat_half_mode == 2 || hq < 1024 || hr * 8 <= hq);
-    const bool half_ok = half_wanted && ensure_half(ws);
-    // First pass on the centred 8-bit mirror (k_gemm8.hip, L2Sqr): half the bytes of the fp16 pass again; its keys are lower
+    // First pass on the centred 8-bit mirror (k_gemm8.hip): half the bytes of the fp16 pass again; its keys are lower
     // bounds of the distances, its exact stage walks the hit list until the k-th distance is below the next bound
     // (k_flat_tail_lb).  What it cannot close in flat_i8_kprime rows goes through this function again (fp16 pass next).
-    const bool i8 = i8_first;
+    // Every tier falls through to the next when its mirror cannot be allocated (ensure_*: false).
+    const bool i8_first = allow_i8 && allow_half && kprime_min == 0 && flat_gemm_mode != 1 && (d_dk_hint ? i8_valid.load() : i8_applicable(ksel));
+    const bool i8 = i8_first && ensure_i8(ws);
+    const bool half_wanted = !i8 && allow_half && flat_half_mode != 1 && kprime_h <= 1024 && n > kprime_h &&
+                             (flat_half_mode == 2 || hq < 1024 || hr * 8 <= hq);
+    const bool half_ok = half_wanted && ensure_half(ws);
     const bool gemm = i8 || flat_gemm_mode == 2 || (flat_gemm_mode == 0 && (nq > 64 || half_ok));
     const bool half = !i8 && half_ok && gemm;
     if (half) kprime = kprime_h;
     constexpr uint32_t CAND_CAP = 8192;
     const bool i8_second = i8 && d_dk_hint != nullptr;
-    if (i8) {
-        kprime = i8_second ? CAND_CAP : flat_i8_kprime;  // (second attempt: the exact stage may walk the whole candidate list)
-        ensure_i8(ws);
-    }
-    if (!half && !i8) ensure_tiled(ws);
+    if (i8) kprime = i8_second ? CAND_CAP : flat_i8_kprime;  // (second attempt: the exact stage may walk the whole candidate list)
     if (!half && !i8) launch_row_sqnorm(d_q, nq, (uint32_t)dim, ws.qsq.as<float>(), s);  // (the fp16 / 8-bit passes: k_query_prep_*)
+    if (!half && !i8 && !ensure_tiled(ws)) {  // no mirror at all: the strict-order scan over the rows themselves
+        flat_exact_device(ws, d_q, ws.qsq.as<float>(), nq, ksel, k, d_idx, d_dist, d_cnt);
+        return;
+    }
     const uint32_t capp = topk_capacity(i8 ? 64u : kprime);  // (8-bit pass: only its sample's lists -- rank <= 64 -- use these buffers)
     const uint32_t capk = topk_capacity(ksel);
     const uint64_t gq = gemm_group();
@@ -850,7 +911,7 @@ void Index::flat_debug_keys(Workspace &ws, const float *d_q, uint64_t nq, int ti
     const uint64_t gq = gemm_group(), ngroups = (nq + gq - 1) / gq, nq_pad = ngroups * gq;
     if (tier == 2) {  // 8-bit operands: keys are lower bounds, D >= key + qoff (h_qerr = qoff; h_dx = l1, l2, |mu|, 0)
         VDB_REQUIRE(!elem_u8 && (dim & 3) == 0 && gemm8_supported((uint32_t)dim), "debug keys: the index has no 8-bit pass");
-        ensure_i8(ws);
+        VDB_REQUIRE(ensure_i8(ws), "debug keys: the 8-bit mirror could not be allocated");
         const uint64_t n_s8 = gemm8_sample_rows(n, 1), ld8 = (n_s8 + 63) & ~63ull;
         ws.qsq.reserve(nq_pad * sizeof(float));
         ws.qfrag_g.reserve(nq_pad * size_t(mfma_dim_pad((uint32_t)dim)));
@@ -876,7 +937,7 @@ void Index::flat_debug_keys(Workspace &ws, const float *d_q, uint64_t nq, int ti
     }
     const bool half = tier == 0;
     VDB_REQUIRE(!half || ensure_half(ws), "debug keys: the index holds no fp16 mirror");
-    if (!half) ensure_tiled(ws);
+    if (!half) VDB_REQUIRE(ensure_tiled(ws), "debug keys: the split-bf16 mirror could not be allocated");
     const uint64_t n_s = gemm_sample_rows(n, 1), ld = (n_s + 63) & ~63ull;
     ws.qsq.reserve(nq_pad * sizeof(float));
     ws.qfrag_g.reserve(nq_pad * size_t(mfma_dim_pad((uint32_t)dim)) * sizeof(float));

@@ -27,6 +27,11 @@ inline bool devbuf_efence() {
     }();
     return on;
 }
+// (testing aid) every DevBuf allocation of at least this many bytes fails as if the device were out of memory; 0 = off
+inline std::atomic<size_t> &devbuf_fail_over() {
+    static std::atomic<size_t> v{0};
+    return v;
+}
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -40,15 +45,24 @@ struct DevBuf {
         p = base = nullptr;
         cap = 0;
     }
+    static void dev_malloc(void **out, size_t bytes) {
+        const size_t lim = devbuf_fail_over().load();
+        hipError_t e = (lim && bytes >= lim) ? hipErrorOutOfMemory : hipMalloc(out, bytes);
+        if (e == hipErrorOutOfMemory) {
+            (void)hipGetLastError();  // (not sticky, but the slot is read by the next VDB_SYNC)
+            throw AllocError("device allocation of " + std::to_string(bytes) + " bytes failed: out of memory");
+        }
+        VDB_HIP(e);
+    }
     static void alloc(size_t want, void **base_out, void **p_out) {
         if (!devbuf_efence()) {
-            VDB_HIP(hipMalloc(base_out, want));
+            dev_malloc(base_out, want);
             *p_out = *base_out;
             return;
         }
         constexpr size_t G = size_t(2) << 20;
         const size_t total = (want + G - 1) / G * G;
-        VDB_HIP(hipMalloc(base_out, total));
+        dev_malloc(base_out, total);
         *p_out = static_cast<char *>(*base_out) + ((total - want) & ~size_t(255));
     }
     // contents are NOT preserved
@@ -229,7 +243,10 @@ struct Index {
     DevBuf d_tiled;
     std::atomic<bool> tiled_built{false};  // d_tiled covers rows [0, n); kept in step by add_rows / swap_remove once built
     std::mutex tiled_mu;            // read-side calls are re-entrant: one of them builds, the others wait
-    void ensure_tiled(Workspace &ws);
+    bool ensure_tiled(Workspace &ws);  // false: the split-bf16 mirror could not be allocated (the exact scan answers)
+    uint64_t tiled_failed_n = ~0ull, half_failed_n = ~0ull, i8_failed_n = ~0ull;  // row count at which a mirror's allocation failed (not retried until it changes)
+    std::atomic<uint64_t> mirror_alloc_failures{0};
+    void prepare_flat(bool all_tiers);  // builds now what the first Flat search would build (vdb_index_prepare)
     uint64_t hbm_bytes_per_row() const;  // resident bytes per row over all per-row buffers (rows, norms, mirrors, codes, links)
     // scaled fp16 mirror for k_flat_gemm<GEMM_F16> (k_half.hip): rows stored as fp16(x * 2^(13 - half_exp)), every row
     // norm < 2^half_exp; half_dx_* = measured rounding error of the mirror (max |dx_r|, max |dx_r| / |x_r|)
@@ -270,7 +287,8 @@ struct Index {
     std::atomic<uint64_t> i8_rows_walked{0};          // (measurement) not maintained in production
     std::mutex i8_mu;
     bool i8_applicable(uint32_t ksel) const;
-    void ensure_i8(Workspace &ws);
+    bool ensure_i8(Workspace &ws);  // false: the mirror could not be allocated (the next tier answers)
+    void ensure_i8_locked(Workspace &ws);
     // Row-major fp16 image of the rows, same scale and rounding as d_tiled_h (so half_dx_* bound its error as well): the
     // operand of the HNSW walk's certified pre-pass (hnsw.hip, hnsw_half_dots).  Built on the first walk that wants it,
     // extended when rows were added since, rebuilt when the scale changed.

@@ -278,6 +278,10 @@ class GpuIndex:
                                                   _ptr(qsq, L.f32p), _ptr(qerr, L.f32p), _ptr(dx, L.f32p)))
         return keys, qsq, qerr, {"dx_abs": float(dx[0]), "dx_rel": float(dx[1]), "xsq_max": float(dx[2]), "xsq_min_pos": float(dx[3])}
 
+    def prepare(self, all_tiers: bool = False):
+        """build now the operand mirrors the first Flat search would build (vdb_index_prepare); all_tiers: those of the redo tiers too"""
+        L.check(self._lib.vdb_index_prepare(self._h, 1 if all_tiers else 0))
+
     def set_flat_mode(self, mode: int):
         L.check(self._lib.vdb_flat_set_mode(self._h, int(mode)))
 
