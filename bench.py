@@ -170,13 +170,18 @@ def hbm_roofline(kernel, p, extra=None):
 def pmc_traffic(kernel, rows, dim, nq):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this very command (profiles/
     r03_pmc_traffic.json: counters cannot be collected inside a timed run) -- only for the workload they were collected on"""
-    try:
-        e = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"))).get(kernel)
-    except (OSError, ValueError):
+    e = src = None
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):  # the latest passes that hold this kernel
+        try:
+            e = json.load(open(os.path.join(ROOT, "profiles", name))).get(kernel)
+        except (OSError, ValueError):
+            e = None
+        if e and e.get("workload") == {"rows": rows, "dim": dim, "queries_per_step": nq}:
+            src = name
+            break
+    if not src:
         return None
-    if not e or e.get("workload") != {"rows": rows, "dim": dim, "queries_per_step": nq}:
-        return None
-    return {"traffic": e["hbm_side_bytes"], "traffic_source": "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate "
+    return {"traffic": e["hbm_side_bytes"], "traffic_source": f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate "
                                                               "passes of `bench.py --legs none`, per launch; not collected in this run)"}
 
 

@@ -85,14 +85,14 @@ __device__ __forceinline__ float hnsw_exact_dist(const HnswDev &g, const float *
         const float4 *x4 = reinterpret_cast<const float4 *>(x);
         const float4 *q4 = reinterpret_cast<const float4 *>(qlds);
 #pragma unroll 8
-        for (uint32_t t = 0; t < g.dim / 4; t++) {
-            float4 v = x4[t];
-            float4 q = q4[t];
-            float p;
-            p = v.x * q.x; acc = acc + p;
-            p = v.y * q.y; acc = acc + p;
-            p = v.z * q.z; acc = acc + p;
-            p = v.w * q.w; acc = acc + p;
+        for (uint32_t t = 0; t < g.dim / 4; t++) {  // (products first, then the chain of adds: see hnsw_exact_dists_regs)
+            const float4 v = x4[t];
+            const float4 q = q4[t];
+            const float p0 = v.x * q.x, p1 = v.y * q.y, p2 = v.z * q.z, p3 = v.w * q.w;
+            acc = acc + p0;
+            acc = acc + p1;
+            acc = acc + p2;
+            acc = acc + p3;
         }
     } else {
         for (uint32_t t = 0; t < g.dim; t++) {
@@ -369,15 +369,25 @@ __device__ __forceinline__ float hnsw_exact_dists_regs(const HnswDev &g, const f
 #pragma unroll
             for (int k = 0; k < NG; k++) buf[in][k] = rp[k][Lr * 8];
             __builtin_amdgcn_sched_barrier(0);
+            // The chain is the 32 dependent adds of a line (10.9 cycles each: tools/fold_chain_probe.cpp); a multiply in front of every
+            // add -- what `p = v.x * q.x; a = a + p` compiles to, each add waiting for the multiply issued just before it -- made an
+            // element 15.6 cycles.  The products of a chunk are formed first, packed (2 x v_pk_mul_f32: the same IEEE products), one chunk
+            // ahead of their adds, so that they issue in the shadow of the previous chunk's adds: 11.9 cycles per element.
+            // The chain is the 32 dependent adds of a line (10.9 cycles each: tools/fold_chain_probe.cpp); a multiply in front of every
+            // add -- what `p = v.x * q.x; a = a + p` compiles to, each add waiting for the multiply issued just before it -- made an
+            // element 15.6 cycles.  The products of a chunk are formed first, packed (2 x v_pk_mul_f32: the same IEEE products), one chunk
+            // ahead of their adds: 11.9 cycles per element in the probe.  (Pinning the issue order further -- every LDS read and multiply
+            // behind one particular add, statement by statement -- measured 4.5 % SLOWER per call on the same box and was dropped.)
             float a = acc;
+            v4f pr = cur[0] * qv[0];
 #pragma unroll
             for (int c = 0; c < 8; c++) {
-                const v4f v = cur[c], qq = qv[c];
-                float p;
-                p = v.x * qq.x; a = a + p;
-                p = v.y * qq.y; a = a + p;
-                p = v.z * qq.z; a = a + p;
-                p = v.w * qq.w; a = a + p;
+                const v4f pc = pr;
+                if (c + 1 < 8) pr = cur[c + 1] * qv[c + 1];
+                a = a + pc.x;
+                a = a + pc.y;
+                a = a + pc.z;
+                a = a + pc.w;
                 cur[c] = *reinterpret_cast<const v4f *>(sb + off[c]);
                 qv[c] = q4[L1 * 8 + c];
                 __builtin_amdgcn_sched_barrier(0);
@@ -560,6 +570,9 @@ __global__ __launch_bounds__(64, 2) void k_hnsw_search(HnswDev g, const float *_
 #else
 #define HNSW_TICK(acc, t_prev)
 #endif
+    // (Round 4 tried a look-ahead here: the next pop is known before the inserts of an expansion -- the smaller of the pool's runner-up and
+    // the smallest new candidate -- so its link row and visited test-and-set can be requested under the inserts and the next pop scan.
+    // Correct, counters equal, and worth nothing: -1.5 % ... +2 % per call on the same box, profiles/r04_ab_hnsw_lookahead.txt.  Removed.)
     while (pool_n > 0 && !overflow) {
 #ifdef HNSW_STAMP
         unsigned long long t_prev = wall_clock64();
@@ -568,7 +581,8 @@ __global__ __launch_bounds__(64, 2) void k_hnsw_search(HnswDev g, const float *_
         // pop_first: smallest pair in the pool.  The same pass drops the pairs that can no longer be expanded (>= worst:
         // popping one of them would only end the walk, and only when nothing better is left), so the pool stays at the
         // few hundred live candidates instead of growing towards its capacity and being re-scanned every expansion.
-        uint64_t best = PAIR_NONE;
+        uint64_t best = PAIR_NONE;  // per lane: its smallest live pair and where the compaction put it
+        uint32_t best_pos = 0;
         {
             uint32_t kept = 0;
             for (uint32_t base = 0; base < pool_n; base += 64) {
@@ -580,26 +594,20 @@ __global__ __launch_bounds__(64, 2) void k_hnsw_search(HnswDev g, const float *_
                 __builtin_amdgcn_wave_barrier();
                 if (live) pool[kept + before] = v;  // kept + before <= i: never overwrites unread entries
                 __builtin_amdgcn_wave_barrier();
+                if (live && v < best) {
+                    best = v;
+                    best_pos = kept + before;
+                }
                 kept += __builtin_popcountll(mask);
-                best = live && v < best ? v : best;
             }
             pool_n = kept;
         }
+        const uint64_t mine = best;
         best = wave_min_u64(best);
         if (best == PAIR_NONE) break;  // check_candidate fails for everything left (size == ef and every pair >= worst)
-        // remove it (pairs are unique)
-        for (uint32_t base = 0; base < pool_n; base += 64) {
-            uint32_t i = base + lane;
-            bool hit = i < pool_n && pool[i] == best;
-            uint64_t mask = __ballot(hit);
-            if (mask) {
-                uint64_t lastv = pool[pool_n - 1];
-                __builtin_amdgcn_wave_barrier();
-                if (hit) pool[i] = lastv;
-                break;
-            }
-        }
-        pool_n--;
+        // remove it (pairs are unique): its slot is overwritten with PAIR_NONE, which the next scan drops like any pair >= worst
+        // (no second pass over the pool to find and move it, as rounds 1 - 3 had)
+        if (mine == best) pool[best_pos] = PAIR_NONE;
         n_exp++;
         HNSW_TICK(tk_pop, t_prev)
         const uint32_t p = uint32_t(best);

@@ -207,11 +207,13 @@ __global__ __launch_bounds__(256) void k_query_prep_h(const float *__restrict__ 
 #pragma unroll
                     for (int u = 0; u < 8; u++) v[u] = s4[i + u];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        qs = qs + v[u].x * v[u].x;
-                        qs = qs + v[u].y * v[u].y;
-                        qs = qs + v[u].z * v[u].z;
-                        qs = qs + v[u].w * v[u].w;
+                    for (int u = 0; u < 8; u++) {  // products first, then the chain of adds (a multiply in front of every add: 15.6 instead of 11.9
+                                                  // cycles per element, tools/fold_chain_probe.cpp); the same separately rounded values
+                        const float p0 = v[u].x * v[u].x, p1 = v[u].y * v[u].y, p2 = v[u].z * v[u].z, p3 = v[u].w * v[u].w;
+                        qs = qs + p0;
+                        qs = qs + p1;
+                        qs = qs + p2;
+                        qs = qs + p3;
                     }
                 }
                 j = i * 4;

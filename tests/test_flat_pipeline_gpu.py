@@ -46,7 +46,8 @@ def test_begin_end_equals_synchronous_call(n, dim, style):
     oi, od, oc = O.flat_knn_batch(base, batches[0][:16], k, 0, nthreads=8)
     assert np.array_equal(outs[0][0][:16].cpu().numpy().astype(np.uint64), oi) and np.array_equal(outs[0][1][:16].cpu().numpy(), od)
     if style == "clusters":
-        assert ix.get_stat("flat_i8_redo") + ix.get_stat("flat_half_redo") + ix.flat_fallback_count() > 0  # the redo paths ran inside _end
+        # the redo paths ran inside _end: the second 8-bit attempt (k_redo.hip) and / or the tiers behind it
+        assert ix.get_stat("flat_i8_second_queries") + ix.get_stat("flat_i8_redo") + ix.get_stat("flat_half_redo") + ix.flat_fallback_count() > 0
     with pytest.raises(vdb.VdbError):
         ix.flat_knn_device_end(None)
     ix.close()
