@@ -652,7 +652,11 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
     // (8-bit pass: planned for 64 guaranteed hits, ~1000 expected -- its exact stage takes tau itself as the bound of everything
     // outside the hit list, so a list shorter than flat_i8_kprime is no failure)
     mfma_sample_plan(n, i8 ? 64u : kprime, &s_step, &s_rank, i8 ? flat_i8_hits : 1024u);
-    const uint64_t n_s = i8 ? gemm8_sample_rows(n, s_step) : (gemm ? gemm_sample_rows(n, s_step) : mfma_sample_rows(n, s_step));
+    // 8-bit pass with many sampled units: the sample kernel hands the selection ONE value per (query, unit), the unit's smallest key --
+    // 48 x fewer values to write and select from (1M rows: 31 MB -> 0.65 MB per 1000 queries); k_gemm8.hip, launch_flat_gemm8_sample
+    const bool unit_min = i8 && flat_i8_unit_min != 1 && gemm8_sample_units(n, s_step) >= 16ull * s_rank;
+    const uint64_t n_s = i8 ? (unit_min ? gemm8_sample_units(n, s_step) : gemm8_sample_rows(n, s_step))
+                            : (gemm ? gemm_sample_rows(n, s_step) : mfma_sample_rows(n, s_step));
     const uint64_t ld_s = (n_s + 63) & ~63ull;
     const uint32_t nl_s = topk_num_lists(n_s);
     const size_t qf = mfma_qfrag_floats((uint32_t)dim);
@@ -695,7 +699,7 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
     } else {
         if (i8)
             launch_flat_gemm8_sample(d_tiled_i8.p, n, (uint32_t)dim, ws.qfrag_g.p, d_qscale, (uint32_t)ngroups, d_rowc_i8.as<float>(), s_step,
-                                     ws.dense.as<float>(), ld_s, num_cu, s);
+                                     ws.dense.as<float>(), ld_s, num_cu, s, unit_min ? 1 : 0);
         else if (gemm)  // the sample through the 128-query kernel too: same arithmetic as the filter, 4x fewer re-reads of the sample
             launch_flat_gemm_sample(xt, n, (uint32_t)dim, ws.qfrag_g.as<float>(), d_qmul, (uint32_t)ngroups,
                                     d_sq.as<float>(), cosine, s_step, ws.dense.as<float>(), ld_s, num_cu, s);

@@ -40,7 +40,8 @@ struct Gemm8Args {
     uint64_t n;
     uint32_t KB, n_units, ngroups;
     uint32_t unit_step;   // G8_SAMPLE: every unit_step-th unit is scored (n_units counts the sampled ones); else 1
-    float *out;           // G8_SAMPLE: dense keys out[q*ld + v*16*TW + row in unit] (+inf past n)
+    float *out;           // G8_SAMPLE: dense keys out[q*ld + v*16*TW + row in unit] (+inf past n); unit_min: out[q*ld + v] = the unit's smallest key
+    uint32_t unit_min;    // G8_SAMPLE: 1 = one value per (query, sampled unit) instead of one per row (see launch_flat_gemm8_sample)
     uint64_t ld;
     const float *tau;     // [ngroups*128]
     uint64_t *cand;       // [ngroups*128][cap]
@@ -414,6 +415,9 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
                 }
                 stage_n = 0;
             };
+            float umin[NH];  // (G8_SAMPLE with unit_min)
+#pragma unroll
+            for (int h = 0; h < NH; h++) umin[h] = INFINITY;
 #pragma unroll
             for (int t = 0; t < TW; t++) {
                 const float4 c4 = *reinterpret_cast<const float4 *>(&c_s[wave * 64 + t * 16 + 4 * g4]);
@@ -434,6 +438,13 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
                     p01 *= sq2;
                     p23 *= sq2;
                     const f32x2 k01 = __builtin_elementwise_fma(p01, m01, c01), k23 = __builtin_elementwise_fma(p23, m23, c23);
+                    if (MODE == G8_SAMPLE && a.unit_min) {  // (wave-uniform) the running minimum of this lane's query of half h over the unit's rows
+                        float m4;
+                        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m4) : "v"(rb32 + 0 < n ? k01.x : INFINITY), "v"(rb32 + 1 < n ? k01.y : INFINITY),
+                            "v"(rb32 + 2 < n ? k23.x : INFINITY));
+                        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(umin[h]) : "v"(m4), "v"(rb32 + 3 < n ? k23.y : INFINITY), "v"(umin[h]));
+                        continue;
+                    }
                     if (MODE == G8_SAMPLE) {
                         if (u_raw < a.n_units) {  // wave-uniform: waves past the last sampled unit write nothing
                             float4 kv;
@@ -465,6 +476,17 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
                         }
                         stage_n += np;
                     }
+                }
+            }
+            if (MODE == G8_SAMPLE && a.unit_min && u_raw < a.n_units) {
+                // the four lanes r, r + 16, r + 32, r + 48 hold the same query's rows 4 g4 .. 4 g4 + 3 of every tile: one minimum per query
+                // (v_min ignores a NaN operand: NaN keys never set a threshold, as they never pass one)
+#pragma unroll
+                for (int h = 0; h < NH; h++) {
+                    float m = umin[h];
+                    m = fminf(m, __shfl_xor(m, 16));
+                    m = fminf(m, __shfl_xor(m, 32));
+                    if (g4 == 0) a.out[(uint64_t(grp) * G8_BQ + h * 16 + r) * a.ld + u_raw] = m;
                 }
             }
             if (MODE == G8_FILTER && stage_n) drain();  // once per unit
@@ -670,15 +692,25 @@ uint64_t gemm8_sample_rows(uint64_t n, uint32_t unit_step) {
     return (units + unit_step - 1) / unit_step * (16 * G8_TW);
 }
 // dense keys of the sample for every query of every group: out[q*ld + j], j < gemm8_sample_rows(n, unit_step), +inf past n
+// unit_min: one value per (query, sampled unit) -- the smallest key of the unit's 48 rows -- instead of one per row: out[q*ld + v],
+// v < gemm8_sample_units(n, unit_step).  The r-th smallest of these minima is >= the r-th smallest sampled key (so a threshold taken from
+// it lets at least as many rows through: the sample plan's guarantee stands) and equals it unless two of the r smallest rows share a
+// unit (r (r - 1) / 2 in n_units: the caller uses it when the units are many); the selection then reads 48 x fewer values.
+uint64_t gemm8_sample_units(uint64_t n, uint32_t unit_step) {
+    const uint64_t units = ((n + 15) / 16 + G8_TW - 1) / G8_TW;
+    return (units + unit_step - 1) / unit_step;
+}
 void launch_flat_gemm8_sample(const void *XT, uint64_t n, uint32_t dim, const void *qfrag, const float *qscale, uint32_t ngroups,
-                              const float *rowc, uint32_t unit_step, float *out, uint64_t ld, int num_cu, hipStream_t s) {
+                              const float *rowc, uint32_t unit_step, float *out, uint64_t ld, int num_cu, hipStream_t s, int unit_min) {
     if (n == 0 || ngroups == 0) return;
-    VDB_REQUIRE(unit_step >= 1 && (ld & 3) == 0 && ld >= gemm8_sample_rows(n, unit_step), "flat_gemm8: ld must cover the sample");
+    VDB_REQUIRE(unit_step >= 1 && (ld & 3) == 0 && ld >= (unit_min ? gemm8_sample_units(n, unit_step) : gemm8_sample_rows(n, unit_step)),
+                "flat_gemm8: ld must cover the sample");
     VDB_REQUIRE(ngroups <= 65535, "flat_gemm8: too many query groups");
     Gemm8Args a = gemm8_args(XT, n, dim, qfrag, qscale, ngroups, rowc);
     a.unit_step = unit_step;
     a.out = out;
     a.ld = ld;
+    a.unit_min = unit_min ? 1u : 0u;
     flat_gemm8_dispatch<G8_SAMPLE>(a, num_cu, s);
 }
 

@@ -287,9 +287,50 @@ __global__ __launch_bounds__(256) void k_select_tau_small(const float *__restric
     }
 }
 
+// A short sample and a small rank (the unit minima of the 8-bit pass: ~160 values, rank 8): one wave per query holds the keys in
+// registers (up to 8 per lane, as (value, position) pairs so that equal values are distinct) and takes the smallest kth times.
+__global__ __launch_bounds__(256) void k_select_tau_tiny(const float *__restrict__ keys, uint64_t ld, uint32_t n, uint32_t kth,
+                                                         uint32_t nq_real, uint32_t nq, float *__restrict__ tau) {
+    const uint32_t lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    if (q >= nq_real) {  // padding query of a batch: let nothing through (see Index::flat_knn_device)
+        if (lane == 0) tau[q] = -INFINITY;
+        return;
+    }
+    uint64_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t i = j * 64 + lane;
+        v[j] = i < n ? pair_key(keys[uint64_t(q) * ld + i], i) : PAIR_NONE;  // (NaN keys order last, as in the other selections)
+    }
+    uint64_t last = 0, cur = PAIR_NONE;
+    for (uint32_t it = 0; it < kth; it++) {  // the smallest pair above the previous one
+        uint64_t m = PAIR_NONE;
+#pragma unroll
+        for (int j = 0; j < 8; j++) m = (v[j] > last || it == 0) && v[j] < m ? v[j] : m;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const uint64_t o = __shfl_xor(m, off);
+            m = o < m ? o : m;
+        }
+        cur = m;
+        if (m == PAIR_NONE) break;
+        last = m;
+    }
+    if (lane == 0) {
+        const float t = cur == PAIR_NONE ? INFINITY : f32_from_orderable(uint32_t(cur >> 32));
+        tau[q] = t == t ? t : INFINITY;  // fewer than kth finite keys -> +inf (a NaN key in rank: likewise)
+    }
+}
+
 void launch_select_tau(const float *keys, uint64_t ld, uint32_t n, uint32_t nq, uint32_t nq_real, uint32_t kth, float *tau,
                        hipStream_t s) {
     if (nq == 0) return;
+    if (kth >= 1 && kth <= 64 && n <= 512) {
+        hipLaunchKernelGGL(k_select_tau_tiny, dim3((nq + 3) / 4), dim3(256), 0, s, keys, ld, n, kth, nq_real, nq, tau);
+        VDB_HIP(hipGetLastError());
+        return;
+    }
     if (kth >= 1 && kth <= 64 && n >= 4 * 512) {  // small rank in a long sample: the subset bound
         hipLaunchKernelGGL(k_select_tau_small, dim3(nq), dim3(256), 0, s, keys, ld, n, kth, nq_real, tau);
         VDB_HIP(hipGetLastError());

@@ -236,7 +236,8 @@ void launch_flat_gemm8_filter(const void *XT, uint64_t n, uint32_t dim, const vo
                               const float *rowc, const float *tau, uint64_t *cand, uint32_t *cnt, uint32_t cap, int debug, int num_cu,
                               hipStream_t s, uint32_t hits_expected = 0);
 void launch_flat_gemm8_sample(const void *XT, uint64_t n, uint32_t dim, const void *qfrag, const float *qscale, uint32_t ngroups,
-                              const float *rowc, uint32_t unit_step, float *out, uint64_t ld, int num_cu, hipStream_t s);
+                              const float *rowc, uint32_t unit_step, float *out, uint64_t ld, int num_cu, hipStream_t s, int unit_min = 0);
+uint64_t gemm8_sample_units(uint64_t n, uint32_t unit_step);
 // xsq_cos != null / cosine != 0: the Cosine form -- unit rows / unit queries (k_i8.hip); xsq_cos = the rows' cached strict-fold |x|^2
 void launch_i8_col_mean(const float *X, uint64_t n, uint32_t dim, float *part /* I8_MEAN_CHUNKS * dim */, float *mu, hipStream_t s,
                         const float *xsq_cos = nullptr);
