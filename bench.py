@@ -372,6 +372,7 @@ def main():
                          "latent factor, for informative ANN recall; clustered = 1024 Gaussian clusters (--cluster-spread x sigma inside); "
                          "neardup = gistlike with 1 %% near-duplicate rows in groups of 20")
     ap.add_argument("--cluster-spread", type=float, default=0.15, help="--data clustered: noise inside a cluster in units of the per-dimension sigma")
+    ap.add_argument("--pq-bits", type=int, choices=[4, 8], default=4, help="pq_flat / hnsw_pq: bits per code (8: 256 centroids per group, pq_table.rs:142-145)")
     ap.add_argument("--mode", type=int, default=0, help="flat mode: 0 auto, 1 exact scan, 2 MFMA forced")
     ap.add_argument("--half", type=int, default=0, help="flat: fp16 first pass of large query batches: 0 auto, 1 off, 2 forced")
     ap.add_argument("--i8", type=int, default=0, help="flat (L2Sqr): 8-bit first pass: 0 auto, 1 off, 2 forced")
@@ -511,11 +512,11 @@ def main():
         # trains on the same first 10000 rows (same seed) -> identical centroids; codes are encoded per shard on the GPU.
         m = dim // 3
         tr = vdb.GpuIndex(dim, args.dist, device=local_rank)
-        tr.add_device(base.data_ptr(), min(n, 10000))
-        tr.pq_build(n_bits=4, m=m, train_n=0, max_iter=20, tol=1e-6, seed=42)
+        tr.add_device(base.data_ptr(), min(n, 10000 if args.pq_bits == 4 else 20000))
+        tr.pq_build(n_bits=args.pq_bits, m=m, train_n=0, max_iter=20 if args.pq_bits == 4 else 5, tol=1e-6, seed=42)
         cent = tr.pq_export()["centroids"]
         del tr
-        ix.pq_attach(4, m, cent, None)
+        ix.pq_attach(args.pq_bits, m, cent, None)
     if wl == "ivf":
         # IVFIndex::from_vec_set (ivf_index.rs:66-118): sqrt(N) clusters, k-means on 10000 sampled rows, 10 iterations
         t_b = time.perf_counter()
@@ -724,7 +725,7 @@ def main():
         np.savez(args.dump, idx=res[0].cpu().numpy(), dist=res[1].cpu().numpy(), cnt=res[2].cpu().numpy())
     qps = nq * args.steps / elapsed
     dname = "L2Sqr" if args.dist == "l2sqr" else "Cosine"
-    names = {"flat": ("Flat brute force", "flat_knn_gist1m"), "pq_flat": (f"PQ-Flat 4-bit m={dim // 3}, ADC ef={ef}", "pq_flat_knn_gist1m"),
+    names = {"flat": ("Flat brute force", "flat_knn_gist1m"), "pq_flat": (f"PQ-Flat {args.pq_bits}-bit m={dim // 3}, ADC ef={ef}", "pq_flat_knn_gist1m" + ("_8bit" if args.pq_bits == 8 else "")),
              "hnsw": (f"HNSW M=16 efc=200, ef={ef}", f"hnsw_knn_gistlike_{n}"),
              "hnsw_pq": (f"HNSW M=16 efc=200 + PQ 4-bit m={dim // 3}, ef={ef}", f"hnsw_pq_knn_gistlike_{n}"),
              "ivf": (f"IVF {int(round(n ** 0.5))} clusters, n_probes={ef}", f"ivf_knn_gistlike_{n}")}[wl]

@@ -498,6 +498,8 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         pq_set_adc16_sample((int)value);
     else if (n == "pq_adc16")
         pq_set_adc16((int)value);
+    else if (n == "pq_adc8_sliced")  // 8-bit codes: 0 = eight queries per pass on sliced 16-bit tables (k_pq_adc16x8), 1 = one query per pass
+        pq_set_adc8_sliced((int)value);
     else if (n == "flat_sample_thin")
         mfma_set_sample_thin((int)value);
     else if (n == "flat_gemm_tw")

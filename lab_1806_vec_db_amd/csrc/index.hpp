@@ -104,6 +104,7 @@ struct ProfEntry {
 struct Workspace {
     hipStream_t stream = nullptr;
     DevBuf q, qsq, qfrag, qfrag_g, qaux, dense, lists, keys_a, keys_b, keys_c, flags, out_idx, out_dist, out_cnt, lut, misc;
+    DevBuf pq_img16, pq_aux16;     // 8-bit PQ codes: the sliced 16-bit table images of a round of queries, their minima / offsets / steps (pq.hip)
     DevBuf small_part, small_cnt;  // k_flat_small: per-workgroup key lists, arrival counters (zero between launches)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     struct Pending {

@@ -85,6 +85,8 @@ static std::atomic<int> g_adc_fast{1};
 void pq_set_adc_fast(int v) { g_adc_fast = v; }
 static std::atomic<int> g_adc16_sample{0};  // threshold sample on the quantised tables (L2Sqr): 0 auto (on with the quantised scan), 1 off (f32 sample)
 void pq_set_adc16_sample(int v) { g_adc16_sample = v; }
+static std::atomic<int> g_adc8_sliced{0};  // 8-bit codes: 0 = eight queries per pass on sliced 16-bit tables (k_pq_adc16x8), 1 = one query per pass on a byte table (k_pq_adc8)
+void pq_set_adc8_sliced(int v) { g_adc8_sliced = v; }
 static std::atomic<int> g_adc16{0};  // quantised first pass of the threshold-filter scan: 0 auto (4-bit, L2Sqr, 16-B code words), 1 off
 void pq_set_adc16(int v) { g_adc16 = v; }
 constexpr uint32_t ADC_WGBUF = 2048;  // LDS hit buffer entries per workgroup (MODE 1)
@@ -1025,6 +1027,235 @@ __global__ __launch_bounds__(1024) void k_pq_adc8(Adc8Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 8-bit codes, EIGHT queries per pass (round 4).  k_pq_adc8 above reads the whole code mirror once per QUERY (one byte table per query
+// fills the LDS): 320 GB of code bytes per 1000 queries at 1M rows, m = 320 -- 44 ms.  The 4-bit scan's scheme (k_pq_adc16: 16-bit
+// entries, 8 queries side by side in a 16-B LDS entry, one ds_read_b128 per (row, group) for all eight) needs 256 entries x 16 B = 4 KB
+// per group here, 1.3 MB for the table of 8 queries: it does not fit.  So the table is cut into SLICES of 32 groups (128 KB, two 16-B
+// code words of a row): a workgroup keeps 4 rows per thread (4096 rows), and for every slice loads the slice of the image into LDS and
+// adds the slice's 32 lookups to the rows' eight packed 16-bit sums, which stay in registers across the slices.  The image of a query
+// group is re-read from L2 by every workgroup (1.3 MB against the 1.3 MB of code bytes of its 4096 rows), the code mirror once per 8
+// queries.  Same quantisation and the same superset proof as k_pq_adc16 (entries floor((lut - mn_g) / D), D = sum of ranges / 65000:
+// M + D S16 <= the reference's f32 sum up to its gamma_m, so S <= tau implies S16 <= T16); the candidates' exact f32 sums, the
+// (adc, idx) order and the re-rank are k_pq_adc_exact8's and the merge's, unchanged.  L2Sqr tables (as the one-byte scan).
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t ADC16X8_RPT = 4;       // rows per thread
+constexpr uint32_t ADC16X8_GS = 32;       // groups per slice (two 16-B code words)
+constexpr uint32_t ADC16X8_WGBUF = 2048;  // LDS hit buffer entries per workgroup
+
+// per query: the minimum of every group's 256 table entries (mn[q][g]), M = their sum, D = sum of the ranges / 65000
+__global__ __launch_bounds__(256) void k_pq_quant16x8_stats(const float *__restrict__ lut, uint32_t m, uint32_t nq, float *__restrict__ mn_out,
+                                                            double *__restrict__ qM, double *__restrict__ qD, uint32_t *__restrict__ qflag) {
+    const uint32_t q = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    __shared__ double sR[4], sM[4];
+    __shared__ uint32_t sbad;
+    if (t == 0) sbad = 0;
+    __syncthreads();
+    const float *lq = lut + uint64_t(q) * m * 256;
+    double R = 0.0, M = 0.0;
+    bool bad = false;
+    for (uint32_t g = wave; g < m; g += 4) {  // a wave per group: 4 entries per lane
+        const float4 e = reinterpret_cast<const float4 *>(lq + uint64_t(g) * 256)[lane];
+        const float v[4] = {e.x, e.y, e.z, e.w};
+        float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (!(v[j] >= 0.0f) || v[j] > 3.0e38f) bad = true;  // NaN, negative, inf: the query takes the f32 scan
+            mn = fminf(mn, v[j]);
+            mx = fmaxf(mx, v[j]);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            mn = fminf(mn, __shfl_xor(mn, off));
+            mx = fmaxf(mx, __shfl_xor(mx, off));
+        }
+        if (lane == 0) {
+            mn_out[uint64_t(q) * m + g] = mn;
+            R += double(mx) - double(mn);
+            M += double(mn);
+        }
+    }
+    if (__ballot(bad) != 0 && lane == 0) atomicOr(&sbad, 1u);
+    if (lane == 0) {
+        sR[wave] = R;
+        sM[wave] = M;
+    }
+    __syncthreads();
+    if (t == 0) {
+        R = (sR[0] + sR[1]) + (sR[2] + sR[3]);
+        M = (sM[0] + sM[1]) + (sM[2] + sM[3]);
+        const bool flag = sbad != 0 || !(R < 1.0e300) || !(fabs(M) < 1.0e300);
+        qM[q] = M;
+        qD[q] = (!flag && R > 0.0) ? R / 65000.0 : 1.0;
+        qflag[q] = flag ? 1u : 0u;
+    }
+}
+// the image: img[(grp * m_pad + g) * 256 + c] = 8 x u16, slot b = floor((lut[8 grp + b][g][c] - mn) / D) (0 for g >= m, for query slots
+// past nq and for flagged queries: padded code bytes select entry 0 of an all-zero group).  One thread per 16-B entry.
+__global__ __launch_bounds__(256) void k_pq_quant16x8_img(const float *__restrict__ lut, const float *__restrict__ mn, const double *__restrict__ qD,
+                                                          const uint32_t *__restrict__ qflag, uint32_t m, uint32_t m_pad, uint32_t nq,
+                                                          uint4 *__restrict__ img) {
+    const uint32_t grp = blockIdx.y, g = blockIdx.x, c = threadIdx.x;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    if (g < m) {
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint32_t q = grp * 8 + b;
+            if (q < nq && qflag[q] == 0) {
+                const double y = (double(lut[(uint64_t(q) * m + g) * 256 + c]) - double(mn[uint64_t(q) * m + g])) / qD[q];
+                double x = floor(y);
+                x = x < 0.0 ? 0.0 : (x > 65000.0 ? 65000.0 : x);  // (unreachable clamps: the sum of the maxima is <= 65000)
+                w[b >> 1] |= uint32_t(x) << (16 * (b & 1));
+            }
+        }
+    }
+    img[(uint64_t(grp) * m_pad + g) * 256 + c] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+struct Adc16x8Args {
+    const uint4 *codes_t;   // word-major mirror of the (zero-padded) code rows
+    uint64_t n;
+    uint32_t nwords, m;     // 16-B code words per row; groups of the table
+    uint32_t nslices;       // slices of 32 groups of the image (m_pad = 32 nslices)
+    const uint4 *img;       // [ngrp][m_pad * 256] 16-B entries
+    const double *qM, *qD;  // [nq] of the 16-bit quantisation
+    const uint32_t *qflag;
+    const float *tau;
+    uint32_t nq;
+    uint64_t rows_per_wg;   // multiple of 64
+    uint64_t *cand;         // [nq][cap] row ids
+    uint32_t *cnt;          // [nq]
+    uint32_t cap;
+};
+
+__global__ __launch_bounds__(1024) void k_pq_adc16x8(Adc16x8Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem168[];
+    constexpr uint32_t RPT = ADC16X8_RPT, GS = ADC16X8_GS;
+    uint4 *tab = reinterpret_cast<uint4 *>(smem168);                                   // [GS][256] entries of 8 x u16
+    uint32_t *hit_row = reinterpret_cast<uint32_t *>(smem168 + size_t(GS) * 256 * 16);  // [WGBUF]
+    uint32_t *hit_q = hit_row + ADC16X8_WGBUF;                                         // [WGBUF] slot | rank << 8
+    uint32_t *hit_n = hit_q + ADC16X8_WGBUF;                                           // [0] entries, [1..8] per-slot counts, [9..16] bases
+    int32_t *thr = reinterpret_cast<int32_t *>(hit_n + 20);                            // [8] T16 per slot (-1: unused / flagged)
+    const uint32_t tid = threadIdx.x, q0 = blockIdx.y * 8, m = a.m, nwords = a.nwords;
+    if (tid < 17) hit_n[tid] = 0;
+    if (tid < 8) {
+        int32_t T = -1;
+        const uint32_t q = q0 + tid;
+        if (q < a.nq && a.qflag[q] == 0) {
+            const double x = floor((double(a.tau[q]) * (1.0 + 2.0 * double(m) * 0x1p-24) - a.qM[q] * (1.0 - 1e-12)) / a.qD[q]) + 2.0;
+            // tau = +inf / NaN: everything passes -> the candidate list overflows and the query takes the f32 scan
+            T = !(x < 70000.0) ? 70000 : (x < 0.0 ? -1 : (int32_t)x);
+        }
+        thr[tid] = T;
+    }
+    __syncthreads();
+    int32_t T[8];
+#pragma unroll
+    for (int b = 0; b < 8; b++) T[b] = thr[b];
+    const uint4 *img = a.img + uint64_t(blockIdx.y) * a.nslices * GS * 256;
+    const uint64_t r_begin = uint64_t(blockIdx.x) * a.rows_per_wg;
+    const uint64_t r_end = r_begin + a.rows_per_wg < a.n ? r_begin + a.rows_per_wg : a.n;
+    for (uint64_t rb = r_begin; rb < r_end; rb += uint64_t(RPT) * 1024) {
+        uint32_t acc[RPT][4];
+        const uint4 *cw[RPT];
+        bool valid[RPT];
+#pragma unroll
+        for (int j = 0; j < (int)RPT; j++) {
+            acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0u;
+            const uint64_t row = rb + uint64_t(j) * 1024 + tid;
+            valid[j] = row < r_end;
+            const uint64_t lrow = valid[j] ? row : r_end - 1;  // (idle lanes re-read a valid row: see k_pq_adc16)
+            cw[j] = a.codes_t + (lrow >> 6) * nwords * 64 + (lrow & 63);
+        }
+        for (uint32_t sl = 0; sl < a.nslices; sl++) {
+            __syncthreads();  // the previous slice's readers are done
+            {
+                const uint4 *src = img + uint64_t(sl) * GS * 256;
+#pragma unroll
+                for (int i = 0; i < 8; i++) tab[i * 1024 + tid] = src[i * 1024 + tid];
+            }
+            // the slice's two code words of the thread's rows (zero words past the mirror's last: entry 0 of an all-zero group)
+            uint4 c0[RPT], c1[RPT];
+            const uint32_t w0 = 2 * sl, w1 = 2 * sl + 1;
+#pragma unroll
+            for (int j = 0; j < (int)RPT; j++) {
+                c0[j] = w0 < nwords ? cw[j][w0 * 64] : make_uint4(0u, 0u, 0u, 0u);
+                c1[j] = w1 < nwords ? cw[j][w1 * 64] : make_uint4(0u, 0u, 0u, 0u);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < (int)RPT; j++) {
+                const uint32_t words[8] = {c0[j].x, c0[j].y, c0[j].z, c0[j].w, c1[j].x, c1[j].y, c1[j].z, c1[j].w};
+                uint32_t a0 = acc[j][0], a1 = acc[j][1], a2 = acc[j][2], a3 = acc[j][3];
+                // software pipeline over the 8 words: the four lookups of word k + 1 are issued before the sums of word k are taken
+                uint4 E[2][4];
+                auto issue = [&](int k, uint4 *e) {
+#pragma unroll
+                    for (int b = 0; b < 4; b++) e[b] = tab[(4 * k + b) * 256 + ((words[k] >> (8 * b)) & 0xffu)];
+                };
+                issue(0, E[0]);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (k + 1 < 8) {
+                        issue(k + 1, E[(k + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks these reads below the adds of word k)
+                    }
+                    const uint4 *e = E[k & 1];
+                    a0 = a0 + e[0].x + e[1].x;
+                    a1 = a1 + e[0].y + e[1].y;
+                    a2 = a2 + e[0].z + e[1].z;
+                    a3 = a3 + e[0].w + e[1].w;
+                    a0 = a0 + e[2].x + e[3].x;
+                    a1 = a1 + e[2].y + e[3].y;
+                    a2 = a2 + e[2].z + e[3].z;
+                    a3 = a3 + e[2].w + e[3].w;
+                    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));  // (keeps the four running sums four: see k_pq_adc16)
+                }
+                acc[j][0] = a0;
+                acc[j][1] = a1;
+                acc[j][2] = a2;
+                acc[j][3] = a3;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < (int)RPT; j++) {
+            const int32_t s[8] = {int32_t(acc[j][0] & 0xffffu), int32_t(acc[j][0] >> 16), int32_t(acc[j][1] & 0xffffu), int32_t(acc[j][1] >> 16),
+                                  int32_t(acc[j][2] & 0xffffu), int32_t(acc[j][2] >> 16), int32_t(acc[j][3] & 0xffffu), int32_t(acc[j][3] >> 16)};
+            const uint32_t row = uint32_t(rb + uint64_t(j) * 1024 + tid);
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                if (valid[j] && s[b] <= T[b]) {
+                    const uint32_t pos = atomicAdd(hit_n, 1u);
+                    if (pos < ADC16X8_WGBUF) {
+                        hit_row[pos] = row;
+                        hit_q[pos] = b;
+                    } else {
+                        atomicAdd(&a.cnt[q0 + b], a.cap + 1);  // mark the query as overflowed (-> f32 scan)
+                    }
+                }
+            }
+        }
+        // hand the block's hits to the per-query candidate lists (one global atomic per query), leave an empty buffer
+        __syncthreads();
+        uint32_t total = hit_n[0];
+        if (total > ADC16X8_WGBUF) total = ADC16X8_WGBUF;
+        for (uint32_t i = tid; i < total; i += 1024) {
+            const uint32_t r_ = atomicAdd(&hit_n[1 + hit_q[i]], 1u);
+            hit_q[i] |= r_ << 8;
+        }
+        __syncthreads();
+        if (tid < 8 && hit_n[1 + tid] > 0) hit_n[9 + tid] = atomicAdd(&a.cnt[q0 + tid], hit_n[1 + tid]);
+        __syncthreads();
+        for (uint32_t i = tid; i < total; i += 1024) {
+            const uint32_t b = hit_q[i] & 0xffu, r_ = hit_q[i] >> 8;
+            const uint32_t slot = hit_n[9 + b] + r_;
+            if (slot < a.cap) a.cand[uint64_t(q0 + b) * a.cap + slot] = hit_row[i];
+        }
+        __syncthreads();
+        if (tid < 17) hit_n[tid] = 0;
+    }
+}
+
 // exact f32 ADC sums of the candidates of an 8-bit table, strict group order (pq_table.rs:254-292), the query's f32 table read
 // from global memory (327 KB at m = 320: L2-resident while its workgroup runs).  Row ids in, pair keys out (PAIR_NONE above tau).
 __global__ __launch_bounds__(256) void k_pq_adc_exact8(const uint8_t *__restrict__ codes, uint32_t enc_dim, uint32_t m, const float *__restrict__ lut,
@@ -1795,12 +2026,48 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
                 }
                 hipLaunchKernelGGL(k_pq_tau_from16, dim3((unsigned)((gn + 255) / 256)), dim3(256), 0, s, d_tau + g0, d_qM + g0, d_qD + g0, d_qflag + g0,
                                    (uint32_t)pq.m, (uint32_t)gn);
-                const uint32_t nwg = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ix.num_cu, (4ull * ix.num_cu + gn - 1) / gn));
-                a.rows_per_wg = ((n + nwg - 1) / nwg + 63) / 64 * 64;
-                const uint32_t nwg_eff = (uint32_t)((n + a.rows_per_wg - 1) / a.rows_per_wg);
-                ix.prof_begin(ws, "pq_adc", double(gn) * double(n) * pq.enc_dim);
-                hipLaunchKernelGGL(k_pq_adc8<false>, dim3(nwg_eff, (unsigned)gn), dim3(1024), lds8, s, a);
-                ix.prof_end(ws);
+                const uint32_t nsl = (uint32_t)((pq.m + ADC16X8_GS - 1) / ADC16X8_GS), m_pad16 = nsl * ADC16X8_GS;
+                const size_t lds168 = size_t(ADC16X8_GS) * 256 * 16 + size_t(ADC16X8_WGBUF) * 8 + (20 + 8) * 4 + 16;
+                if (g_adc8_sliced != 1 && lds168 <= 158 * 1024) {
+                    // eight queries per pass over the code mirror: 16-bit tables in slices of 32 groups (k_pq_adc16x8)
+                    const uint32_t ngrp = (uint32_t)((gn + 7) / 8);
+                    ws.pq_img16.reserve(size_t(ngrp) * m_pad16 * 256 * sizeof(uint4));
+                    ws.pq_aux16.reserve(gn * pq.m * sizeof(float) + gn * (2 * sizeof(double) + sizeof(uint32_t)) + 64);
+                    double *qM16 = ws.pq_aux16.as<double>(), *qD16 = qM16 + gn;
+                    uint32_t *qf16 = reinterpret_cast<uint32_t *>(qD16 + gn);
+                    float *mn16 = reinterpret_cast<float *>(qf16 + ((gn + 3) & ~uint64_t(3)));
+                    const float *lutg = ws.lut.as<float>() + g0 * lsz;
+                    hipLaunchKernelGGL(k_pq_quant16x8_stats, dim3((unsigned)gn), dim3(256), 0, s, lutg, (uint32_t)pq.m, (uint32_t)gn, mn16, qM16, qD16, qf16);
+                    hipLaunchKernelGGL(k_pq_quant16x8_img, dim3(m_pad16, ngrp), dim3(256), 0, s, lutg, mn16, qD16, qf16, (uint32_t)pq.m, m_pad16,
+                                       (uint32_t)gn, ws.pq_img16.as<uint4>());
+                    Adc16x8Args b{};
+                    b.codes_t = pq.d_codes_t.as<uint4>();
+                    b.n = n;
+                    b.nwords = nw8;
+                    b.m = (uint32_t)pq.m;
+                    b.nslices = nsl;
+                    b.img = ws.pq_img16.as<uint4>();
+                    b.qM = qM16;
+                    b.qD = qD16;
+                    b.qflag = qf16;
+                    b.tau = d_tau + g0;
+                    b.nq = (uint32_t)gn;
+                    b.rows_per_wg = uint64_t(ADC16X8_RPT) * 1024;  // one block of rows per workgroup: every slice of the image is loaded once
+                    b.cand = ws.lists.as<uint64_t>();
+                    b.cnt = d_hits + g0;
+                    b.cap = cap;
+                    func_max_lds(reinterpret_cast<const void *>(&k_pq_adc16x8), int(160 * 1024));
+                    ix.prof_begin(ws, "pq_adc", double(ngrp) * double(n) * pq.enc_dim);
+                    hipLaunchKernelGGL(k_pq_adc16x8, dim3((unsigned)((n + b.rows_per_wg - 1) / b.rows_per_wg), ngrp), dim3(1024), lds168, s, b);
+                    ix.prof_end(ws);
+                } else {
+                    const uint32_t nwg = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ix.num_cu, (4ull * ix.num_cu + gn - 1) / gn));
+                    a.rows_per_wg = ((n + nwg - 1) / nwg + 63) / 64 * 64;
+                    const uint32_t nwg_eff = (uint32_t)((n + a.rows_per_wg - 1) / a.rows_per_wg);
+                    ix.prof_begin(ws, "pq_adc", double(gn) * double(n) * pq.enc_dim);
+                    hipLaunchKernelGGL(k_pq_adc8<false>, dim3(nwg_eff, (unsigned)gn), dim3(1024), lds8, s, a);
+                    ix.prof_end(ws);
+                }
                 pq.adc16_queries += gn;
                 hipLaunchKernelGGL(k_pq_adc_exact8, dim3((unsigned)gn), dim3(256), 0, s, pq.d_codes.as<uint8_t>(), (uint32_t)pq.enc_dim, (uint32_t)pq.m,
                                    ws.lut.as<float>() + g0 * lsz, d_tau + g0, ws.lists.as<uint64_t>(), d_hits + g0, cap, d_valid + g0);

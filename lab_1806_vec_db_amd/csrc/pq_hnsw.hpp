@@ -12,6 +12,7 @@ void pq_build(Index &ix, uint64_t n_bits, uint64_t m, uint64_t train_n, uint64_t
 void pq_clear(Index &ix);
 void pq_set_adc_fast(int v);
 void pq_set_adc16(int v);
+void pq_set_adc8_sliced(int v);  // 8-bit codes: 0 = eight queries per pass on sliced 16-bit tables, 1 = one query per pass (byte table)
 void pq_set_adc16_sample(int v);  // threshold sample of the quantised scan on the quantised tables too: 0 auto, 1 off (f32 sample)  // quantised first pass of the ADC scan: 0 auto, 1 off
 void flat_knn_pq_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef,
                         uint64_t *d_idx, float *d_dist, uint64_t *d_cnt);

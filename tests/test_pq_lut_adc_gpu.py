@@ -202,10 +202,11 @@ def test_quantised_scan_with_padded_code_words(dim, m, dist, kind):
     ix.close()
 
 
-@pytest.mark.parametrize("dim,m", [(64, 16), (80, 20), (96, 33), (128, 64)])
+@pytest.mark.parametrize("dim,m", [(64, 16), (80, 20), (96, 33), (128, 64), (384, 96)])
 def test_quantised_scan_of_8_bit_codes(dim, m):
-    """n_bits = 8 (256 centroids per group, pq_table.rs:142-145) on its own quantised pass: one query per pass, a one-byte table in
-    LDS, exact f32 sums for the candidates (k_pq_adc8 / k_pq_adc_exact8).  Same answers as the f32 scan (pq_adc16 = 1) and as
+    """n_bits = 8 (256 centroids per group, pq_table.rs:142-145) on its own quantised passes: eight queries per pass on 16-bit tables cut
+    into slices of 32 groups (k_pq_adc16x8; whole and missing second code words of a slice, one and two slices) and one query per pass on a
+    one-byte table (k_pq_adc8), exact f32 sums for the candidates (k_pq_adc_exact8).  Same answers as the f32 scan (pq_adc16 = 1) and as
     the oracle, whole and padded code words, ties, a degenerate query; Cosine tables keep the f32 scan."""
     import lab_1806_vec_db_amd as vdb
     from oracle import oracle as O
@@ -214,7 +215,7 @@ def test_quantised_scan_of_8_bit_codes(dim, m):
     rng = np.random.default_rng(dim * 7 + m)
     base = (rng.standard_normal((n, dim)) * rng.uniform(0.2, 2.0, dim)).astype(np.float32)
     base[35000:35010] = base[:10]
-    qs = (base[rng.integers(0, n, 10)] + 0.1 * rng.standard_normal((10, dim))).astype(np.float32)
+    qs = (base[rng.integers(0, n, 19)] + 0.1 * rng.standard_normal((19, dim))).astype(np.float32)  # three query groups, the last with 3
     qs[3, 2] = np.nan  # unquantisable table -> the f32 scan answers that query
     for dist, kind in (("l2sqr", 0), ("cosine", 1)):
         ix = vdb.GpuIndex(dim, dist)
@@ -224,9 +225,16 @@ def test_quantised_scan_of_8_bit_codes(dim, m):
         opq = O.PQ.from_centroids(dim, m, 8, kind, pq["centroids"])
         opq.set_codes(pq["codes"])
         for ef in (100, 700):
-            a = ix.knn_pq(qs, 10, ef)
+            a = ix.knn_pq(qs, 10, ef)  # (eight queries per pass on sliced 16-bit tables: k_pq_adc16x8, round 4)
             ran = ix.get_stat("pq_adc16_queries")
             assert (ran > 0) == (kind == 0)
+            ix.set_param("pq_adc8_sliced", 1)  # one query per pass on a byte table (k_pq_adc8): the same candidates' exact sums
+            try:
+                a1 = ix.knn_pq(qs, 10, ef)
+            finally:
+                ix.set_param("pq_adc8_sliced", 0)
+            assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a, a1)), (dist, ef)
+            ran = ix.get_stat("pq_adc16_queries")
             ix.set_param("pq_adc16", 1)
             try:
                 b = ix.knn_pq(qs, 10, ef)
@@ -234,7 +242,7 @@ def test_quantised_scan_of_8_bit_codes(dim, m):
                 ix.set_param("pq_adc16", 0)
             assert ix.get_stat("pq_adc16_queries") == ran
             assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a, b)), (dist, ef)
-            for q in range(10):
+            for q in range(19):
                 oi, od = O.flat_knn_pq(base, opq, qs[q], 10, ef, kind)
                 assert a[0][q, :len(oi)].tolist() == oi.tolist(), (dist, ef, q)
                 assert np.array_equal(a[1][q, :len(od)], od, equal_nan=True)
