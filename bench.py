@@ -23,6 +23,7 @@ At N=1 (default flags) the same run also reports, under "legs", every other item
   flat_f32_operands  the same 1000-query step with the fp16 first pass switched off: the split-bf16 kernel streams the
                      4-B/element rows mirror, so ITS roofline is on N*d*4 bytes per corpus pass -- the figure the
                      ">= 70 % of HBM roofline" target is defined on
+  flat_cosine        the same 1000-query step under Cosine, the reference's default table distance (8-bit pass on unit rows)
   flat_B32, flat_B1  calls of 32 queries (SURVEY 8d's headline batch) and of 1 query
   config1_gist_1000  BASELINE config 1: the reference's own data/gist_1000.bin x data/gist_test.bin, Flat, L2Sqr, k=10,
                      GPU beside the CPU oracle serial and on all cores (protocol of examples/bench.rs:403-433)
@@ -808,6 +809,9 @@ def main():
         ix.close()
         del ix
         torch.cuda.empty_cache()
+        if args.dist == "l2sqr" and not from_file:
+            legs["flat_cosine"] = leg_flat_other_metric(vdb, O, torch, device, local_rank, timed, step_stats, queries, outs, args, n, dim, nq, k, host_base,
+                                                        threads, attainable, gen)
         legs["config1_gist_1000"] = leg_config1(vdb, O, torch, device, local_rank, threads, k)
         del host_base
         legs.update(legs_ann(vdb, O, torch, device, local_rank, timed, step_stats, args, threads, attainable, from_file))
@@ -936,6 +940,38 @@ def leg_flat_f32(ix, timed, step_stats, queries, nq, k, outs, args, n, dim, ref,
             "hbm_bytes_per_row": ix.get_stat("hbm_bytes_per_row")}
 
 
+def leg_flat_other_metric(vdb, O, torch, device, local_rank, timed, step_stats, queries, outs, args, n, dim, nq, k, host_base, threads, attainable, gen):
+    """the headline step under Cosine -- the reference's DEFAULT table distance (pyo3/mod.rs:73, distance/mod.rs:60-69): the same corpus
+    and queries, the 8-bit pass on unit rows; parity against the oracle's Cosine answers on a bounded sample (the CPU needs ~70 ms per query
+    and core for a Cosine scan of 1M x 960)"""
+    base = gen(torch, n, dim, 1806, device)
+    torch.cuda.synchronize()  # (the library copies the rows on its own stream)
+    cx = vdb.GpuIndex(dim, "cosine", device=local_rank)
+    cx.add_device(base.data_ptr(), n)
+    del base
+    torch.cuda.empty_cache()
+    fn = lambda: cx.flat_knn_device(queries.data_ptr(), nq, k, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr())  # noqa: E731
+    el, _ = timed(cx, fn, args.steps, max(1, args.warmup))
+    r = with_attainable(flat_roofline(cx, n, dim, nq), attainable)
+    leg = {"value": round(nq * args.steps / el, 1), "unit": "queries/s", "steps": args.steps, "ms_per_step": round(el / args.steps * 1e3, 3),
+           "step_ms": step_stats(), "queries_per_step": nq, "dist": "Cosine", "roofline": r,
+           "i8_pass": {"queries": cx.get_stat("flat_i8_queries"), "passed_on_to_fp16": cx.get_stat("flat_i8_redo")},
+           "hbm_bytes_per_row": cx.get_stat("hbm_bytes_per_row")}
+    if O is not None and host_base is not None:
+        ncpu = min(96, nq, max(args.cpu_queries, 0))
+        if ncpu:
+            t0 = time.perf_counter()
+            ci, cd, cc = O.flat_knn_batch(host_base, queries[:ncpu].cpu().numpy(), k, O.COSINE, nthreads=threads)
+            cpu_s = time.perf_counter() - t0
+            gi, gd = outs[0][:ncpu].cpu().numpy().astype(np.uint64), outs[1][:ncpu].cpu().numpy()
+            leg["parity"] = {"queries_checked": ncpu, "indices_identical": bool(np.array_equal(gi, ci)), "distances_bit_exact": bool(np.array_equal(gd, cd))}
+            leg["recall_at_10"] = float(np.mean([O.recall(ci[q], gi[q]) for q in range(ncpu)]))
+            leg["cpu_baseline"] = {"value": round(ncpu / cpu_s, 2), "unit": "queries/s", "cores": threads, "kind": "port",
+                                   "sample": f"FlatIndex::knn (Cosine): {ncpu} of the {nq} queries against the full {n}x{dim} corpus, one query per thread"}
+    cx.close()
+    return leg
+
+
 def leg_flat_small(ix, timed, queries, b, k, outs, args, n, dim, ref, attainable):
     """calls of b queries (B=32 is the batch the HBM-bound roofline QPS = B*BW/(N*d*4) is quoted on; B=1 the
     reference's own per-call semantics); the first b rows of the headline's results are the check"""
@@ -1040,6 +1076,7 @@ def legs_ann(vdb, O, torch, device, local_rank, timed, step_stats, args, threads
     o_dist = torch.zeros((nq, k), dtype=torch.float32, device=device)
     o_cnt = torch.zeros((nq,), dtype=torch.int64, device=device)
     t_idx = torch.zeros((nq, k), dtype=torch.int64, device=device)
+    torch.cuda.synchronize()  # (the library reads the rows on its own streams)
     ncpu = min(args.cpu_queries, nq)
     okind = O.L2SQR if O is not None else 0
 
