@@ -737,7 +737,8 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
                double(hbm_passes) * double(n) * dim * (i8 ? 1 : (half ? sizeof(uint16_t) : sizeof(float))));
     if (i8)
         launch_flat_gemm8_filter(d_tiled_i8.p, n, (uint32_t)dim, ws.qfrag_g.p, d_qscale, (uint32_t)ngroups, d_rowc_i8.as<float>(), d_tau,
-                                 d_cand, d_hits, CAND_CAP, flat_gemm_debug, num_cu, s, i8_second ? CAND_CAP : 0u);
+                                 d_cand, d_hits, CAND_CAP, flat_gemm_debug, num_cu, s,
+                                 i8_second ? CAND_CAP : std::max<uint32_t>(64u, s_step * s_rank));  // (expected hits per query: sizes the hand-over blocks)
     else if (gemm)
         launch_flat_gemm_filter(xt, n, (uint32_t)dim, ws.qfrag_g.as<float>(), d_qmul, (uint32_t)ngroups,
                                 d_sq.as<float>(), cosine, d_tau, d_cand, d_hits, CAND_CAP, flat_gemm_debug, num_cu, s);

@@ -598,15 +598,18 @@ static void flat_gemm8_launch(const Gemm8Args &a0, int num_cu, hipStream_t s) {
             if (S > 1 && units >= 2048) {
                 a.coop = S;
                 g_gemm8_last_coop = S;
+                // (0.55 of the buffer while a full buffer cost the query its answer from this tier; entries beyond it now spill to the
+                // candidate lists directly, so the blocks are sized for 0.8 and the sample plan's own expectation: 125k-row shard 2 -> 6
+                // units per block)
                 const double per_unit = 8.0 * 48.0 * 128.0 * double(a.hits_expected ? a.hits_expected : 1024u) / double(a.n);
-                const double b = double(G8_WGBUF_RES) * 0.55 / per_unit;
+                const double b = double(G8_WGBUF_RES) * 0.8 / per_unit;
                 a.coop_block = b < 1.0 ? 1u : (b > 4096.0 ? 4096u : uint32_t(b));
                 flat_gemm8_launch1<KC, MODE, false, false, true>(a, num_cu, s);  // default loads: the members meet in the L2
                 return;
             }
         }
         if (MODE == G8_FILTER) g_gemm8_last_coop = 0;
-        if (MODE == G8_FILTER && a.hits_expected > 1024) {
+        if (MODE == G8_FILTER && a.hits_expected > 2048) {
             // thresholds made for long hit lists (the second attempt, k_redo.hip): the plain form hands its buffer over in blocks too
             // (a workgroup's share of a group's hits: 128 queries x hits / workgroups, against 1536 entries)
             const double per_unit = 8.0 * 48.0 * 128.0 * double(a.hits_expected) / double(a.n);
