@@ -170,7 +170,7 @@ def hbm_roofline(kernel, p, extra=None):
 
 def pmc_traffic(kernel, rows, dim, nq):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this very command (profiles/
-    r03_pmc_traffic.json: counters cannot be collected inside a timed run) -- only for the workload they were collected on"""
+    r04_pmc_traffic.json (then r03_pmc_traffic.json): counters cannot be collected inside a timed run) -- only for the workload they were collected on"""
     e = src = None
     for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):  # the latest passes that hold this kernel
         try:
