@@ -111,8 +111,15 @@ __device__ __forceinline__ float hnsw_exact_dist(const HnswDev &g, const float *
     return s - t2;
 }
 
-// ADC distance of code row idx (pq_table.rs:239-301); lut in LDS or global
+// ADC distance of code row idx (pq_table.rs:239-301); lut in LDS or global.  COS is the table's metric as a compile-time fact: with
+// `if (g.cosine)` inside the unrolled lookups every one of a row's 320 lookups carried two branches (1 187 in the kernel).
+template <bool COS>
+__device__ __forceinline__ float hnsw_adc_dist_t(const HnswDev &g, const float *lut, float qsq, uint32_t idx);
 __device__ __forceinline__ float hnsw_adc_dist(const HnswDev &g, const float *lut, float qsq, uint32_t idx) {
+    return g.cosine ? hnsw_adc_dist_t<true>(g, lut, qsq, idx) : hnsw_adc_dist_t<false>(g, lut, qsq, idx);
+}
+template <bool COS>
+__device__ __forceinline__ float hnsw_adc_dist_t(const HnswDev &g, const float *lut, float qsq, uint32_t idx) {
     const uint8_t *cr = g.codes + uint64_t(idx) * g.enc_dim;
     float sum = 0.0f, cdp = 0.0f;
     const uint32_t kc = g.pq_kc, m = g.pq_m;
@@ -144,18 +151,18 @@ __device__ __forceinline__ float hnsw_adc_dist(const HnswDev &g, const float *lu
                         for (int j = 0; j < 8; j++) {  // nibble j of the word = group 32w + 8wi + j (low nibble of a byte first)
                             const uint32_t at = (w * 32 + 8 * wi + j) * 16 + ((words[wi] >> (4 * j)) & 0xf);
                             t[j] = lut[at];
-                            if (g.cosine) c[j] = g.cent_cache[at];
+                            if (COS) c[j] = g.cent_cache[at];
                         }
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
                             sum = sum + t[j];
-                            if (g.cosine) cdp = cdp + c[j];
+                            if (COS) cdp = cdp + c[j];
                         }
                     }
                 }
             });
         }
-        if (!g.cosine) return sum;
+        if (!COS) return sum;
         float den0 = fmaxf(sqrtf(cdp) * sqrtf(qsq), 1e-10f);
         float r0 = sum / den0;
         return 1.0f - r0;
@@ -166,19 +173,19 @@ __device__ __forceinline__ float hnsw_adc_dist(const HnswDev &g, const float *lu
             uint32_t i = 2 * b;
             if (i < m) {
                 sum = sum + lut[i * kc + (u & 0xf)];
-                if (g.cosine) cdp = cdp + g.cent_cache[i * kc + (u & 0xf)];
+                if (COS) cdp = cdp + g.cent_cache[i * kc + (u & 0xf)];
             }
             i++;
             if (i < m) {
                 sum = sum + lut[i * kc + (u >> 4)];
-                if (g.cosine) cdp = cdp + g.cent_cache[i * kc + (u >> 4)];
+                if (COS) cdp = cdp + g.cent_cache[i * kc + (u >> 4)];
             }
         } else {
             sum = sum + lut[b * kc + u];
-            if (g.cosine) cdp = cdp + g.cent_cache[b * kc + u];
+            if (COS) cdp = cdp + g.cent_cache[b * kc + u];
         }
     }
-    if (!g.cosine) return sum;
+    if (!COS) return sum;
     float den = fmaxf(sqrtf(cdp) * sqrtf(qsq), 1e-10f);
     float r = sum / den;
     return 1.0f - r;
@@ -417,7 +424,11 @@ __device__ __forceinline__ float hnsw_exact_dists_regs(const HnswDev &g, const f
 // ties included since the inequality is strict; tau only moves down while the expansion is replayed).  Rows that survive are
 // scored exactly (hnsw_exact_dists_regs); the counters count every fresh row as before.
 
-template <int R, bool ADC>
+// LUT_LDS (ADC walk, round 4): the query's table is in LDS as a COMPILE-TIME fact.  With a run-time choice between the LDS copy and the
+// global table the lookups were generic-address loads (flat_load_dword: 64-bit address arithmetic per lookup, and flat operations complete
+// out of order, so every use waited for vmcnt(0) AND lgkmcnt(0)): 969 of them in the kernel.  Known to be LDS they are ds_read_b32 with
+// the group's offset as an immediate and counted waits.
+template <int R, bool ADC, bool LUT_LDS = false>
 __global__ __launch_bounds__(64, 2) void k_hnsw_search(HnswDev g, const float *__restrict__ Q,
                                                     const float *__restrict__ qsq_all,
                                                     const float *__restrict__ lut_all, uint32_t lut_in_lds,
@@ -437,22 +448,21 @@ __global__ __launch_bounds__(64, 2) void k_hnsw_search(HnswDev g, const float *_
     const float qsq = qsq_all[q];
     uint32_t *vis = visited + uint64_t(q) * visited_words;
 
-    const float *lut = nullptr;
+    const float *lg = ADC ? lut_all + uint64_t(q) * g.pq_m * g.pq_kc : nullptr;
+    (void)lut_in_lds;  // (the launcher picks LUT_LDS from it)
     if (ADC) {
-        const float *lg = lut_all + uint64_t(q) * g.pq_m * g.pq_kc;
-        if (lut_in_lds) {
+        if constexpr (LUT_LDS)
             for (uint32_t i = lane; i < g.pq_m * g.pq_kc; i += 64) fl[i] = lg[i];
-            lut = fl;
-        } else {
-            lut = lg;
-        }
     } else {
         for (uint32_t i = lane; i < g.dim; i += 64) fl[i] = Q[uint64_t(q) * g.dim + i];
     }
     __syncthreads();
 
     auto dist_of = [&](uint32_t idx) -> float {
-        return ADC ? hnsw_adc_dist(g, lut, qsq, idx) : hnsw_exact_dist(g, fl, qsq, idx);
+        if constexpr (ADC && LUT_LDS)
+            return hnsw_adc_dist(g, fl, qsq, idx);  // (fl: provably shared memory -> LDS instructions)
+        else
+            return ADC ? hnsw_adc_dist(g, lg, qsq, idx) : hnsw_exact_dist(g, fl, qsq, idx);
     };
 
     unsigned long long n_dist = 0, n_exp = 0, n_drop = 0, n_half = 0;  // (n_half: rows scored by the half-precision pre-pass, n_drop: ruled out by it)
@@ -1538,8 +1548,14 @@ template <int R, bool ADC>
 static void hnsw_launch(const HnswDev &g, const float *d_q, const float *qsq, const float *lut, uint32_t lut_in_lds,
                         uint32_t ef, uint32_t *vis, uint64_t vwords, uint64_t *out, unsigned long long *stats,
                         uint32_t *err, uint32_t nq, size_t lds, hipStream_t s) {
-    func_max_lds(reinterpret_cast<const void *>(&k_hnsw_search<R, ADC>), int(160 * 1024));
-    hipLaunchKernelGGL((k_hnsw_search<R, ADC>), dim3(nq), dim3(64), lds, s, g, d_q, qsq, lut, lut_in_lds, ef, vis,
+    if (ADC && lut_in_lds) {
+        func_max_lds(reinterpret_cast<const void *>(&k_hnsw_search<R, ADC, true>), int(160 * 1024));
+        hipLaunchKernelGGL((k_hnsw_search<R, ADC, true>), dim3(nq), dim3(64), lds, s, g, d_q, qsq, lut, lut_in_lds, ef, vis, vwords, out,
+                           stats, err);
+        return;
+    }
+    func_max_lds(reinterpret_cast<const void *>(&k_hnsw_search<R, ADC, false>), int(160 * 1024));
+    hipLaunchKernelGGL((k_hnsw_search<R, ADC, false>), dim3(nq), dim3(64), lds, s, g, d_q, qsq, lut, lut_in_lds, ef, vis,
                        vwords, out, stats, err);
 }
 
