@@ -301,6 +301,18 @@ __device__ __forceinline__ float hnsw_exact_dists_dma(const HnswDev &g, const fl
 #ifndef HNSW_REG_DEPTH
 #define HNSW_REG_DEPTH 8
 #endif
+#ifdef HNSW_STAMP2  // measurement build: wall-clock ticks (100 MHz) inside hnsw_exact_dists_regs: set-up + first loads issued | first line arrived and
+                    // transposed | the fold's lines | epilogue; [4] = calls
+__device__ unsigned long long g_hnsw_st2[8];
+#define HNSW_T2(i)                                                     \
+    {                                                                  \
+        const unsigned long long _n = wall_clock64();                  \
+        if (lane == 0) atomicAdd(&g_hnsw_st2[i], _n - _t2);            \
+        _t2 = _n;                                                      \
+    }
+#else
+#define HNSW_T2(i)
+#endif
 constexpr uint32_t HNSW_REG_STAGE = 2 * 4096;  // two line blocks: the transpose runs one line ahead of the fold
 // NG = groups of 8 compacted rows that are fetched (ceil(nfresh / 8) <= NG): after the half-precision pre-pass most
 // expansions are left with a handful of rows, and a whole-instruction `if` would cost the counted waits (see below)
@@ -308,6 +320,10 @@ template <int NG>
 __device__ __forceinline__ float hnsw_exact_dists_regs(const HnswDev &g, const float *qlds, float qsq, uint32_t nb, bool fresh,
                                                        unsigned char *stage, uint32_t lane) {
     constexpr int D = NG == 4 ? HNSW_REG_DEPTH / 2 : HNSW_REG_DEPTH;  // 16 NG D registers of lines in flight + 64 of the line being folded
+#ifdef HNSW_STAMP2
+    unsigned long long _t2 = wall_clock64();
+    if (lane == 0) atomicAdd(&g_hnsw_st2[4], 1ull);
+#endif
     const uint32_t nlines = g.dim / 32;
     const uint64_t fm = __ballot(fresh);
     const uint32_t nfresh = (uint32_t)__builtin_popcountll(fm);  // <= 32: the fresh lanes are all below max_m0 <= 32
@@ -339,6 +355,7 @@ __device__ __forceinline__ float hnsw_exact_dists_regs(const HnswDev &g, const f
         __builtin_amdgcn_sched_barrier(0);  // loads return in issue order: line 0 has to be the first one issued
     });
     float acc = 0.0f;
+    HNSW_T2(0)
     const v4f *q4 = reinterpret_cast<const v4f *>(qlds);
     // reader: lane r < 32 folds compacted row r = 8 kr + gr (lanes >= 32 mirror them, their result is not used)
     const uint32_t kr = (lane >> 3) & 3, gr = lane & 7, rot = (gr + (kr & 1)) & 7;
@@ -365,6 +382,10 @@ __device__ __forceinline__ float hnsw_exact_dists_regs(const HnswDev &g, const f
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef HNSW_STAMP2
+    acc += cur[0].x * 0.0f;  // (the first line must have arrived before the clock is read)
+#endif
+    HNSW_T2(1)
     for (uint32_t L0 = 0; L0 < nlines; L0 += D) {
         static_for<D>([&](auto ic) {  // (compile-time indices: the line buffers must stay in registers)
             constexpr int i = decltype(ic)::value, in = (i + 1) % D;
@@ -402,6 +423,10 @@ __device__ __forceinline__ float hnsw_exact_dists_regs(const HnswDev &g, const f
             acc = L < nlines ? a : acc;
         });
     }
+#ifdef HNSW_STAMP2
+    acc = __shfl(acc, lane);
+#endif
+    HNSW_T2(2)
     float d;
     if (g.cosine) {
         float den = fmaxf(sqrtf(xs) * sqrtf(qsq), 1e-10f);
@@ -412,7 +437,9 @@ __device__ __forceinline__ float hnsw_exact_dists_regs(const HnswDev &g, const f
         float t2 = 2.0f * acc;
         d = s2 - t2;
     }
-    return __shfl(d, rank);  // back to the lane the neighbour came from
+    d = __shfl(d, rank);  // back to the lane the neighbour came from
+    HNSW_T2(3)
+    return d;
 }
 
 
@@ -1971,6 +1998,15 @@ void hnsw_knn_device(Index &ix, Workspace &ws, const float *d_q, uint64_t nq, ui
         std::fprintf(stderr, "hnsw stamps: %llu distance evaluations, %llu through the half-precision pre-pass, %llu ruled out by it\n", st[0], st[3], st[2]);
         std::fprintf(stderr, "hnsw stamps (us per expansion): pop %.2f, links + visited %.2f, distances %.2f, inserts %.2f\n", tk[0] * per,
                      tk[1] * per, tk[2] * per, tk[3] * per);
+#ifdef HNSW_STAMP2
+        unsigned long long t2[8];
+        VDB_HIP(hipMemcpyFromSymbol(t2, HIP_SYMBOL(g_hnsw_st2), sizeof(t2)));
+        const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        VDB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_hnsw_st2), zero, sizeof(zero)));
+        const double pc = t2[4] ? 0.01 / double(t2[4]) : 0.0;
+        std::fprintf(stderr, "hnsw_exact_dists_regs (us per call, %llu calls): set-up + loads issued %.2f, first line there %.2f, fold of the lines %.2f, epilogue %.2f\n",
+                     t2[4], t2[0] * pc, t2[1] * pc, t2[2] * pc, t2[3] * pc);
+#endif
     }
 #endif
     if (!ws.pending.empty()) {
