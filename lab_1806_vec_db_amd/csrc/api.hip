@@ -534,7 +534,7 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
     }
     else if (n == "debug_alloc_fail_over")  // (testing aid, process-wide) device allocations of at least this many bytes fail; 0 = off
         devbuf_fail_over() = (size_t)value;
-    else if (n == "flat_i8_unit_min")  // threshold sample of the 8-bit pass: one value per sampled unit when the units are many (0 auto, 1 off)
+    else if (n == "flat_i8_unit_min")  // threshold sample of the 8-bit pass: one value per sampled unit when the units are many (0 auto, 1 off, 2 on from 2 x rank units: tests)
         idx->ix.flat_i8_unit_min = (int)value;
     else if (n == "flat_i8_second")  // second 8-bit attempt with thresholds from the first walk's k-th distances: 0 on, 1 off
         idx->ix.flat_i8_second = (int)value;

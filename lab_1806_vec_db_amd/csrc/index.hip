@@ -654,7 +654,7 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
     mfma_sample_plan(n, i8 ? 64u : kprime, &s_step, &s_rank, i8 ? flat_i8_hits : 1024u);
     // 8-bit pass with many sampled units: the sample kernel hands the selection ONE value per (query, unit), the unit's smallest key --
     // 48 x fewer values to write and select from (1M rows: 31 MB -> 0.65 MB per 1000 queries); k_gemm8.hip, launch_flat_gemm8_sample
-    const bool unit_min = i8 && flat_i8_unit_min != 1 && gemm8_sample_units(n, s_step) >= 16ull * s_rank;
+    const bool unit_min = i8 && flat_i8_unit_min != 1 && gemm8_sample_units(n, s_step) >= (flat_i8_unit_min == 2 ? 2ull : 16ull) * s_rank;  // (2: tests force it on short samples)
     const uint64_t n_s = i8 ? (unit_min ? gemm8_sample_units(n, s_step) : gemm8_sample_rows(n, s_step))
                             : (gemm ? gemm_sample_rows(n, s_step) : mfma_sample_rows(n, s_step));
     const uint64_t ld_s = (n_s + 63) & ~63ull;

@@ -416,3 +416,37 @@ def test_i8_on_clustered_rows_and_the_auto_off_rule(mods, dist, spread):
     if spread < 0.3:
         assert ix.get_stat("flat_i8_redo") - r0 > nq // 4
     ix.close()
+
+
+@pytest.mark.parametrize("dist", ["l2sqr", "cosine"])
+def test_i8_threshold_sample_by_unit_minima(mods, dist):
+    """the threshold sample hands the selection one value per (query, sampled unit) -- the unit's smallest key -- and the selection of a short
+    sample is one wave per query (k_select_tau_tiny): production uses it from ~786k rows on (>= 16 x rank sampled units); forced here on 130k
+    rows.  The threshold is >= the dense sample's (at least as many hits), the answers are the same bits and the oracle's."""
+    vdb, O = mods
+    n, dim, nq = 130000, 128, 300
+    rng = np.random.default_rng(21)
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    ix = vdb.GpuIndex(dim, dist)
+    ix.batch_add(base)
+    ix.set_flat_mode(2)
+    ix.set_param("flat_i8_stats", 1)
+    ix.set_param("flat_i8_unit_min", 1)  # dense sample
+    idx0, d0, cnt0 = ix.flat_knn(qs, 10)
+    hits0 = ix.get_stat("flat_i8_hits_sum")
+    ix.set_param("flat_i8_stats", 1)  # (resets the counters)
+    ix.set_param("flat_i8_unit_min", 2)  # unit minima, forced
+    idx1, d1, cnt1 = ix.flat_knn(qs, 10)
+    hits1 = ix.get_stat("flat_i8_hits_sum")
+    assert ix.get_stat("flat_i8_queries") == 2 * nq and ix.get_stat("flat_i8_redo") <= nq // 8
+    np.testing.assert_array_equal(idx0, idx1)
+    np.testing.assert_array_equal(d0, d1)
+    np.testing.assert_array_equal(cnt0, cnt1)
+    print(f"{dist}: hits per query dense sample {hits0 / nq:.0f}, unit minima {hits1 / nq:.0f}")
+    assert hits1 >= hits0  # the r-th smallest unit minimum is never below the r-th smallest sampled key
+    assert hits1 <= 3 * hits0
+    sel = np.arange(0, nq, 6)
+    oi, od, oc = O.flat_knn_batch(base, qs[sel], 10, O.L2SQR if dist == "l2sqr" else O.COSINE, nthreads=8)
+    _check_all(idx1[sel], d1[sel], cnt1[sel], oi, od, oc)
+    ix.close()
