@@ -346,6 +346,10 @@ __global__ __launch_bounds__(512) void k_query_prep_i8(const float *__restrict__
 void launch_query_prep_i8(const float *Q, uint32_t nq, uint32_t nq_pad, uint32_t dim, const float *mu, float l1, float l2, float *qsq,
                           float *qscale, float *qoff, uint32_t *hits, void *qfrag, hipStream_t s, int cosine) {
     if (nq_pad == 0) return;
+    if (size_t(8) * dim * sizeof(float) > size_t(48) * 1024) {  // (dims above 1536: more dynamic LDS than a kernel gets without asking)
+        func_max_lds(reinterpret_cast<const void *>(&k_query_prep_i8<true>), int(64 * 1024));
+        func_max_lds(reinterpret_cast<const void *>(&k_query_prep_i8<false>), int(64 * 1024));
+    }
     if (cosine)
         hipLaunchKernelGGL(k_query_prep_i8<true>, dim3((nq_pad + 3) / 4), dim3(512), size_t(8) * dim * sizeof(float), s, Q, nq, nq_pad, dim, mu,
                            l1, l2, qsq, qscale, qoff, hits, reinterpret_cast<uint4 *>(qfrag));

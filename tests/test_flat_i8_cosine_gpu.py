@@ -51,7 +51,7 @@ def test_cosine_keys_are_lower_bounds(mods, name, dim):
     ix.close()
 
 
-@pytest.mark.parametrize("dim,n,nq", [(960, 40000, 200), (128, 50000, 130), (192, 30011, 97), (320, 20000, 70), (1024, 20000, 129)])
+@pytest.mark.parametrize("dim,n,nq", [(960, 40000, 200), (128, 50000, 130), (192, 30011, 97), (320, 20000, 70), (1024, 20000, 129), (1536, 17000, 70)])
 def test_cosine_i8_pass_parity(mods, dim, n, nq):
     vdb, O = mods
     if dim == 960:
