@@ -276,10 +276,12 @@ struct Index {
     uint64_t i8_mu_rows = 0;    // table size when mu / lambda were measured
     float i8_l1 = 0.0f, i8_l2 = 0.0f, i8_mu_norm = 0.0f;
     int flat_i8_mode = 0;       // 0 auto, 1 off, 2 on even after many uncertified queries
-    // rows the exact stage of the FIRST attempt may walk per query (64 per round); the second attempt walks the whole list.  8 rounds: a
-    // query that needs 5 - 8 (loosely clustered data: half of them) closes here for ~15 us per extra round instead of costing a second pass over
-    // the mirror; on separable data nothing walks more than 4, on tight clusters the 4 wasted rounds are ~0.1 of a 3-ms step
-    uint32_t flat_i8_kprime = 512;
+    // rows the exact stage of the FIRST attempt may walk per query (64 per round); the second attempt walks the whole candidate list.
+    // 2048 = 32 rounds, i.e. the whole hit list of the sample plan's ~1000 hits: a query that exhausts its list is certified by the threshold
+    // itself, and only what then is still open pays a second pass over the mirror.  Measured at 1M x 960 (bench.py --data ..., same box):
+    // separable data never walk more than 4 rounds whatever the limit; loose clusters 1.51 ms per step at 512 / 1024 / 2048 (their
+    // stragglers need the second attempt's longer lists either way); tight clusters 3.03 / 2.89 / 2.47 ms
+    uint32_t flat_i8_kprime = 2048;
     int flat_i8_unit_min = 0;       // threshold sample of the 8-bit pass by unit minima when the sampled units are many: 0 auto, 1 off
     int flat_i8_second = 0;         // second 8-bit attempt with thresholds from the first walk (k_redo.hip): 0 on, 1 off
     std::atomic<uint64_t> i8_second_queries{0}, i8_second_redo{0};
