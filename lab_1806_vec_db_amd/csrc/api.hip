@@ -536,6 +536,8 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         devbuf_fail_over() = (size_t)value;
     else if (n == "flat_i8_unit_min")  // threshold sample of the 8-bit pass: one value per sampled unit when the units are many (0 auto, 1 off, 2 on from 2 x rank units: tests)
         idx->ix.flat_i8_unit_min = (int)value;
+    else if (n == "flat_i8_full")  // second 8-bit attempt of a handful of queries: all candidates at once (0 on, 1 off: rounds of 63 rows)
+        idx->ix.flat_i8_full = (int)value;
     else if (n == "flat_i8_second")  // second 8-bit attempt with thresholds from the first walk's k-th distances: 0 on, 1 off
         idx->ix.flat_i8_second = (int)value;
     else if (n == "flat_i8_stats") {  // (measurement) collect per-query rounds / hits of the 8-bit pass's exact stage; setting it resets them

@@ -790,7 +790,11 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
         t.out_dist = d_dist;
         t.out_count = d_cnt;
         t.tau = d_tau;
-        if (i8)
+        if (i8 && i8_second && nq <= 96 && flat_i8_full != 1) {
+            // a handful of queries on their second attempt: all their candidates at once instead of a chain of 63-row rounds (k_exact.hip)
+            ws.keys_b.reserve(nq * size_t(CAND_CAP) * sizeof(uint64_t));
+            launch_flat_full_lb(t, (uint32_t)nq, ws.keys_b.as<uint64_t>(), ws.keys_c.as<uint64_t>(), s);
+        } else if (i8)
             launch_flat_tail_lb(t, (uint32_t)nq, s);
         else
             launch_flat_tail64(t, (uint32_t)nq, s);

@@ -282,6 +282,7 @@ struct Index {
     // separable data never walk more than 4 rounds whatever the limit; loose clusters 1.51 ms per step at 512 / 1024 / 2048 (their
     // stragglers need the second attempt's longer lists either way); tight clusters 3.03 / 2.89 / 2.47 ms
     uint32_t flat_i8_kprime = 2048;
+    int flat_i8_full = 0;           // second attempt of <= 96 queries: all candidates evaluated at once (0 on, 1 off: the walk)
     int flat_i8_unit_min = 0;       // threshold sample of the 8-bit pass by unit minima when the sampled units are many: 0 auto, 1 off
     int flat_i8_second = 0;         // second 8-bit attempt with thresholds from the first walk (k_redo.hip): 0 on, 1 off
     std::atomic<uint64_t> i8_second_queries{0}, i8_second_redo{0};

@@ -545,10 +545,13 @@ template <int FOLD>
 __global__ __launch_bounds__(256, 4) void k_rerank_pc(const float *__restrict__ X, uint32_t dim, const float *__restrict__ Q,
                                                       int metric, const float *__restrict__ xsq, const float *__restrict__ qsq,
                                                       const uint64_t *__restrict__ cand, uint64_t *__restrict__ out,
-                                                      uint32_t ncand, uint32_t ldc) {
+                                                      uint32_t ncand_max, uint32_t ldc, const uint32_t *__restrict__ cnt) {
     extern __shared__ float4 rp_smem[];  // [dim/4] query, then two [64 rows][9] float4 product tiles
     __shared__ uint64_t scand[64];
     const uint32_t q = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j0 = blockIdx.x * 64;
+    // cnt != null: counted lists (the first cnt[q] slots of a row hold candidates; a count above the capacity = an overflowed list: nothing
+    // of it is evaluated, the caller flags the query)
+    const uint32_t ncand = cnt ? (cnt[q] <= ncand_max ? cnt[q] : 0u) : ncand_max;
     if (j0 >= ncand) {  // block-uniform: this block only pads the row
         if (threadIdx.x < 64 && j0 + threadIdx.x < ldc) out[uint64_t(q) * ldc + j0 + threadIdx.x] = PAIR_NONE;
         return;
@@ -583,17 +586,18 @@ __global__ __launch_bounds__(256, 4) void k_rerank_pc(const float *__restrict__ 
 
 void launch_rerank(const float *X, uint32_t dim, const float *Q, uint32_t nq, int metric, const float *xsq,
                    const float *qsq, const uint64_t *cand, uint64_t *out, uint32_t ncand, uint32_t ldc,
-                   hipStream_t s) {
+                   hipStream_t s, const uint32_t *cnt) {
     if (nq == 0 || ncand == 0) return;
     if ((dim & 3) == 0 && dim >= 64 && dim <= 8192) {
         dim3 grid((std::max(ncand, ldc) + 63) / 64, nq), block(256);
         const size_t lds = (size_t(dim / 4) + 2 * 64 * 9) * sizeof(float4);
         if (metric == MET_L2_DIRECT)
-            hipLaunchKernelGGL((k_rerank_pc<FOLD_L2>), grid, block, lds, s, X, dim, Q, metric, xsq, qsq, cand, out, ncand, ldc);
+            hipLaunchKernelGGL((k_rerank_pc<FOLD_L2>), grid, block, lds, s, X, dim, Q, metric, xsq, qsq, cand, out, ncand, ldc, cnt);
         else
-            hipLaunchKernelGGL((k_rerank_pc<FOLD_DOT>), grid, block, lds, s, X, dim, Q, metric, xsq, qsq, cand, out, ncand, ldc);
+            hipLaunchKernelGGL((k_rerank_pc<FOLD_DOT>), grid, block, lds, s, X, dim, Q, metric, xsq, qsq, cand, out, ncand, ldc, cnt);
         return;
     }
+    VDB_REQUIRE(cnt == nullptr, "rerank: counted lists need dim % 4 == 0");
     dim3 grid((std::max(ncand, ldc) + 63) / 64, nq), block(64);  // the tail blocks only pad
     if (metric == MET_L2_DIRECT)
         hipLaunchKernelGGL((k_rerank<FOLD_L2>), grid, block, 0, s, X, dim, Q, metric, xsq, qsq, cand, out, ncand, ldc);
@@ -1174,6 +1178,42 @@ void launch_flat_tail_lb(const FlatTailArgs &a0, uint32_t nq, hipStream_t s) {
 #ifdef VDB_TAIL_STAMPS
     if (stamps) tail_stamps_report(stamps, nq, s);
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The exact stage of the SECOND 8-bit attempt for a handful of queries (k_redo.hip).  Their thresholds were derived from an upper bound
+// of the k-th distance, so every row that can matter is in the candidate list; walking it in rounds of 63 rows is a chain of 30 - 130
+// dependent rounds for the long lists such queries have (measured: the ~2 % stragglers of loosely clustered data cost 0.5 ms of a 1.5-ms
+// step).  Few queries leave the chip idle, so ALL their candidates are evaluated at once instead (k_rerank_pc over the counted lists),
+// the k smallest selected, and the query certified against its threshold: every row outside the list has key > tau.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_flat_finish_lb(FlatTailArgs a, const uint64_t *__restrict__ exact_sorted, uint32_t lde) {
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    const uint32_t cnt_q = a.cnt[q];
+    const uint64_t e = lane < a.ksel ? exact_sorted[uint64_t(q) * lde + lane] : PAIR_NONE;
+    const uint64_t ek = __shfl(e, a.ksel - 1);
+    uint8_t flag = 1;
+    if (lane == 0 && cnt_q <= a.cap) flag = flat_certify_lb(ek, a.tau[q], q, a);
+    const bool ok = lane < a.ksel && e != PAIR_NONE;
+    if (lane < a.ksel) {
+        a.out_idx[uint64_t(q) * a.kstride + lane] = ok ? uint64_t(uint32_t(e)) + a.id_offset : 0;
+        a.out_dist[uint64_t(q) * a.kstride + lane] = ok ? f32_from_orderable(uint32_t(e >> 32)) : 0.0f;
+    }
+    const uint32_t count = __builtin_popcountll(__ballot(ok));
+    if (lane == 0) {
+        if (a.out_count) a.out_count[q] = count;
+        a.flags[q] = flag;
+        if (a.qstat) a.qstat[q] = 0xFFu | ((cnt_q < 0xFFFFFFu ? cnt_q : 0xFFFFFFu) << 8);
+    }
+}
+void launch_flat_full_lb(const FlatTailArgs &a, uint32_t nq, uint64_t *exact_keys /* nq x a.cap */, uint64_t *topk /* nq x topk_capacity(ksel) */,
+                         hipStream_t s) {
+    if (nq == 0) return;
+    VDB_REQUIRE(a.ksel >= 1 && a.ksel <= 64 && (a.dim & 3) == 0 && a.se.qoff && a.tau, "flat_full_lb: unsupported shape");
+    launch_rerank(a.X, a.dim, a.Q, nq, a.metric, a.xsq, a.qsq, a.cand, exact_keys, a.cap, a.cap, s, a.cnt);
+    launch_topk_merge_counted(exact_keys, a.cap, a.cnt, nq, a.ksel, topk, s);  // (four waves, bitonic: the serial one-wave merge took 49 us over 8192 slots)
+    hipLaunchKernelGGL(k_flat_finish_lb, dim3(nq), dim3(64), 0, s, a, topk, topk_capacity(a.ksel));
+    VDB_HIP(hipGetLastError());
 }
 
 void launch_certify(const uint64_t *exact_sorted, uint32_t lde, const uint64_t *approx_sorted, uint32_t lda,

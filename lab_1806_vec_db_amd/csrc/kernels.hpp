@@ -22,7 +22,7 @@ void launch_scan_exact(const float *X, uint64_t n, uint32_t dim, const float *Q,
 // exact distance of every candidate: in/out are pair keys [nq][ldc]; PAIR_NONE entries pass through
 void launch_rerank(const float *X, uint32_t dim, const float *Q, uint32_t nq, int metric, const float *xsq,
                    const float *qsq, const uint64_t *cand, uint64_t *out, uint32_t ncand, uint32_t ldc,
-                   hipStream_t s);
+                   hipStream_t s, const uint32_t *cnt = nullptr);  // cnt: counted lists (first cnt[q] slots of a row)
 // first `ksel` pair keys of each query -> (u64 id + id_offset, f32 distance) at out[q*kstride + j],
 // out_count[q] = number of valid pairs
 void launch_finalize(const uint64_t *keys, uint32_t ldk, uint32_t nq, uint32_t ksel, uint32_t kstride,
@@ -72,6 +72,8 @@ struct FlatTailArgs {
 // the exact stage behind the 8-bit pass: walks the hit list in key order, 64 keys per round (kprime / 64 rounds at most)
 bool flat_tail_lb_supported(uint32_t dim, uint32_t kprime, uint32_t ksel);
 void launch_flat_tail_lb(const FlatTailArgs &a, uint32_t nq, hipStream_t s);
+// all candidates of a few queries evaluated at once (the second 8-bit attempt of a handful of queries): exact_keys nq x a.cap, topk nq x topk_capacity(ksel)
+void launch_flat_full_lb(const FlatTailArgs &a, uint32_t nq, uint64_t *exact_keys, uint64_t *topk, hipStream_t s);
 void flat_tail_lb_set_nw(int v);  // waves per query: 0 auto, 8 / 4 / 2 / 1
 bool flat_tail64_supported(uint32_t dim, uint32_t kprime, uint32_t ksel);
 void launch_flat_tail64(const FlatTailArgs &a, uint32_t nq, hipStream_t s);
