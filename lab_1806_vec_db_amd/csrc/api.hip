@@ -498,7 +498,7 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         pq_set_adc16_sample((int)value);
     else if (n == "pq_adc16")
         pq_set_adc16((int)value);
-    else if (n == "pq_adc8_sliced")  // 8-bit codes: 0 = eight queries per pass on sliced 16-bit tables (k_pq_adc16x8), 1 = one query per pass
+    else if (n == "pq_adc8_sliced")  // 8-bit codes: 0 = 16 queries per pass on sliced one-byte tables (k_pq_adc8x16), 1 = one query per pass (k_pq_adc8), 2 = 8 per pass on sliced 16-bit tables
         pq_set_adc8_sliced((int)value);
     else if (n == "flat_sample_thin")
         mfma_set_sample_thin((int)value);
@@ -641,6 +641,14 @@ int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out) {
         *out = idx->ix.ivf.last_kept.load();
     else if (n == "pq_adc16_queries")
         *out = idx->ix.pq.adc16_queries.load();
+    else if (n == "pq_q8_overflow")
+        *out = idx->ix.pq.q8_overflow.load();
+    else if (n == "pq_q8_short")
+        *out = idx->ix.pq.q8_short.load();
+    else if (n == "pq_q8_hits_sum")
+        *out = idx->ix.pq.q8_hits_sum.load();
+    else if (n == "pq_q8_hits_max")
+        *out = idx->ix.pq.q8_hits_max.load();
     else if (n == "hbm_bytes_per_row")
         *out = idx->ix.hbm_bytes_per_row();
     else

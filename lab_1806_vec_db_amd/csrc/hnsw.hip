@@ -301,6 +301,12 @@ __device__ __forceinline__ float hnsw_exact_dists_dma(const HnswDev &g, const fl
 #ifndef HNSW_REG_DEPTH
 #define HNSW_REG_DEPTH 8
 #endif
+#ifndef HNSW_REG_DEPTH4
+#define HNSW_REG_DEPTH4 (HNSW_REG_DEPTH / 2)
+#endif
+#ifndef HNSW_LB
+#define HNSW_LB 2
+#endif
 #ifdef HNSW_STAMP2  // measurement build: wall-clock ticks (100 MHz) inside hnsw_exact_dists_regs: set-up + first loads issued | first line arrived and
                     // transposed | the fold's lines | epilogue; [4] = calls
 __device__ unsigned long long g_hnsw_st2[8];
@@ -319,7 +325,7 @@ constexpr uint32_t HNSW_REG_STAGE = 2 * 4096;  // two line blocks: the transpose
 template <int NG>
 __device__ __forceinline__ float hnsw_exact_dists_regs(const HnswDev &g, const float *qlds, float qsq, uint32_t nb, bool fresh,
                                                        unsigned char *stage, uint32_t lane) {
-    constexpr int D = NG == 4 ? HNSW_REG_DEPTH / 2 : HNSW_REG_DEPTH;  // 16 NG D registers of lines in flight + 64 of the line being folded
+    constexpr int D = NG == 4 ? HNSW_REG_DEPTH4 : HNSW_REG_DEPTH;  // 16 NG D registers of lines in flight + 64 of the line being folded
 #ifdef HNSW_STAMP2
     unsigned long long _t2 = wall_clock64();
     if (lane == 0) atomicAdd(&g_hnsw_st2[4], 1ull);
@@ -456,7 +462,7 @@ __device__ __forceinline__ float hnsw_exact_dists_regs(const HnswDev &g, const f
 // out of order, so every use waited for vmcnt(0) AND lgkmcnt(0)): 969 of them in the kernel.  Known to be LDS they are ds_read_b32 with
 // the group's offset as an immediate and counted waits.
 template <int R, bool ADC, bool LUT_LDS = false>
-__global__ __launch_bounds__(64, 2) void k_hnsw_search(HnswDev g, const float *__restrict__ Q,
+__global__ __launch_bounds__(64, HNSW_LB) void k_hnsw_search(HnswDev g, const float *__restrict__ Q,
                                                     const float *__restrict__ qsq_all,
                                                     const float *__restrict__ lut_all, uint32_t lut_in_lds,
                                                     uint32_t ef, uint32_t *__restrict__ visited,

@@ -156,6 +156,8 @@ struct PQState {
     DevBuf d_codes_t;                // word-major mirror of d_codes for the quantised ADC scan (pq.hip: k_pq_tile_codes)
     bool codes_t_valid = false;
     std::atomic<uint64_t> adc16_queries{0};  // queries whose ADC scan ran on the quantised tables (k_pq_adc16)
+    std::atomic<uint64_t> q8_overflow{0}, q8_short{0};  // 8-bit codes: queries the quantised pass handed to the f32 scan (list overflowed | fewer than ef sums at or below tau)
+    std::atomic<uint64_t> q8_hits_sum{0}, q8_hits_max{0};  // candidates of the quantised pass (sum over queries, largest list)
 };
 
 struct HNSWState {

@@ -85,7 +85,7 @@ static std::atomic<int> g_adc_fast{1};
 void pq_set_adc_fast(int v) { g_adc_fast = v; }
 static std::atomic<int> g_adc16_sample{0};  // threshold sample on the quantised tables (L2Sqr): 0 auto (on with the quantised scan), 1 off (f32 sample)
 void pq_set_adc16_sample(int v) { g_adc16_sample = v; }
-static std::atomic<int> g_adc8_sliced{0};  // 8-bit codes: 0 = eight queries per pass on sliced 16-bit tables (k_pq_adc16x8), 1 = one query per pass on a byte table (k_pq_adc8)
+static std::atomic<int> g_adc8_sliced{0};  // 8-bit codes: 0 = sixteen queries per pass on sliced one-byte tables (k_pq_adc8x16), 1 = one query per pass on a byte table (k_pq_adc8), 2 = eight queries per pass on sliced 16-bit tables (k_pq_adc16x8)
 void pq_set_adc8_sliced(int v) { g_adc8_sliced = v; }
 static std::atomic<int> g_adc16{0};  // quantised first pass of the threshold-filter scan: 0 auto (4-bit, L2Sqr, 16-B code words), 1 off
 void pq_set_adc16(int v) { g_adc16 = v; }
@@ -1045,7 +1045,8 @@ constexpr uint32_t ADC16X8_WGBUF = 2048;  // LDS hit buffer entries per workgrou
 
 // per query: the minimum of every group's 256 table entries (mn[q][g]), M = their sum, D = sum of the ranges / 65000
 __global__ __launch_bounds__(256) void k_pq_quant16x8_stats(const float *__restrict__ lut, uint32_t m, uint32_t nq, float *__restrict__ mn_out,
-                                                            double *__restrict__ qM, double *__restrict__ qD, uint32_t *__restrict__ qflag) {
+                                                            double *__restrict__ qM, double *__restrict__ qD, uint32_t *__restrict__ qflag,
+                                                            double divisor) {
     const uint32_t q = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     __shared__ double sR[4], sM[4];
     __shared__ uint32_t sbad;
@@ -1086,7 +1087,7 @@ __global__ __launch_bounds__(256) void k_pq_quant16x8_stats(const float *__restr
         M = (sM[0] + sM[1]) + (sM[2] + sM[3]);
         const bool flag = sbad != 0 || !(R < 1.0e300) || !(fabs(M) < 1.0e300);
         qM[q] = M;
-        qD[q] = (!flag && R > 0.0) ? R / 65000.0 : 1.0;
+        qD[q] = (!flag && R > 0.0) ? R / divisor : 1.0;  // (65000 for 16-bit entries; k_pq_adc8x16: see there)
         qflag[q] = flag ? 1u : 0u;
     }
 }
@@ -1256,9 +1257,223 @@ __global__ __launch_bounds__(1024) void k_pq_adc16x8(Adc16x8Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 8-bit codes, SIXTEEN queries per pass on one-byte entries (round 4, second step).  k_pq_adc16x8 is bound by the LDS: a group's 256
+// entries of 16 B span 4 KB, the 16 lanes of a ds_read_b128 quarter hit random 4-bank groups (expected worst load ~4.3 against the 2 of
+// a conflict-free read), 0.27 cycles per lane lookup.  The conflicts are in the data (the codes); what can change is how many queries
+// one 16-B lookup serves: here an entry holds ONE BYTE for each of 16 queries,
+//     e8[g][c] = min(255, floor((lut[g][c] - mn_g) / D)),   D = sum_g range_g / min(65000, 512 m)
+// so the same LDS time serves twice the queries and the code mirror is read once per 16 of them.  The minimum with 255 only LOWERS an
+// entry (M + D S8 <= the f32 sum still holds, as in k_pq_adc8) and it only touches entries far up a group's range -- lookups of rows
+// that are far from the query in that group; D itself is the 16-bit pass's (R / 65000 from m = 127 on), so rows near the threshold
+// keep the resolution they had.  The sums of a row stay below 2^16 without saturation or wrap: sum_g e8 <= sum_g range_g / D <=
+// 65000.  A dword of an entry holds slots 4d, 4d+2, 4d+1, 4d+3 (bytes 0 .. 3): `x & 0x00ff00ff` is the pair of 16-bit addends of slots
+// (4d, 4d+1) and one v_perm_b32 that of (4d+2, 4d+3); eight packed 16-bit pairs per row, two rows per thread (2048 rows per workgroup),
+// slices of 16 groups (see the kernel).  Same superset rule, same exact stage and order.  L2Sqr tables.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t ADC8X16_RPT = 2;       // rows per thread
+constexpr uint32_t ADC8X16_GS = 16;       // groups per slice (one 16-B code word): 16 x 256 x 16 B = 64 KB, two blocks in LDS
+constexpr uint32_t ADC8X16_WGBUF = 2048;  // LDS hit buffer entries per workgroup
+
+// the image: img[(grp * m_pad + g) * 256 + c] = 16 bytes, slot b of dword b / 4 at byte {0, 2, 1, 3}[b % 4] (0 for g >= m, for query
+// slots past nq and for flagged queries).  One thread per 16-B entry.
+__global__ __launch_bounds__(256) void k_pq_quant8x16_img(const float *__restrict__ lut, const float *__restrict__ mn, const double *__restrict__ qD,
+                                                          const uint32_t *__restrict__ qflag, uint32_t m, uint32_t m_pad, uint32_t nq,
+                                                          uint4 *__restrict__ img) {
+    const uint32_t grp = blockIdx.y, g = blockIdx.x, c = threadIdx.x;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    if (g < m) {
+#pragma unroll
+        for (int b = 0; b < 16; b++) {
+            const uint32_t q = grp * 16 + b;
+            if (q < nq && qflag[q] == 0) {
+                const double y = (double(lut[(uint64_t(q) * m + g) * 256 + c]) - double(mn[uint64_t(q) * m + g])) / qD[q];
+                double x = floor(y);
+                x = x < 0.0 ? 0.0 : (x > 255.0 ? 255.0 : x);
+                const int j = b & 3, pos = j == 1 ? 2 : (j == 2 ? 1 : j);
+                w[b >> 2] |= uint32_t(x) << (8 * pos);
+            }
+        }
+    }
+    img[(uint64_t(grp) * m_pad + g) * 256 + c] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// 16-B piece per lane from global memory straight into LDS (no register destination): lane l's piece lands at lds_dst + 16 l
+__device__ __forceinline__ void pq_glds16(const void *gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+// The slices are 16 groups (one code word, 64 KB) in TWO LDS blocks: while a slice is scanned the next one is on its way into the other
+// block by LDS-DMA and the rows' next code words into registers -- with one 128-KB block the workgroup stood still for every load (all
+// waves at the barrier: ~5 k of ~23 k cycles per slice).
+__global__ __launch_bounds__(1024) void k_pq_adc8x16(Adc16x8Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem816[];
+    constexpr uint32_t RPT = ADC8X16_RPT, GS = ADC8X16_GS, BLK = GS * 256 * 16;        // 64 KB per block
+    uint32_t *hit_row = reinterpret_cast<uint32_t *>(smem816 + 2 * size_t(BLK));       // [WGBUF]
+    uint32_t *hit_q = hit_row + ADC8X16_WGBUF;                                         // [WGBUF] slot | rank << 8
+    uint32_t *hit_n = hit_q + ADC8X16_WGBUF;                                           // [0] entries, [1..16] per-slot counts, [17..32] bases
+    int32_t *thr = reinterpret_cast<int32_t *>(hit_n + 36);                            // [16] T8 per slot (-1: unused / flagged)
+    const uint32_t tid = threadIdx.x, q0 = blockIdx.y * 16, m = a.m, nwords = a.nwords, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the lookups form LDS byte addresses themselves: the table has to start at LDS address 0 (it does: the kernel has no static LDS);
+    // were it ever not so, every query of the group is marked as overflowed and answered by the f32 scan
+    typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const v4u_t *lds_u4;
+    typedef __attribute__((address_space(3))) unsigned char *lds_b;
+    if ((uint32_t)(uintptr_t)(lds_b)smem816 != 0u) {
+        if (tid < 16 && q0 + tid < a.nq && blockIdx.x == 0) atomicAdd(&a.cnt[q0 + tid], a.cap + 1);
+        return;
+    }
+    if (tid < 33) hit_n[tid] = 0;
+    if (tid < 16) {
+        int32_t T = -1;
+        const uint32_t q = q0 + tid;
+        if (q < a.nq && a.qflag[q] == 0) {
+            const double x = floor((double(a.tau[q]) * (1.0 + 2.0 * double(m) * 0x1p-24) - a.qM[q] * (1.0 - 1e-12)) / a.qD[q]) + 2.0;
+            // tau = +inf / NaN: everything passes -> the candidate list overflows and the query takes the f32 scan
+            T = !(x < 70000.0) ? 70000 : (x < 0.0 ? -1 : (int32_t)x);
+        }
+        thr[tid] = T;
+    }
+    const uint4 *img = a.img + uint64_t(blockIdx.y) * a.nslices * GS * 256;
+    const uint64_t r_begin = uint64_t(blockIdx.x) * a.rows_per_wg;
+    const uint64_t r_end = r_begin + a.rows_per_wg < a.n ? r_begin + a.rows_per_wg : a.n;
+    uint32_t four = 4u, blk1 = BLK;
+    asm volatile("" : "+s"(four), "+s"(blk1));
+    // slice sl -> block bk: 4 DMA instructions per wave (4096 entries of 16 B, wave w moves entries 1024 i + 64 w .. + 63)
+    auto dma = [&](uint32_t sl, uint32_t bk) {
+        const uint4 *src = img + uint64_t(sl) * GS * 256 + tid;
+#pragma unroll
+        for (int i = 0; i < 4; i++) pq_glds16(src + i * 1024, bk * BLK + (i * 1024 + wave * 64) * 16);
+    };
+    for (uint64_t rb = r_begin; rb < r_end; rb += uint64_t(RPT) * 1024) {
+        uint32_t acc[RPT][8];
+        const uint4 *cw[RPT];
+        bool valid[RPT];
+        uint4 cnext[RPT];
+        __syncthreads();  // (thresholds / counters written; the previous block's readers are done)
+        dma(0, 0);
+#pragma unroll
+        for (int j = 0; j < (int)RPT; j++) {
+#pragma unroll
+            for (int d = 0; d < 8; d++) acc[j][d] = 0u;
+            const uint64_t row = rb + uint64_t(j) * 1024 + tid;
+            valid[j] = row < r_end;
+            const uint64_t lrow = valid[j] ? row : r_end - 1;  // (idle lanes re-read a valid row: see k_pq_adc16)
+            cw[j] = a.codes_t + (lrow >> 6) * nwords * 64 + (lrow & 63);
+            cnext[j] = cw[j][0];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        auto slice = [&](uint32_t sl, auto bkc) {
+            constexpr uint32_t BK = decltype(bkc)::value;
+            uint32_t words[RPT][4];
+#pragma unroll
+            for (int j = 0; j < (int)RPT; j++) {
+                words[j][0] = cnext[j].x;
+                words[j][1] = cnext[j].y;
+                words[j][2] = cnext[j].z;
+                words[j][3] = cnext[j].w;
+            }
+            if (sl + 1 < a.nslices) {  // the next slice: its entries into the other block, the rows' next code word into registers
+                dma(sl + 1, BK ^ 1u);
+#pragma unroll
+                for (int j = 0; j < (int)RPT; j++) cnext[j] = sl + 1 < nwords ? cw[j][uint64_t(sl + 1) * 64] : make_uint4(0u, 0u, 0u, 0u);
+            }
+            // entry address = code byte x 16 + group x 4096 (+ 64 KB in block 1): the byte comes out of its word shifted in ONE
+            // instruction (SDWA source select), the group part is the immediate offset of the ds_read
+            uint4 E[2][4];
+            auto issue = [&](int t, uint4 *e) {
+                const int j = t >> 2, k = t & 3;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    uint32_t off;
+                    if (b == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(off) : "s"(four), "v"(words[j][k]));
+                    if (b == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(off) : "s"(four), "v"(words[j][k]));
+                    if (b == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(off) : "s"(four), "v"(words[j][k]));
+                    if (b == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(off) : "s"(four), "v"(words[j][k]));
+                    if (BK) off += blk1;
+                    const v4u_t ev = *(lds_u4)(uintptr_t)(off + (4 * k + b) * 4096);
+                    e[b] = make_uint4(ev.x, ev.y, ev.z, ev.w);
+                }
+            };
+            issue(0, E[0]);
+#pragma unroll
+            for (int t = 0; t < 4 * (int)RPT; t++) {
+                if (t + 1 < 4 * (int)RPT) {
+                    issue(t + 1, E[(t + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);  // (the reads of step t + 1 stay above the sums of step t)
+                }
+                const uint4 *e = E[t & 1];
+                const int j = t >> 2;
+                const uint32_t x[4][4] = {{e[0].x, e[1].x, e[2].x, e[3].x}, {e[0].y, e[1].y, e[2].y, e[3].y},
+                                          {e[0].z, e[1].z, e[2].z, e[3].z}, {e[0].w, e[1].w, e[2].w, e[3].w}};
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    constexpr uint32_t MK = 0x00ff00ffu, SEL = 0x0c030c01u;  // bytes 0, 2 | bytes 1, 3 as 16-bit pairs
+                    uint32_t A = acc[j][2 * d], B = acc[j][2 * d + 1];
+                    A = A + (x[d][0] & MK) + (x[d][1] & MK);
+                    A = A + (x[d][2] & MK) + (x[d][3] & MK);
+                    B = B + __builtin_amdgcn_perm(0u, x[d][0], SEL) + __builtin_amdgcn_perm(0u, x[d][1], SEL);
+                    B = B + __builtin_amdgcn_perm(0u, x[d][2], SEL) + __builtin_amdgcn_perm(0u, x[d][3], SEL);
+                    acc[j][2 * d] = A;
+                    acc[j][2 * d + 1] = B;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next slice has landed (DMA is not counted by the compiler)
+            __syncthreads();                                    // ... for every wave, and this slice's readers are done
+        };
+        for (uint32_t sl = 0; sl < a.nslices; sl += 2) {
+            slice(sl, std::integral_constant<uint32_t, 0>{});
+            if (sl + 1 < a.nslices) slice(sl + 1, std::integral_constant<uint32_t, 1>{});
+        }
+#pragma unroll
+        for (int j = 0; j < (int)RPT; j++) {
+            const uint32_t row = uint32_t(rb + uint64_t(j) * 1024 + tid);
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const int32_t sb = int32_t((b & 1) ? (acc[j][b >> 1] >> 16) : (acc[j][b >> 1] & 0xffffu));
+                if (valid[j] && sb <= thr[b]) {
+                    const uint32_t pos = atomicAdd(hit_n, 1u);
+                    if (pos < ADC8X16_WGBUF) {
+                        hit_row[pos] = row;
+                        hit_q[pos] = b;
+                    } else {
+                        atomicAdd(&a.cnt[q0 + b], a.cap + 1);  // mark the query as overflowed (-> f32 scan)
+                    }
+                }
+            }
+        }
+        // hand the block's hits to the per-query candidate lists (one global atomic per query), leave an empty buffer
+        __syncthreads();
+        uint32_t total = hit_n[0];
+        if (total > ADC8X16_WGBUF) total = ADC8X16_WGBUF;
+        for (uint32_t i = tid; i < total; i += 1024) {
+            const uint32_t r_ = atomicAdd(&hit_n[1 + hit_q[i]], 1u);
+            hit_q[i] |= r_ << 8;
+        }
+        __syncthreads();
+        if (tid < 16 && hit_n[1 + tid] > 0) hit_n[17 + tid] = atomicAdd(&a.cnt[q0 + tid], hit_n[1 + tid]);
+        __syncthreads();
+        for (uint32_t i = tid; i < total; i += 1024) {
+            const uint32_t b = hit_q[i] & 0xffu, r_ = hit_q[i] >> 8;
+            const uint32_t slot = hit_n[17 + b] + r_;
+            if (slot < a.cap) a.cand[uint64_t(q0 + b) * a.cap + slot] = hit_row[i];
+        }
+        __syncthreads();
+        if (tid < 33) hit_n[tid] = 0;
+    }
+}
+
 // exact f32 ADC sums of the candidates of an 8-bit table, strict group order (pq_table.rs:254-292), the query's f32 table read
-// from global memory (327 KB at m = 320: L2-resident while its workgroup runs).  Row ids in, pair keys out (PAIR_NONE above tau).
-__global__ __launch_bounds__(256) void k_pq_adc_exact8(const uint8_t *__restrict__ codes, uint32_t enc_dim, uint32_t m, const float *__restrict__ lut,
+// from global memory (327 KB at m = 320: L2-resident while its workgroups run).  Row ids in, pair keys out (PAIR_NONE above tau).
+// The code bytes of a candidate come as 16-B words from the word-major mirror (one load per 16 groups; byte loads from the row-major
+// codes were 320 loads per candidate), 16 table entries in flight, then their 16 adds in group order; gridDim.y workgroups share a
+// query's candidates.
+__global__ __launch_bounds__(256) void k_pq_adc_exact8(const uint4 *__restrict__ codes_t, uint32_t nwords, uint32_t m, const float *__restrict__ lut,
                                                        const float *__restrict__ tau, uint64_t *__restrict__ cand, const uint32_t *__restrict__ cnt,
                                                        uint32_t cap, uint32_t *__restrict__ valid) {
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
@@ -1268,19 +1483,24 @@ __global__ __launch_bounds__(256) void k_pq_adc_exact8(const uint8_t *__restrict
     const float t = tau[q];
     uint64_t *cq = cand + uint64_t(q) * cap;
     uint32_t kept = 0;
-    for (uint32_t i = tid; i < total; i += 256) {
+    for (uint32_t i = blockIdx.y * 256 + tid; i < total; i += 256 * gridDim.y) {
         const uint32_t row = uint32_t(cq[i]);
-        const uint8_t *cb = codes + uint64_t(row) * enc_dim;
+        const uint4 *cw = codes_t + uint64_t(row >> 6) * nwords * 64 + (row & 63);
         float sum = 0.0f;
         uint32_t g = 0;
-        for (; g + 8 <= m; g += 8) {  // 8 table entries in flight, then 8 adds in group order
-            float e[8];
+        for (uint32_t w = 0; w < nwords && g < m; w++, g += 16) {
+            const uint4 c = cw[uint64_t(w) * 64];
+            const uint32_t cc[4] = {c.x, c.y, c.z, c.w};
+            if (g + 16 <= m) {
+                float e[16];
 #pragma unroll
-            for (int j = 0; j < 8; j++) e[j] = lq[(g + j) * 256 + cb[g + j]];
+                for (int j = 0; j < 16; j++) e[j] = lq[(g + j) * 256 + ((cc[j >> 2] >> (8 * (j & 3))) & 0xffu)];
 #pragma unroll
-            for (int j = 0; j < 8; j++) sum = sum + e[j];
+                for (int j = 0; j < 16; j++) sum = sum + e[j];
+            } else {
+                for (uint32_t j = 0; g + j < m; j++) sum = sum + lq[(g + j) * 256 + ((cc[j >> 2] >> (8 * (j & 3))) & 0xffu)];
+            }
         }
-        for (; g < m; g++) sum = sum + lq[g * 256 + cb[g]];
         const bool keep = sum <= t;
         cq[i] = keep ? pair_key(sum, row) : PAIR_NONE;
         kept += keep ? 1u : 0u;
@@ -2028,7 +2248,42 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
                                    (uint32_t)pq.m, (uint32_t)gn);
                 const uint32_t nsl = (uint32_t)((pq.m + ADC16X8_GS - 1) / ADC16X8_GS), m_pad16 = nsl * ADC16X8_GS;
                 const size_t lds168 = size_t(ADC16X8_GS) * 256 * 16 + size_t(ADC16X8_WGBUF) * 8 + (20 + 8) * 4 + 16;
-                if (g_adc8_sliced != 1 && lds168 <= 158 * 1024) {
+                const size_t lds816 = 2 * size_t(ADC8X16_GS) * 256 * 16 + size_t(ADC8X16_WGBUF) * 8 + (36 + 16) * 4 + 16;
+                if (g_adc8_sliced == 0 && lds816 <= 158 * 1024) {
+                    // sixteen queries per pass over the code mirror: one-byte entries in slices of 16 groups (k_pq_adc8x16)
+                    const uint32_t nsl8 = (uint32_t)((pq.m + ADC8X16_GS - 1) / ADC8X16_GS), m_pad8 = nsl8 * ADC8X16_GS;
+                    const uint32_t ngrp = (uint32_t)((gn + 15) / 16);
+                    ws.pq_img16.reserve(size_t(ngrp) * m_pad8 * 256 * sizeof(uint4));
+                    ws.pq_aux16.reserve(gn * pq.m * sizeof(float) + gn * (2 * sizeof(double) + sizeof(uint32_t)) + 64);
+                    double *qM16 = ws.pq_aux16.as<double>(), *qD16 = qM16 + gn;
+                    uint32_t *qf16 = reinterpret_cast<uint32_t *>(qD16 + gn);
+                    float *mn16 = reinterpret_cast<float *>(qf16 + ((gn + 3) & ~uint64_t(3)));
+                    const float *lutg = ws.lut.as<float>() + g0 * lsz;
+                    hipLaunchKernelGGL(k_pq_quant16x8_stats, dim3((unsigned)gn), dim3(256), 0, s, lutg, (uint32_t)pq.m, (uint32_t)gn, mn16, qM16, qD16, qf16,
+                                       std::min(65000.0, 512.0 * double(pq.m)));
+                    hipLaunchKernelGGL(k_pq_quant8x16_img, dim3(m_pad8, ngrp), dim3(256), 0, s, lutg, mn16, qD16, qf16, (uint32_t)pq.m, m_pad8,
+                                       (uint32_t)gn, ws.pq_img16.as<uint4>());
+                    Adc16x8Args b{};
+                    b.codes_t = pq.d_codes_t.as<uint4>();
+                    b.n = n;
+                    b.nwords = nw8;
+                    b.m = (uint32_t)pq.m;
+                    b.nslices = nsl8;
+                    b.img = ws.pq_img16.as<uint4>();
+                    b.qM = qM16;
+                    b.qD = qD16;
+                    b.qflag = qf16;
+                    b.tau = d_tau + g0;
+                    b.nq = (uint32_t)gn;
+                    b.rows_per_wg = uint64_t(ADC8X16_RPT) * 1024;  // one block of rows per workgroup: every slice of the image is loaded once
+                    b.cand = ws.lists.as<uint64_t>();
+                    b.cnt = d_hits + g0;
+                    b.cap = cap;
+                    func_max_lds(reinterpret_cast<const void *>(&k_pq_adc8x16), int(160 * 1024));
+                    ix.prof_begin(ws, "pq_adc", double(ngrp) * double(n) * pq.enc_dim);
+                    hipLaunchKernelGGL(k_pq_adc8x16, dim3((unsigned)((n + b.rows_per_wg - 1) / b.rows_per_wg), ngrp), dim3(1024), lds816, s, b);
+                    ix.prof_end(ws);
+                } else if (g_adc8_sliced != 1 && lds168 <= 158 * 1024) {
                     // eight queries per pass over the code mirror: 16-bit tables in slices of 32 groups (k_pq_adc16x8)
                     const uint32_t ngrp = (uint32_t)((gn + 7) / 8);
                     ws.pq_img16.reserve(size_t(ngrp) * m_pad16 * 256 * sizeof(uint4));
@@ -2037,7 +2292,7 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
                     uint32_t *qf16 = reinterpret_cast<uint32_t *>(qD16 + gn);
                     float *mn16 = reinterpret_cast<float *>(qf16 + ((gn + 3) & ~uint64_t(3)));
                     const float *lutg = ws.lut.as<float>() + g0 * lsz;
-                    hipLaunchKernelGGL(k_pq_quant16x8_stats, dim3((unsigned)gn), dim3(256), 0, s, lutg, (uint32_t)pq.m, (uint32_t)gn, mn16, qM16, qD16, qf16);
+                    hipLaunchKernelGGL(k_pq_quant16x8_stats, dim3((unsigned)gn), dim3(256), 0, s, lutg, (uint32_t)pq.m, (uint32_t)gn, mn16, qM16, qD16, qf16, 65000.0);
                     hipLaunchKernelGGL(k_pq_quant16x8_img, dim3(m_pad16, ngrp), dim3(256), 0, s, lutg, mn16, qD16, qf16, (uint32_t)pq.m, m_pad16,
                                        (uint32_t)gn, ws.pq_img16.as<uint4>());
                     Adc16x8Args b{};
@@ -2069,7 +2324,7 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
                     ix.prof_end(ws);
                 }
                 pq.adc16_queries += gn;
-                hipLaunchKernelGGL(k_pq_adc_exact8, dim3((unsigned)gn), dim3(256), 0, s, pq.d_codes.as<uint8_t>(), (uint32_t)pq.enc_dim, (uint32_t)pq.m,
+                hipLaunchKernelGGL(k_pq_adc_exact8, dim3((unsigned)gn, gn <= 2048 ? 4u : 1u), dim3(256), 0, s, pq.d_codes_t.as<uint4>(), nw8, (uint32_t)pq.m,
                                    ws.lut.as<float>() + g0 * lsz, d_tau + g0, ws.lists.as<uint64_t>(), d_hits + g0, cap, d_valid + g0);
                 launch_topk_merge_counted(ws.lists.as<uint64_t>(), cap, d_hits + g0, (uint32_t)gn, efk, ws.keys_a.as<uint64_t>() + g0 * cape, s);
             }
@@ -2077,6 +2332,20 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
             VDB_HIP(hipMemcpyAsync(hv, d_hits, 2 * nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             VDB_SYNC(s);
             const uint64_t need = std::min<uint64_t>(efk, n);
+            uint64_t hsum = 0, hmax = 0, n_over = 0, n_short = 0;
+            for (uint64_t q = 0; q < nq; q++) {
+                if (hv[q] > cap)
+                    n_over++;
+                else {
+                    hsum += hv[q];
+                    hmax = std::max<uint64_t>(hmax, hv[q]);
+                    if (hv[nq + q] < need) n_short++;
+                }
+            }
+            pq.q8_overflow += n_over;
+            pq.q8_short += n_short;
+            pq.q8_hits_sum += hsum;
+            if (hmax > pq.q8_hits_max) pq.q8_hits_max = hmax;
             for (uint64_t q = 0; q < nq; q++)
                 if (hv[q] > cap || hv[nq + q] < need) dense_group(q, 1);  // overflowed / short / unquantisable: the f32 scan answers
             return;

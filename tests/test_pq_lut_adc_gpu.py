@@ -204,10 +204,11 @@ def test_quantised_scan_with_padded_code_words(dim, m, dist, kind):
 
 @pytest.mark.parametrize("dim,m", [(64, 16), (80, 20), (96, 33), (128, 64), (384, 96)])
 def test_quantised_scan_of_8_bit_codes(dim, m):
-    """n_bits = 8 (256 centroids per group, pq_table.rs:142-145) on its own quantised passes: eight queries per pass on 16-bit tables cut
-    into slices of 32 groups (k_pq_adc16x8; whole and missing second code words of a slice, one and two slices) and one query per pass on a
-    one-byte table (k_pq_adc8), exact f32 sums for the candidates (k_pq_adc_exact8).  Same answers as the f32 scan (pq_adc16 = 1) and as
-    the oracle, whole and padded code words, ties, a degenerate query; Cosine tables keep the f32 scan."""
+    """n_bits = 8 (256 centroids per group, pq_table.rs:142-145) on its own quantised passes: sixteen queries per pass on one-byte tables
+    cut into slices of 32 groups (k_pq_adc8x16; whole and missing second code words of a slice, one to three slices, two query groups, the
+    second with 3 queries), eight per pass on 16-bit tables (k_pq_adc16x8) and one query per pass on a one-byte table (k_pq_adc8), exact f32
+    sums for the candidates (k_pq_adc_exact8).  Same answers as the f32 scan (pq_adc16 = 1) and as the oracle, whole and padded code words,
+    ties, a degenerate query; Cosine tables keep the f32 scan."""
     import lab_1806_vec_db_amd as vdb
     from oracle import oracle as O
 
@@ -225,15 +226,16 @@ def test_quantised_scan_of_8_bit_codes(dim, m):
         opq = O.PQ.from_centroids(dim, m, 8, kind, pq["centroids"])
         opq.set_codes(pq["codes"])
         for ef in (100, 700):
-            a = ix.knn_pq(qs, 10, ef)  # (eight queries per pass on sliced 16-bit tables: k_pq_adc16x8, round 4)
+            a = ix.knn_pq(qs, 10, ef)  # (sixteen queries per pass on sliced one-byte tables: k_pq_adc8x16, round 4)
             ran = ix.get_stat("pq_adc16_queries")
             assert (ran > 0) == (kind == 0)
-            ix.set_param("pq_adc8_sliced", 1)  # one query per pass on a byte table (k_pq_adc8): the same candidates' exact sums
-            try:
-                a1 = ix.knn_pq(qs, 10, ef)
-            finally:
-                ix.set_param("pq_adc8_sliced", 0)
-            assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a, a1)), (dist, ef)
+            for variant in (1, 2):  # one query per pass on a byte table (k_pq_adc8) | eight per pass on sliced 16-bit tables (k_pq_adc16x8)
+                ix.set_param("pq_adc8_sliced", variant)
+                try:
+                    a1 = ix.knn_pq(qs, 10, ef)
+                finally:
+                    ix.set_param("pq_adc8_sliced", 0)
+                assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a, a1)), (dist, ef, variant)
             ran = ix.get_stat("pq_adc16_queries")
             ix.set_param("pq_adc16", 1)
             try:

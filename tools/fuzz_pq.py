@@ -42,19 +42,22 @@ while time.time() < t_end:
     opq = O.PQ.from_centroids(dim, m, n_bits, kind, pq["centroids"])
     opq.set_codes(pq["codes"])
     a16, s16 = int(rng.choice([0, 0, 1])), int(rng.choice([0, 0, 1]))
+    v8 = int(rng.choice([0, 0, 1, 2]))  # 8-bit codes: scan variant (k_pq_adc8x16 / k_pq_adc8 / k_pq_adc16x8)
     ix.set_param("pq_adc16", a16)
     ix.set_param("pq_sample16", s16)
+    ix.set_param("pq_adc8_sliced", v8)
     try:
         idx, d, cnt = ix.knn_pq(qs, k, ef)
     finally:
         ix.set_param("pq_adc16", 0)
         ix.set_param("pq_sample16", 0)
+        ix.set_param("pq_adc8_sliced", 0)
     ok = True
     for q in range(nq):
         oi, od = O.flat_knn_pq(base, opq, qs[q], k, ef, kind)
         c = int(cnt[q])
         ok = ok and c == len(oi) and idx[q, :c].tolist() == oi.tolist() and np.array_equal(d[q, :c], od, equal_nan=True)
-    print(f"#{it} dim {dim} n {n} bits {n_bits} m {m} nq {nq} k {k} ef {ef} {dist} style {style} adc16 {a16} sample16 {s16}: "
+    print(f"#{it} dim {dim} n {n} bits {n_bits} m {m} nq {nq} k {k} ef {ef} {dist} style {style} adc16 {a16} sample16 {s16} scan8 {v8}: "
           f"{'ok' if ok else 'MISMATCH'} quantised {ix.get_stat('pq_adc16_queries')}", flush=True)
     bad += 0 if ok else 1
     ix.close()
