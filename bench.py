@@ -320,7 +320,7 @@ def compact_line(out, full_path=None):
          "dtype": out["dtype"], "data": out["data"], "config": out["config"], "recall_at_10": out.get("recall_at_10"),
          "parity": out.get("parity"), "roofline": cr,
          "cpu_baseline": {k_: cb[k_] for k_ in ("value", "unit", "cores", "kind", "sample")} if cb else None}
-    for k_ in ("i8_pass", "half_pass", "fallback_queries", "filter_work"):
+    for k_ in ("i8_pass", "half_pass", "fallback_queries", "filter_work", "pq8_pass"):
         if out.get(k_) is not None:
             c[k_] = out[k_]
     legs = out.get("legs")
@@ -757,6 +757,11 @@ def main():
             out["filter_work"] = filter_work
     else:
         out["config"]["ef"] = ef
+    if wl == "pq_flat" and args.pq_bits == 8:
+        # what the quantised pass of the 8-bit codes handed on (whole run incl. warm-up and the parity call)
+        out["pq8_pass"] = {"queries": ix.get_stat("pq_adc16_queries"), "candidates": ix.get_stat("pq_q8_hits_sum"),
+                           "largest_list": ix.get_stat("pq_q8_hits_max"), "lists_overflowed_to_f32_scan": ix.get_stat("pq_q8_overflow"),
+                           "lists_short_to_f32_scan": ix.get_stat("pq_q8_short")}
     if wl == "ivf":
         out["config"]["host_build_s"] = round(build_s, 1)
     if wl in ("hnsw", "hnsw_pq"):

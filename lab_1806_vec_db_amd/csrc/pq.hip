@@ -1468,42 +1468,85 @@ __global__ __launch_bounds__(1024) void k_pq_adc8x16(Adc16x8Args a) {
     }
 }
 
-// exact f32 ADC sums of the candidates of an 8-bit table, strict group order (pq_table.rs:254-292), the query's f32 table read
-// from global memory (327 KB at m = 320: L2-resident while its workgroups run).  Row ids in, pair keys out (PAIR_NONE above tau).
-// The code bytes of a candidate come as 16-B words from the word-major mirror (one load per 16 groups; byte loads from the row-major
-// codes were 320 loads per candidate), 16 table entries in flight, then their 16 adds in group order; gridDim.y workgroups share a
-// query's candidates.
-__global__ __launch_bounds__(256) void k_pq_adc_exact8(const uint4 *__restrict__ codes_t, uint32_t nwords, uint32_t m, const float *__restrict__ lut,
-                                                       const float *__restrict__ tau, uint64_t *__restrict__ cand, const uint32_t *__restrict__ cnt,
-                                                       uint32_t cap, uint32_t *__restrict__ valid) {
+// exact f32 ADC sums of the candidates of an 8-bit table, strict group order (pq_table.rs:254-292).  Row ids in, pair keys out
+// (PAIR_NONE above tau).  One workgroup per query, a candidate per thread: the query's f32 table (327 KB at m = 320) passes through LDS in
+// slices of 32 groups, loaded with coalesced 16-B reads, and every thread adds its candidate's 32 entries of the slice to its running sum
+// -- the order of the adds is the group order.  (Reading the table in place cost a 64-B sector per 4-B entry, from L2 / the Infinity
+// Cache once some thirty queries' tables were in use per XCD: 1.97 ms per 1000 queries for ~1000 candidates each; code bytes one at a
+// time from the row-major codes were 320 more loads per candidate.)  The code bytes come as 16-B words from the word-major mirror.
+constexpr uint32_t EXACT8_GS = 32;  // groups per slice: 32 KB of LDS
+constexpr uint32_t EXACT8_CPT = 4;  // candidates per thread and pass over the table
+// ROWMAJOR: the 32 code bytes of a slice are two 16-B words of the row-major code row (enc_dim % 16 == 0: aligned); otherwise they come
+// from the word-major mirror, whose 16-B words of one row lie 1 KB apart (a 64-B sector each: 4x the bytes)
+template <bool ROWMAJOR>
+__global__ __launch_bounds__(1024) void k_pq_adc_exact8(const uint8_t *__restrict__ codes, uint32_t enc_dim, const uint4 *__restrict__ codes_t, uint32_t nwords,
+                                                        uint32_t m, const float *__restrict__ lut, const float *__restrict__ tau, uint64_t *__restrict__ cand,
+                                                        const uint32_t *__restrict__ cnt, uint32_t cap, uint32_t *__restrict__ valid) {
+    __shared__ __attribute__((aligned(16))) float tab[EXACT8_GS * 256];
+    constexpr int CPT = (int)EXACT8_CPT;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const uint32_t total = cnt[q];
-    if (total > cap) return;  // overflowed list: the query is redone by the f32 scan
+    if (total > cap || total == 0) return;  // overflowed list: the query is redone by the f32 scan
     const float *lq = lut + uint64_t(q) * m * 256;
     const float t = tau[q];
     uint64_t *cq = cand + uint64_t(q) * cap;
     uint32_t kept = 0;
-    for (uint32_t i = blockIdx.y * 256 + tid; i < total; i += 256 * gridDim.y) {
-        const uint32_t row = uint32_t(cq[i]);
-        const uint4 *cw = codes_t + uint64_t(row >> 6) * nwords * 64 + (row & 63);
-        float sum = 0.0f;
-        uint32_t g = 0;
-        for (uint32_t w = 0; w < nwords && g < m; w++, g += 16) {
-            const uint4 c = cw[uint64_t(w) * 64];
-            const uint32_t cc[4] = {c.x, c.y, c.z, c.w};
-            if (g + 16 <= m) {
-                float e[16];
+    for (uint32_t base = 0; base < total; base += CPT * 1024) {
+        uint32_t row[CPT];
+        const uint4 *cw[CPT];
+        float sum[CPT];
 #pragma unroll
-                for (int j = 0; j < 16; j++) e[j] = lq[(g + j) * 256 + ((cc[j >> 2] >> (8 * (j & 3))) & 0xffu)];
+        for (int c = 0; c < CPT; c++) {
+            const uint32_t i = base + c * 1024 + tid;
+            row[c] = uint32_t(cq[i < total ? i : base]);
+            cw[c] = ROWMAJOR ? reinterpret_cast<const uint4 *>(codes + uint64_t(row[c]) * enc_dim)
+                             : codes_t + uint64_t(row[c] >> 6) * nwords * 64 + (row[c] & 63);
+            sum[c] = 0.0f;
+        }
+        const uint32_t nlive = total - base < CPT * 1024 ? total - base : CPT * 1024;  // candidates of this pass
+        for (uint32_t g0 = 0; g0 < m; g0 += EXACT8_GS) {
+            const uint32_t ng = m - g0 < EXACT8_GS ? m - g0 : EXACT8_GS;
+            __syncthreads();  // the previous slice's readers are done
+            {
+                const float4 *src = reinterpret_cast<const float4 *>(lq + uint64_t(g0) * 256);
+                for (uint32_t e = tid; e < ng * 64; e += 1024) reinterpret_cast<float4 *>(tab)[e] = src[e];
+            }
+            const uint32_t w0 = g0 / 16;
+            uint4 c0[CPT], c1[CPT];
 #pragma unroll
-                for (int j = 0; j < 16; j++) sum = sum + e[j];
-            } else {
-                for (uint32_t j = 0; g + j < m; j++) sum = sum + lq[(g + j) * 256 + ((cc[j >> 2] >> (8 * (j & 3))) & 0xffu)];
+            for (int c = 0; c < CPT; c++) {
+                if (uint32_t(c) * 1024 < nlive) {  // (uniform: whole candidate ranks past the list are skipped)
+                    c0[c] = cw[c][ROWMAJOR ? uint64_t(w0) : uint64_t(w0) * 64];
+                    c1[c] = w0 + 1 < nwords ? cw[c][ROWMAJOR ? uint64_t(w0 + 1) : uint64_t(w0 + 1) * 64] : make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < CPT; c++) {
+                if (uint32_t(c) * 1024 >= nlive) continue;
+                const uint32_t cc[8] = {c0[c].x, c0[c].y, c0[c].z, c0[c].w, c1[c].x, c1[c].y, c1[c].z, c1[c].w};
+                float sm = sum[c];
+                if (ng == EXACT8_GS) {
+                    float e[EXACT8_GS];
+#pragma unroll
+                    for (int j = 0; j < (int)EXACT8_GS; j++) e[j] = tab[j * 256 + ((cc[j >> 2] >> (8 * (j & 3))) & 0xffu)];
+#pragma unroll
+                    for (int j = 0; j < (int)EXACT8_GS; j++) sm = sm + e[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < (int)EXACT8_GS; j++)
+                        if ((uint32_t)j < ng) sm = sm + tab[j * 256 + ((cc[j >> 2] >> (8 * (j & 3))) & 0xffu)];
+                }
+                sum[c] = sm;
             }
         }
-        const bool keep = sum <= t;
-        cq[i] = keep ? pair_key(sum, row) : PAIR_NONE;
-        kept += keep ? 1u : 0u;
+#pragma unroll
+        for (int c = 0; c < CPT; c++) {
+            const uint32_t i = base + c * 1024 + tid;
+            const bool live = i < total, keep = live && sum[c] <= t;
+            if (live) cq[i] = keep ? pair_key(sum[c], row[c]) : PAIR_NONE;
+            kept += keep ? 1u : 0u;
+        }
     }
     if (kept) atomicAdd(&valid[q], kept);
 }
@@ -2198,7 +2241,8 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
         if (q8 && n_s8 >= 2 * uint64_t(efk) && n_s8 >= 64ull * rank8) {
             const uint64_t ld_s = (n_s8 + 63) & ~63ull;
             const uint32_t nl_s = topk_num_lists(n_s8);
-            const uint32_t cap = (uint32_t)std::min<uint64_t>(65536, std::max<uint64_t>(4096, 4ull * rank8 * step8));
+            // (lists of ~1000 expected candidates reach 4000 on a query in a thousand: 8192 entries keep those off the f32 scan)
+            const uint32_t cap = (uint32_t)std::min<uint64_t>(65536, std::max<uint64_t>(8192, 4ull * rank8 * step8));
             const uint64_t GQ = std::max<uint64_t>(64, std::min<uint64_t>(2048, (size_t(256) << 20) / (ld_s * sizeof(float))));
             const uint64_t gq_max = std::min<uint64_t>(GQ, nq);
             ws.dense.reserve(gq_max * ld_s * sizeof(float));
@@ -2324,8 +2368,14 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
                     ix.prof_end(ws);
                 }
                 pq.adc16_queries += gn;
-                hipLaunchKernelGGL(k_pq_adc_exact8, dim3((unsigned)gn, gn <= 2048 ? 4u : 1u), dim3(256), 0, s, pq.d_codes_t.as<uint4>(), nw8, (uint32_t)pq.m,
-                                   ws.lut.as<float>() + g0 * lsz, d_tau + g0, ws.lists.as<uint64_t>(), d_hits + g0, cap, d_valid + g0);
+                if (pq.enc_dim % 16 == 0)
+                    hipLaunchKernelGGL(k_pq_adc_exact8<true>, dim3((unsigned)gn), dim3(1024), 0, s, pq.d_codes.as<uint8_t>(), (uint32_t)pq.enc_dim,
+                                       pq.d_codes_t.as<uint4>(), nw8, (uint32_t)pq.m, ws.lut.as<float>() + g0 * lsz, d_tau + g0, ws.lists.as<uint64_t>(),
+                                       d_hits + g0, cap, d_valid + g0);
+                else
+                    hipLaunchKernelGGL(k_pq_adc_exact8<false>, dim3((unsigned)gn), dim3(1024), 0, s, pq.d_codes.as<uint8_t>(), (uint32_t)pq.enc_dim,
+                                       pq.d_codes_t.as<uint4>(), nw8, (uint32_t)pq.m, ws.lut.as<float>() + g0 * lsz, d_tau + g0, ws.lists.as<uint64_t>(),
+                                       d_hits + g0, cap, d_valid + g0);
                 launch_topk_merge_counted(ws.lists.as<uint64_t>(), cap, d_hits + g0, (uint32_t)gn, efk, ws.keys_a.as<uint64_t>() + g0 * cape, s);
             }
             uint32_t *hv = static_cast<uint32_t *>(ws.pinned(2 * nq * sizeof(uint32_t)));
