@@ -563,6 +563,8 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         gemm8_set_res((int)value);
     else if (n == "flat_gemm8_coop")
         gemm8_set_coop((int)value);
+    else if (n == "flat_gemm8_grid")  // measurement: workgroups of the cooperative filter (64 / 128 / 192 / 256; 0 = one per CU)
+        gemm8_set_grid((int)value);
     else if (n == "flat_gemm_coop")
         gemm_set_coop((int)value);
     else if (n == "flat_half_kmul") {  // its shortlist: max(64, kmul * k) rows per query

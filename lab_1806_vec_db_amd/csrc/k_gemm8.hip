@@ -112,7 +112,7 @@ __global__ __launch_bounds__(512, 1) void k_flat_gemm8(Gemm8Args a) {
     // correctness -- on a chip that dispatches differently the members only stop sharing.
     const uint32_t coopS = (RES && MODE == G8_FILTER) ? a.coop : 0u;
     const bool coop = coopS > 1;
-    const uint32_t c_li = blockIdx.x >> 3, c_member = coop ? c_li % coopS : 0u, c_slices = coop ? 32u / coopS : 1u;
+    const uint32_t c_li = blockIdx.x >> 3, c_member = coop ? c_li % coopS : 0u, c_slices = coop ? (gridDim.x >> 3) / coopS : 1u;  // (256 workgroups: 32 per XCD)
     const uint32_t c_stride = c_slices * 64u, c_base0 = ((coop ? c_li / coopS : 0u) * 8u) * 8u + (blockIdx.x & 7u), c_base = c_base0 + wave * 8u;
     const uint32_t c_steps = c_base < a.n_units ? (a.n_units - c_base + c_stride - 1) / c_stride : 0u;       // this wave's units per group
     const uint32_t c_steps_max = c_base0 < a.n_units ? (a.n_units - c_base0 + c_stride - 1) / c_stride : 0u;  // wave 0's: the most of the workgroup
@@ -581,6 +581,8 @@ void gemm8_set_sample_res(int v) { g_gemm8_sample_res = v; }
 
 static std::atomic<int> g_gemm8_coop{0};  // 0 auto (cooperative sets when the shape allows), 1 off
 void gemm8_set_coop(int v) { g_gemm8_coop = v; }
+static std::atomic<int> g_gemm8_grid{0};  // measurement switch: workgroups of the cooperative filter (0 = 256; a multiple of 64: whole sets on every XCD)
+void gemm8_set_grid(int v) { g_gemm8_grid = (v >= 64 && v <= 256 && v % 64 == 0) ? v : 0; }
 static std::atomic<uint32_t> g_gemm8_last_coop{0};  // set size of the most recent filter launch (0: no sets)
 uint32_t gemm8_last_coop() { return g_gemm8_last_coop; }
 
@@ -604,7 +606,7 @@ static void flat_gemm8_launch(const Gemm8Args &a0, int num_cu, hipStream_t s) {
                 const double per_unit = 8.0 * 48.0 * 128.0 * double(a.hits_expected ? a.hits_expected : 1024u) / double(a.n);
                 const double b = double(G8_WGBUF_RES) * 0.8 / per_unit;
                 a.coop_block = b < 1.0 ? 1u : (b > 4096.0 ? 4096u : uint32_t(b));
-                flat_gemm8_launch1<KC, MODE, false, false, true>(a, num_cu, s);  // default loads: the members meet in the L2
+                flat_gemm8_launch1<KC, MODE, false, false, true>(a, g_gemm8_grid ? (int)g_gemm8_grid : num_cu, s);  // default loads: the members meet in the L2
                 return;
             }
         }

@@ -229,6 +229,7 @@ void gemm8_set_burst(int v);
 uint32_t gemm8_last_coop();   // set size of the most recent 8-bit filter launch (0: no cooperative sets)
 uint32_t gemm_last_coop();
 void gemm_set_coop(int v);    // the same for the fp16 / split-bf16 filter kernel
+void gemm8_set_grid(int v);   // measurement: workgroups of the cooperative 8-bit filter (0 = one per CU)
 void gemm8_set_coop(int v);   // 0 auto (the workgroups of an XCD share one row stream through its L2 when the shape allows), 1 off
 void gemm8_set_res(int v);
 void gemm8_set_sample_res(int v);    // 0 auto (the query group's whole image resident in LDS when it fits), 1 off (chunked staging)
