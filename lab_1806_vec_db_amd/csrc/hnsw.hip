@@ -307,6 +307,15 @@ __device__ __forceinline__ float hnsw_exact_dists_dma(const HnswDev &g, const fl
 #ifndef HNSW_LB
 #define HNSW_LB 2
 #endif
+#ifndef HNSW_FOLD_PRODUCTS
+#define HNSW_FOLD_PRODUCTS 1  // 0: the round-3 / early round-4 fold (raw rows through the transpose, products in the folding layout)
+#endif
+#ifndef HNSW_FOLD_FREE
+#define HNSW_FOLD_FREE 1  // no scheduling barrier between the chunks of a line (0: pinned chunk by chunk -- 8 % slower per one-query call)
+#endif
+#ifndef HNSW_ABL
+#define HNSW_ABL 0  // measurement builds (tools/hnsw_ablate.sh; WRONG distances): 1 = no row-line loads inside the fold, 2 = no query re-reads, 4 = no LDS transpose
+#endif
 #ifdef HNSW_STAMP2  // measurement build: wall-clock ticks (100 MHz) inside hnsw_exact_dists_regs: set-up + first loads issued | first line arrived and
                     // transposed | the fold's lines | epilogue; [4] = calls
 __device__ unsigned long long g_hnsw_st2[8];
@@ -373,6 +382,67 @@ __device__ __forceinline__ float hnsw_exact_dists_regs(const HnswDev &g, const f
     // ahead through two LDS blocks: while line L is folded from registers (cur / qv), line L+1 is written to the other block
     // and every chunk register is re-read for line L+1 right after its last use.
     static_assert(D % 2 == 0, "the LDS block of a line is chosen by the parity of its ring slot");
+#if HNSW_FOLD_PRODUCTS
+    // What the transpose carries is the PRODUCTS.  tools/hnsw_ablate.sh: a one-query call's fold is the sum of its instructions' issue
+    // times, not a chain with shadows to hide work in -- 30 lines x (32 adds + 16 packed multiplies + 16 ds_read_b128 + NG writes + NG
+    // loads) took 7.2 us where the 960 adds alone take 2.05 (5 cycles per dependent add).  In the loaded layout all 64 lanes hold
+    // different data (lane 8g+j: chunk (j + g + (k & 1)) mod 8 of row 8k + g), in the folding layout lanes 32 .. 63 mirror lanes 0 .. 31:
+    // multiplying BEFORE the transpose takes 2 NG packed multiplies per line instead of 16, and the query is read as the two chunks a
+    // lane needs per line (even / odd k) instead of all eight.  Same IEEE products, same order of the adds.
+    v4f cur[8];
+    const uint32_t cqe = (jj + gg) & 7, cqo = (jj + gg + 1) & 7;  // this lane's query chunk of a line for even / odd k
+    v4f qe = q4[cqe], qo = q4[cqo];                               // ... of line 0
+    {
+#pragma unroll
+        for (int k = 0; k < NG; k++) *reinterpret_cast<v4f *>(stage + k * 1024 + 16 * lane) = buf[0][k] * ((k & 1) ? qo : qe);
+        const uint32_t Ld = (uint32_t)D < last ? (uint32_t)D : last;
+#pragma unroll
+        for (int k = 0; k < NG; k++) buf[0][k] = rp[k][Ld * 8];
+        const uint32_t Lq = 1u < last ? 1u : last;
+        qe = q4[Lq * 8 + cqe];
+        qo = q4[Lq * 8 + cqo];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 8; c++) cur[c] = *reinterpret_cast<const v4f *>(stage + off[c]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#ifdef HNSW_STAMP2
+    acc += cur[0].x * 0.0f;  // (the first line must have arrived before the clock is read)
+#endif
+    HNSW_T2(1)
+    for (uint32_t L0 = 0; L0 < nlines; L0 += D) {
+        static_for<D>([&](auto ic) {  // (compile-time indices: the line buffers must stay in registers)
+            constexpr int i = decltype(ic)::value, in = (i + 1) % D;
+            const uint32_t L = L0 + i;
+            const uint32_t L2 = L + 2 < last ? L + 2 : last, Lr = L + 1 + D < last ? L + 1 + D : last;
+            unsigned char *sb = stage + ((i + 1) & 1) * 4096;  // block of line L+1
+#pragma unroll
+            for (int k = 0; k < NG; k++) *reinterpret_cast<v4f *>(sb + k * 1024 + 16 * lane) = buf[in][k] * ((k & 1) ? qo : qe);  // (qe / qo: line L+1's)
+#pragma unroll
+            for (int k = 0; k < NG; k++) buf[in][k] = rp[k][Lr * 8];
+            qe = q4[L2 * 8 + cqe];
+            qo = q4[L2 * 8 + cqo];
+            __builtin_amdgcn_sched_barrier(0);
+            float a = acc;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const v4f pc = cur[c];
+                a = a + pc.x;
+                a = a + pc.y;
+                a = a + pc.z;
+                a = a + pc.w;
+                cur[c] = *reinterpret_cast<const v4f *>(sb + off[c]);
+#if !HNSW_FOLD_FREE
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+            acc = L < nlines ? a : acc;
+#if HNSW_FOLD_FREE < 2
+            __builtin_amdgcn_sched_barrier(0);  // (the next line's products stay below this line's adds: they need the query chunks read above)
+#endif
+        });
+    }
+#else
     v4f cur[8], qv[8];
     {
 #pragma unroll
@@ -398,10 +468,14 @@ __device__ __forceinline__ float hnsw_exact_dists_regs(const HnswDev &g, const f
             const uint32_t L = L0 + i;
             const uint32_t L1 = L + 1 < last ? L + 1 : last, Lr = L + 1 + D < last ? L + 1 + D : last;
             unsigned char *sb = stage + ((i + 1) & 1) * 4096;  // block of line L+1
+            if (!(HNSW_ABL & 4)) {
 #pragma unroll
-            for (int k = 0; k < NG; k++) *reinterpret_cast<v4f *>(sb + k * 1024 + 16 * lane) = buf[in][k];
+                for (int k = 0; k < NG; k++) *reinterpret_cast<v4f *>(sb + k * 1024 + 16 * lane) = buf[in][k];
+            }
+            if (!(HNSW_ABL & 1)) {
 #pragma unroll
-            for (int k = 0; k < NG; k++) buf[in][k] = rp[k][Lr * 8];
+                for (int k = 0; k < NG; k++) buf[in][k] = rp[k][Lr * 8];
+            }
             __builtin_amdgcn_sched_barrier(0);
             // The chain is the 32 dependent adds of a line (10.9 cycles each: tools/fold_chain_probe.cpp); a multiply in front of every
             // add -- what `p = v.x * q.x; a = a + p` compiles to, each add waiting for the multiply issued just before it -- made an
@@ -422,13 +496,14 @@ __device__ __forceinline__ float hnsw_exact_dists_regs(const HnswDev &g, const f
                 a = a + pc.y;
                 a = a + pc.z;
                 a = a + pc.w;
-                cur[c] = *reinterpret_cast<const v4f *>(sb + off[c]);
-                qv[c] = q4[L1 * 8 + c];
+                if (!(HNSW_ABL & 4)) cur[c] = *reinterpret_cast<const v4f *>(sb + off[c]);
+                if (!(HNSW_ABL & 2)) qv[c] = q4[L1 * 8 + c];
                 __builtin_amdgcn_sched_barrier(0);
             }
             acc = L < nlines ? a : acc;
         });
     }
+#endif
 #ifdef HNSW_STAMP2
     acc = __shfl(acc, lane);
 #endif

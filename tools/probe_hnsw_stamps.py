@@ -14,8 +14,10 @@ tr.pq_build(n_bits=4, m=320, train_n=0, max_iter=20, tol=1e-6, seed=42)
 ix.pq_attach(4, 320, tr.pq_export()["centroids"], None); tr.close()
 qs = gist_lowrank_gpu(torch, 1000, 960, 1807, dev)
 o_idx = torch.zeros((1000, 10), dtype=torch.int64, device=dev); o_dist = torch.zeros((1000, 10), dtype=torch.float32, device=dev); o_cnt = torch.zeros((1000,), dtype=torch.int64, device=dev)
-for use_pq in (False, True):
-    for nq in (1, 32, 1000):
+import os
+exact_only = os.environ.get('HNSW_STAMPS_EXACT_ONLY') == '1'
+for use_pq in ((False,) if exact_only else (False, True)):
+    for nq in ((1, 1000) if exact_only else (1, 32, 1000)):
         for it in range(3):
             torch.cuda.synchronize(); t = time.perf_counter()
             ix.hnsw_knn_device(qs.data_ptr(), nq, 10, 128, o_idx.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr(), use_pq=use_pq)
