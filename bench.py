@@ -750,7 +750,7 @@ def main():
     if wl == "flat":
         out["config"]["queries_per_corpus_pass"] = 128 if (nq > 64 or (roofline or {}).get("kernel") in ("flat_half", "flat_i8")) else 64
         out["fallback_queries"] = ix.flat_fallback_count()
-        out["i8_pass"] = {"queries": ix.get_stat("flat_i8_queries"), "passed_on_to_fp16": ix.get_stat("flat_i8_redo")}
+        out["i8_pass"] = {"queries": ix.get_stat("flat_i8_queries"), "second_attempts": ix.get_stat("flat_i8_second_queries"), "passed_on_to_fp16": ix.get_stat("flat_i8_redo")}
         out["half_pass"] = {"queries": ix.get_stat("flat_half_queries"), "redone_split_bf16": ix.get_stat("flat_half_redo")}
         out["hbm_bytes_per_row"] = ix.get_stat("hbm_bytes_per_row")
         if filter_work:
