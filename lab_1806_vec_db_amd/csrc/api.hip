@@ -538,6 +538,11 @@ int vdb_set_param(vdb_index *idx, const char *name, int64_t value) {
         idx->ix.flat_i8_unit_min = (int)value;
     else if (n == "flat_i8_full")  // second 8-bit attempt of a handful of queries: all candidates at once (0 on, 1 off: rounds of 63 rows)
         idx->ix.flat_i8_full = (int)value;
+    else if (n == "flat_i8_refine") {  // hit keys of the 8-bit pass tightened from the fp16 row image before the walk: 0 auto, 1 off, 2 always
+        idx->ix.flat_i8_refine = (int)value;
+        idx->ix.i8_refine_on = 0;
+        idx->ix.i8_refine_calls = 0;
+    }
     else if (n == "flat_i8_second")  // second 8-bit attempt with thresholds from the first walk's k-th distances: 0 on, 1 off
         idx->ix.flat_i8_second = (int)value;
     else if (n == "flat_i8_stats") {  // (measurement) collect per-query rounds / hits of the 8-bit pass's exact stage; setting it resets them
@@ -643,6 +648,10 @@ int vdb_get_stat(const vdb_index *idx, const char *name, uint64_t *out) {
         *out = idx->ix.ivf.last_kept.load();
     else if (n == "pq_adc16_queries")
         *out = idx->ix.pq.adc16_queries.load();
+    else if (n == "flat_i8_refine_queries")
+        *out = idx->ix.i8_refine_queries.load();
+    else if (n == "flat_i8_refine_on")
+        *out = (uint64_t)idx->ix.i8_refine_on.load();
     else if (n == "pq_q8_overflow")
         *out = idx->ix.pq.q8_overflow.load();
     else if (n == "pq_q8_short")

@@ -114,6 +114,81 @@ __device__ __forceinline__ float half_dots32(const uint16_t *__restrict__ rows_h
 }
 
 
+// half_diffs32: the same fetch, but sum_i (h_i - q'_i)^2 with q' = q * sx in LDS (the scale is a power of two: q' is exact), returned times
+// inv_sx^2 -- |x~ - q|^2 for the image row x~ = h / sx, every term non-negative, so the computed value is within (d + 4) u RELATIVE of the
+// real one whatever the order.  This is the form that survives cancellation: the dot form's error is ~ |dx||q|, this one's |dx||x - q|
+// (k_redo.hip: k_flat_refine_half).
+__device__ __forceinline__ float half_diffs32(const uint16_t *__restrict__ rows_h, uint32_t dim, float inv_sx, const float *qlds, uint32_t nb,
+                                              bool fresh, uint32_t lane) {
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    constexpr int D = HALF_ROWS_DEPTH;
+    const uint32_t nlines = dim / 64, last = nlines - 1;
+    const uint64_t fm = __ballot(fresh);
+    const uint32_t nfresh = (uint32_t)__builtin_popcountll(fm);
+    const uint32_t rank = (uint32_t)__builtin_popcountll(fm & ((1ull << lane) - 1));
+    const uint32_t cnb = (uint32_t)__builtin_amdgcn_ds_permute(int((fresh ? rank : nfresh + (lane - rank)) * 4), int(nb));
+    const uint32_t gg = lane >> 3, jj = lane & 7;
+    const v4u *rp[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t src = 8 * k + gg;
+        const uint32_t nbk = __shfl(cnb, src < nfresh ? src : 0u);
+        rp[k] = reinterpret_cast<const v4u *>(rows_h + uint64_t(nbk) * dim) + jj;
+    }
+    v4u buf[D][4];
+    static_for<D>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const uint32_t Li = (uint32_t)i < last ? (uint32_t)i : last;
+#pragma unroll
+        for (int k = 0; k < 4; k++) buf[i][k] = rp[k][Li * 8];
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const v4f *q4 = reinterpret_cast<const v4f *>(qlds) + jj * 2;  // the 8 query columns of this lane's chunk
+    for (uint32_t L0 = 0; L0 < nlines; L0 += D) {
+        static_for<D>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const uint32_t L = L0 + i;
+            const uint32_t Lc = L < last ? L : last, Ln = L + D < last ? L + D : last;
+            v4u cur[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) cur[k] = buf[i][k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) buf[i][k] = rp[k][Ln * 8];
+            __builtin_amdgcn_sched_barrier(0);
+            const v4f qa = q4[Lc * 16], qb = q4[Lc * 16 + 1];
+            const float qv[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float a = acc[k];
+                const uint32_t w[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const h2 h = __builtin_bit_cast(h2, w[e]);
+                    const float t0 = (float)h.x - qv[2 * e], t1 = (float)h.y - qv[2 * e + 1];
+                    a = __builtin_fmaf(t0, t0, a);
+                    a = __builtin_fmaf(t1, t1, a);
+                }
+                acc[k] = L < nlines ? a : acc[k];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        acc[k] += __shfl_xor(acc[k], 1);
+        acc[k] += __shfl_xor(acc[k], 2);
+        acc[k] += __shfl_xor(acc[k], 4);
+    }
+    // compacted row r = 8k + g: its sum sits in acc[k] of the lanes of group g
+    const uint32_t src = 8 * (lane & 7), kr = (lane >> 3) & 3;
+    const float s0 = __shfl(acc[0], src), s1 = __shfl(acc[1], src), s2 = __shfl(acc[2], src), s3 = __shfl(acc[3], src);
+    const float sr = kr == 0 ? s0 : (kr == 1 ? s1 : (kr == 2 ? s2 : s3));
+    return __shfl(sr, rank) * (inv_sx * inv_sx);  // back to the lane the neighbour came from; the scale is a power of two
+}
+
+
 // approximate distance `a` of a row with cached |x|^2 = xs against a query with |q|^2 = qsq from an approximate dot product S
 // whose distance to the real x.q is at most `op` (the operand term: rounding of the image[s]), and the bound E (see the
 // header comment); metric: MET_L2_CACHED, MET_L2_DIRECT or MET_COSINE

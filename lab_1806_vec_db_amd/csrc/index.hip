@@ -784,8 +784,23 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
         t.id_offset = id_offset;
         // (flags, then -- measurement builds of a call, flat_i8_stats -- one word per query of exact-stage statistics)
         const size_t st_off = (nq + 15) & ~size_t(15);
-        t.flags = static_cast<uint8_t *>(ws.pinned(i8 && flat_i8_stats ? st_off + nq * sizeof(uint32_t) : nq));
-        if (i8 && flat_i8_stats) t.qstat = reinterpret_cast<uint32_t *>(t.flags + st_off);
+        // (the rounds walked also steer the fp16 refinement of the hit keys: collected on every first attempt while that is on auto)
+        const bool want_stats = i8 && (flat_i8_stats || (!i8_second && flat_i8_refine == 0 && nq >= 64));
+        t.flags = static_cast<uint8_t *>(ws.pinned(want_stats ? st_off + nq * sizeof(uint32_t) : nq));
+        if (want_stats) t.qstat = reinterpret_cast<uint32_t *>(t.flags + st_off);
+        p.stats = want_stats;
+        p.refined = false;
+        if (i8 && !i8_second && !cosine && nq >= 64 && flat_i8_refine != 1) {
+            // long walks (tight clusters): the keys of the hits are tightened from the row-major fp16 image first (k_redo.hip)
+            bool on = flat_i8_refine == 2;
+            if (flat_i8_refine == 0 && i8_refine_on.load() != 0) on = (i8_refine_calls.fetch_add(1) % 32u) != 31u;  // (the 32nd: a probe without)
+            if (on && ensure_rows_h(ws)) {
+                launch_flat_refine_half(d_rows_h.as<uint16_t>(), (uint32_t)dim, half_sx(), half_dx_abs, half_dx_rel, d_q, d_sq.as<float>(), d_qoff, d_cand,
+                                        CAND_CAP, d_hits, (uint32_t)nq, CAND_CAP, s);  // (a list holds up to CAND_CAP hits; the walk selects among all of them)
+                p.refined = true;
+                i8_refine_queries += nq;
+            }
+        }
         t.out_idx = d_idx;
         t.out_dist = d_dist;
         t.out_count = d_cnt;
@@ -854,6 +869,22 @@ void Index::flat_knn_finish(Workspace &ws, FlatPending &p) {
     if (i8 && !i8_second) {
         i8_queries += nq;
         if (!try_second) i8_redo += redo.size();  // (with a second attempt: what THAT passes on, counted below)
+        if (p.stats && flat_i8_refine == 0 && nq >= 64 && dist == 0) {
+            // auto rule of the fp16 refinement: it costs half the f32 bytes of every hit (~0.5 ms per 1000 queries), a round of the walk
+            // ~0.1 ms per 1000 queries -- on when the walks average 6 rounds, off again when a probe call without it averages under 4
+            const uint32_t *qs = reinterpret_cast<const uint32_t *>(flags + ((nq + 15) & ~size_t(15)));
+            uint64_t rs = 0;
+            for (uint64_t q = 0; q < nq; q++) rs += std::min<uint32_t>(qs[q] & 0xFFu, 32u);  // (0xFF: a list evaluated whole)
+            const double mean_rounds = double(rs) / double(nq);
+            if (!p.refined) {
+                const int was = i8_refine_on.load();
+                const int now = was ? (mean_rounds >= 4.0 ? 1 : 0) : (mean_rounds >= 6.0 ? 1 : 0);
+                if (now != was) {
+                    i8_refine_on = now;
+                    i8_refine_calls = 0;
+                }
+            }
+        }
         if (flat_i8_stats) {
             const uint32_t *qs = reinterpret_cast<const uint32_t *>(flags + ((nq + 15) & ~size_t(15)));
             uint64_t hs = 0, hm = 0;

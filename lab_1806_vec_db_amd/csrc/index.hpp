@@ -184,6 +184,8 @@ struct FlatPending {
     bool half = false;
     bool i8 = false;      // first pass on the 8-bit mirror (its uncertified queries go to the fp16 / split-bf16 tiers)
     bool i8_second = false;  // ... its second attempt: thresholds from the first walk's k-th distances (k_redo.hip)
+    bool stats = false;      // the exact stage wrote one word of statistics per query behind the flags
+    bool refined = false;    // the hit keys were tightened from the fp16 image before the walk
     uint32_t kprime = 0, ksel = 0;
     uint64_t nq = 0, k = 0;
     const float *d_q = nullptr;
@@ -285,6 +287,10 @@ struct Index {
     // stragglers need the second attempt's longer lists either way); tight clusters 3.03 / 2.89 / 2.47 ms
     uint32_t flat_i8_kprime = 2048;
     int flat_i8_full = 0;           // second attempt of <= 96 queries: all candidates evaluated at once (0 on, 1 off: the walk)
+    int flat_i8_refine = 0;         // hit keys tightened from the fp16 row image before the walk (k_flat_refine_half): 0 auto (on while the walks are long), 1 off, 2 always
+    std::atomic<int> i8_refine_on{0};        // auto state
+    std::atomic<uint32_t> i8_refine_calls{0};  // first-attempt calls since the state changed (every 32nd call of the on state runs without: the probe)
+    std::atomic<uint64_t> i8_refine_queries{0};  // queries whose hit lists were refined
     int flat_i8_unit_min = 0;       // threshold sample of the 8-bit pass by unit minima when the sampled units are many: 0 auto, 1 off
     int flat_i8_second = 0;         // second 8-bit attempt with thresholds from the first walk (k_redo.hip): 0 on, 1 off
     std::atomic<uint64_t> i8_second_queries{0}, i8_second_redo{0};
