@@ -117,9 +117,11 @@ __device__ __forceinline__ float half_dots32(const uint16_t *__restrict__ rows_h
 // half_diffs32: the same fetch, but sum_i (h_i - q'_i)^2 with q' = q * sx in LDS (the scale is a power of two: q' is exact), returned times
 // inv_sx^2 -- |x~ - q|^2 for the image row x~ = h / sx, every term non-negative, so the computed value is within (d + 4) u RELATIVE of the
 // real one whatever the order.  This is the form that survives cancellation: the dot form's error is ~ |dx||q|, this one's |dx||x - q|
-// (k_redo.hip: k_flat_refine_half).
+// (k_redo.hip: k_flat_refine_half).  UNIT: the image row is scaled by inv_sx / |x_r| (cached norm) on the fly and the LDS holds the unit query:
+// |x^~ - q^|^2, the difference form of the Cosine keys' terms.
+template <bool UNIT = false>
 __device__ __forceinline__ float half_diffs32(const uint16_t *__restrict__ rows_h, uint32_t dim, float inv_sx, const float *qlds, uint32_t nb,
-                                              bool fresh, uint32_t lane) {
+                                              bool fresh, uint32_t lane, const float *__restrict__ xsq = nullptr) {
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     constexpr int D = HALF_ROWS_DEPTH;
@@ -130,11 +132,13 @@ __device__ __forceinline__ float half_diffs32(const uint16_t *__restrict__ rows_
     const uint32_t cnb = (uint32_t)__builtin_amdgcn_ds_permute(int((fresh ? rank : nfresh + (lane - rank)) * 4), int(nb));
     const uint32_t gg = lane >> 3, jj = lane & 7;
     const v4u *rp[4];
+    float rs[4] = {1.0f, 1.0f, 1.0f, 1.0f};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t src = 8 * k + gg;
         const uint32_t nbk = __shfl(cnb, src < nfresh ? src : 0u);
         rp[k] = reinterpret_cast<const v4u *>(rows_h + uint64_t(nbk) * dim) + jj;
+        if (UNIT) rs[k] = inv_sx / sqrtf(xsq[nbk]);  // image row -> (nearly) unit row: h * rs
     }
     v4u buf[D][4];
     static_for<D>([&](auto ic) {
@@ -166,7 +170,8 @@ __device__ __forceinline__ float half_diffs32(const uint16_t *__restrict__ rows_
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const h2 h = __builtin_bit_cast(h2, w[e]);
-                    const float t0 = (float)h.x - qv[2 * e], t1 = (float)h.y - qv[2 * e + 1];
+                    const float t0 = UNIT ? __builtin_fmaf((float)h.x, rs[k], -qv[2 * e]) : (float)h.x - qv[2 * e];
+                    const float t1 = UNIT ? __builtin_fmaf((float)h.y, rs[k], -qv[2 * e + 1]) : (float)h.y - qv[2 * e + 1];
                     a = __builtin_fmaf(t0, t0, a);
                     a = __builtin_fmaf(t1, t1, a);
                 }
@@ -185,7 +190,7 @@ __device__ __forceinline__ float half_diffs32(const uint16_t *__restrict__ rows_
     const uint32_t src = 8 * (lane & 7), kr = (lane >> 3) & 3;
     const float s0 = __shfl(acc[0], src), s1 = __shfl(acc[1], src), s2 = __shfl(acc[2], src), s3 = __shfl(acc[3], src);
     const float sr = kr == 0 ? s0 : (kr == 1 ? s1 : (kr == 2 ? s2 : s3));
-    return __shfl(sr, rank) * (inv_sx * inv_sx);  // back to the lane the neighbour came from; the scale is a power of two
+    return __shfl(sr, rank) * (UNIT ? 1.0f : inv_sx * inv_sx);  // back to the lane the neighbour came from; the scale is a power of two
 }
 
 

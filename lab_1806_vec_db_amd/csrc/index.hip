@@ -790,13 +790,13 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
         if (want_stats) t.qstat = reinterpret_cast<uint32_t *>(t.flags + st_off);
         p.stats = want_stats;
         p.refined = false;
-        if (i8 && !i8_second && !cosine && nq >= 64 && flat_i8_refine != 1) {
+        if (i8 && !i8_second && nq >= 64 && flat_i8_refine != 1) {
             // long walks (tight clusters): the keys of the hits are tightened from the row-major fp16 image first (k_redo.hip)
             bool on = flat_i8_refine == 2;
             if (flat_i8_refine == 0 && i8_refine_on.load() != 0) on = (i8_refine_calls.fetch_add(1) % 32u) != 31u;  // (the 32nd: a probe without)
             if (on && ensure_rows_h(ws)) {
-                launch_flat_refine_half(d_rows_h.as<uint16_t>(), (uint32_t)dim, half_sx(), half_dx_abs, half_dx_rel, d_q, d_sq.as<float>(), d_qoff, d_cand,
-                                        CAND_CAP, d_hits, (uint32_t)nq, CAND_CAP, s);  // (a list holds up to CAND_CAP hits; the walk selects among all of them)
+                launch_flat_refine_half(d_rows_h.as<uint16_t>(), (uint32_t)dim, half_sx(), half_dx_abs, half_dx_rel, cosine, d_q, d_sq.as<float>(),
+                                        ws.qsq.as<float>(), d_qoff, d_cand, CAND_CAP, d_hits, (uint32_t)nq, CAND_CAP, s);  // (a list holds up to CAND_CAP hits; the walk selects among all of them)
                 p.refined = true;
                 i8_refine_queries += nq;
             }
@@ -869,7 +869,7 @@ void Index::flat_knn_finish(Workspace &ws, FlatPending &p) {
     if (i8 && !i8_second) {
         i8_queries += nq;
         if (!try_second) i8_redo += redo.size();  // (with a second attempt: what THAT passes on, counted below)
-        if (p.stats && flat_i8_refine == 0 && nq >= 64 && dist == 0) {
+        if (p.stats && flat_i8_refine == 0 && nq >= 64) {
             // auto rule of the fp16 refinement: it costs half the f32 bytes of every hit (~0.5 ms per 1000 queries), a round of the walk
             // ~0.1 ms per 1000 queries -- on when the walks average 6 rounds, off again when a probe call without it averages under 4
             const uint32_t *qs = reinterpret_cast<const uint32_t *>(flags + ((nq + 15) & ~size_t(15)));

@@ -106,18 +106,24 @@ void launch_i8_tau_from_dk(const float *dk, uint32_t nq, uint32_t nq_pad, const 
 // a = fl(A) within (d + 4) u relative (all terms non-negative), so  D >= lb := max(0, sqrt(a (1 - (d + 4) u)) - |dx_r|)^2  and the key
 // becomes the larger of the 8-bit key and lb - O_q (the keys' terms: D >= key + O_q); the walk (k_flat_tail_lb) and its certification run
 // unchanged on the tightened list.  The f32 evaluation of lb rounds a handful of times: every step is pushed down by 4 u relative.
-// Keys that are not finite keep the 8-bit value.  A wave per 64 hits (32 rows at a time).  L2Sqr only: the Cosine keys bound the distance
-// of UNIT vectors, whose difference form needs a per-row scale (not built).  Costs half the f32 bytes of EVERY hit, so it only runs where
-// the walks are long (Index::flat_i8_refine: auto by the rounds walked).
+// Keys that are not finite keep the 8-bit value.  A wave per 64 hits (32 rows at a time).  Cosine: the keys bound the distance of the
+// UNIT vectors, 2 (1 - cos) = |x^ - q^|^2 >= key + O_q, and the same inequality holds for them with the image row scaled by 1 / |x_r|
+// (cached norm) on the fly, the unit query in LDS and the slack |dx_r| / |x_r| + (d + 16) u (the norms' own rounding); rows and queries
+// whose cached norms are not plain numbers keep their keys.  Costs half the f32 bytes of EVERY hit, so it only runs where the walks are
+// long (Index::flat_i8_refine: auto by the rounds walked).
+template <bool COS>
 __global__ __launch_bounds__(64) void k_flat_refine_half(const uint16_t *__restrict__ rows_h, uint32_t dim, float sx, float dx_abs, float dx_rel,
-                                                         const float *__restrict__ Q, const float *__restrict__ xsq,
+                                                         const float *__restrict__ Q, const float *__restrict__ xsq, const float *__restrict__ qsq,
                                                          const float *__restrict__ qoff, uint64_t *__restrict__ cand, uint32_t cap,
                                                          const uint32_t *__restrict__ cnt) {
-    extern __shared__ __attribute__((aligned(16))) float rf_q[];  // [dim]: q * sx
+    extern __shared__ __attribute__((aligned(16))) float rf_q[];  // [dim]: q * sx (Cosine: q / |q|)
     const uint32_t q = blockIdx.y, lane = threadIdx.x;
     const uint32_t total = cnt[q];
     if (total > cap || blockIdx.x * 64 >= total) return;  // (an overflowed list is redone anyway)
-    for (uint32_t i = lane; i < dim; i += 64) rf_q[i] = Q[uint64_t(q) * dim + i] * sx;  // (a power of two: exact)
+    const float qs = COS ? qsq[q] : 1.0f;
+    if (COS && !(qs >= 1e-30f && qs <= 1e30f)) return;  // (block-uniform: such a query keeps its 8-bit keys)
+    const float qmul = COS ? 1.0f / sqrtf(qs) : sx;      // (sx is a power of two: exact)
+    for (uint32_t i = lane; i < dim; i += 64) rf_q[i] = Q[uint64_t(q) * dim + i] * qmul;
     __syncthreads();
     constexpr float u = 0x1p-24f;
     const float oq = qoff[q], inv_sx = 1.0f / sx;
@@ -128,25 +134,38 @@ __global__ __launch_bounds__(64) void k_flat_refine_half(const uint16_t *__restr
         const uint64_t c = live ? cand[uint64_t(q) * cap + j] : PAIR_NONE;
         const uint32_t nb = live ? uint32_t(c) : 0u;
         if (__ballot(live) == 0) continue;  // wave-uniform
-        const float a = half_diffs32(rows_h, dim, inv_sx, rf_q, nb, live, lane);
+        const float a = half_diffs32<COS>(rows_h, dim, inv_sx, rf_q, nb, live, lane, xsq);
         if (live) {
-            const float nx = sqrtf(xsq[nb]) * 1.001f;  // (cached strict fold: within gamma_d of |x|^2)
-            const float dxr = fminf(dx_abs, dx_rel * nx) * 1.001f;
-            float sr = sqrtf(a * (1.0f - float(dim + 8) * u)) * (1.0f - 4.0f * u) - dxr;
+            const float xs = xsq[nb];
+            const float nx = sqrtf(xs) * 1.001f;  // (cached strict fold: within gamma_d of |x|^2)
+            float slack = fminf(dx_abs, dx_rel * nx) * 1.001f;  // |x - x~|
+            bool okrow = true;
+            if (COS) {
+                // unit vectors: |x^ - x^~| <= |dx| / |x| + the relative error of the cached norm and of 1 / sqrt; |q^ - q^c| likewise; the
+                // per-element roundings of h * rs and q * qmul: together below (d + 16) u
+                okrow = xs >= 1e-30f && xs <= 1e30f;
+                slack = slack / (sqrtf(xs) * 0.999f) * 1.002f + float(dim + 16) * u;
+            }
+            float sr = sqrtf(a * (1.0f - float(dim + 8) * u)) * (1.0f - 4.0f * u) - slack;
             sr = sr > 0.0f ? sr * (1.0f - 4.0f * u) : 0.0f;
-            const float lb = sr * sr * (1.0f - 4.0f * u);
+            const float lb = sr * sr * (1.0f - 4.0f * u);  // <= |x - q|^2 (Cosine: <= |x^ - q^|^2 = 2 (1 - cos))
             const float kn = (lb - oq) - 4.0f * u * (fabsf(lb) + fabsf(oq));
             const float ko = f32_from_orderable(uint32_t(c >> 32));
-            const bool fin = a - a == 0.0f && dxr - dxr == 0.0f && kn - kn == 0.0f;  // (NaN / inf anywhere: the 8-bit key stays)
+            const bool fin = okrow && a - a == 0.0f && slack - slack == 0.0f && kn - kn == 0.0f;  // (NaN / inf anywhere: the 8-bit key stays)
             if (fin && kn > ko) cand[uint64_t(q) * cap + j] = pair_key(kn, nb);
         }
     }
 }
-void launch_flat_refine_half(const uint16_t *rows_h, uint32_t dim, float sx, float dx_abs, float dx_rel, const float *Q, const float *xsq,
-                             const float *qoff, uint64_t *cand, uint32_t cap, const uint32_t *cnt, uint32_t nq, uint32_t max_hits, hipStream_t s) {
+void launch_flat_refine_half(const uint16_t *rows_h, uint32_t dim, float sx, float dx_abs, float dx_rel, int cosine, const float *Q, const float *xsq,
+                             const float *qsq, const float *qoff, uint64_t *cand, uint32_t cap, const uint32_t *cnt, uint32_t nq, uint32_t max_hits,
+                             hipStream_t s) {
     if (nq == 0 || max_hits == 0) return;
-    hipLaunchKernelGGL(k_flat_refine_half, dim3((max_hits + 63) / 64, nq), dim3(64), dim * sizeof(float), s, rows_h, dim, sx, dx_abs, dx_rel, Q, xsq,
-                       qoff, cand, cap, cnt);
+    if (cosine)
+        hipLaunchKernelGGL(k_flat_refine_half<true>, dim3((max_hits + 63) / 64, nq), dim3(64), dim * sizeof(float), s, rows_h, dim, sx, dx_abs, dx_rel, Q,
+                           xsq, qsq, qoff, cand, cap, cnt);
+    else
+        hipLaunchKernelGGL(k_flat_refine_half<false>, dim3((max_hits + 63) / 64, nq), dim3(64), dim * sizeof(float), s, rows_h, dim, sx, dx_abs, dx_rel, Q,
+                           xsq, qsq, qoff, cand, cap, cnt);
     VDB_HIP(hipGetLastError());
 }
 

@@ -256,9 +256,10 @@ void launch_scatter_results(const uint64_t *ri, const float *rd, const uint64_t 
                             uint64_t *o_idx, float *o_dist, uint64_t *o_cnt, hipStream_t s);
 void launch_gather_dk(const float *o_dist, const uint64_t *o_cnt, const uint64_t *rows, uint64_t nr, uint32_t k, uint32_t ksel, float *dk,
                       hipStream_t s);
-// tighter lower-bound keys for the hit lists of the 8-bit pass from the row-major fp16 image, L2Sqr (k_redo.hip); max_hits = longest list to cover
-void launch_flat_refine_half(const uint16_t *rows_h, uint32_t dim, float sx, float dx_abs, float dx_rel, const float *Q, const float *xsq,
-                             const float *qoff, uint64_t *cand, uint32_t cap, const uint32_t *cnt, uint32_t nq, uint32_t max_hits, hipStream_t s);
+// tighter lower-bound keys for the hit lists of the 8-bit pass from the row-major fp16 image (k_redo.hip); max_hits = longest list to cover
+void launch_flat_refine_half(const uint16_t *rows_h, uint32_t dim, float sx, float dx_abs, float dx_rel, int cosine, const float *Q, const float *xsq,
+                             const float *qsq, const float *qoff, uint64_t *cand, uint32_t cap, const uint32_t *cnt, uint32_t nq, uint32_t max_hits,
+                             hipStream_t s);
 void launch_i8_tau_from_dk(const float *dk, uint32_t nq, uint32_t nq_pad, const float *qoff, const float *qsq, float xsq_max, float mu_norm,
                            uint32_t dim, int cosine, float *tau, hipStream_t s);
 void mfma_set_sample_thin(int v);

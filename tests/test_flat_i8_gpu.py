@@ -456,19 +456,25 @@ def test_i8_threshold_sample_by_unit_minima(mods, dist):
     ix.close()
 
 
-def test_i8_hit_keys_refined_from_the_fp16_image(mods):
+@pytest.mark.parametrize("dist", ["l2sqr", "cosine"])
+def test_i8_hit_keys_refined_from_the_fp16_image(mods, dist):
     """tight clusters: the 8-bit keys' worst-case slack (a dot-product bound: ~2 |dx||q|) is wider than the spread of a cluster's distances, so
     the walk evaluates hundreds of rows in key order; k_flat_refine_half (k_redo.hip) replaces every hit's key by the larger lower bound the
-    row-major fp16 image gives in DIFFERENCE form (sqrt(D) >= |x~ - q| - |dx_r|) before the walk.  Same answers as without and as the oracle,
-    far fewer rounds; the auto rule turns it on from the rounds the walks take, leaves it off on separable rows, and Cosine (keys of unit
-    vectors) is not refined."""
+    row-major fp16 image gives in DIFFERENCE form (sqrt(D) >= |x~ - q| - |dx_r|; Cosine: the same for the unit vectors) before the walk.
+    Same answers as without and as the oracle, far fewer rounds; the auto rule turns it on from the rounds the walks take and leaves it off on
+    separable rows; rows and queries whose norms are not plain numbers keep their keys."""
     from conftest import gist_clustered
 
     vdb, O = mods
     n, dim, nq = 120_000, 960, 384
     base = gist_clustered(n, dim=dim, seed=21, clusters=64, spread=0.15)
     qs = gist_clustered(nq, dim=dim, seed=22, clusters=64, spread=0.15)
-    ix = vdb.GpuIndex(dim, "l2sqr")
+    base[777] = 0.0          # a zero row (Cosine: clamp active: its key is -FLT_MAX and stays) ...
+    if dist == "l2sqr":      # ... and one whose squared norm underflows (a Cosine index with such a row certifies nothing on the 8-bit pass:
+        base[778] = base[5] * np.float32(1e-20)  # flat_certify_lb checks the index's smallest positive norm)
+    qs[3] = 0.0              # a zero query
+    kind = O.L2SQR if dist == "l2sqr" else O.COSINE
+    ix = vdb.GpuIndex(dim, dist)
     ix.batch_add(base)
     ix.set_param("flat_i8_stats", 1)
 
@@ -486,9 +492,9 @@ def test_i8_hit_keys_refined_from_the_fp16_image(mods):
     for x, y in zip(a, b):
         np.testing.assert_array_equal(x, y)
     sel = np.arange(0, nq, 6)
-    oi, od, oc = O.flat_knn_batch(base, qs[sel], 10, O.L2SQR, nthreads=8)
+    oi, od, oc = O.flat_knn_batch(base, qs[sel], 10, kind, nthreads=8)
     _check_all(b[0][sel], b[1][sel], b[2][sel], oi, od, oc)
-    print(f"rounds of the first walk (capped at 8 per query) without / with refined keys: {r_off} / {r_on} for {nq} queries")
+    print(f"{dist}: rounds of the first walk (capped at 8 per query) without / with refined keys: {r_off} / {r_on} for {nq} queries")
     assert r_on * 2 < r_off
     # auto: the first call sees the long walks, the next ones run refined; every 32nd call of the on state is a probe without
     ix.set_param("flat_i8_refine", 0)
@@ -499,22 +505,13 @@ def test_i8_hit_keys_refined_from_the_fp16_image(mods):
     for x, y in zip(a, c):
         np.testing.assert_array_equal(x, y)
     ix.close()
-    # Cosine: not refined, answers the oracle's
-    ix = vdb.GpuIndex(dim, "cosine")
-    ix.batch_add(base)
-    ix.set_param("flat_i8_refine", 2)
-    g = ix.flat_knn(qs[:128], 10)
-    assert ix.get_stat("flat_i8_refine_queries") == 0
-    oi, od, oc = O.flat_knn_batch(base, qs[:32], 10, O.COSINE, nthreads=8)
-    _check_all(g[0][:32], g[1][:32], g[2][:32], oi, od, oc)
-    ix.close()
     # separable rows: never on
     base2, qs2 = gist_like(100_000, dim=dim, seed=23), gist_like(128, dim=dim, seed=24)
-    ix = vdb.GpuIndex(dim, "l2sqr")
+    ix = vdb.GpuIndex(dim, dist)
     ix.batch_add(base2)
     for _ in range(3):
         g = ix.flat_knn(qs2, 10)
     assert ix.get_stat("flat_i8_refine_on") == 0 and ix.get_stat("flat_i8_refine_queries") == 0
-    oi, od, oc = O.flat_knn_batch(base2, qs2[:32], 10, O.L2SQR, nthreads=8)
+    oi, od, oc = O.flat_knn_batch(base2, qs2[:32], 10, kind, nthreads=8)
     _check_all(g[0][:32], g[1][:32], g[2][:32], oi, od, oc)
     ix.close()
