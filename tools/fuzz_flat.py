@@ -51,12 +51,14 @@ while time.time() < t_end:
     sec, umin = int(rng2.choice([0, 0, 0, 1])), int(rng2.choice([0, 0, 1]))  # round 4: second 8-bit attempt off / unit-minima sample off
     ix.set_param("flat_i8_second", sec)
     ix.set_param("flat_i8_unit_min", umin)
+    ref = int(rng2.choice([0, 0, 2, 2, 1]))  # hit keys refined from the fp16 image: auto / always / off (k_flat_refine_half)
+    ix.set_param("flat_i8_refine", ref)
     idx, d, cnt = ix.flat_knn(qs, k)
     oi, od, oc = O.flat_knn_batch(base, qs, k, kind, nthreads=16)
     ok = cnt.tolist() == oc.tolist() and all(idx[q, :int(cnt[q])].tolist() == oi[q][:int(cnt[q])].tolist() and
                                              np.array_equal(d[q, :int(cnt[q])], od[q][:int(cnt[q])]) for q in range(nq))
     print(f"#{it} dim {dim} n {n} nq {nq} k {k} {dist} style {style}: {'ok' if ok else 'MISMATCH'} "
-          f"i8 {ix.get_stat('flat_i8_queries')} second {ix.get_stat('flat_i8_second_queries')} passed on {ix.get_stat('flat_i8_redo')} tail {nw} sets {ix.get_stat('flat_gemm8_coop_sets')} half {ix.get_stat('flat_half_queries')} redo {ix.get_stat('flat_half_redo')} fallback {ix.flat_fallback_count()}", flush=True)
+          f"i8 {ix.get_stat('flat_i8_queries')} second {ix.get_stat('flat_i8_second_queries')} passed on {ix.get_stat('flat_i8_redo')} tail {nw} refine {ref}:{ix.get_stat('flat_i8_refine_queries')} sets {ix.get_stat('flat_gemm8_coop_sets')} half {ix.get_stat('flat_half_queries')} redo {ix.get_stat('flat_half_redo')} fallback {ix.flat_fallback_count()}", flush=True)
     bad += 0 if ok else 1
     del ix
 print(f"done: {it} configurations, {bad} mismatches")
