@@ -784,8 +784,7 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
         t.id_offset = id_offset;
         // (flags, then -- measurement builds of a call, flat_i8_stats -- one word per query of exact-stage statistics)
         const size_t st_off = (nq + 15) & ~size_t(15);
-        // (the rounds walked also steer the fp16 refinement of the hit keys: collected on every first attempt while that is on auto)
-        const bool want_stats = i8 && (flat_i8_stats || (!i8_second && flat_i8_refine == 0 && nq >= 64));
+        const bool want_stats = i8 && flat_i8_stats;
         t.flags = static_cast<uint8_t *>(ws.pinned(want_stats ? st_off + nq * sizeof(uint32_t) : nq));
         if (want_stats) t.qstat = reinterpret_cast<uint32_t *>(t.flags + st_off);
         p.stats = want_stats;
@@ -856,7 +855,7 @@ void Index::flat_knn_finish(Workspace &ws, FlatPending &p) {
     // the exact scan), scatter the results
     std::vector<uint64_t> redo;
     for (uint64_t q = 0; q < nq; q++)
-        if (flags[q]) redo.push_back(q);
+        if (flags[q] & 1u) redo.push_back(q);  // (bits 1..7: rounds the 8-bit pass's exact stage walked)
     if (half) {
         half_queries += nq;
         half_redo += redo.size();
@@ -869,12 +868,12 @@ void Index::flat_knn_finish(Workspace &ws, FlatPending &p) {
     if (i8 && !i8_second) {
         i8_queries += nq;
         if (!try_second) i8_redo += redo.size();  // (with a second attempt: what THAT passes on, counted below)
-        if (p.stats && flat_i8_refine == 0 && nq >= 64) {
+        if (flat_i8_refine == 0 && nq >= 64) {
             // auto rule of the fp16 refinement: it costs half the f32 bytes of every hit (~0.5 ms per 1000 queries), a round of the walk
             // ~0.1 ms per 1000 queries -- on when the walks average 6 rounds, off again when a probe call without it averages under 4
-            const uint32_t *qs = reinterpret_cast<const uint32_t *>(flags + ((nq + 15) & ~size_t(15)));
+            // (the rounds come with the flags: bits 1..7)
             uint64_t rs = 0;
-            for (uint64_t q = 0; q < nq; q++) rs += std::min<uint32_t>(qs[q] & 0xFFu, 32u);  // (0xFF: a list evaluated whole)
+            for (uint64_t q = 0; q < nq; q++) rs += std::min<uint32_t>(flags[q] >> 1, 32u);
             const double mean_rounds = double(rs) / double(nq);
             if (!p.refined) {
                 const int was = i8_refine_on.load();

@@ -1103,7 +1103,7 @@ __global__ __launch_bounds__(NW * 64, PCD ? 4 : 1) void k_flat_tail_lb(FlatTailA
     const uint32_t count = __builtin_popcountll(__ballot(ok));
     if (lane == 0) {
         if (a.out_count) a.out_count[q] = count;
-        a.flags[q] = flag;
+        a.flags[q] = uint8_t(flag | ((rounds_done < 127u ? rounds_done : 127u) << 1));  // bit 0: not certified; bits 1..7: rounds walked (the host's refinement rule)
         if (a.qstat) a.qstat[q] = rounds_done | ((cnt_q < 0xFFFFFFu ? cnt_q : 0xFFFFFFu) << 8);
     }
 }
