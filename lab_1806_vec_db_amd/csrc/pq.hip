@@ -1127,6 +1127,11 @@ struct Adc16x8Args {
     uint64_t *cand;         // [nq][cap] row ids
     uint32_t *cnt;          // [nq]
     uint32_t cap;
+    // k_pq_adc8x16<SAMPLE>: the quantised sums of every blk_step-th block of 1024 rows, as floats (+inf past the table), [nq][ld_s]
+    uint32_t blk_step = 0;
+    uint64_t n_sb = 0;      // sampled blocks
+    float *s8_out = nullptr;
+    uint64_t ld_s = 0;
 };
 
 __global__ __launch_bounds__(1024) void k_pq_adc16x8(Adc16x8Args a) {
@@ -1310,6 +1315,9 @@ __device__ __forceinline__ void pq_glds16(const void *gsrc, uint32_t lds_dst) {
 // The slices are 16 groups (one code word, 64 KB) in TWO LDS blocks: while a slice is scanned the next one is on its way into the other
 // block by LDS-DMA and the rows' next code words into registers -- with one 128-KB block the workgroup stood still for every load (all
 // waves at the barrier: ~5 k of ~23 k cycles per slice).
+// SAMPLE: the threshold sample on the same image (it was a pass of its own on one-byte tables of ONE query per workgroup, k_pq_adc8<true> +
+// k_pq_quant8: 0.97 ms per 1000 queries): a workgroup scores RPT sampled blocks of 1024 rows for its 16 queries and writes the sums.
+template <bool SAMPLE>
 __global__ __launch_bounds__(1024) void k_pq_adc8x16(Adc16x8Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem816[];
     constexpr uint32_t RPT = ADC8X16_RPT, GS = ADC8X16_GS, BLK = GS * 256 * 16;        // 64 KB per block
@@ -1328,7 +1336,7 @@ __global__ __launch_bounds__(1024) void k_pq_adc8x16(Adc16x8Args a) {
         return;
     }
     if (tid < 33) hit_n[tid] = 0;
-    if (tid < 16) {
+    if (!SAMPLE && tid < 16) {
         int32_t T = -1;
         const uint32_t q = q0 + tid;
         if (q < a.nq && a.qflag[q] == 0) {
@@ -1339,8 +1347,9 @@ __global__ __launch_bounds__(1024) void k_pq_adc8x16(Adc16x8Args a) {
         thr[tid] = T;
     }
     const uint4 *img = a.img + uint64_t(blockIdx.y) * a.nslices * GS * 256;
-    const uint64_t r_begin = uint64_t(blockIdx.x) * a.rows_per_wg;
-    const uint64_t r_end = r_begin + a.rows_per_wg < a.n ? r_begin + a.rows_per_wg : a.n;
+    // SAMPLE: ONE pass; thread tid's j-th row is row tid of sampled block RPT blockIdx.x + j (block b = rows [b blk_step 1024, + 1024))
+    const uint64_t r_begin = SAMPLE ? 0 : uint64_t(blockIdx.x) * a.rows_per_wg;
+    const uint64_t r_end = SAMPLE ? 1 : (r_begin + a.rows_per_wg < a.n ? r_begin + a.rows_per_wg : a.n);
     uint32_t four = 4u, blk1 = BLK;
     asm volatile("" : "+s"(four), "+s"(blk1));
     // slice sl -> block bk: 4 DMA instructions per wave (4096 entries of 16 B, wave w moves entries 1024 i + 64 w .. + 63)
@@ -1360,9 +1369,10 @@ __global__ __launch_bounds__(1024) void k_pq_adc8x16(Adc16x8Args a) {
         for (int j = 0; j < (int)RPT; j++) {
 #pragma unroll
             for (int d = 0; d < 8; d++) acc[j][d] = 0u;
-            const uint64_t row = rb + uint64_t(j) * 1024 + tid;
-            valid[j] = row < r_end;
-            const uint64_t lrow = valid[j] ? row : r_end - 1;  // (idle lanes re-read a valid row: see k_pq_adc16)
+            const uint64_t sblk = uint64_t(blockIdx.x) * RPT + j;
+            const uint64_t row = SAMPLE ? sblk * a.blk_step * 1024 + tid : rb + uint64_t(j) * 1024 + tid;
+            valid[j] = SAMPLE ? (sblk < a.n_sb && row < a.n) : row < r_end;
+            const uint64_t lrow = valid[j] ? row : (SAMPLE ? a.n - 1 : r_end - 1);  // (idle lanes re-read a valid row: see k_pq_adc16)
             cw[j] = a.codes_t + (lrow >> 6) * nwords * 64 + (lrow & 63);
             cnext[j] = cw[j][0];
         }
@@ -1429,6 +1439,19 @@ __global__ __launch_bounds__(1024) void k_pq_adc8x16(Adc16x8Args a) {
         for (uint32_t sl = 0; sl < a.nslices; sl += 2) {
             slice(sl, std::integral_constant<uint32_t, 0>{});
             if (sl + 1 < a.nslices) slice(sl + 1, std::integral_constant<uint32_t, 1>{});
+        }
+        if constexpr (SAMPLE) {
+#pragma unroll
+            for (int j = 0; j < (int)RPT; j++) {
+                const uint64_t sblk = uint64_t(blockIdx.x) * RPT + j;
+                if (sblk >= a.n_sb) continue;  // uniform
+#pragma unroll
+                for (int b = 0; b < 16; b++) {
+                    const uint32_t sb = (b & 1) ? (acc[j][b >> 1] >> 16) : (acc[j][b >> 1] & 0xffffu);
+                    if (q0 + b < a.nq) a.s8_out[uint64_t(q0 + b) * a.ld_s + sblk * 1024 + tid] = valid[j] ? float(sb) : INFINITY;
+                }
+            }
+            return;
         }
 #pragma unroll
         for (int j = 0; j < (int)RPT; j++) {
@@ -2255,8 +2278,11 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
             ws.qaux.reserve(nq * (2 * sizeof(double) + sizeof(uint32_t)));
             double *d_qM = ws.qaux.as<double>(), *d_qD = d_qM + nq;
             uint32_t *d_qflag = reinterpret_cast<uint32_t *>(d_qD + nq);
-            hipLaunchKernelGGL(k_pq_quant8, dim3((unsigned)nq), dim3(256), 0, s, ws.lut.as<float>(), (uint32_t)pq.m, m8, (uint32_t)nq,
-                               ws.qfrag_g.as<uint8_t>(), d_qM, d_qD, d_qflag);
+            const size_t lds816 = 2 * size_t(ADC8X16_GS) * 256 * 16 + size_t(ADC8X16_WGBUF) * 8 + (36 + 16) * 4 + 16;
+            const bool use816 = g_adc8_sliced == 0 && lds816 <= 158 * 1024;  // sixteen queries per pass, sample included (k_pq_adc8x16)
+            if (!use816)
+                hipLaunchKernelGGL(k_pq_quant8, dim3((unsigned)nq), dim3(256), 0, s, ws.lut.as<float>(), (uint32_t)pq.m, m8, (uint32_t)nq,
+                                   ws.qfrag_g.as<uint8_t>(), d_qM, d_qD, d_qflag);
             func_max_lds(reinterpret_cast<const void *>(&k_pq_adc8<false>), int(160 * 1024));
             func_max_lds(reinterpret_cast<const void *>(&k_pq_adc8<true>), int(160 * 1024));
             for (uint64_t g0 = 0; g0 < nq; g0 += GQ) {
@@ -2278,9 +2304,50 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
                 a.blk_step = step8;
                 a.s8_out = ws.dense.as<float>();
                 a.ld_s = ld_s;
-                // every workgroup loads its query's 80-KB table: few workgroups per query, enough of them to fill the chip
-                const uint32_t gx = (uint32_t)std::min<uint64_t>(n_sb8, std::max<uint64_t>(1, (2ull * ix.num_cu + gn - 1) / gn));
-                hipLaunchKernelGGL(k_pq_adc8<true>, dim3(gx, (unsigned)gn), dim3(1024), lds8, s, a);
+                // the image of the sixteen-query scan, needed by its sample already
+                const uint32_t nsl8 = (uint32_t)((pq.m + ADC8X16_GS - 1) / ADC8X16_GS), m_pad8 = nsl8 * ADC8X16_GS;
+                const uint32_t ngrp816 = (uint32_t)((gn + 15) / 16);
+                double *qM16 = nullptr, *qD16 = nullptr;
+                uint32_t *qf16 = nullptr;
+                Adc16x8Args b816{};
+                if (use816) {
+                    ws.pq_img16.reserve(size_t(ngrp816) * m_pad8 * 256 * sizeof(uint4));
+                    ws.pq_aux16.reserve(gn * pq.m * sizeof(float) + gn * (2 * sizeof(double) + sizeof(uint32_t)) + 64);
+                    qM16 = ws.pq_aux16.as<double>();
+                    qD16 = qM16 + gn;
+                    qf16 = reinterpret_cast<uint32_t *>(qD16 + gn);
+                    float *mn16 = reinterpret_cast<float *>(qf16 + ((gn + 3) & ~uint64_t(3)));
+                    const float *lutg = ws.lut.as<float>() + g0 * lsz;
+                    hipLaunchKernelGGL(k_pq_quant16x8_stats, dim3((unsigned)gn), dim3(256), 0, s, lutg, (uint32_t)pq.m, (uint32_t)gn, mn16, qM16, qD16, qf16,
+                                       std::min(65000.0, 512.0 * double(pq.m)));
+                    hipLaunchKernelGGL(k_pq_quant8x16_img, dim3(m_pad8, ngrp816), dim3(256), 0, s, lutg, mn16, qD16, qf16, (uint32_t)pq.m, m_pad8,
+                                       (uint32_t)gn, ws.pq_img16.as<uint4>());
+                    b816.codes_t = pq.d_codes_t.as<uint4>();
+                    b816.n = n;
+                    b816.nwords = nw8;
+                    b816.m = (uint32_t)pq.m;
+                    b816.nslices = nsl8;
+                    b816.img = ws.pq_img16.as<uint4>();
+                    b816.qM = qM16;
+                    b816.qD = qD16;
+                    b816.qflag = qf16;
+                    b816.tau = d_tau + g0;
+                    b816.nq = (uint32_t)gn;
+                    b816.rows_per_wg = uint64_t(ADC8X16_RPT) * 1024;  // one block of rows per workgroup: every slice of the image is loaded once
+                    b816.cand = ws.lists.as<uint64_t>();
+                    b816.cnt = d_hits + g0;
+                    b816.cap = cap;
+                    b816.blk_step = step8;
+                    b816.n_sb = n_sb8;
+                    b816.s8_out = ws.dense.as<float>();
+                    b816.ld_s = ld_s;
+                    func_max_lds(reinterpret_cast<const void *>(&k_pq_adc8x16<true>), int(160 * 1024));
+                    hipLaunchKernelGGL(k_pq_adc8x16<true>, dim3((unsigned)((n_sb8 + ADC8X16_RPT - 1) / ADC8X16_RPT), ngrp816), dim3(1024), lds816, s, b816);
+                } else {
+                    // every workgroup loads its query's 80-KB table: few workgroups per query, enough of them to fill the chip
+                    const uint32_t gx = (uint32_t)std::min<uint64_t>(n_sb8, std::max<uint64_t>(1, (2ull * ix.num_cu + gn - 1) / gn));
+                    hipLaunchKernelGGL(k_pq_adc8<true>, dim3(gx, (unsigned)gn), dim3(1024), lds8, s, a);
+                }
                 if (n_s8 <= select_tau_max_n()) {
                     launch_select_tau(ws.dense.as<float>(), ld_s, (uint32_t)n_s8, (uint32_t)gn, (uint32_t)gn, rank8, d_tau + g0, s);
                 } else {
@@ -2288,44 +2355,19 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
                     launch_topk_merge(ws.lists.as<uint64_t>(), nl_s, cape, (uint32_t)gn, rank8, ws.keys_a.as<uint64_t>() + g0 * cape, s);
                     launch_extract_tau(ws.keys_a.as<uint64_t>() + g0 * cape, cape, (uint32_t)gn, rank8, d_tau + g0, s);
                 }
-                hipLaunchKernelGGL(k_pq_tau_from16, dim3((unsigned)((gn + 255) / 256)), dim3(256), 0, s, d_tau + g0, d_qM + g0, d_qD + g0, d_qflag + g0,
-                                   (uint32_t)pq.m, (uint32_t)gn);
+                if (use816)  // (the sample's sums are in the scan's own quantisation)
+                    hipLaunchKernelGGL(k_pq_tau_from16, dim3((unsigned)((gn + 255) / 256)), dim3(256), 0, s, d_tau + g0, qM16, qD16, qf16, (uint32_t)pq.m,
+                                       (uint32_t)gn);
+                else
+                    hipLaunchKernelGGL(k_pq_tau_from16, dim3((unsigned)((gn + 255) / 256)), dim3(256), 0, s, d_tau + g0, d_qM + g0, d_qD + g0, d_qflag + g0,
+                                       (uint32_t)pq.m, (uint32_t)gn);
                 const uint32_t nsl = (uint32_t)((pq.m + ADC16X8_GS - 1) / ADC16X8_GS), m_pad16 = nsl * ADC16X8_GS;
                 const size_t lds168 = size_t(ADC16X8_GS) * 256 * 16 + size_t(ADC16X8_WGBUF) * 8 + (20 + 8) * 4 + 16;
-                const size_t lds816 = 2 * size_t(ADC8X16_GS) * 256 * 16 + size_t(ADC8X16_WGBUF) * 8 + (36 + 16) * 4 + 16;
-                if (g_adc8_sliced == 0 && lds816 <= 158 * 1024) {
+                if (use816) {
                     // sixteen queries per pass over the code mirror: one-byte entries in slices of 16 groups (k_pq_adc8x16)
-                    const uint32_t nsl8 = (uint32_t)((pq.m + ADC8X16_GS - 1) / ADC8X16_GS), m_pad8 = nsl8 * ADC8X16_GS;
-                    const uint32_t ngrp = (uint32_t)((gn + 15) / 16);
-                    ws.pq_img16.reserve(size_t(ngrp) * m_pad8 * 256 * sizeof(uint4));
-                    ws.pq_aux16.reserve(gn * pq.m * sizeof(float) + gn * (2 * sizeof(double) + sizeof(uint32_t)) + 64);
-                    double *qM16 = ws.pq_aux16.as<double>(), *qD16 = qM16 + gn;
-                    uint32_t *qf16 = reinterpret_cast<uint32_t *>(qD16 + gn);
-                    float *mn16 = reinterpret_cast<float *>(qf16 + ((gn + 3) & ~uint64_t(3)));
-                    const float *lutg = ws.lut.as<float>() + g0 * lsz;
-                    hipLaunchKernelGGL(k_pq_quant16x8_stats, dim3((unsigned)gn), dim3(256), 0, s, lutg, (uint32_t)pq.m, (uint32_t)gn, mn16, qM16, qD16, qf16,
-                                       std::min(65000.0, 512.0 * double(pq.m)));
-                    hipLaunchKernelGGL(k_pq_quant8x16_img, dim3(m_pad8, ngrp), dim3(256), 0, s, lutg, mn16, qD16, qf16, (uint32_t)pq.m, m_pad8,
-                                       (uint32_t)gn, ws.pq_img16.as<uint4>());
-                    Adc16x8Args b{};
-                    b.codes_t = pq.d_codes_t.as<uint4>();
-                    b.n = n;
-                    b.nwords = nw8;
-                    b.m = (uint32_t)pq.m;
-                    b.nslices = nsl8;
-                    b.img = ws.pq_img16.as<uint4>();
-                    b.qM = qM16;
-                    b.qD = qD16;
-                    b.qflag = qf16;
-                    b.tau = d_tau + g0;
-                    b.nq = (uint32_t)gn;
-                    b.rows_per_wg = uint64_t(ADC8X16_RPT) * 1024;  // one block of rows per workgroup: every slice of the image is loaded once
-                    b.cand = ws.lists.as<uint64_t>();
-                    b.cnt = d_hits + g0;
-                    b.cap = cap;
-                    func_max_lds(reinterpret_cast<const void *>(&k_pq_adc8x16), int(160 * 1024));
-                    ix.prof_begin(ws, "pq_adc", double(ngrp) * double(n) * pq.enc_dim);
-                    hipLaunchKernelGGL(k_pq_adc8x16, dim3((unsigned)((n + b.rows_per_wg - 1) / b.rows_per_wg), ngrp), dim3(1024), lds816, s, b);
+                    func_max_lds(reinterpret_cast<const void *>(&k_pq_adc8x16<false>), int(160 * 1024));
+                    ix.prof_begin(ws, "pq_adc", double(ngrp816) * double(n) * pq.enc_dim);
+                    hipLaunchKernelGGL(k_pq_adc8x16<false>, dim3((unsigned)((n + b816.rows_per_wg - 1) / b816.rows_per_wg), ngrp816), dim3(1024), lds816, s, b816);
                     ix.prof_end(ws);
                 } else if (g_adc8_sliced != 1 && lds168 <= 158 * 1024) {
                     // eight queries per pass over the code mirror: 16-bit tables in slices of 32 groups (k_pq_adc16x8)
