@@ -2243,7 +2243,7 @@ static void pq_adc_shortlist(Index &ix, Workspace &ws, const float *d_q, uint64_
         launch_topk_merge(ws.lists.as<uint64_t>(), nl, cape, (uint32_t)gn, efk, ws.keys_a.as<uint64_t>() + g0 * cape, s);
     };
 
-    // ---- 8-bit codes: one query per pass on a one-byte table in LDS (k_pq_adc8, see there) ------------------------------------
+    // ---- 8-bit codes: sixteen queries per pass on one-byte table entries (k_pq_adc8x16; pq_adc8_sliced = 1 / 2: the earlier forms) ------
     {
         const uint32_t nw8 = (uint32_t)((pq.enc_dim + 15) / 16), m8 = 16 * nw8;
         const size_t lds8 = size_t(m8) * 256 + ADC8_WGBUF * 4 + 16;
