@@ -310,6 +310,9 @@ __device__ __forceinline__ float hnsw_exact_dists_dma(const HnswDev &g, const fl
 #ifndef HNSW_FOLD_PRODUCTS
 #define HNSW_FOLD_PRODUCTS 1  // 0: the round-3 / early round-4 fold (raw rows through the transpose, products in the folding layout)
 #endif
+#ifndef HNSW_NG3
+#define HNSW_NG3 1  // 0: expansions of 17 .. 24 fresh rows take the four-group form
+#endif
 #ifndef HNSW_FOLD_FREE
 #define HNSW_FOLD_FREE 1  // no scheduling barrier between the chunks of a line (0: pinned chunk by chunk -- 8 % slower per one-query call)
 #endif
@@ -334,7 +337,7 @@ constexpr uint32_t HNSW_REG_STAGE = 2 * 4096;  // two line blocks: the transpose
 template <int NG>
 __device__ __forceinline__ float hnsw_exact_dists_regs(const HnswDev &g, const float *qlds, float qsq, uint32_t nb, bool fresh,
                                                        unsigned char *stage, uint32_t lane) {
-    constexpr int D = NG == 4 ? HNSW_REG_DEPTH4 : HNSW_REG_DEPTH;  // 16 NG D registers of lines in flight + 64 of the line being folded
+    constexpr int D = NG >= 3 ? HNSW_REG_DEPTH4 : HNSW_REG_DEPTH;  // 16 NG D registers of lines in flight + 64 of the line being folded
 #ifdef HNSW_STAMP2
     unsigned long long _t2 = wall_clock64();
     if (lane == 0) atomicAdd(&g_hnsw_st2[4], 1ull);
@@ -763,8 +766,15 @@ __global__ __launch_bounds__(64, HNSW_LB) void k_hnsw_search(HnswDev g, const fl
                         }
                         const uint32_t nneed = (uint32_t)__builtin_popcountll(__ballot(need));
                         float de = 0.0f;
-                        if (nneed > 16)
+                        if (nneed > 24)
                             de = hnsw_exact_dists_regs<4>(g, fl, qsq, nb, need, stage, lane);
+#if HNSW_NG3
+                        else if (nneed > 16)  // (17 .. 24 rows -- the typical expansion of a lone walk: three groups of 8, a load, a write and two multiplies less per line)
+                            de = hnsw_exact_dists_regs<3>(g, fl, qsq, nb, need, stage, lane);
+#else
+                        else if (nneed > 16)
+                            de = hnsw_exact_dists_regs<4>(g, fl, qsq, nb, need, stage, lane);
+#endif
                         else if (nneed > 8)
                             de = hnsw_exact_dists_regs<2>(g, fl, qsq, nb, need, stage, lane);
                         else if (nneed > 0)
