@@ -360,9 +360,18 @@ bool Index::ensure_rows_h(Workspace &ws) {
     if (elem_u8 || dim % 64 != 0 || dim > 4096 || n == 0 || !ensure_half(ws)) return false;
     std::lock_guard<std::mutex> g(rows_h_mu);
     if (rows_h_n == n && rows_h_exp == half_exp) return true;
+    if (rows_h_failed_n == n) return false;
     uint64_t r0 = rows_h_n;
     if (rows_h_exp != half_exp || rows_h_n > n) r0 = 0;
-    d_rows_h.grow(n * dim * sizeof(uint16_t) + 16, r0 * dim * sizeof(uint16_t), ws.stream);
+    try {
+        d_rows_h.grow(n * dim * sizeof(uint16_t) + 16, r0 * dim * sizeof(uint16_t), ws.stream);
+    } catch (const AllocError &) {  // the image is an accelerator (pre-passes, key refinement): its callers go on without it
+        d_rows_h.release();
+        rows_h_n = 0;
+        rows_h_failed_n = n;
+        mirror_alloc_failures += 1;
+        return false;
+    }
     launch_rows_to_half(d_rows.as<float>() + r0 * dim, (n - r0) * dim, half_sx(), d_rows_h.as<uint16_t>() + r0 * dim, ws.stream);
     VDB_SYNC(ws.stream);
     rows_h_n = n;

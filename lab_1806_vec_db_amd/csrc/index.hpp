@@ -310,6 +310,7 @@ struct Index {
     // extended when rows were added since, rebuilt when the scale changed.
     DevBuf d_rows_h;
     uint64_t rows_h_n = 0;
+    uint64_t rows_h_failed_n = ~0ull;  // row count at which the image's allocation failed (not retried until it changes)
     int rows_h_exp = 0;
     std::mutex rows_h_mu;
     bool ensure_rows_h(Workspace &ws);  // false: this index has no fp16 image (dim, element type, extreme norms)

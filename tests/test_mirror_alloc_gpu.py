@@ -107,3 +107,38 @@ def test_prepare_on_a_fresh_index(mods):
     small.batch_add(np.ones((5, 12), dtype=np.float32))
     small.prepare(all_tiers=True)
     small.close()
+
+
+def test_key_refinement_without_room_for_the_fp16_image(mods):
+    """the row-major fp16 image behind the refinement of the 8-bit pass's hit keys (k_flat_refine_half) is an accelerator: when it cannot be
+    allocated the search goes on with the 8-bit keys (same answers), the failure is counted once and not retried until the table changes"""
+    from conftest import gist_clustered
+
+    vdb, O = mods
+    n, dim, nq = 60_000, 192, 128
+    base = gist_clustered(n, dim=dim, seed=31, clusters=32, spread=0.15)
+    qs = gist_clustered(nq, dim=dim, seed=32, clusters=32, spread=0.15)
+    oi, od, oc = O.flat_knn_batch(base, qs, 10, O.L2SQR, nthreads=8)
+    ix = vdb.GpuIndex(dim, "l2sqr")
+    ix.batch_add(base)
+    try:
+        ix.flat_knn(qs[:8], 10)  # the 8-bit mirror exists now
+        ix.set_param("flat_i8_refine", 2)  # always: wants the fp16 images (2 x 2 B per element)
+        ix.set_param("debug_alloc_fail_over", n * dim * 3 // 2)
+        f0 = ix.get_stat("mirror_alloc_failures")
+        idx, d, cnt = ix.flat_knn(qs, 10)
+        _check(idx, d, cnt, oi, od, oc)
+        assert ix.get_stat("flat_i8_refine_queries") == 0 and ix.get_stat("mirror_alloc_failures") > f0
+        f1 = ix.get_stat("mirror_alloc_failures")
+        idx, d, cnt = ix.flat_knn(qs, 10)
+        _check(idx, d, cnt, oi, od, oc)
+        assert ix.get_stat("mirror_alloc_failures") == f1
+        ix.set_param("debug_alloc_fail_over", 0)  # memory is back, the table changes: built and used
+        ix.batch_add(base[:8])
+        idx, d, cnt = ix.flat_knn(qs, 10)
+        assert ix.get_stat("flat_i8_refine_queries") == nq
+        oi2, od2, oc2 = O.flat_knn_batch(np.concatenate([base, base[:8]]), qs, 10, O.L2SQR, nthreads=8)
+        _check(idx, d, cnt, oi2, od2, oc2)
+    finally:
+        ix.set_param("debug_alloc_fail_over", 0)
+        ix.close()
