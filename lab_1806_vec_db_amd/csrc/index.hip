@@ -791,23 +791,25 @@ void Index::flat_knn_enqueue(Workspace &ws, const float *d_q, uint64_t nq, uint6
         t.cosine = cosine;
         t.se = se;
         t.id_offset = id_offset;
+        // long walks (tight clusters): the keys of the hits are tightened from the row-major fp16 image first (k_redo.hip).  Decided -- and the
+        // image built, which may use the pinned block -- before this call takes its flags from that block.
+        bool refine = false;
+        if (i8 && !i8_second && nq >= 64 && flat_i8_refine != 1) {
+            bool on = flat_i8_refine == 2;
+            if (flat_i8_refine == 0 && i8_refine_on.load() != 0) on = (i8_refine_calls.fetch_add(1) % 32u) != 31u;  // (the 32nd: a probe without)
+            refine = on && ensure_rows_h(ws);
+        }
         // (flags, then -- measurement builds of a call, flat_i8_stats -- one word per query of exact-stage statistics)
         const size_t st_off = (nq + 15) & ~size_t(15);
         const bool want_stats = i8 && flat_i8_stats;
         t.flags = static_cast<uint8_t *>(ws.pinned(want_stats ? st_off + nq * sizeof(uint32_t) : nq));
         if (want_stats) t.qstat = reinterpret_cast<uint32_t *>(t.flags + st_off);
         p.stats = want_stats;
-        p.refined = false;
-        if (i8 && !i8_second && nq >= 64 && flat_i8_refine != 1) {
-            // long walks (tight clusters): the keys of the hits are tightened from the row-major fp16 image first (k_redo.hip)
-            bool on = flat_i8_refine == 2;
-            if (flat_i8_refine == 0 && i8_refine_on.load() != 0) on = (i8_refine_calls.fetch_add(1) % 32u) != 31u;  // (the 32nd: a probe without)
-            if (on && ensure_rows_h(ws)) {
-                launch_flat_refine_half(d_rows_h.as<uint16_t>(), (uint32_t)dim, half_sx(), half_dx_abs, half_dx_rel, cosine, d_q, d_sq.as<float>(),
-                                        ws.qsq.as<float>(), d_qoff, d_cand, CAND_CAP, d_hits, (uint32_t)nq, CAND_CAP, s);  // (a list holds up to CAND_CAP hits; the walk selects among all of them)
-                p.refined = true;
-                i8_refine_queries += nq;
-            }
+        p.refined = refine;
+        if (refine) {
+            launch_flat_refine_half(d_rows_h.as<uint16_t>(), (uint32_t)dim, half_sx(), half_dx_abs, half_dx_rel, cosine, d_q, d_sq.as<float>(),
+                                    ws.qsq.as<float>(), d_qoff, d_cand, CAND_CAP, d_hits, (uint32_t)nq, CAND_CAP, s);  // (a list holds up to CAND_CAP hits; the walk selects among all of them)
+            i8_refine_queries += nq;
         }
         t.out_idx = d_idx;
         t.out_dist = d_dist;
